@@ -1,0 +1,39 @@
+"""Case definitions shared by tests/golden/make_golden.py (which ran the
+reference) and the tests (which run the oracle / the HIP engine)."""
+import os
+
+import numpy as np
+import torch
+
+from oracle import weights as W
+from oracle.unet import UNetConfig
+from oracle.vae import VAEConfig
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+UNET_CFGS = {
+    "unet_mc32_mm": (UNetConfig(model_channels=32), 4, 16),
+    "unet_mc64_mm": (UNetConfig(model_channels=64), 2, 8),
+    "unet_mc32_cam": (UNetConfig(model_channels=32, bbox_cond=False, use_lidar=False), 3, 16),
+}
+VAE_CFGS = {
+    "vae_cam32": VAEConfig(in_channels=3, out_ch=3, ch=32),
+    "vae_lidar32": VAEConfig(in_channels=2, out_ch=2, ch=32, lidar_adapter=True),
+}
+UNET_SEED, VAE_SEED, OPS_SEED = 7, 11, 1
+
+
+def load(name):
+    with np.load(os.path.join(GOLDEN, name + ".npz")) as z:
+        return {k: torch.from_numpy(z[k]) if z[k].dtype != object else z[k] for k in z.files}
+
+
+def rel_l2(a, b):
+    a, b = a.double(), b.double()
+    return float((a - b).norm() / b.norm().clamp_min(1e-30))
+
+
+def op_sd(prefix, shapes):
+    """state dict for a per-operator golden: the reference module was filled with
+    synth_param(prefix + key) (make_golden.py), local keys are returned."""
+    return {k: torch.from_numpy(W.synth_param(prefix + k, s, OPS_SEED)) for k, s in shapes.items()}
