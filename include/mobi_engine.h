@@ -1,0 +1,277 @@
+/*
+ * mobi_engine.h -- C ABI of the MI355X (gfx950) denoising engine for MObI's
+ * camera+lidar sampling path.
+ *
+ * The reference has no FFI on this path: every FLOP runs inside PyTorch ops
+ * called from Python (boundary B2).  Each entry point below
+ * therefore names the reference *call site(s)* whose arithmetic it replaces
+ * (paths relative to the reference repo root).  INTEGRATION.md shows the
+ * ctypes binding a reference maintainer would add.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes, no torch / C++ types.
+ *   - every tensor is a caller-allocated DEVICE buffer; the library never
+ *     allocates, frees or retains memory.  Scratch space is passed in `ws`
+ *     with the size given by the matching *_workspace_bytes query.
+ *   - asynchronous on `stream` (a hipStream_t passed as void*), no internal
+ *     synchronisation, graph-capture safe.
+ *   - returns MOBI_OK (0) or a negative error code; never throws.
+ *   - activations are channels-last: [image][y][x][channel], channel
+ *     contiguous, in a 16-bit storage type selected by `dtype`
+ *     (MOBI_F16 | MOBI_BF16).  All accumulation / statistics are fp32.
+ *   - "T" below means that 16-bit storage type.
+ */
+#ifndef MOBI_ENGINE_H_
+#define MOBI_ENGINE_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MOBI_ABI_VERSION 1
+
+enum { MOBI_OK = 0, MOBI_ERR_ARG = -1, MOBI_ERR_UNSUPPORTED = -2, MOBI_ERR_LAUNCH = -3, MOBI_ERR_ALIGN = -4 };
+enum { MOBI_F16 = 0, MOBI_BF16 = 1 };
+
+int mobi_abi_version(void);
+const char* mobi_error_string(int code);
+/* sizeof() of a parameter struct as the library was compiled; bindings compare it with
+ * their own layout before the first call.  id: 0 igemm, 1 groupnorm, 2 layernorm,
+ * 3 attention, 4 ctx_attention, 5 skinny_linear, 6 conv_small_cin, 7 conv_small_cout,
+ * 8 ddim_step.  Returns 0 for an unknown id. */
+size_t mobi_struct_size(int id);
+
+/* ---------------------------------------------------------------------------
+ * Implicit-GEMM convolution / linear layer on the matrix cores.
+ *   out[m][n] = epilogue( scale * sum_k A[m][k] * W[n][k] )
+ * where row m is an output pixel (image, y, x) and k runs over
+ * (tap, channel) of the gathered input window.  A 1x1 convolution and an
+ * nn.Linear over tokens are the kh = kw = 1 case.
+ * Replaces: nn.Conv2d / nn.Linear calls of ResBlock (openaimodel.py:255-275),
+ * Downsample (:158-160), Upsample incl. the F.interpolate(nearest, x2) before
+ * it (:109-119), torch.cat([h, hs.pop()], 1) feeding a ResBlock (:893-894),
+ * SpatialTransformer proj_in/proj_out (attention.py:306,311), every Linear of
+ * CrossAttention / FeedForward / GEGLU (attention.py:38-65,162-194), and the
+ * VAE's Conv2d layers incl. the asymmetric-pad stride-2 Downsample
+ * (model.py:47,66,72-79,92,102) and AttnBlock q/k/v/proj_out + both bmm
+ * (model.py:178-202).
+ * ------------------------------------------------------------------------- */
+enum { MOBI_EPI_NONE = 0, MOBI_EPI_GEGLU = 1 };
+enum { MOBI_OUT_ROWS = 0,        /* T   [m][cout]                               */
+       MOBI_OUT_TRANSPOSED = 1,  /* T   [image][cout][hout*wout]                */
+       MOBI_OUT_ROWS_F32 = 2 };  /* f32 [m][cout]                               */
+
+typedef struct mobi_igemm_params {
+  const void* src0;      /* T, channels-last, c0 channels                              */
+  const void* src1;      /* T or NULL: second source concatenated after src0's channels */
+  int32_t c0, c1;        /* channel counts (c1 = 0 without src1); each % 32 == 0        */
+  int32_t batch;         /* images                                                      */
+  int32_t hin, win;      /* stored spatial size of the sources                          */
+  int32_t upsample;      /* 1: the logical input is the nearest-neighbour x2 of sources */
+  int32_t hout, wout;    /* output spatial size                                         */
+  int32_t kh, kw, stride, pad_h, pad_w; /* pad = top / left zero padding; reads past the
+                                           bottom / right edge are zero as well          */
+  int64_t src_img_stride;  /* elements between images of src0/src1; 0 = dense           */
+  const void* weight;    /* T [groups][n_packed][kh*kw*(c0+c1)], k contiguous, k = tap*C + c */
+  int32_t groups;        /* 1: one weight matrix; == batch: one weight matrix per image  */
+  int64_t w_group_stride;/* elements between the per-group weight matrices              */
+  int32_t n_packed;      /* rows of W; GEGLU: units of u value rows then u gate rows,
+                            u = 40 if n_packed % 160 == 0 else 32 (zero-padded)          */
+  int32_t cout;          /* logical output columns                                       */
+  const float* bias;     /* [cout] or NULL (GEGLU: [n_packed], packed like the rows)     */
+  const float* rowvec;   /* f32 [batch][cout] or NULL: per-image additive vector         */
+  int32_t rowvec_stride; /* elements between images of rowvec; 0 = cout                  */
+  const void* residual;  /* T [m][cout] or NULL                                          */
+  int64_t res_img_stride;/* elements between images of residual; 0 = dense               */
+  void* out;
+  int64_t out_img_stride;/* elements between images of out; 0 = dense                    */
+  int32_t out_mode;      /* MOBI_OUT_*                                                   */
+  int32_t epilogue;      /* MOBI_EPI_*                                                   */
+  float scale;           /* multiplies the accumulator before bias (1.0f normally)       */
+  int32_t dtype;
+} mobi_igemm_params;
+
+int mobi_igemm(const mobi_igemm_params* p, void* stream);
+
+/* ---------------------------------------------------------------------------
+ * GroupNorm (32 groups) with optional fused SiLU over one or two
+ * channel-concatenated sources.  Replaces GroupNorm32 + nn.SiLU
+ * (ldm/modules/diffusionmodules/util.py:199-216, openaimodel.py:211-236,
+ * 832-836), Normalize (attention.py:77-78, model.py:38-39) + nonlinearity
+ * (model.py:33-35), and the torch.cat in front of an output ResBlock.
+ * ------------------------------------------------------------------------- */
+typedef struct mobi_groupnorm_params {
+  const void* src0;
+  const void* src1;        /* or NULL */
+  int32_t c0, c1;
+  int32_t batch, hw;
+  const float* gamma;      /* [c0+c1] */
+  const float* beta;
+  float eps;
+  int32_t silu;            /* 1: y = y * sigmoid(y) */
+  void* out;               /* T [batch][hw][c0+c1] */
+  void* ws;                /* mobi_groupnorm_workspace_bytes(batch, hw) bytes */
+  int32_t dtype;
+} mobi_groupnorm_params;
+
+size_t mobi_groupnorm_workspace_bytes(int32_t batch, int32_t hw);
+int mobi_groupnorm(const mobi_groupnorm_params* p, void* stream);
+
+/* LayerNorm over the channel axis of token rows (nn.LayerNorm, eps 1e-5,
+ * attention.py:213-223,232-256).  `images` blocks of `rows_per_image` rows; the
+ * image strides allow the camera / lidar halves of the interleaved batch
+ * (x[::2], x[1::2], attention.py:246-247) to be addressed without a copy. */
+typedef struct mobi_layernorm_params {
+  const void* src; void* out;
+  int32_t images, rows_per_image, channels;
+  int64_t src_img_stride, out_img_stride;   /* elements; 0 = dense */
+  const float* gamma; const float* beta; float eps;
+  int32_t dtype;
+} mobi_layernorm_params;
+int mobi_layernorm(const mobi_layernorm_params* p, void* stream);
+
+/* ---------------------------------------------------------------------------
+ * Fused attention  out = softmax(q k^T * scale) v, one launch for all images
+ * and heads (CrossAttention.forward, attention.py:171-194: rearrange, einsum,
+ * softmax, einsum, rearrange).  v is consumed TRANSPOSED ([channel][token]) as
+ * written by mobi_igemm with MOBI_OUT_TRANSPOSED.  Image strides let the
+ * cross-modal calls read the partner modality in place (attention.py:245-261).
+ * dh % 8 == 0 and dh <= 160.
+ * ------------------------------------------------------------------------- */
+typedef struct mobi_attention_params {
+  const void* q;  int64_t q_img_stride;  int32_t q_row_stride;    /* T [image][tq][...], head h at column h*dh */
+  const void* k;  int64_t k_img_stride;  int32_t k_row_stride;    /* T [image][tk][...]                         */
+  const void* vt; int64_t vt_img_stride; int32_t vt_row_stride;   /* T [image][heads*dh][tk...]                 */
+  void* out;      int64_t out_img_stride; int32_t out_row_stride; /* T [image][tq][heads*dh]                    */
+  int32_t images, heads, dh, tq, tk;
+  float scale;
+  int32_t dtype;
+} mobi_attention_params;
+int mobi_attention(const mobi_attention_params* p, void* stream);
+
+/* Attention against a handful of context tokens (tk <= 8): the bbox adapter
+ * (attention.py:237-243, tk = 2).  k, v are fp32 [image][tk][heads*dh]. */
+typedef struct mobi_ctx_attention_params {
+  const void* q; void* out;                   /* T [image][tq][heads*dh] */
+  const float* k; const float* v;
+  int32_t images, heads, dh, tq, tk;
+  float scale;
+  int32_t dtype;
+} mobi_ctx_attention_params;
+int mobi_ctx_attention(const mobi_ctx_attention_params* p, void* stream);
+
+/* Row softmax fp32 -> T (AttnBlock, model.py:189-190). */
+int mobi_softmax_rows(const float* src, void* out, int64_t rows, int32_t cols, int32_t dtype, void* stream);
+
+/* ---------------------------------------------------------------------------
+ * Small dense layers on fp32 vectors (m <= 64 rows):
+ *   out[m][n] = post( sum_k W[n][k] * pre(x[m][k]) + b[n] )
+ * time_embed MLP and every ResBlock emb_layers (openaimodel.py:627-631,
+ * 219-225, 874-875), attn2's to_v/to_out on the reference token
+ * (attention.py:235), the bbox adapter's to_k/to_v.
+ * ------------------------------------------------------------------------- */
+enum { MOBI_ACT_NONE = 0, MOBI_ACT_SILU = 1 };
+typedef struct mobi_skinny_linear_params {
+  const float* x; int32_t m, k; int32_t x_row_stride;   /* elements */
+  const void* weight;      /* T [n][k] */
+  const float* bias;       /* [n] or NULL */
+  float* out; int32_t n; int32_t out_row_stride;
+  int32_t pre_act, post_act;
+  int32_t dtype;
+} mobi_skinny_linear_params;
+int mobi_skinny_linear(const mobi_skinny_linear_params* p, void* stream);
+
+/* Sinusoidal timestep embedding (util.py:151-171); `freqs` is the fp32 table
+ * exp(-ln(1e4) * i / half) computed by the host exactly as the reference does. */
+int mobi_timestep_embedding(const int64_t* t, const float* freqs, float* out, int32_t n, int32_t half,
+                            void* stream);
+
+/* ---------------------------------------------------------------------------
+ * Direct convolutions for the thin ends of the networks.
+ * small_cin: fp32 NCHW sources (up to 3, concatenated on channels: the
+ *   torch.cat([x, inpaint_image, inpaint_mask], 1) of ddim.py:170 feeding
+ *   input_blocks.0; the VAE encoders' conv_in / conv_in_lidar,
+ *   model.py:384-401; post_quant_conv, autoencoder.py:70) -> T channels-last
+ *   or fp32 NCHW.  Total input channels <= 16.
+ * small_cout: T channels-last -> fp32 NCHW with cout <= 8 (UNet `out.2`,
+ *   openaimodel.py:832-836; VAE conv_out / conv_out_lidar / encoder conv_out,
+ *   model.py:447-452,580-585), optional clamp (ddpm.py:1476,1504).
+ * ------------------------------------------------------------------------- */
+typedef struct mobi_conv_small_cin_params {
+  const float* src[3]; int32_t c[3];      /* unused sources: NULL / 0 */
+  int32_t batch, h, w;
+  int32_t kh, kw, pad_h, pad_w;
+  const float* weight;     /* f32 [cout][cin_total*kh*kw], k = (c*kh + ky)*kw + kx (OIHW flattened) */
+  const float* bias;
+  int32_t cout;
+  void* out; int32_t out_f32_nchw;         /* 0: T channels-last, 1: fp32 NCHW */
+  int32_t dtype;
+} mobi_conv_small_cin_params;
+int mobi_conv_small_cin(const mobi_conv_small_cin_params* p, void* stream);
+
+typedef struct mobi_conv_small_cout_params {
+  const void* src; int32_t cin;            /* T channels-last; cin % 8 == 0 */
+  int32_t batch, h, w;
+  int32_t kh, kw, pad_h, pad_w;
+  const void* weight;      /* T [cout][kh*kw*cin], k = tap*cin + c */
+  const float* bias;
+  int32_t cout;
+  float* out;              /* fp32 NCHW */
+  int32_t clamp; float clamp_lo, clamp_hi;
+  float in_scale;          /* unused (1.0f) */
+  int32_t dtype;
+} mobi_conv_small_cout_params;
+int mobi_conv_small_cout(const mobi_conv_small_cout_params* p, void* stream);
+
+/* ---------------------------------------------------------------------------
+ * Sampler arithmetic on the fp32 latent state (NCHW, n elements flat).
+ * ------------------------------------------------------------------------- */
+/* p_sample_ddim, ddim.py:180-213 / get_x_prev_and_pred_x0, plms.py:199-214:
+ *   e      = e_uncond + cfg_scale * (e_cond - e_uncond)   (e_uncond NULL: e = e_cond)
+ *   pred   = (x - sqrt_one_minus_at * e) / sqrt(a_t)
+ *   x_prev = sqrt(a_prev) * pred + sqrt(1 - a_prev - sigma^2) * e + sigma * noise * temperature
+ * `e_out` (or NULL) receives e (PLMS keeps it in old_eps). */
+typedef struct mobi_ddim_step_params {
+  const float* x; const float* e_cond; const float* e_uncond; const float* noise;
+  float* x_prev; float* pred_x0; float* e_out;
+  int64_t n;
+  float cfg_scale, a_t, a_prev, sigma_t, sqrt_one_minus_at, temperature;
+} mobi_ddim_step_params;
+int mobi_ddim_step(const mobi_ddim_step_params* p, void* stream);
+
+/* out = c0*e0 + c1*e1 + c2*e2 + c3*e3, the Adams-Bashforth mixes of plms.py:219-233
+ * (null pointers are skipped). */
+int mobi_lincomb4(float* out, const float* e0, const float* e1, const float* e2, const float* e3,
+                  float c0, float c1, float c2, float c3, int64_t n, void* stream);
+
+/* ddim.py:145-148 with q_sample (ddpm.py:284-287):
+ *   img = (sa[t]*x0 + s1ma[t]*noise) * mask + (1 - mask) * img
+ * mask is [batch][1][hw] broadcast over `channels`. */
+int mobi_mask_blend(float* img, const float* x0, const float* noise, const float* mask,
+                    float sqrt_ac_t, float sqrt_1m_ac_t, int32_t batch, int32_t channels, int32_t hw,
+                    void* stream);
+
+/* DiagonalGaussianDistribution.sample with supplied noise and the latent scale
+ * (distributions.py:25-37, ddpm.py:601-608): moments f32 NCHW [b][2c][hw] ->
+ * z f32 [b][c][hw], written at channel offset `out_c_off` of an NCHW tensor with
+ * `out_c_total` channels (the torch.cat of ddpm.py:1021). */
+int mobi_posterior_sample(const float* moments, const float* noise, float* out, int32_t batch, int32_t c,
+                          int32_t hw, int32_t out_c_total, int32_t out_c_off, float scale, void* stream);
+
+/* F.interpolate(mode="nearest") on fp32 NCHW (ddpm.py:1020): index-only. */
+int mobi_nearest_resize(const float* src, float* out, int32_t planes, int32_t hin, int32_t win,
+                        int32_t hout, int32_t wout, int32_t out_plane_stride, void* stream);
+
+/* Layout converters at the API boundary (tests, module-level calls). */
+int mobi_nchw_f32_to_nhwc(const float* src, void* out, int32_t batch, int32_t c, int32_t hw, int32_t dtype,
+                          void* stream);
+int mobi_nhwc_to_nchw_f32(const void* src, float* out, int32_t batch, int32_t c, int32_t hw, int32_t dtype,
+                          void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MOBI_ENGINE_H_ */

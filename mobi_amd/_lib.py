@@ -1,0 +1,147 @@
+"""ctypes binding of libmobi_hip.so (include/mobi_engine.h).
+
+The product path has NO fallback: if the library cannot be loaded every engine
+call raises `EngineUnavailable` ("the product path must fail
+loudly when the HIP extension is missing").
+"""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libmobi_hip.so")
+
+MOBI_F16, MOBI_BF16 = 0, 1
+EPI_NONE, EPI_GEGLU = 0, 1
+OUT_ROWS, OUT_TRANSPOSED, OUT_ROWS_F32 = 0, 1, 2
+ACT_NONE, ACT_SILU = 0, 1
+
+vp, i32, i64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
+
+
+class EngineUnavailable(RuntimeError):
+    pass
+
+
+class EngineError(RuntimeError):
+    pass
+
+
+class IgemmParams(C.Structure):
+    _fields_ = [("src0", vp), ("src1", vp), ("c0", i32), ("c1", i32), ("batch", i32), ("hin", i32), ("win", i32),
+                ("upsample", i32), ("hout", i32), ("wout", i32), ("kh", i32), ("kw", i32), ("stride", i32),
+                ("pad_h", i32), ("pad_w", i32), ("src_img_stride", i64), ("weight", vp), ("groups", i32),
+                ("w_group_stride", i64), ("n_packed", i32), ("cout", i32), ("bias", vp), ("rowvec", vp), ("rowvec_stride", i32),
+                ("residual", vp), ("res_img_stride", i64), ("out", vp), ("out_img_stride", i64),
+                ("out_mode", i32), ("epilogue", i32), ("scale", f32), ("dtype", i32)]
+
+
+class GroupNormParams(C.Structure):
+    _fields_ = [("src0", vp), ("src1", vp), ("c0", i32), ("c1", i32), ("batch", i32), ("hw", i32), ("gamma", vp),
+                ("beta", vp), ("eps", f32), ("silu", i32), ("out", vp), ("ws", vp), ("dtype", i32)]
+
+
+class LayerNormParams(C.Structure):
+    _fields_ = [("src", vp), ("out", vp), ("images", i32), ("rows_per_image", i32), ("channels", i32),
+                ("src_img_stride", i64), ("out_img_stride", i64), ("gamma", vp), ("beta", vp), ("eps", f32),
+                ("dtype", i32)]
+
+
+class AttentionParams(C.Structure):
+    _fields_ = [("q", vp), ("q_img_stride", i64), ("q_row_stride", i32),
+                ("k", vp), ("k_img_stride", i64), ("k_row_stride", i32),
+                ("vt", vp), ("vt_img_stride", i64), ("vt_row_stride", i32),
+                ("out", vp), ("out_img_stride", i64), ("out_row_stride", i32),
+                ("images", i32), ("heads", i32), ("dh", i32), ("tq", i32), ("tk", i32), ("scale", f32),
+                ("dtype", i32)]
+
+
+class CtxAttentionParams(C.Structure):
+    _fields_ = [("q", vp), ("out", vp), ("k", vp), ("v", vp), ("images", i32), ("heads", i32), ("dh", i32),
+                ("tq", i32), ("tk", i32), ("scale", f32), ("dtype", i32)]
+
+
+class SkinnyLinearParams(C.Structure):
+    _fields_ = [("x", vp), ("m", i32), ("k", i32), ("x_row_stride", i32), ("weight", vp), ("bias", vp),
+                ("out", vp), ("n", i32), ("out_row_stride", i32), ("pre_act", i32), ("post_act", i32),
+                ("dtype", i32)]
+
+
+class ConvSmallCinParams(C.Structure):
+    _fields_ = [("src", vp * 3), ("c", i32 * 3), ("batch", i32), ("h", i32), ("w", i32), ("kh", i32), ("kw", i32),
+                ("pad_h", i32), ("pad_w", i32), ("weight", vp), ("bias", vp), ("cout", i32), ("out", vp),
+                ("out_f32_nchw", i32), ("dtype", i32)]
+
+
+class ConvSmallCoutParams(C.Structure):
+    _fields_ = [("src", vp), ("cin", i32), ("batch", i32), ("h", i32), ("w", i32), ("kh", i32), ("kw", i32),
+                ("pad_h", i32), ("pad_w", i32), ("weight", vp), ("bias", vp), ("cout", i32), ("out", vp),
+                ("clamp", i32), ("clamp_lo", f32), ("clamp_hi", f32), ("in_scale", f32), ("dtype", i32)]
+
+
+class DdimStepParams(C.Structure):
+    _fields_ = [("x", vp), ("e_cond", vp), ("e_uncond", vp), ("noise", vp), ("x_prev", vp), ("pred_x0", vp),
+                ("e_out", vp), ("n", i64), ("cfg_scale", f32), ("a_t", f32), ("a_prev", f32), ("sigma_t", f32),
+                ("sqrt_one_minus_at", f32), ("temperature", f32)]
+
+
+STRUCT_IDS = {0: IgemmParams, 1: GroupNormParams, 2: LayerNormParams, 3: AttentionParams, 4: CtxAttentionParams,
+              5: SkinnyLinearParams, 6: ConvSmallCinParams, 7: ConvSmallCoutParams, 8: DdimStepParams}
+
+# every symbol include/mobi_engine.h declares: name -> (restype, argtypes)
+SYMBOLS = {
+    "mobi_abi_version": (C.c_int, []),
+    "mobi_error_string": (C.c_char_p, [C.c_int]),
+    "mobi_struct_size": (C.c_size_t, [C.c_int]),
+    "mobi_igemm": (C.c_int, [C.POINTER(IgemmParams), vp]),
+    "mobi_groupnorm_workspace_bytes": (C.c_size_t, [i32, i32]),
+    "mobi_groupnorm": (C.c_int, [C.POINTER(GroupNormParams), vp]),
+    "mobi_layernorm": (C.c_int, [C.POINTER(LayerNormParams), vp]),
+    "mobi_attention": (C.c_int, [C.POINTER(AttentionParams), vp]),
+    "mobi_ctx_attention": (C.c_int, [C.POINTER(CtxAttentionParams), vp]),
+    "mobi_softmax_rows": (C.c_int, [vp, vp, i64, i32, i32, vp]),
+    "mobi_skinny_linear": (C.c_int, [C.POINTER(SkinnyLinearParams), vp]),
+    "mobi_timestep_embedding": (C.c_int, [vp, vp, vp, i32, i32, vp]),
+    "mobi_conv_small_cin": (C.c_int, [C.POINTER(ConvSmallCinParams), vp]),
+    "mobi_conv_small_cout": (C.c_int, [C.POINTER(ConvSmallCoutParams), vp]),
+    "mobi_ddim_step": (C.c_int, [C.POINTER(DdimStepParams), vp]),
+    "mobi_lincomb4": (C.c_int, [vp, vp, vp, vp, vp, f32, f32, f32, f32, i64, vp]),
+    "mobi_mask_blend": (C.c_int, [vp, vp, vp, vp, f32, f32, i32, i32, i32, vp]),
+    "mobi_posterior_sample": (C.c_int, [vp, vp, vp, i32, i32, i32, i32, i32, f32, vp]),
+    "mobi_nearest_resize": (C.c_int, [vp, vp, i32, i32, i32, i32, i32, i32, vp]),
+    "mobi_nchw_f32_to_nhwc": (C.c_int, [vp, vp, i32, i32, i32, i32, vp]),
+    "mobi_nhwc_to_nchw_f32": (C.c_int, [vp, vp, i32, i32, i32, i32, vp]),
+}
+
+_lib = None
+
+
+def load():
+    """Load the library once, bind every symbol, verify struct layouts."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise EngineUnavailable(f"{LIB_PATH} not built: run `python -m mobi_amd.build` (needs hipcc). "
+                                "The MObI engine has no CPU or PyTorch fallback.")
+    try:
+        lib = C.CDLL(LIB_PATH)
+    except OSError as e:
+        raise EngineUnavailable(f"cannot load {LIB_PATH}: {e}") from e
+    for name, (res, args) in SYMBOLS.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise EngineUnavailable(f"{LIB_PATH} does not export {name}") from e
+        fn.restype, fn.argtypes = res, args
+    for sid, cls in STRUCT_IDS.items():
+        want = lib.mobi_struct_size(sid)
+        if want != C.sizeof(cls):
+            raise EngineUnavailable(f"ABI mismatch: {cls.__name__} is {C.sizeof(cls)} bytes in the binding, "
+                                    f"{want} in the library")
+    _lib = lib
+    return lib
+
+
+def check(code, what):
+    if code != 0:
+        raise EngineError(f"{what} failed: {load().mobi_error_string(code).decode()} ({code})")

@@ -1,0 +1,261 @@
+// Fused attention for gfx950:  out = softmax(q k^T * scale) v  without materialising
+// the score matrix (CrossAttention.forward, attention.py:171-194).
+//
+// Block = 4 waves, each wave owns 32 query rows; the block walks the keys in tiles
+// of 64 that all four waves share through LDS.  MFMA 32x32x16, fp32 accumulate.
+//   S^T[key][q]  = K[key][:] . Q[q][:]      (A = K rows from LDS, B = Q held in registers)
+// so every lane owns ONE query column: the running max / sum of the online softmax
+// are per-lane scalars and the only cross-lane step is one xor-32 shuffle.
+//   O^T[d][q]   += V^T[d][key] . P^T[key][q]
+// P^T is the S^T accumulator itself, converted to T in registers and fed straight back
+// as the B operand (no LDS round trip); V arrives already transposed ([channel][token],
+// written by the V projection's transposed epilogue), so its A fragments are two
+// 8-byte LDS reads in the accumulator's permuted key order
+//   key(j, half) = 16 s + 8 (j >> 2) + 4 half + (j & 3).
+// LDS row strides are odd multiples of the access width (bank-conflict free reads).
+#include "common.h"
+
+namespace mobi {
+
+struct AttnArgs {
+  const void* q; long long q_img; int q_row;
+  const void* k; long long k_img; int k_row;
+  const void* vt; long long vt_img; int vt_row;
+  void* out; long long out_img; int out_row;
+  int heads, dh, tq, tk;
+  float scale;
+};
+
+template <typename T, int KS>
+__global__ __launch_bounds__(256) void attention_kernel(const AttnArgs a) {
+  typedef typename Vec8<T>::type frag_t;
+  constexpr int DT = (KS + 1) / 2;                 // 32-row tiles of the head dim for P.V
+  constexpr int KSTR = KS * 32 + 16;               // bytes per K row in LDS (odd multiple of 16)
+  constexpr int VSTR = 136;                        // bytes per V^T row in LDS (odd multiple of 8)
+  constexpr int K_BYTES = 64 * KSTR;
+  constexpr int V_BYTES = DT * 32 * VSTR;
+  constexpr int KP = (64 * KS * 2 + 255) / 256;    // 16-byte K pieces per thread
+  constexpr int VP = (DT * 32 * 8 + 255) / 256;    // 16-byte V^T pieces per thread
+  __shared__ __attribute__((aligned(16))) unsigned char lds[K_BYTES + V_BYTES];
+  unsigned char* ldsK = lds;
+  unsigned char* ldsV = lds + K_BYTES;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int ql = lane & 31, half = lane >> 5;
+  const int head = blockIdx.y, img = blockIdx.z;
+  const int q0 = blockIdx.x * 128 + wave * 32;
+  const int dh = a.dh;
+
+  const T* __restrict__ qp = reinterpret_cast<const T*>(a.q) + img * a.q_img + head * dh;
+  const T* __restrict__ kp = reinterpret_cast<const T*>(a.k) + img * a.k_img + head * dh;
+  const T* __restrict__ vp = reinterpret_cast<const T*>(a.vt) + img * a.vt_img + (long long)head * dh * a.vt_row;
+  T* __restrict__ op = reinterpret_cast<T*>(a.out) + img * a.out_img + head * dh;
+
+  // Q fragments: lane (q = ql, half) holds Q[q][ks*16 + 8*half .. +8)
+  frag_t qf[KS];
+  {
+    const int qrow = q0 + ql;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const int c = ks * 16 + half * 8;
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (qrow < a.tq && c < dh) v = ld16(qp + (long long)qrow * a.q_row + c);
+      qf[ks] = __builtin_bit_cast(frag_t, v);
+    }
+  }
+
+  const bool v_vec = ((a.vt_row & 7) == 0) && ((reinterpret_cast<uintptr_t>(vp) & 15) == 0);
+  u32x4 kr[KP], vr[VP];
+  auto load_tile = [&](int key0) {
+#pragma unroll
+    for (int i = 0; i < KP; ++i) {
+      const int p = tid + 256 * i;
+      const int row = p / (KS * 2), pc = p - row * (KS * 2);
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (row < 64 && key0 + row < a.tk && pc * 8 < dh) v = ld16(kp + (long long)(key0 + row) * a.k_row + pc * 8);
+      kr[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < VP; ++i) {
+      const int p = tid + 256 * i;
+      const int row = p >> 3, pc = p & 7;
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (row < dh) {
+        const T* src = vp + (long long)row * a.vt_row + key0 + pc * 8;
+        if (v_vec && key0 + pc * 8 + 8 <= a.tk) {
+          v = ld16(src);
+        } else {
+          typename Vec8<T>::type e;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) e[j] = (key0 + pc * 8 + j < a.tk) ? src[j] : (T)0.0f;
+          v = __builtin_bit_cast(u32x4, e);
+        }
+      }
+      vr[i] = v;
+    }
+  };
+  auto store_tile = [&]() {
+#pragma unroll
+    for (int i = 0; i < KP; ++i) {
+      const int p = tid + 256 * i;
+      const int row = p / (KS * 2), pc = p - row * (KS * 2);
+      if (row < 64) st16(ldsK + row * KSTR + pc * 16, kr[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < VP; ++i) {
+      const int p = tid + 256 * i;
+      const int row = p >> 3, pc = p & 7;
+      if (row < DT * 32) {
+        u32x2* d = reinterpret_cast<u32x2*>(ldsV + row * VSTR + pc * 16);
+        d[0] = u32x2{vr[i][0], vr[i][1]};
+        d[1] = u32x2{vr[i][2], vr[i][3]};
+      }
+    }
+  };
+
+  f32x16 o[DT];
+#pragma unroll
+  for (int d = 0; d < DT; ++d)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+
+  const int ntiles = (a.tk + 63) / 64;
+  load_tile(0);
+  store_tile();
+  __syncthreads();
+  for (int t = 0; t < ntiles; ++t) {
+    const int key0 = t * 64;
+    const bool more = t + 1 < ntiles;
+    if (more) load_tile(key0 + 64);
+
+    // ---- S^T = K . Q^T for two 32-key sub-tiles --------------------------------
+    f32x16 s[2];
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[kt][r] = 0.f;
+      const unsigned char* kb = ldsK + (kt * 32 + ql) * KSTR + half * 16;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        frag_t kf = __builtin_bit_cast(frag_t, ld16(kb + ks * 32));
+        s[kt] = mfma32(kf, qf[ks], s[kt]);
+      }
+    }
+    // ---- online softmax (one query column per lane) -----------------------------
+    float mx = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = key0 + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        float v = s[kt][r] * a.scale;
+        v = key < a.tk ? v : -INFINITY;
+        s[kt][r] = v;
+        mx = fmaxf(mx, v);
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m_run, mx);
+    const float alpha = __expf(m_run - m_new);       // first tile: exp(-inf) = 0
+    float psum = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float p = __expf(s[kt][r] - m_new);
+        s[kt][r] = p;
+        psum += p;
+      }
+    l_run = l_run * alpha + psum;
+    m_run = m_new;
+#pragma unroll
+    for (int d = 0; d < DT; ++d)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
+
+    // ---- O^T += V^T . P^T --------------------------------------------------------
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int st = 0; st < 2; ++st) {
+        frag_t pf;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) pf[j] = (T)s[kt][st * 8 + j];
+        const unsigned char* vb = ldsV + ql * VSTR + (kt * 32 + st * 16 + half * 4) * 2;
+#pragma unroll
+        for (int d = 0; d < DT; ++d) {
+          const u32x2 lo = *reinterpret_cast<const u32x2*>(vb + d * 32 * VSTR);
+          const u32x2 hi = *reinterpret_cast<const u32x2*>(vb + d * 32 * VSTR + 16);
+          frag_t vf = __builtin_bit_cast(frag_t, u32x4{lo[0], lo[1], hi[0], hi[1]});
+          o[d] = mfma32(vf, pf, o[d]);
+        }
+      }
+    __syncthreads();                  // every wave is done with this tile's LDS image
+    if (more) {
+      store_tile();
+      __syncthreads();
+    }
+  }
+
+  // ---- normalise and store: lane holds O^T[d][q] for d = 32 dt + 8 g + 4 half + (0..3) -------
+  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  const float inv = 1.0f / l_tot;
+  const int qrow = q0 + ql;
+  if (qrow < a.tq) {
+    T* orow = op + (long long)qrow * a.out_row;
+#pragma unroll
+    for (int d = 0; d < DT; ++d)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int d0 = d * 32 + g * 8 + half * 4;
+        if (d0 < dh) {
+          float f[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) f[j] = o[d][g * 4 + j] * inv;
+          *reinterpret_cast<u32x2*>(orow + d0) = pack4<T>(f);
+        }
+      }
+  }
+}
+
+template <typename T>
+static int launch_attention(const mobi_attention_params* p, const AttnArgs& a, hipStream_t st) {
+  dim3 grid((p->tq + 127) / 128, p->heads, p->images), block(256);
+  const int ks = (p->dh + 15) / 16;
+#define MOBI_ATTN_CASE(KS_) hipLaunchKernelGGL((attention_kernel<T, KS_>), grid, block, 0, st, a)
+  if (ks <= 1) MOBI_ATTN_CASE(1);
+  else if (ks == 2) MOBI_ATTN_CASE(2);
+  else if (ks == 3) MOBI_ATTN_CASE(3);
+  else if (ks == 4) MOBI_ATTN_CASE(4);
+  else if (ks == 5) MOBI_ATTN_CASE(5);
+  else if (ks == 6) MOBI_ATTN_CASE(6);
+  else if (ks <= 8) MOBI_ATTN_CASE(8);
+  else if (ks <= 10) MOBI_ATTN_CASE(10);
+  else return MOBI_ERR_UNSUPPORTED;
+#undef MOBI_ATTN_CASE
+  MOBI_CHECK_LAUNCH();
+  return MOBI_OK;
+}
+
+}  // namespace mobi
+
+extern "C" int mobi_attention(const mobi_attention_params* p, void* stream) {
+  using namespace mobi;
+  if (!p || !p->q || !p->k || !p->vt || !p->out) return MOBI_ERR_ARG;
+  if (p->dtype != MOBI_F16 && p->dtype != MOBI_BF16) return MOBI_ERR_ARG;
+  if (p->images <= 0 || p->heads <= 0 || p->tq <= 0 || p->tk <= 0 || p->dh <= 0) return MOBI_ERR_ARG;
+  if ((p->dh & 7) || p->dh > 160) return MOBI_ERR_UNSUPPORTED;
+  if ((p->q_row_stride & 7) || (p->k_row_stride & 7) || (p->out_row_stride & 3)) return MOBI_ERR_ALIGN;
+  if ((p->q_img_stride & 7) || (p->k_img_stride & 7) || (p->out_img_stride & 3)) return MOBI_ERR_ALIGN;
+  if ((reinterpret_cast<uintptr_t>(p->q) | reinterpret_cast<uintptr_t>(p->k) |
+       reinterpret_cast<uintptr_t>(p->out)) & 15) return MOBI_ERR_ALIGN;
+  if (p->heads > 65535 || p->images > 65535) return MOBI_ERR_UNSUPPORTED;
+  AttnArgs a;
+  a.q = p->q; a.q_img = p->q_img_stride; a.q_row = p->q_row_stride;
+  a.k = p->k; a.k_img = p->k_img_stride; a.k_row = p->k_row_stride;
+  a.vt = p->vt; a.vt_img = p->vt_img_stride; a.vt_row = p->vt_row_stride;
+  a.out = p->out; a.out_img = p->out_img_stride; a.out_row = p->out_row_stride;
+  a.heads = p->heads; a.dh = p->dh; a.tq = p->tq; a.tk = p->tk; a.scale = p->scale;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  return p->dtype == MOBI_F16 ? launch_attention<f16_t>(p, a, st) : launch_attention<bf16_t>(p, a, st);
+}

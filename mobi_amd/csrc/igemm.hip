@@ -1,0 +1,383 @@
+// Implicit-GEMM convolution / linear layer on the gfx950 matrix cores.
+//
+//   out[m][n] = epi( scale * sum_k A[m][k] * W[n][k] ),  m = (image, y, x), k = (tap, channel)
+//
+// Block = 256 threads = 4 waves (2 pixel halves x 2 channel halves).
+// Block tile: 128 pixels x (2 * WAVE_N) channels x 64 k; WAVE_N = 80 (all UNet
+// widths are multiples of 160) or 64.  MFMA 16x16x32, fp32 accumulators.
+// Both operand tiles are staged global -> registers -> LDS (double buffered, one
+// barrier per k-tile) as [row][64 k] with 128-byte rows and a 16-byte-slot XOR
+// swizzle (slot ^= row & 7) that makes the ds_read_b128 fragment reads and the
+// ds_write_b128 staging writes bank-conflict free.
+// The activation tile is a GATHER: each row is an output pixel, each 32-channel
+// chunk of k belongs to one filter tap, so 3x3 / 1x5 / strided / asymmetric-pad
+// convolutions, nearest-x2 upsampling on the load side and the channel concat of
+// two sources never materialise an im2col, an upsampled or a concatenated tensor.
+// Epilogue: accumulators go through a per-wave fp32 LDS tile so that bias,
+// per-image vector, residual and GEGLU are applied on coalesced 16-byte rows.
+#include "common.h"
+
+namespace mobi {
+
+struct IgemmArgs {
+  const void* src0; const void* src1;
+  int c0, c1, C;
+  int hin, win, up, hout, wout, hw_out;
+  int kh, kw, stride, pad_h, pad_w;
+  long long src_img_stride0, src_img_stride1;
+  const void* weight; long long w_group_stride;
+  int n_packed, cout, ktot, nk;
+  int M;                 // rows per group
+  int imgs_per_group;
+  const float* bias; const float* rowvec; int rowvec_stride;
+  const void* residual; long long res_img_stride;
+  void* out; long long out_img_stride;
+  int out_mode, epilogue;
+  float scale;
+  int tiles_m, tiles_n;
+};
+
+template <typename T, int NT, bool TR>
+__global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
+  typedef typename Vec8<T>::type frag_t;
+  constexpr int WAVE_N = NT * 16;
+  constexpr int BN = 2 * WAVE_N;
+  constexpr int X_TILE = 128 * 128;              // bytes per buffer
+  constexpr int W_TILE = BN * 128;
+  constexpr int STAGE_STRIDE = TR ? 36 : (WAVE_N + 4);      // floats
+  constexpr int STAGE_ROWS = TR ? WAVE_N : 32;
+  constexpr int STAGE_BYTES = STAGE_ROWS * STAGE_STRIDE * 4;
+  constexpr int MAIN_BYTES = 2 * X_TILE + 2 * W_TILE;
+  constexpr int LDS_BYTES = MAIN_BYTES > 4 * STAGE_BYTES ? MAIN_BYTES : 4 * STAGE_BYTES;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave & 1, wn = wave >> 1;
+  const int group = blockIdx.z;
+
+  const int nblk = a.tiles_m * a.tiles_n;
+  const int L = xcd_remap(blockIdx.x, nblk);
+  const int tile_n = L % a.tiles_n;
+  const int tile_m = L / a.tiles_n;
+  const int m0 = tile_m * 128;
+  const int n0 = tile_n * BN;
+
+  const T* __restrict__ src0 = reinterpret_cast<const T*>(a.src0);
+  const T* __restrict__ src1 = reinterpret_cast<const T*>(a.src1);
+  const T* __restrict__ wgt = reinterpret_cast<const T*>(a.weight) + (long long)group * a.w_group_stride;
+
+  // ---- staging assignment -------------------------------------------------
+  const int seg = tid & 7;               // 16-byte piece of the 128-byte k row
+  const int slot = seg >> 2;             // which 32-channel chunk of the k-tile
+  const int sub = (seg & 3) * 8;         // channel offset inside the chunk
+  const int row_b = tid >> 3;            // 0..31
+
+  long long x_img[4];
+  int x_h[4], x_w[4];
+  bool x_ok[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int m = m0 + row_b + 32 * i;
+    x_ok[i] = m < a.M;
+    const int mm = x_ok[i] ? m : 0;
+    const int img = mm / a.hw_out;
+    const int rem = mm - img * a.hw_out;
+    const int ho = rem / a.wout;
+    const int wo = rem - ho * a.wout;
+    x_img[i] = (long long)(group * a.imgs_per_group + img);
+    x_h[i] = ho * a.stride - a.pad_h;
+    x_w[i] = wo * a.stride - a.pad_w;
+  }
+  const int cpt = a.C >> 5;              // 32-channel chunks per tap
+  const int taps = a.kh * a.kw;
+  const int hlog = a.hin << a.up, wlog = a.win << a.up;
+  // running (tap, chunk-in-tap) of this thread's chunk slot
+  int cc = slot, tap = 0, ky = 0, kx = 0;
+  while (cc >= cpt) { cc -= cpt; ++tap; if (++kx == a.kw) { kx = 0; ++ky; } }
+
+  u32x4 xr[4], wr[NT];
+
+  auto load_tile = [&](int kt) {
+    // activations
+    const bool chunk_ok = tap < taps;
+    const int ch = cc * 32 + sub;
+    const bool second = ch >= a.c0;
+    const T* __restrict__ base = second ? src1 : src0;
+    const int cs = second ? a.c1 : a.c0;
+    const int chs = second ? ch - a.c0 : ch;
+    const long long istr = second ? a.src_img_stride1 : a.src_img_stride0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int hi = x_h[i] + ky, wi = x_w[i] + kx;
+      const bool ok = chunk_ok && x_ok[i] && hi >= 0 && hi < hlog && wi >= 0 && wi < wlog;
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (ok) {
+        const int hs = hi >> a.up, ws = wi >> a.up;
+        v = ld16(base + x_img[i] * istr + (long long)(hs * a.win + ws) * cs + chs);
+      }
+      xr[i] = v;
+    }
+    // weights
+    const int kk = kt * 64 + seg * 8;
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+      const int n = n0 + row_b + 32 * i;
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (n < a.n_packed && kk < a.ktot) v = ld16(wgt + (long long)n * a.ktot + kk);
+      wr[i] = v;
+    }
+    // advance this thread's chunk by one k-tile (two chunks)
+    cc += 2;
+    while (cc >= cpt) { cc -= cpt; ++tap; if (++kx == a.kw) { kx = 0; ++ky; } }
+  };
+  auto store_tile = [&](int buf) {
+    unsigned char* xb = lds + buf * X_TILE;
+    unsigned char* wb = lds + 2 * X_TILE + buf * W_TILE;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int r = row_b + 32 * i;
+      st16(xb + r * 128 + ((seg ^ (r & 7)) << 4), xr[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+      const int r = row_b + 32 * i;
+      st16(wb + r * 128 + ((seg ^ (r & 7)) << 4), wr[i]);
+    }
+  };
+
+  f32x4 acc[NT][4];
+#pragma unroll
+  for (int i = 0; i < NT; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int r16 = lane & 15, g4 = lane >> 4;
+
+  load_tile(0);
+  store_tile(0);
+  __syncthreads();
+  int buf = 0;
+  for (int kt = 0; kt < a.nk; ++kt) {
+    const bool more = kt + 1 < a.nk;
+    if (more) load_tile(kt + 1);
+    const unsigned char* xb = lds + buf * X_TILE + (wm * 64 + r16) * 128;
+    const unsigned char* wb = lds + 2 * X_TILE + buf * W_TILE + (wn * WAVE_N + r16) * 128;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int sw = ((ks * 4 + g4) ^ (r16 & 7)) << 4;
+      frag_t xf[4], wf[NT];
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi) xf[mi] = __builtin_bit_cast(frag_t, ld16(xb + mi * 16 * 128 + sw));
+#pragma unroll
+      for (int ni = 0; ni < NT; ++ni) wf[ni] = __builtin_bit_cast(frag_t, ld16(wb + ni * 16 * 128 + sw));
+#pragma unroll
+      for (int ni = 0; ni < NT; ++ni)
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+          acc[ni][mi] = TR ? mfma16(xf[mi], wf[ni], acc[ni][mi]) : mfma16(wf[ni], xf[mi], acc[ni][mi]);
+    }
+    if (more) store_tile(buf ^ 1);
+    __syncthreads();
+    buf ^= 1;
+  }
+
+  // ---- epilogue -----------------------------------------------------------
+  float* stage = reinterpret_cast<float*>(lds) + wave * (STAGE_BYTES / 4);
+  const float scale = a.scale;
+  const int nw0 = n0 + wn * WAVE_N;          // first packed column of this wave
+  const int mw0 = m0 + wm * 64;              // first row of this wave
+  T* __restrict__ outT = reinterpret_cast<T*>(a.out);
+  float* __restrict__ outF = reinterpret_cast<float*>(a.out);
+  const T* __restrict__ resid = reinterpret_cast<const T*>(a.residual);
+
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {
+    // (the main loop's last barrier already ordered every wave's fragment reads
+    //  before these writes; passes of one wave are ordered by the waits below)
+    if (!TR) {
+      // D rows = channel (g4*4 + r), cols = pixel (r16): lane owns 4 consecutive channels
+#pragma unroll
+      for (int ml = 0; ml < 2; ++ml)
+#pragma unroll
+        for (int ni = 0; ni < NT; ++ni) {
+          f32x4 v = acc[ni][pass * 2 + ml];
+          v *= scale;
+          *reinterpret_cast<f32x4*>(stage + (ml * 16 + r16) * STAGE_STRIDE + ni * 16 + g4 * 4) = v;
+        }
+    } else {
+      // D rows = pixel (g4*4 + r), cols = channel (r16): lane owns 4 consecutive pixels
+#pragma unroll
+      for (int ml = 0; ml < 2; ++ml)
+#pragma unroll
+        for (int ni = 0; ni < NT; ++ni) {
+          f32x4 v = acc[ni][pass * 2 + ml];
+          v *= scale;
+          *reinterpret_cast<f32x4*>(stage + (ni * 16 + r16) * STAGE_STRIDE + ml * 16 + g4 * 4) = v;
+        }
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);      // lgkmcnt(0): this wave's LDS writes are done
+    __builtin_amdgcn_wave_barrier();
+
+    const int mp0 = mw0 + pass * 32;         // first row of this pass
+    if (!TR) {
+      if (a.epilogue == MOBI_EPI_GEGLU) {
+        constexpr int HALF = WAVE_N / 2;     // a | gate split of the wave's packed columns
+        constexpr int TPR = HALF / 8;
+        const int unit = nw0 / WAVE_N;
+        for (int task = lane; task < 32 * TPR; task += 64) {
+          const int row = task / TPR, cg = task - row * TPR;
+          const int m = mp0 + row;
+          const int oc = unit * HALF + cg * 8;
+          if (m >= a.M || oc >= a.cout) continue;
+          const float* sp = stage + row * STAGE_STRIDE + cg * 8;
+          float o[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            float av = sp[j], gv = sp[HALF + j];
+            if (a.bias) { av += a.bias[nw0 + cg * 8 + j]; gv += a.bias[nw0 + HALF + cg * 8 + j]; }
+            o[j] = av * gelu_erf_f(gv);
+          }
+          const int img = m / a.hw_out, rem = m - img * a.hw_out;
+          const long long gi = (long long)(group * a.imgs_per_group + img);
+          st16(outT + gi * a.out_img_stride + (long long)rem * a.cout + oc, pack8<T>(o));
+        }
+      } else {
+        constexpr int TPR = WAVE_N / 8;
+        for (int task = lane; task < 32 * TPR; task += 64) {
+          const int row = task / TPR, cg = task - row * TPR;
+          const int m = mp0 + row;
+          const int n = nw0 + cg * 8;
+          if (m >= a.M || n >= a.cout) continue;
+          const float* sp = stage + row * STAGE_STRIDE + cg * 8;
+          float o[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) o[j] = sp[j];
+          const int img = m / a.hw_out, rem = m - img * a.hw_out;
+          const long long gi = (long long)(group * a.imgs_per_group + img);
+          if (a.bias) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] += a.bias[n + j];
+          }
+          if (a.rowvec) {
+            const float* rv = a.rowvec + gi * a.rowvec_stride + n;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] += rv[j];
+          }
+          if (resid) {
+            float rf[8];
+            unpack8<T>(ld16(resid + gi * a.res_img_stride + (long long)rem * a.cout + n), rf);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] += rf[j];
+          }
+          const long long off = gi * a.out_img_stride + (long long)rem * a.cout + n;
+          if (a.out_mode == MOBI_OUT_ROWS_F32) {
+            *reinterpret_cast<f32x4*>(outF + off) = f32x4{o[0], o[1], o[2], o[3]};
+            *reinterpret_cast<f32x4*>(outF + off + 4) = f32x4{o[4], o[5], o[6], o[7]};
+          } else {
+            st16(outT + off, pack8<T>(o));
+          }
+        }
+      }
+    } else {
+      // transposed output [image][cout][hw]
+      const bool vec_ok = (a.hw_out & 7) == 0;
+      for (int task = lane; task < WAVE_N * 4; task += 64) {
+        const int crow = task >> 2, pg = task & 3;
+        const int n = nw0 + crow;
+        const int m = mp0 + pg * 8;
+        if (n >= a.cout || m >= a.M) continue;
+        const float* sp = stage + crow * STAGE_STRIDE + pg * 8;
+        float o[8];
+        const float bv = a.bias ? a.bias[n] : 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = sp[j] + bv;
+        if (vec_ok) {
+          const int img = m / a.hw_out, rem = m - img * a.hw_out;
+          const long long gi = (long long)(group * a.imgs_per_group + img);
+          st16(outT + gi * a.out_img_stride + (long long)n * a.hw_out + rem, pack8<T>(o));
+        } else {
+          for (int j = 0; j < 8; ++j) {
+            const int mj = m + j;
+            if (mj >= a.M) break;
+            const int img = mj / a.hw_out, rem = mj - img * a.hw_out;
+            const long long gi = (long long)(group * a.imgs_per_group + img);
+            outT[gi * a.out_img_stride + (long long)n * a.hw_out + rem] = from_f32<T>(o[j]);
+          }
+        }
+      }
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+template <typename T>
+static int launch_igemm(const mobi_igemm_params* p, const IgemmArgs& a, int groups, hipStream_t st) {
+  const bool tr = p->out_mode == MOBI_OUT_TRANSPOSED;
+  const bool nt5 = (a.n_packed % 160) == 0;
+  dim3 grid(a.tiles_m * a.tiles_n, 1, groups), block(256);
+  if (nt5) {
+    if (tr) hipLaunchKernelGGL((igemm_kernel<T, 5, true>), grid, block, 0, st, a);
+    else    hipLaunchKernelGGL((igemm_kernel<T, 5, false>), grid, block, 0, st, a);
+  } else {
+    if (tr) hipLaunchKernelGGL((igemm_kernel<T, 4, true>), grid, block, 0, st, a);
+    else    hipLaunchKernelGGL((igemm_kernel<T, 4, false>), grid, block, 0, st, a);
+  }
+  MOBI_CHECK_LAUNCH();
+  return MOBI_OK;
+}
+
+}  // namespace mobi
+
+extern "C" int mobi_igemm(const mobi_igemm_params* p, void* stream) {
+  using namespace mobi;
+  if (!p || !p->src0 || !p->weight || !p->out) return MOBI_ERR_ARG;
+  if (p->dtype != MOBI_F16 && p->dtype != MOBI_BF16) return MOBI_ERR_ARG;
+  if (p->c0 <= 0 || (p->c0 & 31) || p->c1 < 0 || (p->c1 & 31) || (p->c1 > 0 && !p->src1)) return MOBI_ERR_UNSUPPORTED;
+  if (p->batch <= 0 || p->hin <= 0 || p->win <= 0 || p->hout <= 0 || p->wout <= 0) return MOBI_ERR_ARG;
+  if (p->kh <= 0 || p->kw <= 0 || p->stride <= 0 || p->groups <= 0 || p->batch % p->groups) return MOBI_ERR_ARG;
+  if (p->groups != 1 && p->groups != p->batch) return MOBI_ERR_UNSUPPORTED;
+  if (p->cout <= 0 || p->n_packed <= 0) return MOBI_ERR_ARG;
+  if (p->upsample != 0 && p->upsample != 1) return MOBI_ERR_ARG;
+  const bool geglu = p->epilogue == MOBI_EPI_GEGLU;
+  if (p->epilogue != MOBI_EPI_NONE && !geglu) return MOBI_ERR_ARG;
+  if (p->out_mode < 0 || p->out_mode > 2) return MOBI_ERR_ARG;
+  if (p->out_mode != MOBI_OUT_TRANSPOSED && (p->cout & 7)) return MOBI_ERR_UNSUPPORTED;
+  if (geglu && (p->out_mode != MOBI_OUT_ROWS || p->rowvec || p->residual)) return MOBI_ERR_UNSUPPORTED;
+  if (!geglu && p->n_packed != p->cout) return MOBI_ERR_ARG;
+  if (p->out_mode == MOBI_OUT_TRANSPOSED && (p->rowvec || p->residual)) return MOBI_ERR_UNSUPPORTED;
+  if ((reinterpret_cast<uintptr_t>(p->src0) | reinterpret_cast<uintptr_t>(p->src1) |
+       reinterpret_cast<uintptr_t>(p->weight) | reinterpret_cast<uintptr_t>(p->out) |
+       reinterpret_cast<uintptr_t>(p->residual)) & 15) return MOBI_ERR_ALIGN;
+
+  IgemmArgs a;
+  a.src0 = p->src0; a.src1 = p->src1;
+  a.c0 = p->c0; a.c1 = p->c1; a.C = p->c0 + p->c1;
+  a.hin = p->hin; a.win = p->win; a.up = p->upsample;
+  a.hout = p->hout; a.wout = p->wout; a.hw_out = p->hout * p->wout;
+  a.kh = p->kh; a.kw = p->kw; a.stride = p->stride; a.pad_h = p->pad_h; a.pad_w = p->pad_w;
+  const long long hw_in = (long long)p->hin * p->win;
+  a.src_img_stride0 = p->src_img_stride ? p->src_img_stride : hw_in * p->c0;
+  a.src_img_stride1 = p->src_img_stride ? p->src_img_stride : hw_in * p->c1;
+  if (p->src_img_stride && p->c1) return MOBI_ERR_UNSUPPORTED;
+  a.weight = p->weight; a.w_group_stride = p->groups > 1 ? p->w_group_stride : 0;
+  a.n_packed = p->n_packed; a.cout = p->cout;
+  a.ktot = p->kh * p->kw * a.C;
+  a.nk = (a.ktot + 63) / 64;
+  a.imgs_per_group = p->batch / p->groups;
+  a.M = a.imgs_per_group * a.hw_out;
+  a.bias = p->bias; a.rowvec = p->rowvec; a.residual = p->residual;
+  a.rowvec_stride = p->rowvec_stride ? p->rowvec_stride : p->cout;
+  a.res_img_stride = p->res_img_stride ? p->res_img_stride : (long long)a.hw_out * p->cout;
+  a.out = p->out;
+  a.out_img_stride = p->out_img_stride ? p->out_img_stride : (long long)a.hw_out * p->cout;
+  a.out_mode = p->out_mode; a.epilogue = p->epilogue; a.scale = p->scale;
+  const int bn = (p->n_packed % 160) == 0 ? 160 : 128;
+  a.tiles_m = (a.M + 127) / 128;
+  a.tiles_n = (p->n_packed + bn - 1) / bn;
+  if ((long long)a.tiles_m * a.tiles_n > 0x7fffffffLL) return MOBI_ERR_UNSUPPORTED;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  return p->dtype == MOBI_F16 ? launch_igemm<f16_t>(p, a, p->groups, st) : launch_igemm<bf16_t>(p, a, p->groups, st);
+}

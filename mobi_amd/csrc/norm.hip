@@ -1,0 +1,246 @@
+// GroupNorm(32)+SiLU and LayerNorm for gfx950: HBM-bound streaming kernels,
+// 16-byte accesses, fp32 statistics (the reference's GroupNorm32 computes in fp32,
+// ldm/modules/diffusionmodules/util.py:214-216).
+//
+// GroupNorm runs as two launches:
+//   stats: grid (chunks, images); each block sweeps a chunk of pixels with every thread owning
+//          a fixed 8-channel column, folds per-channel sums into the 32 groups through LDS in
+//          a fixed order (deterministic) and writes one (sum, sumsq) pair per group;
+//   apply: every block first combines its image's chunk partials in fp64 (cancellation-safe
+//          E[x^2] - mean^2), then streams y = x * a[c] + b[c], optional SiLU.
+// Algorithmic bytes: 2 B read (stats) + 2 B read + 2 B written (apply) per element.
+#include "common.h"
+
+namespace mobi {
+
+static inline int gn_chunks(int hw) {
+  int c = (hw + 31) / 32;
+  return c < 1 ? 1 : (c > 64 ? 64 : c);
+}
+
+struct GnArgs {
+  const void* src0; const void* src1;
+  int c0, c1, C, hw, chunks;
+  const float* gamma; const float* beta; float eps; int silu;
+  void* out; float* ws;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void gn_stats_kernel(const GnArgs a) {
+  // LDS: per (row slot, channel) partial sums; rows*C <= 2048+ or C <= 2560 when one slot
+  __shared__ float s_sum[2560 + 512];
+  __shared__ float s_sq[2560 + 512];
+  const int tid = threadIdx.x;
+  const int img = blockIdx.y, chunk = blockIdx.x;
+  const int V = a.C >> 3;                              // 8-channel columns per pixel
+  const int rows = V <= 256 ? 256 / V : 1;             // pixels swept per iteration
+  const int per = (a.hw + a.chunks - 1) / a.chunks;
+  const int p_begin = chunk * per;
+  const int p_end = min(a.hw, p_begin + per);
+  const T* __restrict__ s0 = reinterpret_cast<const T*>(a.src0) + (long long)img * a.hw * a.c0;
+  const T* __restrict__ s1 = a.src1 ? reinterpret_cast<const T*>(a.src1) + (long long)img * a.hw * a.c1 : nullptr;
+
+  const int slot = V <= 256 ? tid / V : 0;
+  const int col0 = V <= 256 ? tid - slot * V : tid;
+  const bool active = V <= 256 ? slot < rows : true;
+  for (int col = col0; col < V; col += 256) {
+    float sum[8], sq[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { sum[j] = 0.f; sq[j] = 0.f; }
+    if (active) {
+      const int c = col * 8;
+      const bool second = c >= a.c0;
+      const T* __restrict__ base = second ? s1 + (c - a.c0) : s0 + c;
+      const int cs = second ? a.c1 : a.c0;
+      for (int p = p_begin + slot; p < p_end; p += rows) {
+        float f[8];
+        unpack8<T>(ld16(base + (long long)p * cs), f);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { sum[j] += f[j]; sq[j] += f[j] * f[j]; }
+      }
+      float* ds = s_sum + slot * a.C + c;
+      float* dq = s_sq + slot * a.C + c;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { ds[j] = sum[j]; dq[j] = sq[j]; }
+    }
+    if (V <= 256) break;
+  }
+  __syncthreads();
+  if (tid < 32) {
+    const int cpg = a.C / 32;
+    float gs = 0.f, gq = 0.f;
+    for (int r = 0; r < rows; ++r)
+      for (int j = 0; j < cpg; ++j) {
+        gs += s_sum[r * a.C + tid * cpg + j];
+        gq += s_sq[r * a.C + tid * cpg + j];
+      }
+    float* w = a.ws + ((long long)(img * a.chunks + chunk) * 32 + tid) * 2;
+    w[0] = gs; w[1] = gq;
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void gn_apply_kernel(const GnArgs a) {
+  __shared__ float s_mean[32], s_rstd[32];
+  const int tid = threadIdx.x;
+  const int img = blockIdx.y;
+  if (tid < 32) {
+    double s = 0.0, q = 0.0;
+    const float* w = a.ws + ((long long)img * a.chunks * 32 + tid) * 2;
+    for (int c = 0; c < a.chunks; ++c) { s += (double)w[c * 64]; q += (double)w[c * 64 + 1]; }
+    const double n = (double)a.hw * (double)(a.C / 32);
+    const double mean = s / n;
+    double var = q / n - mean * mean;
+    var = var < 0.0 ? 0.0 : var;
+    s_mean[tid] = (float)mean;
+    s_rstd[tid] = (float)(1.0 / sqrt(var + (double)a.eps));
+  }
+  __syncthreads();
+  const int V = a.C >> 3;
+  const int cpg = a.C / 32;
+  const long long total = (long long)a.hw * V;
+  const T* __restrict__ s0 = reinterpret_cast<const T*>(a.src0) + (long long)img * a.hw * a.c0;
+  const T* __restrict__ s1 = a.src1 ? reinterpret_cast<const T*>(a.src1) + (long long)img * a.hw * a.c1 : nullptr;
+  T* __restrict__ out = reinterpret_cast<T*>(a.out) + (long long)img * a.hw * a.C;
+  for (long long i = (long long)blockIdx.x * 256 + tid; i < total; i += (long long)gridDim.x * 256) {
+    const int p = (int)(i / V);
+    const int c = (int)(i - (long long)p * V) * 8;
+    const bool second = c >= a.c0;
+    const T* src = second ? s1 + (long long)p * a.c1 + (c - a.c0) : s0 + (long long)p * a.c0 + c;
+    float f[8];
+    unpack8<T>(ld16(src), f);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int g = (c + j) / cpg;
+      const float sc = s_rstd[g] * a.gamma[c + j];
+      float y = (f[j] - s_mean[g]) * sc + a.beta[c + j];
+      if (a.silu) y = silu_f(y);
+      f[j] = y;
+    }
+    st16(out + (long long)p * a.C + c, pack8<T>(f));
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+struct LnArgs {
+  const void* src; void* out;
+  int images, rows, C; long long src_img, out_img;
+  const float* gamma; const float* beta; float eps;
+};
+
+// one wave per token row; C <= 64*8*MAXV
+template <typename T, int MAXV>
+__global__ __launch_bounds__(256) void layernorm_kernel(const LnArgs a) {
+  const int lane = threadIdx.x & 63;
+  const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const long long total = (long long)a.images * a.rows;
+  if (row >= total) return;
+  const int img = (int)(row / a.rows);
+  const int r = (int)(row - (long long)img * a.rows);
+  const T* __restrict__ src = reinterpret_cast<const T*>(a.src) + img * a.src_img + (long long)r * a.C;
+  T* __restrict__ out = reinterpret_cast<T*>(a.out) + img * a.out_img + (long long)r * a.C;
+  const int V = a.C >> 3;
+  float f[MAXV][8];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int v = lane + 64 * i;
+    if (v < V) {
+      unpack8<T>(ld16(src + v * 8), f[i]);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s += f[i][j];
+    }
+  }
+  const float mean = wave_sum(s) / (float)a.C;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int v = lane + 64 * i;
+    if (v < V) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { const float d = f[i][j] - mean; q += d * d; }
+    }
+  }
+  const float rstd = rsqrtf(wave_sum(q) / (float)a.C + a.eps);
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int v = lane + 64 * i;
+    if (v < V) {
+      float o[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] = (f[i][j] - mean) * rstd * a.gamma[v * 8 + j] + a.beta[v * 8 + j];
+      st16(out + v * 8, pack8<T>(o));
+    }
+  }
+}
+
+template <typename T>
+static int launch_gn(const GnArgs& a, int batch, hipStream_t st) {
+  hipLaunchKernelGGL((gn_stats_kernel<T>), dim3(a.chunks, batch), dim3(256), 0, st, a);
+  MOBI_CHECK_LAUNCH();
+  const long long vecs = (long long)a.hw * (a.C >> 3);
+  long long blocks = (vecs + 256 * 4 - 1) / (256 * 4);
+  const long long cap = (2048 + batch - 1) / batch;
+  if (blocks > cap) blocks = cap;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL((gn_apply_kernel<T>), dim3((unsigned)blocks, batch), dim3(256), 0, st, a);
+  MOBI_CHECK_LAUNCH();
+  return MOBI_OK;
+}
+
+template <typename T>
+static int launch_ln(const LnArgs& a, hipStream_t st) {
+  const long long total = (long long)a.images * a.rows;
+  const unsigned blocks = (unsigned)((total + 3) / 4);
+  const int V = a.C >> 3;
+  if (V <= 64) hipLaunchKernelGGL((layernorm_kernel<T, 1>), dim3(blocks), dim3(256), 0, st, a);
+  else if (V <= 128) hipLaunchKernelGGL((layernorm_kernel<T, 2>), dim3(blocks), dim3(256), 0, st, a);
+  else if (V <= 192) hipLaunchKernelGGL((layernorm_kernel<T, 3>), dim3(blocks), dim3(256), 0, st, a);
+  else if (V <= 320) hipLaunchKernelGGL((layernorm_kernel<T, 5>), dim3(blocks), dim3(256), 0, st, a);
+  else return MOBI_ERR_UNSUPPORTED;
+  MOBI_CHECK_LAUNCH();
+  return MOBI_OK;
+}
+
+}  // namespace mobi
+
+extern "C" size_t mobi_groupnorm_workspace_bytes(int32_t batch, int32_t hw) {
+  if (batch <= 0 || hw <= 0) return 0;
+  return (size_t)batch * mobi::gn_chunks(hw) * 32 * 2 * sizeof(float);
+}
+
+extern "C" int mobi_groupnorm(const mobi_groupnorm_params* p, void* stream) {
+  using namespace mobi;
+  if (!p || !p->src0 || !p->out || !p->ws || !p->gamma || !p->beta) return MOBI_ERR_ARG;
+  if (p->dtype != MOBI_F16 && p->dtype != MOBI_BF16) return MOBI_ERR_ARG;
+  if (p->c0 <= 0 || (p->c0 & 31) || p->c1 < 0 || (p->c1 & 31) || (p->c1 > 0 && !p->src1)) return MOBI_ERR_UNSUPPORTED;
+  if (p->batch <= 0 || p->hw <= 0 || p->batch > 65535) return MOBI_ERR_ARG;
+  const int C = p->c0 + p->c1;
+  if (C > 2560) return MOBI_ERR_UNSUPPORTED;
+  if ((reinterpret_cast<uintptr_t>(p->src0) | reinterpret_cast<uintptr_t>(p->src1) |
+       reinterpret_cast<uintptr_t>(p->out)) & 15) return MOBI_ERR_ALIGN;
+  GnArgs a;
+  a.src0 = p->src0; a.src1 = p->c1 ? p->src1 : nullptr; a.c0 = p->c0; a.c1 = p->c1; a.C = C;
+  a.hw = p->hw; a.chunks = gn_chunks(p->hw);
+  a.gamma = p->gamma; a.beta = p->beta; a.eps = p->eps; a.silu = p->silu;
+  a.out = p->out; a.ws = reinterpret_cast<float*>(p->ws);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  return p->dtype == MOBI_F16 ? launch_gn<f16_t>(a, p->batch, st) : launch_gn<bf16_t>(a, p->batch, st);
+}
+
+extern "C" int mobi_layernorm(const mobi_layernorm_params* p, void* stream) {
+  using namespace mobi;
+  if (!p || !p->src || !p->out || !p->gamma || !p->beta) return MOBI_ERR_ARG;
+  if (p->dtype != MOBI_F16 && p->dtype != MOBI_BF16) return MOBI_ERR_ARG;
+  if (p->images <= 0 || p->rows_per_image <= 0 || p->channels <= 0 || (p->channels & 7)) return MOBI_ERR_UNSUPPORTED;
+  if ((p->src_img_stride & 7) || (p->out_img_stride & 7)) return MOBI_ERR_ALIGN;
+  if ((reinterpret_cast<uintptr_t>(p->src) | reinterpret_cast<uintptr_t>(p->out)) & 15) return MOBI_ERR_ALIGN;
+  LnArgs a;
+  a.src = p->src; a.out = p->out; a.images = p->images; a.rows = p->rows_per_image; a.C = p->channels;
+  const long long dense = (long long)p->rows_per_image * p->channels;
+  a.src_img = p->src_img_stride ? p->src_img_stride : dense;
+  a.out_img = p->out_img_stride ? p->out_img_stride : dense;
+  a.gamma = p->gamma; a.beta = p->beta; a.eps = p->eps;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  return p->dtype == MOBI_F16 ? launch_ln<f16_t>(a, st) : launch_ln<bf16_t>(a, st);
+}

@@ -1,0 +1,167 @@
+// Sampler-side fp32 arithmetic on the latent state (tiny, launch-bound; captured in a
+// HIP graph together with the UNet forward by the host).
+#include "common.h"
+
+namespace mobi {
+
+__global__ void ddim_step_kernel(const mobi_ddim_step_params a) {
+  // all coefficient math in fp32, in the reference's operation order (ddim.py:200-212)
+  const float sqrt_at = sqrtf(a.a_t);
+  const float sqrt_aprev = sqrtf(a.a_prev);
+  const float dir_c = sqrtf(1.0f - a.a_prev - a.sigma_t * a.sigma_t);
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < a.n;
+       i += (long long)gridDim.x * blockDim.x) {
+    float e = a.e_cond[i];
+    if (a.e_uncond) {
+      const float eu = a.e_uncond[i];
+      e = eu + a.cfg_scale * (e - eu);
+    }
+    const float x = a.x[i];
+    const float pred = (x - a.sqrt_one_minus_at * e) / sqrt_at;
+    const float dir = dir_c * e;
+    const float nz = a.noise ? a.sigma_t * a.noise[i] * a.temperature : 0.0f;
+    if (a.e_out) a.e_out[i] = e;
+    if (a.pred_x0) a.pred_x0[i] = pred;
+    if (a.x_prev) a.x_prev[i] = sqrt_aprev * pred + dir + nz;
+  }
+}
+
+__global__ void lincomb4_kernel(float* out, const float* e0, const float* e1, const float* e2, const float* e3,
+                                float c0, float c1, float c2, float c3, long long n) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    float v = c0 * e0[i];
+    if (e1) v += c1 * e1[i];
+    if (e2) v += c2 * e2[i];
+    if (e3) v += c3 * e3[i];
+    out[i] = v;
+  }
+}
+
+__global__ void mask_blend_kernel(float* img, const float* x0, const float* noise, const float* mask, float sa,
+                                  float s1, int batch, int channels, int hw) {
+  const long long total = (long long)batch * channels * hw;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int p = (int)(i % hw);
+    const int b = (int)(i / ((long long)channels * hw));
+    const float m = mask[(long long)b * hw + p];
+    const float q = sa * x0[i] + s1 * noise[i];
+    img[i] = q * m + (1.0f - m) * img[i];
+  }
+}
+
+__global__ void posterior_sample_kernel(const float* moments, const float* noise, float* out, int batch, int c, int hw,
+                                        int out_c_total, int out_c_off, float scale) {
+  const long long total = (long long)batch * c * hw;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int p = (int)(i % hw);
+    const long long r = i / hw;
+    const int ch = (int)(r % c);
+    const int b = (int)(r / c);
+    const float mean = moments[((long long)b * 2 * c + ch) * hw + p];
+    float logvar = moments[((long long)b * 2 * c + c + ch) * hw + p];
+    logvar = fminf(fmaxf(logvar, -30.0f), 20.0f);
+    const float z = mean + expf(0.5f * logvar) * noise[i];
+    out[((long long)b * out_c_total + out_c_off + ch) * hw + p] = scale * z;
+  }
+}
+
+__global__ void nearest_resize_kernel(const float* src, float* out, int planes, int hin, int win, int hout, int wout,
+                                      int out_plane_stride) {
+  const long long total = (long long)planes * hout * wout;
+  // PyTorch 'nearest': src = floor(dst * (in / out)) computed in fp32 (legacy nearest)
+  const float sh = (float)hin / (float)hout, sw = (float)win / (float)wout;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int x = (int)(i % wout);
+    const long long r = i / wout;
+    const int y = (int)(r % hout);
+    const int pl = (int)(r / hout);
+    const int sy = min((int)floorf((float)y * sh), hin - 1);
+    const int sx = min((int)floorf((float)x * sw), win - 1);
+    out[(long long)pl * out_plane_stride + (long long)y * wout + x] = src[((long long)pl * hin + sy) * win + sx];
+  }
+}
+
+static inline unsigned egrid(long long n) {
+  long long g = (n + 255) / 256;
+  return (unsigned)(g < 1 ? 1 : (g > 4096 ? 4096 : g));
+}
+
+}  // namespace mobi
+
+using namespace mobi;
+#define ST(stream) reinterpret_cast<hipStream_t>(stream)
+
+extern "C" int mobi_ddim_step(const mobi_ddim_step_params* p, void* stream) {
+  if (!p || !p->x || !p->e_cond || p->n <= 0) return MOBI_ERR_ARG;
+  hipLaunchKernelGGL(ddim_step_kernel, dim3(egrid(p->n)), dim3(256), 0, ST(stream), *p);
+  MOBI_CHECK_LAUNCH();
+  return MOBI_OK;
+}
+
+extern "C" int mobi_lincomb4(float* out, const float* e0, const float* e1, const float* e2, const float* e3, float c0,
+                             float c1, float c2, float c3, int64_t n, void* stream) {
+  if (!out || !e0 || n <= 0) return MOBI_ERR_ARG;
+  hipLaunchKernelGGL(lincomb4_kernel, dim3(egrid(n)), dim3(256), 0, ST(stream), out, e0, e1, e2, e3, c0, c1, c2, c3,
+                     (long long)n);
+  MOBI_CHECK_LAUNCH();
+  return MOBI_OK;
+}
+
+extern "C" int mobi_mask_blend(float* img, const float* x0, const float* noise, const float* mask, float sqrt_ac_t,
+                               float sqrt_1m_ac_t, int32_t batch, int32_t channels, int32_t hw, void* stream) {
+  if (!img || !x0 || !noise || !mask || batch <= 0 || channels <= 0 || hw <= 0) return MOBI_ERR_ARG;
+  hipLaunchKernelGGL(mask_blend_kernel, dim3(egrid((long long)batch * channels * hw)), dim3(256), 0, ST(stream), img,
+                     x0, noise, mask, sqrt_ac_t, sqrt_1m_ac_t, batch, channels, hw);
+  MOBI_CHECK_LAUNCH();
+  return MOBI_OK;
+}
+
+extern "C" int mobi_posterior_sample(const float* moments, const float* noise, float* out, int32_t batch, int32_t c,
+                                     int32_t hw, int32_t out_c_total, int32_t out_c_off, float scale, void* stream) {
+  if (!moments || !noise || !out || batch <= 0 || c <= 0 || hw <= 0 || out_c_off < 0 || out_c_off + c > out_c_total)
+    return MOBI_ERR_ARG;
+  hipLaunchKernelGGL(posterior_sample_kernel, dim3(egrid((long long)batch * c * hw)), dim3(256), 0, ST(stream),
+                     moments, noise, out, batch, c, hw, out_c_total, out_c_off, scale);
+  MOBI_CHECK_LAUNCH();
+  return MOBI_OK;
+}
+
+extern "C" int mobi_nearest_resize(const float* src, float* out, int32_t planes, int32_t hin, int32_t win, int32_t hout,
+                                   int32_t wout, int32_t out_plane_stride, void* stream) {
+  if (!src || !out || planes <= 0 || hin <= 0 || win <= 0 || hout <= 0 || wout <= 0) return MOBI_ERR_ARG;
+  hipLaunchKernelGGL(nearest_resize_kernel, dim3(egrid((long long)planes * hout * wout)), dim3(256), 0, ST(stream),
+                     src, out, planes, hin, win, hout, wout, out_plane_stride);
+  MOBI_CHECK_LAUNCH();
+  return MOBI_OK;
+}
+
+extern "C" int mobi_abi_version(void) { return MOBI_ABI_VERSION; }
+
+extern "C" size_t mobi_struct_size(int id) {
+  switch (id) {
+    case 0: return sizeof(mobi_igemm_params);
+    case 1: return sizeof(mobi_groupnorm_params);
+    case 2: return sizeof(mobi_layernorm_params);
+    case 3: return sizeof(mobi_attention_params);
+    case 4: return sizeof(mobi_ctx_attention_params);
+    case 5: return sizeof(mobi_skinny_linear_params);
+    case 6: return sizeof(mobi_conv_small_cin_params);
+    case 7: return sizeof(mobi_conv_small_cout_params);
+    case 8: return sizeof(mobi_ddim_step_params);
+    default: return 0;
+  }
+}
+
+extern "C" const char* mobi_error_string(int code) {
+  switch (code) {
+    case MOBI_OK: return "ok";
+    case MOBI_ERR_ARG: return "invalid argument";
+    case MOBI_ERR_UNSUPPORTED: return "unsupported shape or mode";
+    case MOBI_ERR_LAUNCH: return "kernel launch failed";
+    case MOBI_ERR_ALIGN: return "pointer or stride not 16-byte aligned";
+    default: return "unknown error";
+  }
+}

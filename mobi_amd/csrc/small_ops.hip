@@ -1,0 +1,370 @@
+// Small / HBM-bound kernels around the matrix-core paths: skinny dense layers on fp32
+// vectors, timestep embedding, few-token context attention, row softmax, direct
+// convolutions for the thin ends of the networks, layout converters.
+#include "common.h"
+
+namespace mobi {
+
+// ---------------------------------------------------------------------------------------
+// skinny linear: one wave per output column, all m <= 64 rows; weights T read 16 B per lane
+// ---------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void skinny_linear_kernel(const mobi_skinny_linear_params a) {
+  const int lane = threadIdx.x & 63;
+  const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (n >= a.n) return;
+  const T* __restrict__ w = reinterpret_cast<const T*>(a.weight) + (long long)n * a.k;
+  const int V = a.k >> 3;
+  for (int m0 = 0; m0 < a.m; m0 += 8) {
+    float acc[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+    for (int v = lane; v < V; v += 64) {
+      float wf[8];
+      unpack8<T>(ld16(w + v * 8), wf);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int m = m0 + i;
+        if (m < a.m) {
+          const float* xp = a.x + (long long)m * a.x_row_stride + v * 8;
+          const f32x4 x0 = *reinterpret_cast<const f32x4*>(xp);
+          const f32x4 x1 = *reinterpret_cast<const f32x4*>(xp + 4);
+          float xf[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const float xv = a.pre_act == MOBI_ACT_SILU ? silu_f(xf[j]) : xf[j];
+            acc[i] += wf[j] * xv;
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const float s = wave_sum(acc[i]);
+      const int m = m0 + i;
+      if (lane == 0 && m < a.m) {
+        float o = s + (a.bias ? a.bias[n] : 0.f);
+        if (a.post_act == MOBI_ACT_SILU) o = silu_f(o);
+        a.out[(long long)m * a.out_row_stride + n] = o;
+      }
+    }
+  }
+}
+
+__global__ void timestep_embedding_kernel(const int64_t* t, const float* freqs, float* out, int n, int half) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n * half) return;
+  const int b = i / half, f = i - b * half;
+  const float arg = (float)t[b] * freqs[f];
+  out[(long long)b * 2 * half + f] = cosf(arg);
+  out[(long long)b * 2 * half + half + f] = sinf(arg);
+}
+
+// ---------------------------------------------------------------------------------------
+// attention against <= 8 context tokens: one thread per (token row, head)
+// ---------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void ctx_attention_kernel(const mobi_ctx_attention_params a) {
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  const long long total = (long long)a.images * a.tq * a.heads;
+  if (idx >= total) return;
+  const int head = (int)(idx % a.heads);
+  const long long row = idx / a.heads;
+  const int img = (int)(row / a.tq);
+  const int C = a.heads * a.dh;
+  const T* __restrict__ q = reinterpret_cast<const T*>(a.q) + row * C + head * a.dh;
+  T* __restrict__ o = reinterpret_cast<T*>(a.out) + row * C + head * a.dh;
+  const float* __restrict__ kb = a.k + (long long)img * a.tk * C + head * a.dh;
+  const float* __restrict__ vb = a.v + (long long)img * a.tk * C + head * a.dh;
+  float s[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) s[j] = 0.f;
+  for (int d = 0; d < a.dh; d += 8) {
+    float qf[8];
+    unpack8<T>(ld16(q + d), qf);
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      if (j < a.tk) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s[j] += qf[e] * kb[(long long)j * C + d + e];
+      }
+  }
+  float mx = -INFINITY;
+#pragma unroll
+  for (int j = 0; j < 8; ++j)
+    if (j < a.tk) { s[j] *= a.scale; mx = fmaxf(mx, s[j]); }
+  float den = 0.f;
+#pragma unroll
+  for (int j = 0; j < 8; ++j)
+    if (j < a.tk) { s[j] = __expf(s[j] - mx); den += s[j]; }
+  const float inv = 1.f / den;
+  for (int d = 0; d < a.dh; d += 8) {
+    float of[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) of[e] = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      if (j < a.tk) {
+        const float pj = s[j] * inv;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) of[e] += pj * vb[(long long)j * C + d + e];
+      }
+    st16(o + d, pack8<T>(of));
+  }
+}
+
+// row softmax fp32 -> T, one wave per row
+template <typename T>
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const float* src, T* out, long long rows, int cols) {
+  const int lane = threadIdx.x & 63;
+  const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* s = src + row * cols;
+  T* o = out + row * cols;
+  float mx = -INFINITY;
+  for (int c = lane; c < cols; c += 64) mx = fmaxf(mx, s[c]);
+  mx = wave_max(mx);
+  float den = 0.f;
+  for (int c = lane; c < cols; c += 64) den += __expf(s[c] - mx);
+  den = wave_sum(den);
+  const float inv = 1.f / den;
+  for (int c = lane; c < cols; c += 64) o[c] = from_f32<T>(__expf(s[c] - mx) * inv);
+}
+
+// ---------------------------------------------------------------------------------------
+// direct conv, few input channels: fp32 NCHW sources -> T channels-last or fp32 NCHW.
+// one thread per (pixel, 8 output channels)
+// ---------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void conv_small_cin_kernel(const mobi_conv_small_cin_params a) {
+  const int ncg = (a.cout + 7) >> 3;
+  const long long hw = (long long)a.h * a.w;
+  const long long total = (long long)a.batch * hw * ncg;
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const int cg = (int)(idx % ncg);
+  const long long pix = idx / ncg;
+  const int img = (int)(pix / hw);
+  const int rem = (int)(pix - (long long)img * hw);
+  const int y = rem / a.w, x = rem - y * a.w;
+  const int cin = a.c[0] + a.c[1] + a.c[2];
+  const int taps = a.kh * a.kw;
+  const int K = cin * taps;
+  float acc[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int co = cg * 8 + j;
+    acc[j] = (a.bias && co < a.cout) ? a.bias[co] : 0.f;
+  }
+  int cbase = 0;
+  for (int s = 0; s < 3; ++s) {
+    if (!a.src[s] || a.c[s] <= 0) continue;
+    const float* __restrict__ sp = a.src[s] + (long long)img * a.c[s] * hw;
+    for (int c = 0; c < a.c[s]; ++c) {
+      for (int ky = 0; ky < a.kh; ++ky) {
+        const int yy = y + ky - a.pad_h;
+        if (yy < 0 || yy >= a.h) continue;
+        for (int kx = 0; kx < a.kw; ++kx) {
+          const int xx = x + kx - a.pad_w;
+          if (xx < 0 || xx >= a.w) continue;
+          const float v = sp[(long long)c * hw + (long long)yy * a.w + xx];
+          const int k = ((cbase + c) * a.kh + ky) * a.kw + kx;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const int co = cg * 8 + j;
+            if (co < a.cout) acc[j] += v * a.weight[(long long)co * K + k];
+          }
+        }
+      }
+    }
+    cbase += a.c[s];
+  }
+  if (a.out_f32_nchw) {
+    float* o = reinterpret_cast<float*>(a.out);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int co = cg * 8 + j;
+      if (co < a.cout) o[((long long)img * a.cout + co) * hw + rem] = acc[j];
+    }
+  } else {
+    T* o = reinterpret_cast<T*>(a.out);
+    st16(o + pix * a.cout + cg * 8, pack8<T>(acc));
+  }
+}
+
+// direct conv, few output channels: T channels-last -> fp32 NCHW; one wave per output pixel
+template <typename T>
+__global__ __launch_bounds__(256) void conv_small_cout_kernel(const mobi_conv_small_cout_params a) {
+  const int lane = threadIdx.x & 63;
+  const long long hw = (long long)a.h * a.w;
+  const long long pix = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (pix >= (long long)a.batch * hw) return;
+  const int img = (int)(pix / hw);
+  const int rem = (int)(pix - (long long)img * hw);
+  const int y = rem / a.w, x = rem - y * a.w;
+  const int vpt = a.cin >> 3;                 // 8-channel vectors per tap
+  const int taps = a.kh * a.kw;
+  const int K = taps * a.cin;
+  const T* __restrict__ src = reinterpret_cast<const T*>(a.src) + (long long)img * hw * a.cin;
+  const T* __restrict__ w = reinterpret_cast<const T*>(a.weight);
+  float acc[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+  for (int v = lane; v < taps * vpt; v += 64) {
+    const int tap = v / vpt, c = (v - tap * vpt) * 8;
+    const int ky = tap / a.kw, kx = tap - ky * a.kw;
+    const int yy = y + ky - a.pad_h, xx = x + kx - a.pad_w;
+    if (yy < 0 || yy >= a.h || xx < 0 || xx >= a.w) continue;
+    float xf[8];
+    unpack8<T>(ld16(src + ((long long)yy * a.w + xx) * a.cin + c), xf);
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      if (j < a.cout) {
+        float wf[8];
+        unpack8<T>(ld16(w + (long long)j * K + tap * a.cin + c), wf);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[j] += xf[e] * wf[e];
+      }
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j)
+    if (j < a.cout) {
+      float s = wave_sum(acc[j]);
+      if (lane == 0) {
+        s += a.bias ? a.bias[j] : 0.f;
+        if (a.clamp) s = fminf(fmaxf(s, a.clamp_lo), a.clamp_hi);
+        a.out[((long long)img * a.cout + j) * hw + rem] = s;
+      }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// layout converters
+// ---------------------------------------------------------------------------------------
+template <typename T>
+__global__ void nchw_to_nhwc_kernel(const float* src, T* out, int batch, int c, int hw) {
+  const long long total = (long long)batch * c * hw;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int ch = (int)(i % c);
+    const long long r = i / c;
+    const int p = (int)(r % hw);
+    const int b = (int)(r / hw);
+    out[i] = from_f32<T>(src[((long long)b * c + ch) * hw + p]);
+  }
+}
+template <typename T>
+__global__ void nhwc_to_nchw_kernel(const T* src, float* out, int batch, int c, int hw) {
+  const long long total = (long long)batch * c * hw;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int p = (int)(i % hw);
+    const long long r = i / hw;
+    const int ch = (int)(r % c);
+    const int b = (int)(r / c);
+    out[i] = to_f32(src[((long long)b * hw + p) * c + ch]);
+  }
+}
+
+static inline unsigned grid_for(long long total, int block, long long cap = 65536) {
+  long long g = (total + block - 1) / block;
+  if (g > cap) g = cap;
+  if (g < 1) g = 1;
+  return (unsigned)g;
+}
+
+}  // namespace mobi
+
+using namespace mobi;
+#define ST(stream) reinterpret_cast<hipStream_t>(stream)
+#define DT_OK(d) ((d) == MOBI_F16 || (d) == MOBI_BF16)
+
+extern "C" int mobi_skinny_linear(const mobi_skinny_linear_params* p, void* stream) {
+  if (!p || !p->x || !p->weight || !p->out) return MOBI_ERR_ARG;
+  if (!DT_OK(p->dtype) || p->m <= 0 || p->m > 64 || p->n <= 0 || p->k <= 0) return MOBI_ERR_ARG;
+  if ((p->k & 7) || (p->x_row_stride & 3)) return MOBI_ERR_UNSUPPORTED;
+  if ((reinterpret_cast<uintptr_t>(p->x) | reinterpret_cast<uintptr_t>(p->weight)) & 15) return MOBI_ERR_ALIGN;
+  const unsigned blocks = (unsigned)((p->n + 3) / 4);
+  if (p->dtype == MOBI_F16) hipLaunchKernelGGL((skinny_linear_kernel<f16_t>), dim3(blocks), dim3(256), 0, ST(stream), *p);
+  else hipLaunchKernelGGL((skinny_linear_kernel<bf16_t>), dim3(blocks), dim3(256), 0, ST(stream), *p);
+  MOBI_CHECK_LAUNCH();
+  return MOBI_OK;
+}
+
+extern "C" int mobi_timestep_embedding(const int64_t* t, const float* freqs, float* out, int32_t n, int32_t half,
+                                       void* stream) {
+  if (!t || !freqs || !out || n <= 0 || half <= 0) return MOBI_ERR_ARG;
+  hipLaunchKernelGGL(timestep_embedding_kernel, dim3(grid_for((long long)n * half, 256)), dim3(256), 0, ST(stream),
+                     t, freqs, out, n, half);
+  MOBI_CHECK_LAUNCH();
+  return MOBI_OK;
+}
+
+extern "C" int mobi_ctx_attention(const mobi_ctx_attention_params* p, void* stream) {
+  if (!p || !p->q || !p->out || !p->k || !p->v) return MOBI_ERR_ARG;
+  if (!DT_OK(p->dtype) || p->images <= 0 || p->heads <= 0 || p->tq <= 0) return MOBI_ERR_ARG;
+  if (p->tk <= 0 || p->tk > 8 || p->dh <= 0 || (p->dh & 7)) return MOBI_ERR_UNSUPPORTED;
+  if ((reinterpret_cast<uintptr_t>(p->q) | reinterpret_cast<uintptr_t>(p->out)) & 15) return MOBI_ERR_ALIGN;
+  const long long total = (long long)p->images * p->tq * p->heads;
+  const unsigned blocks = (unsigned)((total + 255) / 256);
+  if (p->dtype == MOBI_F16) hipLaunchKernelGGL((ctx_attention_kernel<f16_t>), dim3(blocks), dim3(256), 0, ST(stream), *p);
+  else hipLaunchKernelGGL((ctx_attention_kernel<bf16_t>), dim3(blocks), dim3(256), 0, ST(stream), *p);
+  MOBI_CHECK_LAUNCH();
+  return MOBI_OK;
+}
+
+extern "C" int mobi_softmax_rows(const float* src, void* out, int64_t rows, int32_t cols, int32_t dtype, void* stream) {
+  if (!src || !out || rows <= 0 || cols <= 0 || !DT_OK(dtype)) return MOBI_ERR_ARG;
+  const unsigned blocks = (unsigned)((rows + 3) / 4);
+  if (dtype == MOBI_F16) hipLaunchKernelGGL((softmax_rows_kernel<f16_t>), dim3(blocks), dim3(256), 0, ST(stream), src, (f16_t*)out, (long long)rows, cols);
+  else hipLaunchKernelGGL((softmax_rows_kernel<bf16_t>), dim3(blocks), dim3(256), 0, ST(stream), src, (bf16_t*)out, (long long)rows, cols);
+  MOBI_CHECK_LAUNCH();
+  return MOBI_OK;
+}
+
+extern "C" int mobi_conv_small_cin(const mobi_conv_small_cin_params* p, void* stream) {
+  if (!p || !p->src[0] || !p->weight || !p->out) return MOBI_ERR_ARG;
+  if (!DT_OK(p->dtype) || p->batch <= 0 || p->h <= 0 || p->w <= 0 || p->cout <= 0) return MOBI_ERR_ARG;
+  const int cin = p->c[0] + p->c[1] + p->c[2];
+  if (cin <= 0 || cin > 16 || p->kh <= 0 || p->kw <= 0) return MOBI_ERR_UNSUPPORTED;
+  if (!p->out_f32_nchw && (p->cout & 7)) return MOBI_ERR_UNSUPPORTED;
+  const long long total = (long long)p->batch * p->h * p->w * ((p->cout + 7) / 8);
+  const unsigned blocks = (unsigned)((total + 255) / 256);
+  if (p->dtype == MOBI_F16) hipLaunchKernelGGL((conv_small_cin_kernel<f16_t>), dim3(blocks), dim3(256), 0, ST(stream), *p);
+  else hipLaunchKernelGGL((conv_small_cin_kernel<bf16_t>), dim3(blocks), dim3(256), 0, ST(stream), *p);
+  MOBI_CHECK_LAUNCH();
+  return MOBI_OK;
+}
+
+extern "C" int mobi_conv_small_cout(const mobi_conv_small_cout_params* p, void* stream) {
+  if (!p || !p->src || !p->weight || !p->out) return MOBI_ERR_ARG;
+  if (!DT_OK(p->dtype) || p->batch <= 0 || p->h <= 0 || p->w <= 0) return MOBI_ERR_ARG;
+  if (p->cout <= 0 || p->cout > 8 || p->cin <= 0 || (p->cin & 7)) return MOBI_ERR_UNSUPPORTED;
+  if ((reinterpret_cast<uintptr_t>(p->src) | reinterpret_cast<uintptr_t>(p->weight)) & 15) return MOBI_ERR_ALIGN;
+  const long long pixels = (long long)p->batch * p->h * p->w;
+  const unsigned blocks = (unsigned)((pixels + 3) / 4);
+  if (p->dtype == MOBI_F16) hipLaunchKernelGGL((conv_small_cout_kernel<f16_t>), dim3(blocks), dim3(256), 0, ST(stream), *p);
+  else hipLaunchKernelGGL((conv_small_cout_kernel<bf16_t>), dim3(blocks), dim3(256), 0, ST(stream), *p);
+  MOBI_CHECK_LAUNCH();
+  return MOBI_OK;
+}
+
+extern "C" int mobi_nchw_f32_to_nhwc(const float* src, void* out, int32_t batch, int32_t c, int32_t hw, int32_t dtype,
+                                     void* stream) {
+  if (!src || !out || batch <= 0 || c <= 0 || hw <= 0 || !DT_OK(dtype)) return MOBI_ERR_ARG;
+  const unsigned g = grid_for((long long)batch * c * hw, 256, 8192);
+  if (dtype == MOBI_F16) hipLaunchKernelGGL((nchw_to_nhwc_kernel<f16_t>), dim3(g), dim3(256), 0, ST(stream), src, (f16_t*)out, batch, c, hw);
+  else hipLaunchKernelGGL((nchw_to_nhwc_kernel<bf16_t>), dim3(g), dim3(256), 0, ST(stream), src, (bf16_t*)out, batch, c, hw);
+  MOBI_CHECK_LAUNCH();
+  return MOBI_OK;
+}
+
+extern "C" int mobi_nhwc_to_nchw_f32(const void* src, float* out, int32_t batch, int32_t c, int32_t hw, int32_t dtype,
+                                     void* stream) {
+  if (!src || !out || batch <= 0 || c <= 0 || hw <= 0 || !DT_OK(dtype)) return MOBI_ERR_ARG;
+  const unsigned g = grid_for((long long)batch * c * hw, 256, 8192);
+  if (dtype == MOBI_F16) hipLaunchKernelGGL((nhwc_to_nchw_kernel<f16_t>), dim3(g), dim3(256), 0, ST(stream), (const f16_t*)src, out, batch, c, hw);
+  else hipLaunchKernelGGL((nhwc_to_nchw_kernel<bf16_t>), dim3(g), dim3(256), 0, ST(stream), (const bf16_t*)src, out, batch, c, hw);
+  MOBI_CHECK_LAUNCH();
+  return MOBI_OK;
+}

@@ -1,0 +1,130 @@
+"""DDIM sampler on the engine (reference: ldm/models/diffusion/ddim.py -- make_schedule :25-54,
+sample :57-112, ddim_sampling :115-163, p_sample_ddim :166-213).  Same call signature; the
+latent state and every coefficient stay fp32; the per-step arithmetic is one HIP kernel
+(mobi_ddim_step) and the channel concat feeding the UNet is never materialised."""
+import numpy as np
+import torch
+
+from ... import ops
+from ...modules.diffusionmodules.util import (make_ddim_sampling_parameters, make_ddim_timesteps, noise_like)
+
+
+class DDIMSampler(object):
+    def __init__(self, model, schedule="linear", **kwargs):
+        super().__init__()
+        self.model = model
+        self.ddpm_num_timesteps = model.num_timesteps
+        self.schedule = schedule
+
+    def register_buffer(self, name, attr):
+        # the reference pins buffers to "cuda" (ddim.py:19-23); follow the model's device instead
+        if isinstance(attr, torch.Tensor):
+            attr = attr.to(self.model.device)
+        setattr(self, name, attr)
+
+    def make_schedule(self, ddim_num_steps, ddim_discretize="uniform", ddim_eta=0., verbose=True):
+        self.ddim_timesteps = make_ddim_timesteps(ddim_discr_method=ddim_discretize,
+                                                  num_ddim_timesteps=ddim_num_steps,
+                                                  num_ddpm_timesteps=self.ddpm_num_timesteps, verbose=verbose)
+        alphas_cumprod = self.model.alphas_cumprod
+        assert alphas_cumprod.shape[0] == self.ddpm_num_timesteps, "alphas have to be defined for each timestep"
+        to_torch = lambda x: x.clone().detach().to(torch.float32).to(self.model.device)
+        ac = alphas_cumprod.detach().cpu()
+        self.register_buffer("betas", to_torch(self.model.betas))
+        self.register_buffer("alphas_cumprod", to_torch(alphas_cumprod))
+        self.register_buffer("alphas_cumprod_prev", to_torch(self.model.alphas_cumprod_prev))
+        self.register_buffer("sqrt_alphas_cumprod", to_torch(np.sqrt(ac)))
+        self.register_buffer("sqrt_one_minus_alphas_cumprod", to_torch(np.sqrt(1. - ac)))
+        self.register_buffer("log_one_minus_alphas_cumprod", to_torch(np.log(1. - ac)))
+        self.register_buffer("sqrt_recip_alphas_cumprod", to_torch(np.sqrt(1. / ac)))
+        self.register_buffer("sqrt_recipm1_alphas_cumprod", to_torch(np.sqrt(1. / ac - 1)))
+        sig, a, a_prev = make_ddim_sampling_parameters(alphacums=ac, ddim_timesteps=self.ddim_timesteps,
+                                                       eta=ddim_eta, verbose=verbose)
+        self.ddim_sigmas, self.ddim_alphas, self.ddim_alphas_prev = sig, a, a_prev
+        self.ddim_sqrt_one_minus_alphas = np.sqrt(np.float32(1) - a)
+
+    @torch.no_grad()
+    def sample(self, S, batch_size, shape, conditioning=None, callback=None, normals_sequence=None,
+               img_callback=None, quantize_x0=False, eta=0., mask=None, x0=None, temperature=1., noise_dropout=0.,
+               score_corrector=None, corrector_kwargs=None, verbose=True, x_T=None, log_every_t=100,
+               unconditional_guidance_scale=1., unconditional_conditioning=None, **kwargs):
+        if conditioning is not None and not isinstance(conditioning, dict) and conditioning.shape[0] != batch_size:
+            print(f"Warning: Got {conditioning.shape[0]} conditionings but batch-size is {batch_size}")
+        if quantize_x0 or score_corrector is not None or noise_dropout > 0.:
+            raise NotImplementedError("quantize_x0 / score_corrector / noise_dropout are not on MObI's path")
+        self.make_schedule(ddim_num_steps=S, ddim_eta=eta, verbose=verbose)
+        C, H, W = shape
+        return self.ddim_sampling(conditioning, (batch_size, C, H, W), callback=callback, img_callback=img_callback,
+                                  mask=mask, x0=x0, temperature=temperature, x_T=x_T, log_every_t=log_every_t,
+                                  unconditional_guidance_scale=unconditional_guidance_scale,
+                                  unconditional_conditioning=unconditional_conditioning, **kwargs)
+
+    @torch.no_grad()
+    def ddim_sampling(self, cond, shape, x_T=None, callback=None, timesteps=None, mask=None, x0=None,
+                      img_callback=None, log_every_t=100, temperature=1., unconditional_guidance_scale=1.,
+                      unconditional_conditioning=None, mask_noise=None, step_noise=None, **kwargs):
+        device = self.model.betas.device
+        b = shape[0]
+        img = torch.randn(shape, device=device) if x_T is None else x_T.to(device=device, dtype=torch.float32)
+        img = img.contiguous()
+        if timesteps is not None:
+            subset_end = int(min(timesteps / self.ddim_timesteps.shape[0], 1) * self.ddim_timesteps.shape[0]) - 1
+            steps = self.ddim_timesteps[:subset_end]
+        else:
+            steps = self.ddim_timesteps
+        intermediates = {"x_inter": [img], "pred_x0": [img]}
+        time_range = np.flip(steps)
+        total_steps = steps.shape[0]
+        for i, step in enumerate(time_range):
+            index = total_steps - i - 1
+            ts = torch.full((b,), int(step), device=device, dtype=torch.long)
+            if mask is not None:
+                assert x0 is not None
+                nz = mask_noise[i] if mask_noise is not None else torch.randn_like(x0)
+                img = ops.mask_blend_(img.clone(), x0.float().contiguous(), nz.float().contiguous(),
+                                      mask.float().contiguous(),
+                                      float(self.sqrt_alphas_cumprod[int(step)]),
+                                      float(self.sqrt_one_minus_alphas_cumprod[int(step)]))
+            nz = None
+            if float(self.ddim_sigmas[index]) != 0.0:
+                nz = step_noise[i] if step_noise is not None else noise_like(img.shape, device)
+            img, pred_x0 = self.p_sample_ddim(img, cond, ts, index=index, temperature=temperature,
+                                              unconditional_guidance_scale=unconditional_guidance_scale,
+                                              unconditional_conditioning=unconditional_conditioning,
+                                              noise=nz, **kwargs)
+            if callback:
+                callback(i)
+            if img_callback:
+                img_callback(pred_x0, i)
+            if index % log_every_t == 0 or index == total_steps - 1:
+                intermediates["x_inter"].append(img)
+                intermediates["pred_x0"].append(pred_x0)
+        return img, intermediates
+
+    def _eps(self, x, c, t, unconditional_guidance_scale, unconditional_conditioning, kwargs):
+        """Returns (e_cond, e_uncond|None): the classifier-free mix happens in mobi_ddim_step."""
+        if "test_model_kwargs" in kwargs:
+            kw = kwargs["test_model_kwargs"]
+            parts = [x, kw["inpaint_image"], kw["inpaint_mask"]]
+        elif "rest" in kwargs:
+            parts = [x, kwargs["rest"]]
+        else:
+            raise Exception("kwargs must contain either 'test_model_kwargs' or 'rest' key")
+        parts = [p.float().contiguous() for p in parts]
+        if unconditional_conditioning is None or unconditional_guidance_scale == 1.:
+            return self.model.apply_model(parts, t, c), None
+        parts2 = [torch.cat([p] * 2) for p in parts]
+        out = self.model.apply_model(parts2, torch.cat([t] * 2), torch.cat([unconditional_conditioning, c]))
+        e_uncond, e_cond = out.chunk(2)
+        return e_cond.contiguous(), e_uncond.contiguous()
+
+    @torch.no_grad()
+    def p_sample_ddim(self, x, c, t, index, temperature=1., unconditional_guidance_scale=1.,
+                      unconditional_conditioning=None, noise=None, **kwargs):
+        e_cond, e_uncond = self._eps(x, c, t, unconditional_guidance_scale, unconditional_conditioning, kwargs)
+        x_prev, pred_x0, _ = ops.ddim_step(
+            x, e_cond, e_uncond=e_uncond, noise=noise, cfg_scale=float(unconditional_guidance_scale),
+            a_t=float(self.ddim_alphas[index]), a_prev=float(self.ddim_alphas_prev[index]),
+            sigma_t=float(self.ddim_sigmas[index]),
+            sqrt_one_minus_at=float(self.ddim_sqrt_one_minus_alphas[index]), temperature=float(temperature))
+        return x_prev, pred_x0

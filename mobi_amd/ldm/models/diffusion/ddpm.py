@@ -1,0 +1,321 @@
+"""LatentDiffusion (inference subset) on the gfx950 engine.
+
+Mirrors the reference's ldm/models/diffusion/ddpm.py for everything the sampling harness
+touches (scripts/inference_test_bench.py:403-464): DDPM.register_schedule :127-179,
+q_sample :284-287, LatentDiffusion.__init__ :440-531, get_learned_conditioning :610-630,
+get_input :758-834, decode_first_stage :837-901, encode_first_stage :970-1008,
+encode_all_stages :1010-1033, apply_model :1060-1157, decode_sample :1420-1447,
+DiffusionWrapper :1682-1722.  Training (p_losses, optimizers, EMA updates, logging images)
+is out of scope.
+"""
+import warnings
+from contextlib import contextmanager
+from functools import partial
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from ... import ops
+from ...modules.diffusionmodules.util import Linear, extract_into_tensor, make_beta_schedule
+from ...modules.distributions.distributions import DiagonalGaussianDistribution
+from ...util import cat_interleave, default, instantiate_from_config, make_contiguous
+
+
+class DiffusionWrapper(nn.Module):
+    def __init__(self, diff_model_config, conditioning_key):
+        super().__init__()
+        self.diffusion_model = instantiate_from_config(diff_model_config).eval()
+        self.conditioning_key = conditioning_key
+        assert self.conditioning_key in [None, "crossattn"], "MObI uses conditioning_key: crossattn"
+
+    def forward(self, x, t, c_concat=None, c_crossattn=None):
+        if self.conditioning_key is None:
+            return self.diffusion_model(x, t)
+        cc = c_crossattn[0] if len(c_crossattn) == 1 else torch.cat(c_crossattn, 1)
+        return self.diffusion_model(x, t, context=cc)
+
+
+class DDPM(nn.Module):
+    def __init__(self, unet_config, timesteps=1000, beta_schedule="linear", loss_type="l2", ckpt_path=None,
+                 ignore_keys=[], load_only_unet=False, monitor="val/loss", use_ema=True, first_stage_key="image",
+                 image_size=256, channels=3, log_every_t=100, clip_denoised=True, linear_start=1e-4,
+                 linear_end=2e-2, cosine_s=8e-3, given_betas=None, original_elbo_weight=0., v_posterior=0.,
+                 l_simple_weight=1., conditioning_key=None, parameterization="eps", scheduler_config=None,
+                 use_positional_encodings=False, learn_logvar=False, logvar_init=0., u_cond_percent=0):
+        super().__init__()
+        assert parameterization == "eps"
+        self.parameterization = parameterization
+        self.cond_stage_model = None
+        self.clip_denoised = clip_denoised
+        self.log_every_t = log_every_t
+        self.first_stage_key = first_stage_key
+        self.image_size = image_size
+        self.channels = channels
+        self.u_cond_percent = u_cond_percent
+        self.model = DiffusionWrapper(unet_config, conditioning_key)
+        self.use_ema = use_ema
+        if use_ema:
+            raise NotImplementedError("EMA shadow weights are a training feature; MObI ships use_ema: False")
+        self.v_posterior = v_posterior
+        if monitor is not None:
+            self.monitor = monitor
+        self.register_schedule(given_betas=given_betas, beta_schedule=beta_schedule, timesteps=timesteps,
+                               linear_start=linear_start, linear_end=linear_end, cosine_s=cosine_s)
+
+    @property
+    def device(self):
+        return self.betas.device
+
+    def register_schedule(self, given_betas=None, beta_schedule="linear", timesteps=1000, linear_start=1e-4,
+                          linear_end=2e-2, cosine_s=8e-3):
+        betas = given_betas if given_betas is not None else make_beta_schedule(
+            beta_schedule, timesteps, linear_start=linear_start, linear_end=linear_end, cosine_s=cosine_s)
+        alphas = 1. - betas
+        alphas_cumprod = np.cumprod(alphas, axis=0)
+        alphas_cumprod_prev = np.append(1., alphas_cumprod[:-1])
+        self.num_timesteps = int(betas.shape[0])
+        self.linear_start, self.linear_end = linear_start, linear_end
+        f32 = partial(torch.tensor, dtype=torch.float32)
+        self.register_buffer("betas", f32(betas))
+        self.register_buffer("alphas_cumprod", f32(alphas_cumprod))
+        self.register_buffer("alphas_cumprod_prev", f32(alphas_cumprod_prev))
+        self.register_buffer("sqrt_alphas_cumprod", f32(np.sqrt(alphas_cumprod)))
+        self.register_buffer("sqrt_one_minus_alphas_cumprod", f32(np.sqrt(1. - alphas_cumprod)))
+        self.register_buffer("log_one_minus_alphas_cumprod", f32(np.log(1. - alphas_cumprod)))
+        self.register_buffer("sqrt_recip_alphas_cumprod", f32(np.sqrt(1. / alphas_cumprod)))
+        self.register_buffer("sqrt_recipm1_alphas_cumprod", f32(np.sqrt(1. / alphas_cumprod - 1)))
+        posterior_variance = (1 - self.v_posterior) * betas * (1. - alphas_cumprod_prev) / (1. - alphas_cumprod) \
+            + self.v_posterior * betas
+        self.register_buffer("posterior_variance", f32(posterior_variance))
+        self.register_buffer("posterior_log_variance_clipped", f32(np.log(np.maximum(posterior_variance, 1e-20))))
+        self.register_buffer("posterior_mean_coef1", f32(betas * np.sqrt(alphas_cumprod_prev) / (1. - alphas_cumprod)))
+        self.register_buffer("posterior_mean_coef2",
+                             f32((1. - alphas_cumprod_prev) * np.sqrt(alphas) / (1. - alphas_cumprod)))
+
+    @contextmanager
+    def ema_scope(self, context=None):
+        yield None          # use_ema is False in every MObI config (mobi_nusc_512.yaml:47)
+
+    def q_sample(self, x_start, t, noise=None):
+        """sqrt(ac[t]) * x0 + sqrt(1 - ac[t]) * noise; a per-batch-uniform t (the samplers' case)
+        runs as one kernel, a ragged t per image."""
+        noise = default(noise, lambda: torch.randn_like(x_start))
+        x_start = x_start.float().contiguous()
+        out = torch.empty_like(x_start)
+        sa = extract_into_tensor(self.sqrt_alphas_cumprod, t, (t.shape[0],)).tolist()
+        s1 = extract_into_tensor(self.sqrt_one_minus_alphas_cumprod, t, (t.shape[0],)).tolist()
+        for i in range(x_start.shape[0]):
+            out[i] = ops.lincomb4([x_start[i].contiguous(), noise[i].float().contiguous()], [sa[i], s1[i]])
+        return out
+
+    def get_input(self, batch, k):
+        return make_contiguous(batch["image"]), make_contiguous(batch["lidar"])
+
+
+class LatentDiffusion(DDPM):
+    def __init__(self, cond_stage_config, first_stage_config=None, lidar_stage_config=None, num_timesteps_cond=None,
+                 cond_stage_key="image", cond_stage_trainable=False, concat_mode=True, cond_stage_forward=None,
+                 conditioning_key=None, scale_factor=1.0, lidar_scale_factor=1.0, scale_by_std=False,
+                 use_camera=True, use_lidar=False, range_object_norm=False, range_object_norm_scale=0.75,
+                 range_int_norm=False, *args, **kwargs):
+        self.num_timesteps_cond = default(num_timesteps_cond, 1)
+        assert self.num_timesteps_cond == 1 and not scale_by_std
+        self.range_object_norm, self.range_object_norm_scale = range_object_norm, range_object_norm_scale
+        self.range_int_norm = range_int_norm
+        if conditioning_key is None:
+            conditioning_key = "concat" if concat_mode else "crossattn"
+        ckpt_path = kwargs.pop("ckpt_path", None)
+        ignore_keys = kwargs.pop("ignore_keys", [])
+        super().__init__(conditioning_key=conditioning_key, *args, **kwargs)
+        self.learnable_vector = nn.Parameter(torch.randn((1, 1, 768)), requires_grad=False)
+        self.bbox_uncond_vector = nn.Parameter(torch.randn((1, 1, 768)), requires_grad=False)
+        self.proj_out = Linear(1024, 768)
+        self.concat_mode = concat_mode
+        self.cond_stage_trainable = cond_stage_trainable
+        self.cond_stage_key = cond_stage_key
+        self.scale_factor, self.lidar_scale_factor = scale_factor, lidar_scale_factor
+        self.use_camera, self.use_lidar = use_camera, use_lidar
+        if not use_camera and first_stage_config is not None:
+            warnings.warn("No camera input, but first_stage_config is not None. Setting first_stage_config to None.")
+            first_stage_config = None
+        if not use_lidar and lidar_stage_config is not None:
+            warnings.warn("No lidar input, but lidar_stage_config is not None. Setting lidar_stage_config to None.")
+            lidar_stage_config = None
+        self.first_stage_model = self._frozen(first_stage_config)
+        self.cond_stage_model = None if cond_stage_config in (None, "__is_unconditional__") \
+            else self._frozen(cond_stage_config)
+        self.lidar_stage_model = self._frozen(lidar_stage_config)
+        self.cond_stage_forward = cond_stage_forward
+        self.clip_denoised = False
+        if ckpt_path is not None:
+            sd = torch.load(ckpt_path, map_location="cpu")
+            self.load_state_dict(sd.get("state_dict", sd), strict=False)
+
+    @staticmethod
+    def _frozen(config):
+        if config is None:
+            return None
+        model = instantiate_from_config(config).eval()
+        model.requires_grad_(False)
+        return model
+
+    # ---- conditioning -----------------------------------------------------------------
+    def get_learned_conditioning(self, c):
+        c = self.cond_stage_model.encode(c) if hasattr(self.cond_stage_model, "encode") else self.cond_stage_model(c)
+        w, b = self.proj_out.skinny()
+        tok = c["ref_image_token"].float()
+        n, one, d = tok.shape
+        c["ref_image_token"] = ops.skinny_linear(tok.reshape(n * one, d).contiguous(), w, b).reshape(n, one, -1)
+        cond = []
+        if "ref_image" in self.cond_stage_key:
+            cond.append(c["ref_image_token"])
+        if "ref_bbox" in self.cond_stage_key:
+            cond.append(c["ref_bbox_token"].float())
+        return torch.cat(cond, dim=1)
+
+    def process_conditioning(self, cond_data, force_c_encode=False):
+        xc = {k: cond_data[k] for k in self.cond_stage_key}
+        c = self.get_learned_conditioning(xc) if (not self.cond_stage_trainable or force_c_encode) else xc
+        return c, xc
+
+    # ---- first stage --------------------------------------------------------------------
+    @torch.no_grad()
+    def encode_first_stage(self, x, module_name="first_stage_model"):
+        return getattr(self, module_name).encode(x)
+
+    def get_first_stage_encoding(self, encoder_posterior, scale_factor=1):
+        if isinstance(encoder_posterior, DiagonalGaussianDistribution):
+            return encoder_posterior.sample(scale=scale_factor)
+        if isinstance(encoder_posterior, torch.Tensor):
+            return scale_factor * encoder_posterior
+        raise NotImplementedError(type(encoder_posterior))
+
+    def _encode_modality(self, module_name, gt, inpaint, mask, scale, noises=None):
+        """One branch of encode_all_stages (ddpm.py:1013-1021): the two posterior samples and the
+        nearest-resized mask are written straight into the 9-channel tensor (no torch.cat)."""
+        post = self.encode_first_stage(gt, module_name)
+        b, c2, h, w = post.parameters.shape
+        z = torch.empty((b, c2 + 1, h, w), device=gt.device, dtype=torch.float32)
+        n0, n1 = noises if noises is not None else (None, None)
+        post.sample(noise=n0, scale=scale, out=z, c_off=0)
+        self.encode_first_stage(inpaint, module_name).sample(noise=n1, scale=scale, out=z, c_off=c2 // 2)
+        ops.nearest_resize(mask.float().contiguous(), w, w, out=z, c_off=c2)      # size = z.shape[-1] (:1020)
+        return z
+
+    def encode_all_stages(self, image_gt, image_inpaint, image_mask, range_gt, range_inpaint, range_mask,
+                          noises=None):
+        """`noises`: optional dict {cam_gt, cam_inpaint, lidar_gt, lidar_inpaint} for parity runs; otherwise
+        drawn from the CPU generator in the reference's order (distributions.py:36)."""
+        nz = noises or {}
+        z_image = z_lidar = None
+        if self.use_camera:
+            z_image = self._encode_modality("first_stage_model", image_gt, image_inpaint, image_mask,
+                                            self.scale_factor,
+                                            (nz.get("cam_gt"), nz.get("cam_inpaint")) if noises else None)
+        if self.use_lidar:
+            z_lidar = self._encode_modality("lidar_stage_model", range_gt, range_inpaint, range_mask,
+                                            self.lidar_scale_factor,
+                                            (nz.get("lidar_gt"), nz.get("lidar_inpaint")) if noises else None)
+        return z_image, z_lidar
+
+    @torch.no_grad()
+    def decode_first_stage(self, z, predict_cids=False, force_not_quantize=False, module_name="first_stage_model",
+                           clamp=None):
+        assert module_name in ["first_stage_model", "lidar_stage_model"]
+        module = getattr(self, module_name)
+        scale = self.scale_factor if module_name == "first_stage_model" else self.lidar_scale_factor
+        z = ops.lincomb4([z.float().contiguous()], [1. / scale])
+        if self.first_stage_key == "inpaint":
+            z = z[:, :4, :, :].contiguous()
+        return module.decode(z, clamp=clamp)
+
+    # ---- harness entry points ---------------------------------------------------------------
+    @torch.no_grad()
+    def get_input(self, batch, k, force_c_encode=False, bs=None, return_vae_rec=False, noises=None):
+        image_data, lidar_data = super().get_input(batch, k)
+
+        def first(x, n):
+            if isinstance(x, dict):
+                return {kk: first(v, n) for kk, v in x.items()}
+            return x[:n] if isinstance(x, torch.Tensor) else None
+
+        if bs is not None:
+            image_data, lidar_data = first(image_data, bs), first(lidar_data, bs)
+        z_image, z_lidar = self.encode_all_stages(
+            image_gt=image_data.get("GT"), image_inpaint=image_data.get("inpaint_image"),
+            image_mask=image_data.get("inpaint_mask"), range_gt=lidar_data.get("range_data"),
+            range_inpaint=lidar_data.get("range_data_inpaint"), range_mask=lidar_data.get("range_mask"),
+            noises=noises)
+        out = {"z": [], "cond": []}
+        if self.use_camera:
+            out["z"].append(z_image)
+            c, _ = self.process_conditioning(image_data["cond"], force_c_encode=force_c_encode)
+            out["cond"].append(c)
+            if return_vae_rec:
+                out["image_rec"] = self.decode_first_stage(z_image[:, :4, ...], clamp=(-1., 1.))
+        if self.use_lidar:
+            if z_lidar.shape[-1] != self.image_size:
+                warnings.warn("Cropping lidar feature map to match image latent size.")
+            W = z_lidar.shape[-1]
+            left, right = W // 2 - self.image_size // 2, W // 2 + self.image_size // 2
+            pad = (self.image_size - z_lidar.shape[-2]) // 2
+            out["z"].append(F.pad(z_lidar[..., left:right], (0, 0, pad, pad), mode="constant", value=0))
+            bbox = lidar_data["cond"]["ref_bbox"]                       # edited in place, as the reference does
+            bbox[..., 0] = (bbox[..., 0] * W - left) / self.image_size
+            bbox[..., 1] += pad / self.image_size
+            c, _ = self.process_conditioning(lidar_data["cond"], force_c_encode=force_c_encode)
+            out["cond"].append(c)
+            out["z_lidar"] = z_lidar[:, :4, ...]
+            if return_vae_rec:
+                out["lidar_rec"] = self.decode_first_stage(z_lidar[:, :4, ...], module_name="lidar_stage_model",
+                                                           clamp=(-1., 1.))
+        out["z"] = cat_interleave(out["z"])
+        if force_c_encode:
+            out["cond"] = cat_interleave(out["cond"])
+        else:
+            out["cond"] = {kk: cat_interleave([d[kk] for d in out["cond"]]) for kk in self.cond_stage_key}
+        return out
+
+    def apply_model(self, x_noisy, t, cond, return_ids=False):
+        """x_noisy: fp32 [N, 9, h, w] or the un-concatenated list [x, inpaint_image, inpaint_mask]."""
+        if not isinstance(cond, dict):
+            if not isinstance(cond, list):
+                cond = [cond]
+            cond = {"c_crossattn": cond}
+        return self.model(x_noisy, t, **cond)
+
+    @torch.no_grad()
+    def decode_sample(self, sample, z_lidar=None):
+        h_camera = h_lidar = None
+        if self.use_camera and self.use_lidar:
+            h_camera = sample[::2]
+            lid = sample[1::2]
+            bottom = (lid.shape[-2] - z_lidar.shape[-2]) // 2
+            h_lidar = lid[:, :, bottom:bottom + z_lidar.shape[-2], :]
+            if self.image_size != z_lidar.shape[-1]:
+                c = z_lidar.shape[-1] // 2
+                z_lidar[..., c - self.image_size // 2: c + self.image_size // 2] = h_lidar
+                h_lidar = z_lidar
+        elif self.use_camera:
+            h_camera = sample
+        else:
+            bottom = (sample[1::2].shape[-2] - z_lidar.shape[-2]) // 2
+            h_lidar = sample[:, :, bottom:bottom + z_lidar.shape[-2], :]
+            if self.image_size != z_lidar.shape[-1]:
+                c = z_lidar.shape[-1] // 2
+                z_lidar[..., c - self.image_size // 2: c + self.image_size // 2] = h_lidar
+                h_lidar = z_lidar
+        return h_camera, h_lidar
+
+    @torch.no_grad()
+    def log_data(self, batch, data, h_camera, h_lidar, log_metrics=False, return_sample=True, split="val"):
+        """Decode + clamp of ddpm.py:1475-1476,1503-1504.  The cv2 / matplotlib visualisation and the
+        per-sample lidar error metrics (ddpm.py:1478-1612) stay with the harness."""
+        log = {}
+        if self.use_camera:
+            log["image_sample"] = self.decode_first_stage(h_camera, clamp=(-1., 1.))
+        if self.use_lidar:
+            log["lidar_sample"] = self.decode_first_stage(h_lidar, module_name="lidar_stage_model", clamp=(-1., 1.))
+        return log, {}

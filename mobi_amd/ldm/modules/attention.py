@@ -1,0 +1,221 @@
+"""SpatialTransformer / BasicTransformerBlock / CrossAttention / FeedForward on the engine.
+
+Same class names, constructor kwargs and `state_dict` keys as the reference's
+ldm/modules/attention.py (CrossAttention :153-194, BasicTransformerBlock :197-266,
+SpatialTransformer :269-313, FeedForward/GEGLU :38-65); tokens are `[N, T, C]`
+engine tensors, which is the same memory as the channels-last feature map, so the
+reference's rearranges (:307,:310) disappear.
+
+Launch sequence of one transformer block (all HIP, include/mobi_engine.h):
+  attn1      layernorm -> igemm [to_q;to_k] -> igemm to_v (transposed) -> attention
+             -> igemm to_out (+ residual, + attn2 vector)
+  attn2      one key => softmax == 1: to_out(to_v(ref token)) is a per-image vector,
+             two skinny_linear calls, added in attn1's epilogue (exact)
+  adapter    layernorm -> igemm to_q -> skinny k/v -> ctx_attention -> igemm to_out
+             -> igemm connector (+ residual)
+  cross-modal (camera then lidar, in place on the interleaved batch)
+             layernorm(x[::2]) -> igemm to_q ; igemm to_k / to_v(T) on x[1::2] -> attention
+             -> igemm to_out -> igemm connector (+ residual, written back into x[::2]); then
+             the lidar half against the UPDATED camera half (attention.py:257-261)
+  ff         layernorm -> igemm GEGLU -> igemm (+ residual)
+"""
+import torch
+import torch.nn as nn
+
+from ... import ops
+from ..._lib import ACT_NONE, OUT_TRANSPOSED
+from .diffusionmodules.util import Conv2d, GroupNorm32, LayerNorm, Linear, Marker, enter, leave, zero_module
+
+
+def Normalize(in_channels):
+    return GroupNorm32(32, in_channels, eps=1e-6)
+
+
+class GEGLU(nn.Module):
+    def __init__(self, dim_in, dim_out):
+        super().__init__()
+        self.proj = Linear(dim_in, dim_out * 2)
+
+    def forward(self, x):
+        return ops.linear(x, self.proj.packed_geglu())
+
+
+class FeedForward(nn.Module):
+    def __init__(self, dim, dim_out=None, mult=4, glu=False, dropout=0.):
+        super().__init__()
+        if not glu:
+            raise NotImplementedError("MObI's transformer blocks use gated_ff=True")
+        inner_dim = int(dim * mult)
+        dim_out = dim if dim_out is None else dim_out
+        self.net = nn.Sequential(GEGLU(dim, inner_dim), Marker(), Linear(inner_dim, dim_out))
+
+    def forward(self, x, residual=None):
+        return ops.linear(self.net[0](x), self.net[2].packed(), residual=residual)
+
+
+class CrossAttention(nn.Module):
+    def __init__(self, query_dim, context_dim=None, heads=8, dim_head=64, dropout=0.):
+        super().__init__()
+        inner_dim = dim_head * heads
+        context_dim = query_dim if context_dim is None else context_dim
+        self.scale = dim_head ** -0.5
+        self.heads = heads
+        self.inner_dim = inner_dim
+        self.to_q = Linear(query_dim, inner_dim, bias=False)
+        self.to_k = Linear(context_dim, inner_dim, bias=False)
+        self.to_v = Linear(context_dim, inner_dim, bias=False)
+        self.to_out = nn.Sequential(Linear(inner_dim, query_dim), Marker())
+
+    # -- packed projections ---------------------------------------------------------------
+    def _qk_packed(self):
+        def build():
+            w = torch.cat([self.to_q.weight.detach(), self.to_k.weight.detach()], dim=0)
+            return ops.pack_linear(w, None, self.to_q.packed().w.dtype, w.device)
+        key = ("qk", self.to_q.weight._version, self.to_k.weight._version, self.to_q.weight.data_ptr(),
+               self.to_q.packed().w.dtype)
+        c = self.__dict__.setdefault("_qk_cache", {})
+        if c.get("key") != key:
+            c["key"], c["val"] = key, build()
+        return c["val"]
+
+    # -- forms of attention ------------------------------------------------------------------
+    def self_attention(self, xn):
+        """xn: normed tokens [N,T,C] -> attention output before to_out."""
+        c = self.inner_dim
+        qk = ops.linear(xn, self._qk_packed())
+        vt = ops.linear(xn, self.to_v.packed(), out_mode=OUT_TRANSPOSED)
+        return ops.attention(qk[..., :c], qk[..., c:], vt, self.heads, self.scale)
+
+    def token_attention(self, xn, ctx):
+        """Many queries against another token stream `ctx` [N,Tk,Cc] (engine tensor, may be a
+        batch-strided view)."""
+        q = ops.linear(xn, self.to_q.packed())
+        k = ops.linear(ctx, self.to_k.packed())
+        vt = ops.linear(ctx, self.to_v.packed(), out_mode=OUT_TRANSPOSED)
+        return ops.attention(q, k, vt, self.heads, self.scale)
+
+    def context_kv(self, context):
+        """fp32 context [N,tk,Cc] -> (k, v) fp32 [N,tk,C]."""
+        n, tk, cc = context.shape
+        flat = context.reshape(n * tk, cc)
+        wk, _ = self.to_k.skinny()
+        wv, _ = self.to_v.skinny()
+        k = ops.skinny_linear(flat, wk).reshape(n, tk, self.inner_dim)
+        v = ops.skinny_linear(flat, wv).reshape(n, tk, self.inner_dim)
+        return k, v
+
+    def few_token_attention(self, xn, context):
+        """Queries against <= 8 fp32 context tokens."""
+        q = ops.linear(xn, self.to_q.packed())
+        k, v = self.context_kv(context)
+        return ops.ctx_attention(q, k, v, self.heads, self.scale)
+
+    def single_token_vector(self, token):
+        """One key => softmax == 1 => the output is to_out(to_v(token)) for every query.
+        token: fp32 [N, Cc] (row stride free) -> fp32 [N, query_dim]."""
+        wv, _ = self.to_v.skinny()
+        wo, bo = self.to_out[0].skinny()
+        return ops.skinny_linear(ops.skinny_linear(token, wv), wo, bo)
+
+    def forward(self, x, context=None, mask=None):
+        """Reference-compatible call (attention.py:171-194); x: engine tokens [N,T,C];
+        context: None (self-attention), fp32 [N,tk<=8,Cc], or engine tokens."""
+        if mask is not None:
+            raise NotImplementedError("attention masks are not used on MObI's path")
+        if context is None:
+            a = self.self_attention(x)
+        elif context.dtype == torch.float32:
+            if context.shape[1] > 8:
+                raise NotImplementedError("fp32 contexts with more than 8 tokens")
+            a = self.few_token_attention(x, context.contiguous())
+        else:
+            a = self.token_attention(x, context)
+        return ops.linear(a, self.to_out[0].packed())
+
+
+class BasicTransformerBlock(nn.Module):
+    def __init__(self, dim, n_heads, d_head, dropout=0., context_dim=None, gated_ff=True, checkpoint=False,
+                 bbox_cond=False, multimodal=False):
+        super().__init__()
+        self.bbox_cond = bbox_cond
+        self.multimodal = multimodal
+        self.attn1 = CrossAttention(query_dim=dim, heads=n_heads, dim_head=d_head, dropout=dropout)
+        self.ff = FeedForward(dim, dropout=dropout, glu=gated_ff)
+        self.attn2 = CrossAttention(query_dim=dim, context_dim=context_dim, heads=n_heads, dim_head=d_head,
+                                    dropout=dropout)
+        if bbox_cond:
+            self.cond_adapter_attn = CrossAttention(query_dim=dim, context_dim=context_dim, heads=n_heads,
+                                                    dim_head=d_head, dropout=dropout)
+        if multimodal:
+            self.cross_modal_attn_camera = CrossAttention(query_dim=dim, context_dim=dim, heads=n_heads,
+                                                          dim_head=d_head, dropout=dropout)
+            self.cross_modal_attn_lidar = CrossAttention(query_dim=dim, context_dim=dim, heads=n_heads,
+                                                         dim_head=d_head, dropout=dropout)
+        self.norm1 = LayerNorm(dim)
+        self.norm2 = LayerNorm(dim)
+        self.norm3 = LayerNorm(dim)
+        if bbox_cond:
+            self.cond_adapter_norm = LayerNorm(dim)
+            self.cond_adapter_connector = zero_module(Linear(dim, dim))
+        if multimodal:
+            self.cross_modal_norm_camera = LayerNorm(dim)
+            self.cross_modal_connector_camera = zero_module(Linear(dim, dim))
+            self.cross_modal_norm_lidar = LayerNorm(dim)
+            self.cross_modal_connector_lidar = zero_module(Linear(dim, dim))
+        self.checkpoint = checkpoint
+
+    @staticmethod
+    def _ln(norm, x):
+        g, b = norm.affine()
+        return ops.layernorm(x, g, b, norm.eps)
+
+    def forward(self, x, context=None):
+        return self._forward(x, context)
+
+    def _forward(self, x, context=None):
+        """x: engine tokens [N,T,C]; context: fp32 [N, n_ctx, context_dim]."""
+        ctx = context.float().contiguous()
+        # attn1 (self) + attn2 (reference token; norm2 / to_q cancel out of a one-key softmax)
+        a = self.attn1.self_attention(self._ln(self.norm1, x))
+        ref_vec = self.attn2.single_token_vector(ctx[:, 0])
+        x = ops.linear(a, self.attn1.to_out[0].packed(), residual=x, rowvec=ref_vec)
+
+        if self.bbox_cond:
+            a = self.cond_adapter_attn(self._ln(self.cond_adapter_norm, x), context=ctx)
+            x = ops.linear(a, self.cond_adapter_connector.packed(), residual=x)
+
+        if self.multimodal:
+            if x.shape[0] % 2:
+                raise ValueError("multimodal blocks need camera/lidar samples interleaved on an even batch")
+            xc, xl = x[::2], x[1::2]
+            a = self.cross_modal_attn_camera(self._ln(self.cross_modal_norm_camera, xc), context=xl)
+            ops.linear(a, self.cross_modal_connector_camera.packed(), residual=xc, out=xc)
+            a = self.cross_modal_attn_lidar(self._ln(self.cross_modal_norm_lidar, xl), context=xc)
+            ops.linear(a, self.cross_modal_connector_lidar.packed(), residual=xl, out=xl)
+
+        return self.ff(self._ln(self.norm3, x), residual=x)
+
+
+class SpatialTransformer(nn.Module):
+    def __init__(self, in_channels, n_heads, d_head, depth=1, dropout=0., context_dim=None, bbox_cond=False,
+                 multimodal=False):
+        super().__init__()
+        self.in_channels = in_channels
+        inner_dim = n_heads * d_head
+        self.norm = Normalize(in_channels)
+        self.proj_in = Conv2d(in_channels, inner_dim, kernel_size=1, stride=1, padding=0)
+        self.transformer_blocks = nn.ModuleList(
+            [BasicTransformerBlock(inner_dim, n_heads, d_head, dropout=dropout, context_dim=context_dim,
+                                   bbox_cond=bbox_cond, multimodal=multimodal) for _ in range(depth)])
+        self.proj_out = zero_module(Conv2d(inner_dim, in_channels, kernel_size=1, stride=1, padding=0))
+
+    def forward(self, x, context=None):
+        x, ext = enter(x)
+        n, h, w, c = x.shape
+        g, b = self.norm.affine()
+        t = ops.igemm(ops.groupnorm(x, g, b, self.norm.eps, silu=False), self.proj_in.packed())
+        t = t.view(n, h * w, t.shape[3])
+        for block in self.transformer_blocks:
+            t = block(t, context=context)
+        y = ops.igemm(t.view(n, h, w, t.shape[2]), self.proj_out.packed(), residual=x)
+        return leave(y, ext)

@@ -1,0 +1,226 @@
+"""VAE Encoder / Decoder (incl. MObI's lidar adapter) on the gfx950 engine.
+
+Names and `state_dict` keys follow the reference's
+ldm/modules/diffusionmodules/model.py: Normalize :38, Upsample :42-57, Downsample
+:60-79, ResnetBlock :82-141, AttnBlock :151-202, Encoder :368-489, Decoder :492-630.
+Only what MObI's configs instantiate is built (attn_resolutions [], vanilla
+mid attention, conv resampling, temb_channels 0).
+"""
+import torch
+import torch.nn as nn
+
+from .... import engine_dtype, ops
+from ...._lib import OUT_ROWS_F32, OUT_TRANSPOSED
+from .util import Conv2d, GroupNorm32, enter, leave
+
+
+def Normalize(in_channels, num_groups=32):
+    return GroupNorm32(num_groups, in_channels, eps=1e-6)
+
+
+def _gn_swish(norm, x, silu=True):
+    g, b = norm.affine()
+    return ops.groupnorm(x, g, b, norm.eps, silu=silu)
+
+
+class Upsample(nn.Module):
+    def __init__(self, in_channels, with_conv):
+        super().__init__()
+        assert with_conv
+        self.conv = Conv2d(in_channels, in_channels, kernel_size=3, stride=1, padding=1)
+
+    def forward(self, x):
+        return ops.igemm(x, self.conv.packed(), upsample=True, pad=(1, 1))      # nearest x2 folded into the gather
+
+
+class Downsample(nn.Module):
+    def __init__(self, in_channels, with_conv):
+        super().__init__()
+        assert with_conv
+        self.conv = Conv2d(in_channels, in_channels, kernel_size=3, stride=2, padding=0)
+
+    def forward(self, x):
+        # F.pad(x, (0,1,0,1)) + stride-2 conv (model.py:72-76): zero rows/cols past the bottom/right
+        # edge come from the gather's bounds check, no padded copy
+        n, h, w, c = x.shape
+        return ops.igemm(x, self.conv.packed(), stride=2, pad=(0, 0), hout=(h + 1 - 3) // 2 + 1,
+                         wout=(w + 1 - 3) // 2 + 1)
+
+
+class ResnetBlock(nn.Module):
+    def __init__(self, *, in_channels, out_channels=None, conv_shortcut=False, dropout=0.0, temb_channels=512,
+                 kernel_size=3, padding=1):
+        super().__init__()
+        assert temb_channels == 0 and not conv_shortcut, "MObI's VAEs use temb_ch=0, nin shortcuts"
+        out_channels = in_channels if out_channels is None else out_channels
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.norm1 = Normalize(in_channels)
+        self.conv1 = Conv2d(in_channels, out_channels, kernel_size=kernel_size, stride=1, padding=padding)
+        self.norm2 = Normalize(out_channels)
+        self.conv2 = Conv2d(out_channels, out_channels, kernel_size=kernel_size, stride=1, padding=padding)
+        if in_channels != out_channels:
+            self.nin_shortcut = Conv2d(in_channels, out_channels, kernel_size=1, stride=1, padding=0)
+
+    def forward(self, x, temb=None):
+        x, ext = enter(x)
+        h = ops.igemm(_gn_swish(self.norm1, x), self.conv1.packed(), pad=self.conv1.padding)
+        h = _gn_swish(self.norm2, h)
+        xs = ops.igemm(x, self.nin_shortcut.packed()) if self.in_channels != self.out_channels else x
+        return leave(ops.igemm(h, self.conv2.packed(), pad=self.conv2.padding, residual=xs), ext)
+
+
+class AttnBlock(nn.Module):
+    """Single-head attention over all h*w positions (model.py:178-202).  c = 512 does not fit the
+    fused kernel's register budget, so it runs as matrix-core GEMMs with the scores in fp32:
+    S = q k^T / sqrt(c) (per-image weights = k), row softmax, O = P v (weights = v^T)."""
+
+    def __init__(self, in_channels):
+        super().__init__()
+        self.in_channels = in_channels
+        self.norm = Normalize(in_channels)
+        self.q = Conv2d(in_channels, in_channels, kernel_size=1)
+        self.k = Conv2d(in_channels, in_channels, kernel_size=1)
+        self.v = Conv2d(in_channels, in_channels, kernel_size=1)
+        self.proj_out = Conv2d(in_channels, in_channels, kernel_size=1)
+
+    def forward(self, x):
+        x, ext = enter(x)
+        n, h, w, c = x.shape
+        t = h * w
+        hn = _gn_swish(self.norm, x, silu=False)
+        q = ops.igemm(hn, self.q.packed()).view(n, t, 1, c)
+        k = ops.igemm(hn, self.k.packed()).view(n, t, c)
+        vt = ops.igemm(hn, self.v.packed(), out_mode=OUT_TRANSPOSED)                      # [n, c, t]
+        kw = ops.Packed(k, None, 1, 1, c, t, t)
+        s = ops.igemm(q, kw, weight_per_image=True, w_group_stride=t * c, out_mode=OUT_ROWS_F32,
+                      scale=float(int(c) ** (-0.5)))                                      # [n, t, 1, t] fp32
+        p = ops.softmax_rows(s.view(n * t, t), x.dtype).view(n, t, 1, t)
+        vw = ops.Packed(vt, None, 1, 1, t, c, c)
+        o = ops.igemm(p, vw, weight_per_image=True, w_group_stride=c * t).view(n, h, w, c)
+        return leave(ops.igemm(o, self.proj_out.packed(), residual=x), ext)
+
+
+def make_attn(in_channels, attn_type="vanilla"):
+    assert attn_type == "vanilla"
+    return AttnBlock(in_channels)
+
+
+class Encoder(nn.Module):
+    def __init__(self, *, ch, out_ch, ch_mult=(1, 2, 4, 8), num_res_blocks, attn_resolutions, lidar_adapter=False,
+                 dropout=0.0, resamp_with_conv=True, in_channels, resolution, z_channels, double_z=True,
+                 use_linear_attn=False, attn_type="vanilla", **ignore_kwargs):
+        super().__init__()
+        assert not use_linear_attn and len(attn_resolutions) == 0
+        self.ch, self.temb_ch = ch, 0
+        self.num_resolutions, self.num_res_blocks = len(ch_mult), num_res_blocks
+        self.resolution, self.in_channels, self.lidar_adapter = resolution, in_channels, lidar_adapter
+        if lidar_adapter:
+            self.conv_in_lidar = Conv2d(in_channels, ch, kernel_size=(1, 5), stride=1, padding=(0, 2))
+            self.res_block_lidar1 = ResnetBlock(in_channels=ch, out_channels=ch, temb_channels=0,
+                                                kernel_size=(1, 5), padding=(0, 2), dropout=dropout)
+            self.res_block_lidar2 = ResnetBlock(in_channels=ch, out_channels=ch, temb_channels=0,
+                                                kernel_size=(1, 5), padding=(0, 2), dropout=dropout)
+        else:
+            self.conv_in = Conv2d(in_channels, ch, kernel_size=3, stride=1, padding=1)
+        in_ch_mult = (1,) + tuple(ch_mult)
+        self.down = nn.ModuleList()
+        block_in = ch
+        for i_level in range(self.num_resolutions):
+            block, attn = nn.ModuleList(), nn.ModuleList()
+            block_in, block_out = ch * in_ch_mult[i_level], ch * ch_mult[i_level]
+            for _ in range(num_res_blocks):
+                block.append(ResnetBlock(in_channels=block_in, out_channels=block_out, temb_channels=0,
+                                         dropout=dropout))
+                block_in = block_out
+            down = nn.Module()
+            down.block, down.attn = block, attn
+            if i_level != self.num_resolutions - 1:
+                down.downsample = Downsample(block_in, resamp_with_conv)
+            self.down.append(down)
+        self.mid = nn.Module()
+        self.mid.block_1 = ResnetBlock(in_channels=block_in, out_channels=block_in, temb_channels=0, dropout=dropout)
+        self.mid.attn_1 = make_attn(block_in, attn_type=attn_type)
+        self.mid.block_2 = ResnetBlock(in_channels=block_in, out_channels=block_in, temb_channels=0, dropout=dropout)
+        self.norm_out = Normalize(block_in)
+        self.conv_out = Conv2d(block_in, 2 * z_channels if double_z else z_channels, kernel_size=3, stride=1,
+                               padding=1)
+
+    def forward(self, x):
+        """x: fp32 NCHW image / range view -> fp32 NCHW [B, 2*z, h, w]."""
+        cin = self.conv_in_lidar if self.lidar_adapter else self.conv_in
+        w, b = cin.packed_f32()
+        h = ops.conv_small_cin([x.float().contiguous()], w, b, cin.kernel_size[0], cin.kernel_size[1], cin.padding,
+                               engine_dtype())
+        if self.lidar_adapter:
+            h = self.res_block_lidar2(self.res_block_lidar1(h))
+        for i_level in range(self.num_resolutions):
+            for i_block in range(self.num_res_blocks):
+                h = self.down[i_level].block[i_block](h)
+            if i_level != self.num_resolutions - 1:
+                h = self.down[i_level].downsample(h)
+        h = self.mid.block_2(self.mid.attn_1(self.mid.block_1(h)))
+        h = _gn_swish(self.norm_out, h)
+        return ops.conv_small_cout(h, self.conv_out.packed(), pad=self.conv_out.padding)
+
+
+class Decoder(nn.Module):
+    def __init__(self, *, ch, out_ch, ch_mult=(1, 2, 4, 8), num_res_blocks, attn_resolutions, lidar_adapter=False,
+                 dropout=0.0, resamp_with_conv=True, in_channels, resolution, z_channels, give_pre_end=False,
+                 tanh_out=False, use_linear_attn=False, attn_type="vanilla", **ignorekwargs):
+        super().__init__()
+        assert not use_linear_attn and len(attn_resolutions) == 0 and not give_pre_end and not tanh_out
+        self.ch, self.temb_ch = ch, 0
+        self.num_resolutions, self.num_res_blocks = len(ch_mult), num_res_blocks
+        self.resolution, self.in_channels, self.lidar_adapter = resolution, in_channels, lidar_adapter
+        block_in = ch * ch_mult[self.num_resolutions - 1]
+        curr_res = resolution // 2 ** (self.num_resolutions - 1)
+        self.z_shape = (1, z_channels, curr_res, curr_res)
+        self.conv_in = Conv2d(z_channels, block_in, kernel_size=3, stride=1, padding=1)
+        self.mid = nn.Module()
+        self.mid.block_1 = ResnetBlock(in_channels=block_in, out_channels=block_in, temb_channels=0, dropout=dropout)
+        self.mid.attn_1 = make_attn(block_in, attn_type=attn_type)
+        self.mid.block_2 = ResnetBlock(in_channels=block_in, out_channels=block_in, temb_channels=0, dropout=dropout)
+        self.up = nn.ModuleList()
+        for i_level in reversed(range(self.num_resolutions)):
+            block, attn = nn.ModuleList(), nn.ModuleList()
+            block_out = ch * ch_mult[i_level]
+            for _ in range(num_res_blocks + 1):
+                block.append(ResnetBlock(in_channels=block_in, out_channels=block_out, temb_channels=0,
+                                         dropout=dropout))
+                block_in = block_out
+            up = nn.Module()
+            up.block, up.attn = block, attn
+            if i_level != 0:
+                up.upsample = Upsample(block_in, resamp_with_conv)
+            self.up.insert(0, up)
+        if lidar_adapter:
+            self.res_block_lidar1 = ResnetBlock(in_channels=block_in, out_channels=block_in, temb_channels=0,
+                                                kernel_size=(1, 5), padding=(0, 2), dropout=dropout)
+            self.norm_out_lidar1 = Normalize(block_in)
+            self.res_block_lidar2 = ResnetBlock(in_channels=block_in, out_channels=block_in, temb_channels=0,
+                                                kernel_size=(1, 5), padding=(0, 2), dropout=dropout)
+            self.norm_out_lidar2 = Normalize(block_in)
+            self.conv_out_lidar = Conv2d(block_in, out_ch, kernel_size=(1, 5), stride=1, padding=(0, 2))
+        else:
+            self.norm_out = Normalize(block_in)
+            self.conv_out = Conv2d(block_in, out_ch, kernel_size=3, stride=1, padding=1)
+
+    def forward(self, z, clamp=None):
+        """z: fp32 NCHW latent -> fp32 NCHW image; `clamp=(lo, hi)` fuses the torch.clamp the
+        harness applies to every decode (ddpm.py:1476,1504)."""
+        w, b = self.conv_in.packed_f32()
+        h = ops.conv_small_cin([z.float().contiguous()], w, b, 3, 3, (1, 1), engine_dtype())
+        h = self.mid.block_2(self.mid.attn_1(self.mid.block_1(h)))
+        for i_level in reversed(range(self.num_resolutions)):
+            for i_block in range(self.num_res_blocks + 1):
+                h = self.up[i_level].block[i_block](h)
+            if i_level != 0:
+                h = self.up[i_level].upsample(h)
+        if self.lidar_adapter:
+            h = _gn_swish(self.norm_out_lidar1, self.res_block_lidar1(h))    # reference keeps this extra GN+swish (:617-618)
+            h = _gn_swish(self.norm_out_lidar2, self.res_block_lidar2(h))
+            cout = self.conv_out_lidar
+        else:
+            h = _gn_swish(self.norm_out, h)
+            cout = self.conv_out
+        return ops.conv_small_cout(h, cout.packed(), pad=cout.padding, clamp=clamp)

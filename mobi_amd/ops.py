@@ -1,0 +1,396 @@
+"""Thin host wrappers: torch tensors (device memory + stream plumbing) -> C ABI calls.
+
+No arithmetic happens here.  Activations are channels-last tensors
+`[N, H, W, C]` (tokens `[N, T, C]` are the same memory) in float16 / bfloat16;
+a batch-strided view such as `x[::2]` is passed in place through the image
+stride.  Every function raises if the HIP library is unavailable or the tensor
+is not on a ROCm device -- there is no CPU path.
+"""
+import ctypes as C
+import math
+from dataclasses import dataclass
+from typing import Optional
+
+import torch
+
+from . import _lib
+from ._lib import (ACT_NONE, ACT_SILU, EPI_GEGLU, EPI_NONE, MOBI_BF16, MOBI_F16, OUT_ROWS, OUT_ROWS_F32,
+                   OUT_TRANSPOSED)
+
+
+def _dt(t):
+    if t == torch.float16:
+        return MOBI_F16
+    if t == torch.bfloat16:
+        return MOBI_BF16
+    raise TypeError(f"engine storage type must be float16 or bfloat16, got {t}")
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _dev(t):
+    if not t.is_cuda:
+        raise _lib.EngineUnavailable("MObI engine tensors must live on a ROCm device (no CPU path)")
+    return t
+
+
+def _ptr(t):
+    return None if t is None else C.c_void_p(_dev(t).data_ptr())
+
+
+def _img_stride(t):
+    """elements between images; inner dims must be dense."""
+    inner = t[0]
+    if not inner.is_contiguous():
+        raise ValueError("activation tensor must be dense within an image")
+    return t.stride(0) if t.shape[0] > 1 else inner.numel()
+
+
+# --------------------------------------------------------------------------------------
+# weight packing (load time)
+# --------------------------------------------------------------------------------------
+@dataclass
+class Packed:
+    w: torch.Tensor                 # T [n_packed, kh*kw*cin]
+    bias: Optional[torch.Tensor]    # f32
+    kh: int
+    kw: int
+    cin: int
+    cout: int
+    n_packed: int
+    geglu: bool = False
+
+
+def pack_conv(weight, bias, dtype, device):
+    """OIHW fp32 -> [O][kh*kw*I] (k = tap*C + c), the layout mobi_igemm / conv_small_cout read."""
+    o, i, kh, kw = weight.shape
+    w = weight.detach().to(device=device, dtype=torch.float32).permute(0, 2, 3, 1).reshape(o, kh * kw * i)
+    b = None if bias is None else bias.detach().to(device=device, dtype=torch.float32).contiguous()
+    return Packed(w.to(dtype).contiguous(), b, kh, kw, i, o, o)
+
+
+def pack_linear(weight, bias, dtype, device):
+    return pack_conv(weight[:, :, None, None], bias, dtype, device)
+
+
+def geglu_layout(inner):
+    """(unit, n_packed) of the packed GEGLU projection: rows are grouped in units of
+    `unit` value columns followed by `unit` gate columns; unit = 40 when the igemm runs its
+    80-column wave tile (n_packed % 160 == 0), else 32 with a 64-column wave tile."""
+    if inner % 40 == 0 and (2 * inner) % 160 == 0:
+        return 40, 2 * inner
+    units = (inner + 31) // 32
+    n_packed = units * 64
+    if n_packed % 160 == 0:            # keep the kernel on its 64-column wave tile
+        n_packed += 64
+    return 32, n_packed
+
+
+def pack_geglu(weight, bias, dtype, device):
+    """GEGLU.proj (attention.py:38-46): rows [0, inner) are the value half, [inner, 2*inner) the gate."""
+    two_inner, cin = weight.shape
+    inner = two_inner // 2
+    unit, n_packed = geglu_layout(inner)
+    w = weight.detach().to(device=device, dtype=torch.float32)
+    b = bias.detach().to(device=device, dtype=torch.float32)
+    wp = torch.zeros(n_packed, cin, device=device, dtype=torch.float32)
+    bp = torch.zeros(n_packed, device=device, dtype=torch.float32)
+    for u in range((inner + unit - 1) // unit):
+        lo, hi = u * unit, min(inner, (u + 1) * unit)
+        n = hi - lo
+        wp[2 * u * unit: 2 * u * unit + n] = w[lo:hi]
+        wp[2 * u * unit + unit: 2 * u * unit + unit + n] = w[inner + lo: inner + hi]
+        bp[2 * u * unit: 2 * u * unit + n] = b[lo:hi]
+        bp[2 * u * unit + unit: 2 * u * unit + unit + n] = b[inner + lo: inner + hi]
+    return Packed(wp.to(dtype).contiguous(), bp.contiguous(), 1, 1, cin, inner, n_packed, geglu=True)
+
+
+# --------------------------------------------------------------------------------------
+# matrix-core ops
+# --------------------------------------------------------------------------------------
+def igemm(x, pw: Packed, *, x2=None, stride=1, pad=None, upsample=False, hout=None, wout=None, rowvec=None,
+          residual=None, out=None, out_mode=OUT_ROWS, scale=1.0, weight_per_image=False, w_group_stride=0):
+    """x: [N,H,W,C0] (tokens: [N,T,1,C]); x2: optional second source concatenated on channels."""
+    lib = _lib.load()
+    n, hin, win, c0 = x.shape
+    c1 = 0 if x2 is None else x2.shape[3]
+    assert c0 + c1 == pw.cin, (c0, c1, pw.cin)
+    ph, pw_ = (pw.kh // 2, pw.kw // 2) if pad is None else pad
+    hl, wl = (hin * 2, win * 2) if upsample else (hin, win)
+    if hout is None:
+        hout = (hl + 2 * ph - pw.kh) // stride + 1
+        wout = (wl + 2 * pw_ - pw.kw) // stride + 1
+    if out is None:
+        if out_mode == OUT_TRANSPOSED:
+            out = torch.empty((n, pw.cout, hout * wout), device=x.device, dtype=x.dtype)
+        elif out_mode == OUT_ROWS_F32:
+            out = torch.empty((n, hout, wout, pw.cout), device=x.device, dtype=torch.float32)
+        else:
+            out = torch.empty((n, hout, wout, pw.cout), device=x.device, dtype=x.dtype)
+    p = _lib.IgemmParams()
+    p.src0, p.src1 = _ptr(x), _ptr(x2)
+    p.c0, p.c1, p.batch, p.hin, p.win = c0, c1, n, hin, win
+    p.upsample, p.hout, p.wout = int(upsample), hout, wout
+    p.kh, p.kw, p.stride, p.pad_h, p.pad_w = pw.kh, pw.kw, stride, ph, pw_
+    dense_in = hin * win * c0
+    s = _img_stride(x)
+    p.src_img_stride = 0 if s == dense_in else s
+    p.weight = _ptr(pw.w)
+    p.groups = n if weight_per_image else 1
+    p.w_group_stride = w_group_stride
+    p.n_packed, p.cout = pw.n_packed, pw.cout
+    p.bias, p.rowvec, p.residual = _ptr(pw.bias), _ptr(rowvec), _ptr(residual)
+    if rowvec is not None:
+        assert rowvec.dtype == torch.float32 and rowvec.stride(1) == 1 and rowvec.shape == (n, pw.cout)
+        p.rowvec_stride = rowvec.stride(0)
+    dense_out = hout * wout * pw.cout
+    if residual is not None:
+        s = _img_stride(residual)
+        p.res_img_stride = 0 if s == dense_out else s
+    s = _img_stride(out)
+    p.out = _ptr(out)
+    p.out_img_stride = 0 if s == dense_out else s
+    p.out_mode = out_mode
+    p.epilogue = EPI_GEGLU if pw.geglu else EPI_NONE
+    p.scale = scale
+    p.dtype = _dt(x.dtype)
+    _lib.check(lib.mobi_igemm(C.byref(p), _stream()), "mobi_igemm")
+    return out
+
+
+def linear(x, pw: Packed, **kw):
+    """x: [N, T, C] tokens -> [N, T, cout]."""
+    n, t, c = x.shape
+    out = kw.pop("out", None)
+    res = kw.pop("residual", None)
+    if out is not None and out.dim() == 3:
+        out = out.unsqueeze(2) if kw.get("out_mode", OUT_ROWS) != OUT_TRANSPOSED else out
+    if res is not None:
+        res = res.unsqueeze(2)
+    y = igemm(x.unsqueeze(2), pw, out=out, residual=res, **kw)
+    return y if y.dim() == 3 else y.squeeze(2)
+
+
+def groupnorm(x, gamma, beta, eps, silu, x2=None):
+    lib = _lib.load()
+    n, h, w, c0 = x.shape
+    c1 = 0 if x2 is None else x2.shape[3]
+    assert x.is_contiguous() and (x2 is None or x2.is_contiguous())
+    out = torch.empty((n, h, w, c0 + c1), device=x.device, dtype=x.dtype)
+    ws = torch.empty(lib.mobi_groupnorm_workspace_bytes(n, h * w), device=x.device, dtype=torch.uint8)
+    p = _lib.GroupNormParams()
+    p.src0, p.src1, p.c0, p.c1, p.batch, p.hw = _ptr(x), _ptr(x2), c0, c1, n, h * w
+    p.gamma, p.beta, p.eps, p.silu = _ptr(gamma), _ptr(beta), eps, int(silu)
+    p.out, p.ws, p.dtype = _ptr(out), _ptr(ws), _dt(x.dtype)
+    _lib.check(lib.mobi_groupnorm(C.byref(p), _stream()), "mobi_groupnorm")
+    return out
+
+
+def layernorm(x, gamma, beta, eps=1e-5):
+    """x: [N, T, C], possibly a batch-strided view; returns a dense tensor."""
+    lib = _lib.load()
+    n, t, c = x.shape
+    out = torch.empty((n, t, c), device=x.device, dtype=x.dtype)
+    p = _lib.LayerNormParams()
+    p.src, p.out, p.images, p.rows_per_image, p.channels = _ptr(x), _ptr(out), n, t, c
+    s = _img_stride(x)
+    p.src_img_stride = 0 if s == t * c else s
+    p.out_img_stride = 0
+    p.gamma, p.beta, p.eps, p.dtype = _ptr(gamma), _ptr(beta), eps, _dt(x.dtype)
+    _lib.check(lib.mobi_layernorm(C.byref(p), _stream()), "mobi_layernorm")
+    return out
+
+
+def attention(q, k, vt, heads, scale):
+    """q: [N, Tq, >=C] view (row stride may exceed C: fused projections), k: [N, Tk, ...],
+    vt: [N, C, Tk] -> out [N, Tq, C]."""
+    lib = _lib.load()
+    n, tq = q.shape[0], q.shape[1]
+    tk = k.shape[1]
+    c = vt.shape[1]
+    dh = c // heads
+    out = torch.empty((n, tq, c), device=q.device, dtype=q.dtype)
+    p = _lib.AttentionParams()
+    p.q, p.q_img_stride, p.q_row_stride = _ptr(q), q.stride(0), q.stride(1)
+    p.k, p.k_img_stride, p.k_row_stride = _ptr(k), k.stride(0), k.stride(1)
+    p.vt, p.vt_img_stride, p.vt_row_stride = _ptr(vt), vt.stride(0), vt.stride(1)
+    p.out, p.out_img_stride, p.out_row_stride = _ptr(out), out.stride(0), out.stride(1)
+    assert q.stride(2) == 1 and k.stride(2) == 1 and vt.stride(2) == 1
+    p.images, p.heads, p.dh, p.tq, p.tk, p.scale, p.dtype = n, heads, dh, tq, tk, scale, _dt(q.dtype)
+    _lib.check(lib.mobi_attention(C.byref(p), _stream()), "mobi_attention")
+    return out
+
+
+def ctx_attention(q, k, v, heads, scale):
+    """q: [N, T, C] dense T; k, v: [N, tk, C] fp32."""
+    lib = _lib.load()
+    n, t, c = q.shape
+    assert q.is_contiguous() and k.is_contiguous() and v.is_contiguous()
+    out = torch.empty_like(q)
+    p = _lib.CtxAttentionParams()
+    p.q, p.out, p.k, p.v = _ptr(q), _ptr(out), _ptr(k), _ptr(v)
+    p.images, p.heads, p.dh, p.tq, p.tk, p.scale, p.dtype = n, heads, c // heads, t, k.shape[1], scale, _dt(q.dtype)
+    _lib.check(lib.mobi_ctx_attention(C.byref(p), _stream()), "mobi_ctx_attention")
+    return out
+
+
+def softmax_rows(s, dtype):
+    lib = _lib.load()
+    assert s.dtype == torch.float32 and s.is_contiguous()
+    out = torch.empty(s.shape, device=s.device, dtype=dtype)
+    rows = s.numel() // s.shape[-1]
+    _lib.check(lib.mobi_softmax_rows(_ptr(s), _ptr(out), rows, s.shape[-1], _dt(dtype), _stream()), "mobi_softmax_rows")
+    return out
+
+
+# --------------------------------------------------------------------------------------
+# small ops
+# --------------------------------------------------------------------------------------
+def skinny_linear(x, w, bias=None, pre_act=ACT_NONE, post_act=ACT_NONE, out=None):
+    """x: fp32 [m, k] (row stride free), w: T [n, k] -> fp32 [m, n]."""
+    lib = _lib.load()
+    m, k = x.shape
+    n = w.shape[0]
+    assert x.dtype == torch.float32 and x.stride(1) == 1 and w.is_contiguous()
+    if out is None:
+        out = torch.empty((m, n), device=x.device, dtype=torch.float32)
+    p = _lib.SkinnyLinearParams()
+    p.x, p.m, p.k, p.x_row_stride = _ptr(x), m, k, x.stride(0)
+    p.weight, p.bias, p.out, p.n, p.out_row_stride = _ptr(w), _ptr(bias), _ptr(out), n, out.stride(0)
+    p.pre_act, p.post_act, p.dtype = pre_act, post_act, _dt(w.dtype)
+    _lib.check(lib.mobi_skinny_linear(C.byref(p), _stream()), "mobi_skinny_linear")
+    return out
+
+
+def timestep_embedding(t, freqs):
+    lib = _lib.load()
+    n, half = t.shape[0], freqs.shape[0]
+    assert t.dtype == torch.int64 and freqs.dtype == torch.float32
+    out = torch.empty((n, 2 * half), device=t.device, dtype=torch.float32)
+    _lib.check(lib.mobi_timestep_embedding(_ptr(t), _ptr(freqs), _ptr(out), n, half, _stream()),
+               "mobi_timestep_embedding")
+    return out
+
+
+def conv_small_cin(srcs, weight, bias, kh, kw, pad, dtype, out_f32_nchw=False):
+    """srcs: list of fp32 NCHW tensors (<= 3) concatenated on channels; weight fp32 [cout, cin*kh*kw]."""
+    lib = _lib.load()
+    n, _, h, w = srcs[0].shape
+    cout = weight.shape[0]
+    p = _lib.ConvSmallCinParams()
+    for i, s in enumerate(srcs):
+        assert s.dtype == torch.float32 and s.is_contiguous() and s.shape[0] == n and s.shape[2:] == (h, w)
+        p.src[i], p.c[i] = s.data_ptr(), s.shape[1]
+        _dev(s)
+    p.batch, p.h, p.w, p.kh, p.kw, p.pad_h, p.pad_w = n, h, w, kh, kw, pad[0], pad[1]
+    p.weight, p.bias, p.cout = _ptr(weight), _ptr(bias), cout
+    if out_f32_nchw:
+        out = torch.empty((n, cout, h, w), device=srcs[0].device, dtype=torch.float32)
+    else:
+        out = torch.empty((n, h, w, cout), device=srcs[0].device, dtype=dtype)
+    p.out, p.out_f32_nchw, p.dtype = _ptr(out), int(out_f32_nchw), _dt(dtype)
+    _lib.check(lib.mobi_conv_small_cin(C.byref(p), _stream()), "mobi_conv_small_cin")
+    return out
+
+
+def conv_small_cout(x, pw: Packed, pad=None, clamp=None):
+    """x: T [N,H,W,Cin] -> fp32 NCHW [N,cout,H,W]."""
+    lib = _lib.load()
+    n, h, w, cin = x.shape
+    assert x.is_contiguous() and cin == pw.cin
+    out = torch.empty((n, pw.cout, h, w), device=x.device, dtype=torch.float32)
+    p = _lib.ConvSmallCoutParams()
+    ph, pw_ = (pw.kh // 2, pw.kw // 2) if pad is None else pad
+    p.src, p.cin, p.batch, p.h, p.w = _ptr(x), cin, n, h, w
+    p.kh, p.kw, p.pad_h, p.pad_w = pw.kh, pw.kw, ph, pw_
+    p.weight, p.bias, p.cout, p.out = _ptr(pw.w), _ptr(pw.bias), pw.cout, _ptr(out)
+    if clamp is not None:
+        p.clamp, p.clamp_lo, p.clamp_hi = 1, clamp[0], clamp[1]
+    p.in_scale, p.dtype = 1.0, _dt(x.dtype)
+    _lib.check(lib.mobi_conv_small_cout(C.byref(p), _stream()), "mobi_conv_small_cout")
+    return out
+
+
+def to_nhwc(x, dtype):
+    """fp32 NCHW -> T NHWC"""
+    lib = _lib.load()
+    n, c, h, w = x.shape
+    assert x.dtype == torch.float32 and x.is_contiguous()
+    out = torch.empty((n, h, w, c), device=x.device, dtype=dtype)
+    _lib.check(lib.mobi_nchw_f32_to_nhwc(_ptr(x), _ptr(out), n, c, h * w, _dt(dtype), _stream()), "nchw_to_nhwc")
+    return out
+
+
+def to_nchw_f32(x):
+    lib = _lib.load()
+    n, h, w, c = x.shape
+    assert x.is_contiguous()
+    out = torch.empty((n, c, h, w), device=x.device, dtype=torch.float32)
+    _lib.check(lib.mobi_nhwc_to_nchw_f32(_ptr(x), _ptr(out), n, c, h * w, _dt(x.dtype), _stream()), "nhwc_to_nchw")
+    return out
+
+
+# --------------------------------------------------------------------------------------
+# sampler / latent arithmetic (fp32 NCHW)
+# --------------------------------------------------------------------------------------
+def ddim_step(x, e_cond, *, e_uncond=None, noise=None, cfg_scale=1.0, a_t, a_prev, sigma_t, sqrt_one_minus_at,
+              temperature=1.0, want_e=False):
+    lib = _lib.load()
+    for t in (x, e_cond, e_uncond, noise):
+        assert t is None or (t.dtype == torch.float32 and t.is_contiguous())
+    x_prev, pred = torch.empty_like(x), torch.empty_like(x)
+    e_out = torch.empty_like(x) if want_e else None
+    p = _lib.DdimStepParams()
+    p.x, p.e_cond, p.e_uncond, p.noise = _ptr(x), _ptr(e_cond), _ptr(e_uncond), _ptr(noise)
+    p.x_prev, p.pred_x0, p.e_out, p.n = _ptr(x_prev), _ptr(pred), _ptr(e_out), x.numel()
+    p.cfg_scale, p.a_t, p.a_prev, p.sigma_t = cfg_scale, a_t, a_prev, sigma_t
+    p.sqrt_one_minus_at, p.temperature = sqrt_one_minus_at, temperature
+    _lib.check(lib.mobi_ddim_step(C.byref(p), _stream()), "mobi_ddim_step")
+    return x_prev, pred, e_out
+
+
+def lincomb4(es, cs):
+    lib = _lib.load()
+    es = list(es) + [None] * (4 - len(es))
+    cs = list(cs) + [0.0] * (4 - len(cs))
+    out = torch.empty_like(es[0])
+    _lib.check(lib.mobi_lincomb4(_ptr(out), _ptr(es[0]), _ptr(es[1]), _ptr(es[2]), _ptr(es[3]),
+                                 cs[0], cs[1], cs[2], cs[3], out.numel(), _stream()), "mobi_lincomb4")
+    return out
+
+
+def mask_blend_(img, x0, noise, mask, sqrt_ac_t, sqrt_1m_ac_t):
+    lib = _lib.load()
+    b, c, h, w = img.shape
+    _lib.check(lib.mobi_mask_blend(_ptr(img), _ptr(x0), _ptr(noise), _ptr(mask), sqrt_ac_t, sqrt_1m_ac_t,
+                                   b, c, h * w, _stream()), "mobi_mask_blend")
+    return img
+
+
+def posterior_sample(moments, noise, out, c_off, scale):
+    lib = _lib.load()
+    b, c2, h, w = moments.shape
+    c = c2 // 2
+    _lib.check(lib.mobi_posterior_sample(_ptr(moments), _ptr(noise), _ptr(out), b, c, h * w, out.shape[1], c_off,
+                                         scale, _stream()), "mobi_posterior_sample")
+    return out
+
+
+def nearest_resize(src, hout, wout, out=None, c_off=0):
+    """fp32 [B, C, H, W] -> writes planes [B, c_off:c_off+C] of `out` ([B, Ct, hout, wout])."""
+    lib = _lib.load()
+    b, c, h, w = src.shape
+    if out is None:
+        out = torch.empty((b, c, hout, wout), device=src.device, dtype=torch.float32)
+    ct = out.shape[1]
+    if ct == c:
+        _lib.check(lib.mobi_nearest_resize(_ptr(src), _ptr(out), b * c, h, w, hout, wout, hout * wout, _stream()),
+                   "mobi_nearest_resize")
+    else:
+        assert c == 1
+        view = out[:, c_off]
+        _lib.check(lib.mobi_nearest_resize(_ptr(src), C.c_void_p(view.data_ptr()), b, h, w, hout, wout,
+                                           ct * hout * wout, _stream()), "mobi_nearest_resize")
+    return out

@@ -1,0 +1,136 @@
+"""CPU: the C-ABI library builds, loads, exports every symbol include/mobi_engine.h declares, the
+ctypes struct layouts match, and the product path refuses to run without a GPU (no fallback)."""
+import ctypes as C
+import os
+import re
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from mobi_amd import _lib, build
+    build.build(verbose=False)
+    return _lib.load()
+
+
+def test_header_symbols_exported(lib):
+    from mobi_amd import _lib
+    hdr = open(os.path.join(ROOT, "include", "mobi_engine.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(mobi_[a-z0-9_]+)\s*\(", hdr))
+    assert declared, "no declarations parsed"
+    assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
+    for name in declared:
+        assert hasattr(lib, name)
+
+
+def test_struct_layouts_match(lib):
+    from mobi_amd import _lib
+    for sid, cls in _lib.STRUCT_IDS.items():
+        assert lib.mobi_struct_size(sid) == C.sizeof(cls), cls.__name__
+    assert lib.mobi_struct_size(99) == 0
+    assert lib.mobi_abi_version() == 1
+    assert lib.mobi_error_string(-2) == b"unsupported shape or mode"
+
+
+def test_argument_validation_without_gpu(lib):
+    """Validation happens before any launch, so it is checkable on a CPU-only host."""
+    from mobi_amd import _lib
+    p = _lib.IgemmParams()
+    assert lib.mobi_igemm(C.byref(p), None) == -1                      # null pointers
+    a = _lib.AttentionParams()
+    a.q = a.k = a.vt = a.out = 16
+    a.images = a.heads = a.tq = a.tk = 1
+    a.dh, a.dtype = 12, 0
+    assert lib.mobi_attention(C.byref(a), None) == -2                  # dh % 8 != 0
+    a.dh = 168
+    assert lib.mobi_attention(C.byref(a), None) == -2                  # dh > 160
+    g = _lib.GroupNormParams()
+    g.src0 = g.out = g.ws = g.gamma = g.beta = 16
+    g.c0, g.batch, g.hw = 48, 1, 4
+    assert lib.mobi_groupnorm(C.byref(g), None) == -2                  # channels % 32 != 0
+    assert lib.mobi_groupnorm_workspace_bytes(2, 4096) == 2 * 64 * 32 * 2 * 4
+    assert lib.mobi_groupnorm_workspace_bytes(0, 10) == 0
+
+
+def test_no_cpu_fallback():
+    """The product modules must fail loudly off-GPU instead of computing on the CPU."""
+    from mobi_amd import _lib, ops
+    from mobi_amd.ldm.modules.diffusionmodules.openaimodel import ResBlock
+    rb = ResBlock(32, 64, 0.0, out_channels=32)
+    with pytest.raises(_lib.EngineUnavailable):
+        rb(torch.zeros(1, 32, 4, 4), torch.zeros(1, 64))
+    with pytest.raises(_lib.EngineUnavailable):
+        ops.groupnorm(torch.zeros(1, 2, 2, 32, dtype=torch.float16), torch.ones(32), torch.zeros(32), 1e-5, True)
+
+
+def test_product_does_not_import_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "mobi_amd")):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f
+
+
+def test_state_dict_keys_match_reference_layout():
+    """Same parameter names / shapes as the reference modules (checked against the oracle's
+    shape tables, themselves pinned to the reference by the n_params golden)."""
+    from oracle.unet import UNetConfig, unet_param_shapes
+    from oracle.vae import VAEConfig, vae_param_shapes
+    from mobi_amd.ldm.models.autoencoder import AutoencoderKL
+    from mobi_amd.ldm.modules.diffusionmodules.openaimodel import UNetModel
+    net = UNetModel(image_size=8, in_channels=9, out_channels=4, model_channels=64, attention_resolutions=[4, 2, 1],
+                    num_res_blocks=2, channel_mult=[1, 2, 4, 4], num_heads=8, use_spatial_transformer=True,
+                    transformer_depth=1, context_dim=768, legacy=False, bbox_cond=True, use_camera=True,
+                    use_lidar=True)
+    want = unet_param_shapes(UNetConfig(model_channels=64))
+    got = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+    assert got == {k: tuple(s) for k, s in want.items()}
+    for lidar in (False, True):
+        dd = dict(double_z=True, z_channels=4, resolution=64, in_channels=2 if lidar else 3,
+                  out_ch=2 if lidar else 3, ch=32, ch_mult=[1, 2, 4, 4], num_res_blocks=2, attn_resolutions=[],
+                  lidar_adapter=lidar, dropout=0.0)
+        vae = AutoencoderKL(ddconfig=dd, lossconfig={"target": "torch.nn.Identity"}, embed_dim=4)
+        want = vae_param_shapes(VAEConfig(in_channels=dd["in_channels"], out_ch=dd["out_ch"], ch=32,
+                                          lidar_adapter=lidar))
+        got = {k: tuple(v.shape) for k, v in vae.state_dict().items()}
+        assert got == {k: tuple(s) for k, s in want.items()}
+
+
+def test_config_loader_and_instantiate(tmp_path):
+    from mobi_amd.ldm.util import instantiate_from_config, load_config
+    y = tmp_path / "c.yaml"
+    y.write_text("latent_size: 8\nuse_lidar: true\nmodel:\n  target: ldm.modules.diffusionmodules.openaimodel.UNetModel\n"
+                 "  params:\n    image_size: ${latent_size}\n    in_channels: 9\n    out_channels: 4\n"
+                 "    model_channels: 32\n    attention_resolutions: [4, 2, 1]\n    num_res_blocks: 1\n"
+                 "    channel_mult: [1, 2]\n    num_heads: 4\n    use_spatial_transformer: true\n"
+                 "    context_dim: 768\n    legacy: false\n    bbox_cond: true\n    use_lidar: ${use_lidar}\n")
+    cfg = load_config(str(y), ["model.params.num_res_blocks=2"])
+    assert cfg["model"]["params"]["image_size"] == 8 and cfg["model"]["params"]["use_lidar"] is True
+    net = instantiate_from_config(cfg["model"])
+    assert type(net).__module__ == "mobi_amd.ldm.modules.diffusionmodules.openaimodel" and net.multimodal
+
+
+def test_schedules_bit_exact_host_side():
+    """The product's own host-side schedule code against the reference golden tables."""
+    import numpy as np
+    from tests.golden_cases import load
+    from mobi_amd.ldm.modules.diffusionmodules import util as U
+    g = load("schedule_tables")
+    assert np.array_equal(U.make_beta_schedule("linear", 1000, 0.00085, 0.012), g["betas_f64"].numpy())
+    for S in (10, 50, 250, 30):
+        assert np.array_equal(U.make_ddim_timesteps("uniform", S, 1000, verbose=False),
+                              g[f"ddim_timesteps_S{S}"].numpy())
+    ac = g["ddpm_alphas_cumprod"]
+    for S in (10, 50):
+        for eta in (0.0, 1.0):
+            ts = U.make_ddim_timesteps("uniform", S, 1000, verbose=False)
+            sig, a, ap = U.make_ddim_sampling_parameters(ac, ts, eta, verbose=False)
+            tag = f"S{S}_eta{int(eta)}"
+            assert np.array_equal(sig, g[f"ddim_sigmas_{tag}"].numpy())
+            assert np.array_equal(a, g[f"ddim_alphas_{tag}"].numpy())
+            assert np.array_equal(ap, g[f"ddim_alphas_prev_{tag}"].numpy())

@@ -1,0 +1,348 @@
+"""GPU parity, operator level: every C-ABI entry point against a plain PyTorch fp32 (CPU)
+restatement of the same reference op, on the same seeded inputs.
+
+Inputs / weights are first rounded to the engine's 16-bit storage type so the comparison
+isolates the kernel (accumulation order, fp32 statistics, output rounding).  Tolerances are
+relative L2 and are stated per dtype:  fp16 2e-3, bf16 1.5e-2 for 16-bit outputs
+(unit round-off 4.9e-4 / 3.9e-3), 2e-5 for fp32 outputs of fp32 data paths, bit-exact for
+index-only and un-fused fp32 sampler arithmetic.
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import weights as W
+
+pytestmark = pytest.mark.gpu
+
+DT = [torch.float16, torch.bfloat16]
+TOL = {torch.float16: 2e-3, torch.bfloat16: 1.5e-2}
+
+
+def rel(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).norm() / b.norm().clamp_min(1e-30))
+
+
+def rnd(name, shape, dtype, scale=1.0):
+    """deterministic input, rounded to the storage type; returns (fp32 cpu copy, device tensor)."""
+    x = (W.synth_input(name, shape) * scale).to(dtype)
+    return x.float(), x.cuda()
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from mobi_amd import ops as o
+    return o
+
+
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("c0,c1,hw,silu", [(32, 0, 64, True), (320, 0, 4096, True), (320, 0, 4096, False),
+                                           (1280, 1280, 64, True), (1280, 640, 256, True), (640, 320, 1024, True),
+                                           (64, 0, 17, True), (128, 0, 4096, True)])
+def test_groupnorm(ops, dtype, c0, c1, hw, silu):
+    h = int(math.isqrt(hw)) if int(math.isqrt(hw)) ** 2 == hw else 1
+    w = hw // h
+    xf, xd = rnd(f"gn{c0}.{c1}.{hw}", (2, h, w, c0), dtype, 2.0)
+    xf = xf + 0.7                                            # non-zero mean: exercises the variance formula
+    xd = xf.to(dtype).cuda()
+    xf = xd.float().cpu()
+    x2f = x2d = None
+    if c1:
+        x2f, x2d = rnd(f"gn2{c0}.{c1}.{hw}", (2, h, w, c1), dtype)
+    C = c0 + c1
+    g = torch.from_numpy(W.synth_param("g.weight", (C,)))
+    b = torch.from_numpy(W.synth_param("g.bias", (C,)))
+    y = ops.groupnorm(xd, g.cuda(), b.cuda(), 1e-5, silu, x2=x2d)
+    ref_in = xf if x2f is None else torch.cat([xf, x2f], dim=3)
+    ref = F.group_norm(ref_in.permute(0, 3, 1, 2), 32, g, b, 1e-5)
+    ref = F.silu(ref) if silu else ref
+    assert y.shape == (2, h, w, C)
+    assert rel(y.float().permute(0, 3, 1, 2), ref) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("c,t,strided", [(64, 16, False), (320, 4096, False), (640, 100, True), (1280, 64, True)])
+def test_layernorm(ops, dtype, c, t, strided):
+    xf, xd = rnd(f"ln{c}", (4, t, c), dtype, 1.5)
+    g = torch.from_numpy(W.synth_param("ln.weight", (c,)))
+    b = torch.from_numpy(W.synth_param("ln.bias", (c,)))
+    if strided:
+        y = ops.layernorm(xd[1::2], g.cuda(), b.cuda())
+        ref = F.layer_norm(xf[1::2], (c,), g, b, 1e-5)
+    else:
+        y = ops.layernorm(xd, g.cuda(), b.cuda())
+        ref = F.layer_norm(xf, (c,), g, b, 1e-5)
+    assert rel(y.float(), ref) < TOL[dtype]
+
+
+# ---------------------------------------------------------------------------------------------
+def _conv_ref(xf, wf, bias, stride=1, pad=(1, 1), upsample=False, asym=False):
+    x = xf.permute(0, 3, 1, 2)
+    if upsample:
+        x = F.interpolate(x, scale_factor=2, mode="nearest")
+    if asym:
+        x = F.pad(x, (0, 1, 0, 1))
+        pad = (0, 0)
+    return F.conv2d(x, wf, bias, stride=stride, padding=pad).permute(0, 2, 3, 1)
+
+
+IGEMM_CASES = [
+    # name, cin, cout, kh, kw, h, w, stride, upsample, asym
+    ("lin320", 320, 960, 1, 1, 64, 1, 1, False, False),
+    ("c3_64_160", 64, 160, 3, 3, 16, 16, 1, False, False),
+    ("c3_320_320", 320, 320, 3, 3, 32, 32, 1, False, False),
+    ("c3_s2", 64, 64, 3, 3, 16, 16, 2, False, False),
+    ("c3_up", 64, 128, 3, 3, 8, 8, 1, True, False),
+    ("c3_asym", 32, 32, 3, 3, 16, 16, 2, False, True),
+    ("c15", 32, 64, 1, 5, 8, 24, 1, False, False),
+    ("c3_odd", 96, 40, 3, 3, 7, 9, 1, False, False),
+    ("lin_k32", 32, 24, 1, 1, 5, 1, 1, False, False),
+]
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("case", IGEMM_CASES, ids=[c[0] for c in IGEMM_CASES])
+def test_igemm_conv(ops, dtype, case):
+    name, cin, cout, kh, kw, h, w, stride, up, asym = case
+    xf, xd = rnd("x." + name, (3, h, w, cin), dtype)
+    wf = torch.from_numpy(W.synth_param(name + ".weight", (cout, cin, kh, kw))).to(dtype).float()
+    bias = torch.from_numpy(W.synth_param(name + ".bias", (cout,)))
+    pw = ops.pack_conv(wf, bias, dtype, "cuda")
+    pad = (kh // 2, kw // 2)
+    if asym:
+        y = ops.igemm(xd, pw, stride=2, pad=(0, 0), hout=(h + 1 - 3) // 2 + 1, wout=(w + 1 - 3) // 2 + 1)
+    else:
+        y = ops.igemm(xd, pw, stride=stride, pad=pad, upsample=up)
+    ref = _conv_ref(xf, wf, bias, stride, pad, up, asym)
+    assert y.shape == ref.shape
+    assert rel(y.float(), ref) < TOL[dtype] * 0.5
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_igemm_epilogues(ops, dtype):
+    """concat of two sources + per-image vector + residual; fp32 output; transposed output."""
+    x0f, x0d = rnd("e.x0", (4, 8, 8, 64), dtype)
+    x1f, x1d = rnd("e.x1", (4, 8, 8, 32), dtype)
+    rf, rd = rnd("e.res", (4, 8, 8, 160), dtype)
+    wf = torch.from_numpy(W.synth_param("e.weight", (160, 96, 3, 3))).to(dtype).float()
+    bias = torch.from_numpy(W.synth_param("e.bias", (160,)))
+    rv = W.synth_input("e.rowvec", (4, 200))[:, 20:180].contiguous()
+    rvd = W.synth_input("e.rowvec", (4, 200)).cuda()[:, 20:180]               # strided rows
+    pw = ops.pack_conv(wf, bias, dtype, "cuda")
+    ref = _conv_ref(torch.cat([x0f, x1f], 3), wf, bias) + rv[:, None, None, :] + rf
+    y = ops.igemm(x0d, pw, x2=x1d, rowvec=rvd, residual=rd)
+    assert rel(y.float(), ref) < TOL[dtype] * 0.5
+    from mobi_amd._lib import OUT_ROWS_F32, OUT_TRANSPOSED
+    ref2 = _conv_ref(torch.cat([x0f, x1f], 3), wf, bias)
+    y32 = ops.igemm(x0d, pw, x2=x1d, out_mode=OUT_ROWS_F32, scale=0.5)
+    ref_s = _conv_ref(torch.cat([x0f, x1f], 3), wf, None) * 0.5 + bias
+    assert y32.dtype == torch.float32 and rel(y32, ref_s) < 2e-5 * (100 if dtype == torch.bfloat16 else 1) + 1e-6
+    yt = ops.igemm(x0d, pw, x2=x1d, out_mode=OUT_TRANSPOSED)
+    assert yt.shape == (4, 160, 64)
+    assert rel(yt.float(), ref2.reshape(4, 64, 160).permute(0, 2, 1)) < TOL[dtype] * 0.5
+    # transposed with a spatial size that is not a multiple of 8 (scalar store path)
+    xs_f, xs_d = rnd("e.xs", (3, 1, 3, 32), dtype)
+    ws = torch.from_numpy(W.synth_param("e.ws", (40, 32, 1, 1))).to(dtype).float()
+    pws = ops.pack_conv(ws, None, dtype, "cuda")
+    yt = ops.igemm(xs_d, pws, out_mode=OUT_TRANSPOSED)
+    assert rel(yt.float(), _conv_ref(xs_f, ws, None, pad=(0, 0)).reshape(3, 3, 40).permute(0, 2, 1)) < TOL[dtype] * 0.5
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("c", [320, 64, 96])
+def test_igemm_geglu_and_inplace_strided(ops, dtype, c):
+    xf, xd = rnd(f"g.x{c}", (4, 50, c), dtype)
+    wf = torch.from_numpy(W.synth_param(f"g{c}.weight", (8 * c, c))).to(dtype).float()
+    bf = torch.from_numpy(W.synth_param(f"g{c}.bias", (8 * c,)))
+    y = ops.linear(xd, ops.pack_geglu(wf, bf, dtype, "cuda"))
+    a, gate = F.linear(xf, wf, bf).chunk(2, dim=-1)
+    assert y.shape == (4, 50, 4 * c)
+    assert rel(y.float(), a * F.gelu(gate)) < TOL[dtype]
+    # camera/lidar halves updated in place through batch-strided views (attention.py:245-263)
+    w2 = torch.from_numpy(W.synth_param(f"g2{c}.weight", (c, c))).to(dtype).float()
+    b2 = torch.from_numpy(W.synth_param(f"g2{c}.bias", (c,)))
+    pw2 = ops.pack_linear(w2, b2, dtype, "cuda")
+    af, ad = rnd(f"g.a{c}", (2, 50, c), dtype)
+    xd2 = xd.clone()
+    ops.linear(ad, pw2, residual=xd2[::2], out=xd2[::2])
+    ref = xf.clone()
+    ref[::2] = F.linear(af, w2, b2) + xf[::2]
+    assert rel(xd2.float(), ref) < TOL[dtype]
+    assert torch.equal(xd2[1::2], xd[1::2])                       # the other half is untouched
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_igemm_per_image_weights(ops, dtype):
+    """S = q k^T / sqrt(c) and O = P v with one weight matrix per image (VAE AttnBlock)."""
+    from mobi_amd._lib import OUT_ROWS_F32
+    n, t, c = 2, 64, 64
+    qf, qd = rnd("pi.q", (n, t, 1, c), dtype)
+    kf, kd = rnd("pi.k", (n, t, c), dtype)
+    s = ops.igemm(qd, ops.Packed(kd, None, 1, 1, c, t, t), weight_per_image=True, w_group_stride=t * c,
+                  out_mode=OUT_ROWS_F32, scale=c ** -0.5)
+    ref = torch.einsum("ntc,nsc->nts", qf[:, :, 0], kf) * c ** -0.5
+    assert rel(s.view(n, t, t), ref) < 1e-3
+    p = ops.softmax_rows(s.view(n * t, t), dtype)
+    assert rel(p.float().view(n, t, t), torch.softmax(s.view(n, t, t).cpu(), dim=-1)) < TOL[dtype]
+
+
+# ---------------------------------------------------------------------------------------------
+ATTN_CASES = [(8, 8, 64, 64), (8, 16, 100, 100), (8, 40, 256, 256), (8, 80, 64, 64), (8, 160, 64, 64),
+              (4, 32, 1, 1), (8, 8, 4, 4), (8, 40, 4096, 4096), (2, 64, 70, 130), (8, 24, 16, 16)]
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("heads,dh,tq,tk", ATTN_CASES)
+def test_attention(ops, dtype, heads, dh, tq, tk):
+    n, c = 2, heads * dh
+    qf, qd = rnd(f"a.q{dh}.{tq}", (n, tq, c), dtype, 1.5)
+    kf, kd = rnd(f"a.k{dh}.{tk}", (n, tk, c), dtype, 1.5)
+    vf, vd = rnd(f"a.v{dh}.{tk}", (n, tk, c), dtype)
+    vt = vd.permute(0, 2, 1).contiguous()
+    y = ops.attention(qd, kd, vt, heads, dh ** -0.5)
+    sp = lambda t: t.reshape(n, -1, heads, dh).permute(0, 2, 1, 3)
+    sim = torch.einsum("bhid,bhjd->bhij", sp(qf), sp(kf)) * dh ** -0.5
+    ref = torch.einsum("bhij,bhjd->bhid", sim.softmax(-1), sp(vf)).permute(0, 2, 1, 3).reshape(n, tq, c)
+    assert rel(y.float(), ref) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_attention_strided_partner_and_spike(ops, dtype):
+    """q from the camera half, k/v from the lidar half of an interleaved batch (image strides), with
+    q/k packed in one [.., 2C] tensor (row stride > C) and one huge score (online-softmax rescale)."""
+    n, t, heads, dh = 4, 130, 8, 40
+    c = heads * dh
+    xf, xd = rnd("as.qk", (n, t, 2 * c), dtype)
+    xf[0, 5, :dh] *= 6.0
+    xf[1, 77, c:c + dh] = xf[0, 5, :dh]                     # key 77 of the partner matches query 5
+    xd = xf.to(dtype).cuda()
+    xf = xd.float().cpu()
+    vf, vd = rnd("as.v", (n, t, c), dtype)
+    vt = vd.permute(0, 2, 1).contiguous()
+    y = ops.attention(xd[::2, :, :c], xd[1::2, :, c:], vt[1::2], heads, dh ** -0.5)
+    sp = lambda z: z.reshape(z.shape[0], -1, heads, dh).permute(0, 2, 1, 3)
+    sim = torch.einsum("bhid,bhjd->bhij", sp(xf[::2, :, :c]), sp(xf[1::2, :, c:])) * dh ** -0.5
+    ref = torch.einsum("bhij,bhjd->bhid", sim.softmax(-1), sp(vf[1::2])).permute(0, 2, 1, 3).reshape(2, t, c)
+    assert rel(y.float(), ref) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("tk", [1, 2, 8])
+def test_ctx_attention(ops, dtype, tk):
+    n, t, heads, dh = 3, 70, 8, 40
+    c = heads * dh
+    qf, qd = rnd("c.q", (n, t, c), dtype)
+    k = W.synth_input(f"c.k{tk}", (n, tk, c))
+    v = W.synth_input(f"c.v{tk}", (n, tk, c))
+    y = ops.ctx_attention(qd, k.cuda(), v.cuda(), heads, dh ** -0.5)
+    sp = lambda z: z.reshape(n, -1, heads, dh).permute(0, 2, 1, 3)
+    sim = torch.einsum("bhid,bhjd->bhij", sp(qf), sp(k)) * dh ** -0.5
+    ref = torch.einsum("bhij,bhjd->bhid", sim.softmax(-1), sp(v)).permute(0, 2, 1, 3).reshape(n, t, c)
+    assert rel(y.float(), ref) < TOL[dtype]
+
+
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", DT)
+def test_skinny_linear_and_timestep_embedding(ops, dtype):
+    from mobi_amd._lib import ACT_SILU
+    from mobi_amd.ldm.modules.diffusionmodules.util import timestep_embedding
+    from oracle.unet import timestep_embedding as ref_temb
+    x = W.synth_input("s.x", (5, 2, 320))
+    wf = torch.from_numpy(W.synth_param("s.weight", (1288, 320))).to(dtype).float()
+    b = torch.from_numpy(W.synth_param("s.bias", (1288,)))
+    y = ops.skinny_linear(x.cuda()[:, 0], wf.to(dtype).cuda(), b.cuda(), pre_act=ACT_SILU, post_act=ACT_SILU)
+    ref = F.silu(F.linear(F.silu(x[:, 0]), wf, b))
+    assert rel(y, ref) < 2e-5
+    t = torch.tensor([1, 21, 500, 981, 999], dtype=torch.long)
+    e = timestep_embedding(t.cuda(), 320)
+    assert rel(e, ref_temb(t, 320)) < 1e-6
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_small_convs(ops, dtype):
+    # 9-channel input conv from three fp32 NCHW sources (ddim.py:170 + input_blocks.0)
+    a, b, m = W.synth_input("sc.a", (2, 4, 12, 12)), W.synth_input("sc.b", (2, 4, 12, 12)), \
+        (W.synth_input("sc.m", (2, 1, 12, 12)) > 0).float()
+    w = torch.from_numpy(W.synth_param("sc.weight", (64, 9, 3, 3)))
+    bias = torch.from_numpy(W.synth_param("sc.bias", (64,)))
+    y = ops.conv_small_cin([a.cuda(), b.cuda(), m.cuda()], w.reshape(64, -1).cuda(), bias.cuda(), 3, 3, (1, 1), dtype)
+    ref = F.conv2d(torch.cat([a, b, m], 1), w, bias, padding=1).permute(0, 2, 3, 1)
+    assert rel(y.float(), ref) < TOL[dtype] * 0.5
+    # 1x5 lidar conv_in, fp32 NCHW out
+    r = W.synth_input("sc.r", (2, 2, 6, 20))
+    w15 = torch.from_numpy(W.synth_param("sc15.weight", (5, 2, 1, 5)))
+    y = ops.conv_small_cin([r.cuda()], w15.reshape(5, -1).cuda(), None, 1, 5, (0, 2), dtype, out_f32_nchw=True)
+    assert rel(y, F.conv2d(r, w15, None, padding=(0, 2))) < 2e-6
+    # few output channels + clamp
+    xf, xd = rnd("sc.x", (2, 9, 7, 64), dtype)
+    wo = torch.from_numpy(W.synth_param("sco.weight", (3, 64, 3, 3))).to(dtype).float()
+    bo = torch.from_numpy(W.synth_param("sco.bias", (3,)))
+    y = ops.conv_small_cout(xd, ops.pack_conv(wo, bo, dtype, "cuda"), clamp=(-0.5, 0.5))
+    ref = F.conv2d(xf.permute(0, 3, 1, 2), wo, bo, padding=1).clamp(-0.5, 0.5)
+    assert y.shape == ref.shape and rel(y, ref) < 1e-4
+    wl = torch.from_numpy(W.synth_param("scl.weight", (2, 64, 1, 5))).to(dtype).float()
+    y = ops.conv_small_cout(xd, ops.pack_conv(wl, None, dtype, "cuda"))
+    assert rel(y, F.conv2d(xf.permute(0, 3, 1, 2), wl, None, padding=(0, 2))) < 1e-4
+
+
+def test_layout_and_index_ops_bit_exact(ops):
+    x = W.synth_input("l.x", (2, 40, 5, 7))
+    for dtype in DT:
+        y = ops.to_nhwc(x.cuda(), dtype)
+        assert torch.equal(y.cpu(), x.permute(0, 2, 3, 1).to(dtype))
+        assert torch.equal(ops.to_nchw_f32(y).cpu(), x.to(dtype).float())
+    m = (W.synth_input("l.m", (3, 1, 64, 64)) > 0).float()
+    for size in (8, 16, 24):
+        assert torch.equal(ops.nearest_resize(m.cuda(), size, size).cpu(), F.interpolate(m, size=size, mode="nearest"))
+    z = torch.zeros(3, 9, 8, 8).cuda()
+    ops.nearest_resize(m.cuda(), 8, 8, out=z, c_off=8)
+    assert torch.equal(z[:, 8].cpu(), F.interpolate(m, size=8, mode="nearest")[:, 0]) and float(z[:, :8].abs().sum()) == 0
+
+
+def test_sampler_arithmetic_bit_exact(ops):
+    """fp32 latent update, CFG mix, PLMS mixes, mask compositing: the kernels are compiled without
+    FMA contraction and follow the reference's operation order -> identical bits to torch CPU."""
+    from oracle import sampler as S
+    sch = S.Schedule(50, eta=1.0)
+    x, e, eu, nz = (W.synth_input("sa." + k, (4, 4, 16, 16)) for k in "xeun")
+    index = 17
+    ref_e = eu + 5.0 * (e - eu)
+    ref_prev, ref_pred = S._x_prev(sch, index, x, ref_e, nz)
+    xp, pr, eo = ops.ddim_step(x.cuda(), e.cuda(), e_uncond=eu.cuda(), noise=nz.cuda(), cfg_scale=5.0,
+                               a_t=float(sch.alphas[index]), a_prev=float(sch.alphas_prev[index]),
+                               sigma_t=float(sch.sigmas[index]),
+                               sqrt_one_minus_at=float(sch.sqrt_one_minus_alphas[index]), want_e=True)
+    assert torch.equal(eo.cpu(), ref_e) and torch.equal(pr.cpu(), ref_pred) and torch.equal(xp.cpu(), ref_prev)
+    # mask compositing (ddim.py:145-148)
+    x0, mn = W.synth_input("sa.x0", (4, 4, 16, 16)), W.synth_input("sa.mn", (4, 4, 16, 16))
+    mask = (W.synth_input("sa.mask", (4, 1, 16, 16)) > 0).float()
+    ts = torch.full((4,), 341, dtype=torch.long)
+    ref = S.q_sample(sch.buffers, x0, ts, mn) * mask + (1.0 - mask) * x
+    got = ops.mask_blend_(x.clone().cuda(), x0.cuda(), mn.cuda(), mask.cuda(),
+                          float(sch.buffers["sqrt_alphas_cumprod"][341]),
+                          float(sch.buffers["sqrt_one_minus_alphas_cumprod"][341]))
+    assert torch.equal(got.cpu(), ref)
+    # posterior sample (distributions.py:25-37) into a channel slice
+    from oracle.vae import posterior_sample
+    mom = W.synth_input("sa.mom", (2, 8, 6, 6)) * 3.0
+    n = W.synth_input("sa.n", (2, 4, 6, 6))
+    out = torch.zeros(2, 9, 6, 6).cuda()
+    ops.posterior_sample(mom.cuda(), n.cuda(), out, 4, 0.18215)
+    assert rel(out[:, 4:8].cpu(), 0.18215 * posterior_sample(mom, n)) < 1e-6 and float(out[:, :4].abs().sum()) == 0
+    y = ops.lincomb4([x.cuda(), e.cuda(), eu.cuda()], [23 / 12, -16 / 12, 5 / 12])
+    assert rel(y.cpu(), (23 * x - 16 * e + 5 * eu) / 12) < 1e-6
+
+
+def test_error_codes_on_device(ops):
+    from mobi_amd import _lib
+    x = torch.zeros(1, 4, 4, 48, dtype=torch.float16, device="cuda")
+    with pytest.raises(_lib.EngineError):
+        ops.groupnorm(x, torch.ones(48).cuda(), torch.zeros(48).cuda(), 1e-5, True)       # C % 32 != 0
+    q = torch.zeros(1, 4, 24, dtype=torch.float16, device="cuda")
+    with pytest.raises(_lib.EngineError):
+        ops.attention(q, q, q.permute(0, 2, 1).contiguous(), 2, 1.0)                       # dh = 12
