@@ -1,0 +1,231 @@
+#!/usr/bin/env python3
+"""Benchmark of the MObI sampling hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload mobi_nusc_512|mobi_nusc_256]
+                    [--objects B] [--dtype bf16|fp16] [--cfg-scale S] [--e2e] [--no-cpu-baseline]
+
+A "step" is one DDIM denoising step of the whole per-GPU batch: UNet forward on
+2*B interleaved camera/lidar elements (4*B with classifier-free guidance) plus the fp32
+latent update.  Synthetic inputs already resident in HBM, random-init weights of the
+mobi_nusc_512 architecture (1.04 B parameters); there is no checkpoint / dataset offline.
+
+Prints ONE JSON line (rank 0): metric = UNet element-forwards per second over all GPUs
+(= denoising steps/s x UNet batch elements), with `steps_per_s`, `roofline` (dominant
+kernel = the implicit-GEMM conv/linear kernel, algorithmic FLOPs / measured launch time
+against the 2.5 PFLOP/s dense bf16 MFMA peak) and `cpu_baseline` (the CPU oracle --
+the reference graph in PyTorch CPU fp32 -- timed on this host on a bounded sample).
+Multi-GPU: one process per GPU (torchrun), objects sharded, no collective inside the
+denoising loop; `--e2e` adds VAE encode/decode and the all-gather of decoded images.
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WORKLOADS = {  # BASELINE.json configs[2] / configs[1]
+    "mobi_nusc_512": dict(latent=64, objects=8, gflop_per_element=1021.9, gflop_skippable=25.6),
+    "mobi_nusc_256": dict(latent=32, objects=4, gflop_per_element=209.7, gflop_skippable=6.4),
+}
+PEAK_TFLOPS = 2500.0          # dense bf16/fp16 MFMA, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def build_unet(device, seed=0):
+    from mobi_amd.ldm.modules.diffusionmodules.openaimodel import UNetModel
+    net = UNetModel(image_size=64, in_channels=9, out_channels=4, model_channels=320,
+                    attention_resolutions=[4, 2, 1], num_res_blocks=2, channel_mult=[1, 2, 4, 4], num_heads=8,
+                    use_spatial_transformer=True, transformer_depth=1, context_dim=768, legacy=False,
+                    bbox_cond=True, use_camera=True, use_lidar=True)
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for name, p in net.named_parameters():          # also overwrites the zero-initialised layers
+            if p.dim() >= 2:
+                p.normal_(0.0, 1.0 / math.sqrt(p[0].numel()), generator=g)
+            elif name.endswith("weight"):
+                p.copy_(1.0 + 0.1 * torch.randn(p.shape, generator=g))
+            else:
+                p.normal_(0.0, 0.05, generator=g)
+    return net.eval()
+
+
+class SamplerModel:
+    """What DDIMSampler needs from LatentDiffusion (schedule buffers + apply_model)."""
+
+    def __init__(self, net, device):
+        from mobi_amd.ldm.modules.diffusionmodules.util import make_beta_schedule
+        import numpy as np
+        betas = make_beta_schedule("linear", 1000, linear_start=0.00085, linear_end=0.012)
+        ac = np.cumprod(1.0 - betas)
+        f = lambda a: torch.tensor(a, dtype=torch.float32, device=device)
+        self.betas, self.alphas_cumprod = f(betas), f(ac)
+        self.alphas_cumprod_prev = f(np.append(1.0, ac[:-1]))
+        self.num_timesteps, self.device, self.net = 1000, device, net
+
+    def apply_model(self, x, t, c):
+        return self.net(x, t, context=c)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="mobi_nusc_512", choices=list(WORKLOADS))
+    ap.add_argument("--objects", type=int, default=None, help="objects per GPU (default: the config's batch)")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16"])
+    ap.add_argument("--cfg-scale", type=float, default=1.0, help="1.0 = harness default (no CFG)")
+    ap.add_argument("--ddim-steps", type=int, default=50)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        import torch.distributed as dist
+        dist.init_process_group(backend="nccl")          # "nccl" is RCCL on ROCm
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+
+    import mobi_amd
+    from mobi_amd import build, ops
+    build.build(verbose=False)
+    from mobi_amd.ldm.models.diffusion.ddim import DDIMSampler
+    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float16
+    mobi_amd.set_engine_dtype(dtype)
+
+    wl = WORKLOADS[args.workload]
+    B = args.objects or wl["objects"]
+    side = wl["latent"]
+    N = 2 * B                                           # camera/lidar interleaved
+    cfg = args.cfg_scale != 1.0
+    elems = N * (2 if cfg else 1)
+
+    net = build_unet(device).to(device)
+    model = SamplerModel(net, device)
+    sampler = DDIMSampler(model)
+    sampler.make_schedule(args.ddim_steps, ddim_eta=0.0, verbose=False)
+    g = torch.Generator(device="cpu").manual_seed(1234 + rank)
+    mk = lambda *s: torch.randn(*s, generator=g).to(device)
+    img = mk(N, 4, side, side)
+    inpaint = mk(N, 4, side, side)
+    mask = torch.ones(N, 1, side, side)
+    mask[:, :, side // 4: 3 * side // 4, side // 4: 3 * side // 4] = 0
+    mask = mask.to(device)
+    cond, uc = mk(N, 2, 768), mk(N, 2, 768)
+    kw = {"test_model_kwargs": {"inpaint_image": inpaint, "inpaint_mask": mask}}
+    total = sampler.ddim_timesteps.shape[0]
+    steps_desc = list(reversed(sampler.ddim_timesteps.tolist()))
+
+    def one_step(x, i):
+        index = total - 1 - (i % total)
+        ts = torch.full((N,), int(steps_desc[i % total]), device=device, dtype=torch.long)
+        x, _ = sampler.p_sample_ddim(x, cond, ts, index=index, unconditional_guidance_scale=args.cfg_scale,
+                                     unconditional_conditioning=uc if cfg else None, **kw)
+        return x
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    with torch.no_grad():
+        x = img
+        for i in range(args.warmup):
+            x = one_step(x, i)
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            x = one_step(x, args.warmup + i)
+        barrier()
+        dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], device=device)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    finite = bool(torch.isfinite(x).all())
+
+    roofline = None
+    kinds = {}
+    if not args.no_roofline and rank == 0:
+        sink = []
+        ops.set_profiler(sink)
+        with torch.no_grad():
+            one_step(x, args.warmup + args.steps)
+        torch.cuda.synchronize()
+        ops.set_profiler(None)
+        for kind, flops, e0, e1 in sink:
+            k = kinds.setdefault(kind, dict(launches=0, flops=0.0, ms=0.0))
+            k["launches"] += 1
+            k["flops"] += flops
+            k["ms"] += e0.elapsed_time(e1)
+        ig = kinds["igemm"]
+        ach = ig["flops"] / (ig["ms"] * 1e-3) / 1e12
+        roofline = {"bound": "mfma", "kernel": "igemm_kernel", "achieved": round(ach, 2), "peak": PEAK_TFLOPS,
+                    "unit": "TFLOP/s", "frac": round(ach / PEAK_TFLOPS, 4), "traffic": None,
+                    "launches_per_step": ig["launches"],
+                    "avg_launch_us": round(ig["ms"] * 1e3 / ig["launches"], 2),
+                    "gflop_per_launch": round(ig["flops"] / ig["launches"] / 1e9, 3),
+                    "note": "event-bracketed launches of one extra step; algorithmic 2*M*N*K of every conv/linear"}
+        if "attention" in kinds:
+            at = kinds["attention"]
+            roofline["attention_tflops"] = round(at["flops"] / (at["ms"] * 1e-3) / 1e12, 2)
+            roofline["attention_ms_per_step"] = round(at["ms"], 3)
+        roofline["igemm_ms_per_step"] = round(ig["ms"], 3)
+        roofline["norm_ms_per_step"] = round(sum(kinds.get(k, {"ms": 0})["ms"] for k in ("groupnorm", "layernorm")), 3)
+
+    cpu_baseline = None
+    if not args.no_cpu_baseline and rank == 0 and world == 1:
+        from oracle import unet as ounet
+        ncpu = os.cpu_count() or 1
+        torch.set_num_threads(ncpu)
+        sd = {k: v.detach().float().cpu() for k, v in net.state_dict().items()}
+        xc = torch.cat([img[:2], inpaint[:2], mask[:2]], 1).float().cpu()
+        tc = torch.full((2,), 500, dtype=torch.long)
+        with torch.no_grad():
+            t0 = time.perf_counter()
+            ounet.unet_forward(sd, ounet.UNetConfig(), xc, tc, cond[:2].float().cpu())
+            cdt = time.perf_counter() - t0
+        cpu_baseline = {"value": round(2 / cdt, 4), "unit": "UNet element-forwards/s", "cores": ncpu, "kind": "port",
+                        "sample": f"1 denoising step of 1 object (UNet batch 2) at latent {side}x{side}, fp32, "
+                                  f"PyTorch CPU oracle of the reference graph, {cdt:.1f} s"}
+        del sd
+
+    if rank == 0:
+        steps_per_s = args.steps / dt
+        value = steps_per_s * elems * world
+        useful_gf = wl["gflop_per_element"] - wl["gflop_skippable"]
+        out = {
+            "metric": "denoising throughput (UNet element-forwards/s = steps/s x UNet batch)",
+            "value": round(value, 3), "unit": "UNet element-forwards/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": f"{args.workload} UNet denoising step, {B} objects/GPU (UNet batch {elems}), "
+                                   f"latent {side}x{side}, DDIM-{args.ddim_steps} schedule, "
+                                   f"cfg_scale {args.cfg_scale}",
+                       "objects_per_gpu": B, "unet_batch": elems, "latent": side, "sampler": "ddim",
+                       "parallelism": f"dp{world} (objects sharded, no collective in the loop)"},
+            "steps_per_s": round(steps_per_s * world, 4),
+            "model_tflops": round(value * useful_gf / 1e3 / world, 2),
+            "model_frac_of_peak": round(value * useful_gf / 1e3 / world / PEAK_TFLOPS, 4),
+            "finite": finite,
+        }
+        if roofline:
+            out["roofline"] = roofline
+        if cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -5,7 +5,7 @@ latent state and every coefficient stay fp32; the per-step arithmetic is one HIP
 import numpy as np
 import torch
 
-from ... import ops
+from .... import ops
 from ...modules.diffusionmodules.util import (make_ddim_sampling_parameters, make_ddim_timesteps, noise_like)
 
 

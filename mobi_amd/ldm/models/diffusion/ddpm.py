@@ -17,7 +17,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from ... import ops
+from .... import ops
 from ...modules.diffusionmodules.util import Linear, extract_into_tensor, make_beta_schedule
 from ...modules.distributions.distributions import DiagonalGaussianDistribution
 from ...util import cat_interleave, default, instantiate_from_config, make_contiguous

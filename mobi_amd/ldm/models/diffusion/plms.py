@@ -4,7 +4,7 @@ same fp32 update kernel as DDIM; the first step does two UNet evaluations."""
 import numpy as np
 import torch
 
-from ... import ops
+from .... import ops
 from .ddim import DDIMSampler
 
 

@@ -18,6 +18,34 @@ from ._lib import (ACT_NONE, ACT_SILU, EPI_GEGLU, EPI_NONE, MOBI_BF16, MOBI_F16,
                    OUT_TRANSPOSED)
 
 
+# optional launch profiler (bench.py): a list receiving (kind, algorithmic_flops, start_event, end_event)
+_PROFILE = None
+
+
+def set_profiler(sink):
+    global _PROFILE
+    _PROFILE = sink
+
+
+class _Timed:
+    """Brackets one launch with events on the launch stream when a profiler is installed."""
+
+    def __init__(self, kind, flops):
+        self.kind, self.flops = kind, flops
+
+    def __enter__(self):
+        if _PROFILE is not None:
+            self.e0, self.e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+        return self
+
+    def __exit__(self, *exc):
+        if _PROFILE is not None:
+            self.e1.record()
+            _PROFILE.append((self.kind, self.flops, self.e0, self.e1))
+        return False
+
+
 def _dt(t):
     if t == torch.float16:
         return MOBI_F16
@@ -156,7 +184,9 @@ def igemm(x, pw: Packed, *, x2=None, stride=1, pad=None, upsample=False, hout=No
     p.epilogue = EPI_GEGLU if pw.geglu else EPI_NONE
     p.scale = scale
     p.dtype = _dt(x.dtype)
-    _lib.check(lib.mobi_igemm(C.byref(p), _stream()), "mobi_igemm")
+    flops = 2.0 * n * hout * wout * (pw.n_packed if pw.geglu else pw.cout) * pw.kh * pw.kw * pw.cin
+    with _Timed("igemm", flops):
+        _lib.check(lib.mobi_igemm(C.byref(p), _stream()), "mobi_igemm")
     return out
 
 
@@ -184,7 +214,8 @@ def groupnorm(x, gamma, beta, eps, silu, x2=None):
     p.src0, p.src1, p.c0, p.c1, p.batch, p.hw = _ptr(x), _ptr(x2), c0, c1, n, h * w
     p.gamma, p.beta, p.eps, p.silu = _ptr(gamma), _ptr(beta), eps, int(silu)
     p.out, p.ws, p.dtype = _ptr(out), _ptr(ws), _dt(x.dtype)
-    _lib.check(lib.mobi_groupnorm(C.byref(p), _stream()), "mobi_groupnorm")
+    with _Timed("groupnorm", 0.0):
+        _lib.check(lib.mobi_groupnorm(C.byref(p), _stream()), "mobi_groupnorm")
     return out
 
 
@@ -199,7 +230,8 @@ def layernorm(x, gamma, beta, eps=1e-5):
     p.src_img_stride = 0 if s == t * c else s
     p.out_img_stride = 0
     p.gamma, p.beta, p.eps, p.dtype = _ptr(gamma), _ptr(beta), eps, _dt(x.dtype)
-    _lib.check(lib.mobi_layernorm(C.byref(p), _stream()), "mobi_layernorm")
+    with _Timed("layernorm", 0.0):
+        _lib.check(lib.mobi_layernorm(C.byref(p), _stream()), "mobi_layernorm")
     return out
 
 
@@ -217,9 +249,11 @@ def attention(q, k, vt, heads, scale):
     p.k, p.k_img_stride, p.k_row_stride = _ptr(k), k.stride(0), k.stride(1)
     p.vt, p.vt_img_stride, p.vt_row_stride = _ptr(vt), vt.stride(0), vt.stride(1)
     p.out, p.out_img_stride, p.out_row_stride = _ptr(out), out.stride(0), out.stride(1)
-    assert q.stride(2) == 1 and k.stride(2) == 1 and vt.stride(2) == 1
+    for t_ in (q, k, vt):
+        assert t_.shape[2] == 1 or t_.stride(2) == 1
     p.images, p.heads, p.dh, p.tq, p.tk, p.scale, p.dtype = n, heads, dh, tq, tk, scale, _dt(q.dtype)
-    _lib.check(lib.mobi_attention(C.byref(p), _stream()), "mobi_attention")
+    with _Timed("attention", 4.0 * n * heads * tq * tk * dh):
+        _lib.check(lib.mobi_attention(C.byref(p), _stream()), "mobi_attention")
     return out
 
 
@@ -256,11 +290,13 @@ def skinny_linear(x, w, bias=None, pre_act=ACT_NONE, post_act=ACT_NONE, out=None
     assert x.dtype == torch.float32 and x.stride(1) == 1 and w.is_contiguous()
     if out is None:
         out = torch.empty((m, n), device=x.device, dtype=torch.float32)
-    p = _lib.SkinnyLinearParams()
-    p.x, p.m, p.k, p.x_row_stride = _ptr(x), m, k, x.stride(0)
-    p.weight, p.bias, p.out, p.n, p.out_row_stride = _ptr(w), _ptr(bias), _ptr(out), n, out.stride(0)
-    p.pre_act, p.post_act, p.dtype = pre_act, post_act, _dt(w.dtype)
-    _lib.check(lib.mobi_skinny_linear(C.byref(p), _stream()), "mobi_skinny_linear")
+    for m0 in range(0, m, 64):                      # the kernel handles up to 64 rows per launch
+        xs, os_ = x[m0:m0 + 64], out[m0:m0 + 64]
+        p = _lib.SkinnyLinearParams()
+        p.x, p.m, p.k, p.x_row_stride = _ptr(xs), xs.shape[0], k, x.stride(0)
+        p.weight, p.bias, p.out, p.n, p.out_row_stride = _ptr(w), _ptr(bias), _ptr(os_), n, out.stride(0)
+        p.pre_act, p.post_act, p.dtype = pre_act, post_act, _dt(w.dtype)
+        _lib.check(lib.mobi_skinny_linear(C.byref(p), _stream()), "mobi_skinny_linear")
     return out
 
 

@@ -134,3 +134,14 @@ def test_schedules_bit_exact_host_side():
             assert np.array_equal(sig, g[f"ddim_sigmas_{tag}"].numpy())
             assert np.array_equal(a, g[f"ddim_alphas_{tag}"].numpy())
             assert np.array_equal(ap, g[f"ddim_alphas_prev_{tag}"].numpy())
+
+
+def test_every_product_module_imports():
+    import importlib
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "mobi_amd")):
+        for f in files:
+            if f.endswith(".py") and f != "build.py":
+                rel = os.path.relpath(os.path.join(dirpath, f), ROOT)[:-3].replace(os.sep, ".")
+                if rel.endswith(".__init__"):
+                    rel = rel[:-9]
+                importlib.import_module(rel)
