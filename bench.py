@@ -83,6 +83,8 @@ def main():
     ap.add_argument("--ddim-steps", type=int, default=50)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--dump-launches", default=None, help="write per-launch (kind, GFLOP, us) records of one step")
+    ap.add_argument("--cpu-threads", type=int, default=32, help="threads for the CPU-oracle baseline leg")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -162,6 +164,10 @@ def main():
             one_step(x, args.warmup + args.steps)
         torch.cuda.synchronize()
         ops.set_profiler(None)
+        if args.dump_launches:
+            with open(args.dump_launches, "w") as f:
+                for kind, flops, e0, e1 in sink:
+                    f.write(f"{kind}\t{flops / 1e9:.4f}\t{e0.elapsed_time(e1) * 1e3:.2f}\n")
         for kind, flops, e0, e1 in sink:
             k = kinds.setdefault(kind, dict(launches=0, flops=0.0, ms=0.0))
             k["launches"] += 1
@@ -185,7 +191,7 @@ def main():
     cpu_baseline = None
     if not args.no_cpu_baseline and rank == 0 and world == 1:
         from oracle import unet as ounet
-        ncpu = os.cpu_count() or 1
+        ncpu = max(1, min(os.cpu_count() or 1, args.cpu_threads))   # more threads than this slows torch's CPU convs down
         torch.set_num_threads(ncpu)
         sd = {k: v.detach().float().cpu() for k, v in net.state_dict().items()}
         xc = torch.cat([img[:2], inpaint[:2], mask[:2]], 1).float().cpu()
