@@ -92,9 +92,18 @@ typedef struct mobi_igemm_params {
   int32_t epilogue;      /* MOBI_EPI_*                                                   */
   float scale;           /* multiplies the accumulator before bias (1.0f normally)       */
   int32_t dtype;
+  int32_t split_k;       /* <= 1: single pass.  > 1: k is cut into split_k ranges that run as
+                            separate workgroups (fills the chip when m is small, e.g. the 8x8 /
+                            16x16 UNet levels); fp32 partial slabs go to `ws` and a second launch
+                            sums them and applies the epilogue.  Not with GEGLU / transposed /
+                            per-image weights.                                              */
+  void* ws;              /* mobi_igemm_workspace_bytes(p, split_k) bytes, 16-byte aligned  */
 } mobi_igemm_params;
 
 int mobi_igemm(const mobi_igemm_params* p, void* stream);
+/* Library heuristic for split_k (1 = do not split) and the workspace it needs. */
+int mobi_igemm_plan_splits(const mobi_igemm_params* p);
+size_t mobi_igemm_workspace_bytes(const mobi_igemm_params* p, int32_t splits);
 
 /* ---------------------------------------------------------------------------
  * GroupNorm (32 groups) with optional fused SiLU over one or two
@@ -264,6 +273,12 @@ int mobi_posterior_sample(const float* moments, const float* noise, float* out, 
 /* F.interpolate(mode="nearest") on fp32 NCHW (ddpm.py:1020): index-only. */
 int mobi_nearest_resize(const float* src, float* out, int32_t planes, int32_t hin, int32_t win,
                         int32_t hout, int32_t wout, int32_t out_plane_stride, void* stream);
+
+/* torch.cat of up to three fp32 NCHW sources on the channel axis (ddim.py:170; a VAE's image
+ * input) -> T channels-last zero-padded to c_pad channels (c_pad % 32 == 0 feeds mobi_igemm,
+ * whose matching weights are zero-padded on the input-channel axis). */
+int mobi_pack_nchw_sources(const float* s0, const float* s1, const float* s2, int32_t c0, int32_t c1, int32_t c2,
+                           int32_t batch, int32_t hw, int32_t c_pad, void* out, int32_t dtype, void* stream);
 
 /* Layout converters at the API boundary (tests, module-level calls). */
 int mobi_nchw_f32_to_nhwc(const float* src, void* out, int32_t batch, int32_t c, int32_t hw, int32_t dtype,

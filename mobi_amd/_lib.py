@@ -32,7 +32,7 @@ class IgemmParams(C.Structure):
                 ("pad_h", i32), ("pad_w", i32), ("src_img_stride", i64), ("weight", vp), ("groups", i32),
                 ("w_group_stride", i64), ("n_packed", i32), ("cout", i32), ("bias", vp), ("rowvec", vp), ("rowvec_stride", i32),
                 ("residual", vp), ("res_img_stride", i64), ("out", vp), ("out_img_stride", i64),
-                ("out_mode", i32), ("epilogue", i32), ("scale", f32), ("dtype", i32)]
+                ("out_mode", i32), ("epilogue", i32), ("scale", f32), ("dtype", i32), ("split_k", i32), ("ws", vp)]
 
 
 class GroupNormParams(C.Structure):
@@ -93,6 +93,8 @@ SYMBOLS = {
     "mobi_error_string": (C.c_char_p, [C.c_int]),
     "mobi_struct_size": (C.c_size_t, [C.c_int]),
     "mobi_igemm": (C.c_int, [C.POINTER(IgemmParams), vp]),
+    "mobi_igemm_plan_splits": (C.c_int, [C.POINTER(IgemmParams)]),
+    "mobi_igemm_workspace_bytes": (C.c_size_t, [C.POINTER(IgemmParams), i32]),
     "mobi_groupnorm_workspace_bytes": (C.c_size_t, [i32, i32]),
     "mobi_groupnorm": (C.c_int, [C.POINTER(GroupNormParams), vp]),
     "mobi_layernorm": (C.c_int, [C.POINTER(LayerNormParams), vp]),
@@ -108,6 +110,7 @@ SYMBOLS = {
     "mobi_mask_blend": (C.c_int, [vp, vp, vp, vp, f32, f32, i32, i32, i32, vp]),
     "mobi_posterior_sample": (C.c_int, [vp, vp, vp, i32, i32, i32, i32, i32, f32, vp]),
     "mobi_nearest_resize": (C.c_int, [vp, vp, i32, i32, i32, i32, i32, i32, vp]),
+    "mobi_pack_nchw_sources": (C.c_int, [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, i32, vp]),
     "mobi_nchw_f32_to_nhwc": (C.c_int, [vp, vp, i32, i32, i32, i32, vp]),
     "mobi_nhwc_to_nchw_f32": (C.c_int, [vp, vp, i32, i32, i32, i32, vp]),
 }

@@ -35,6 +35,8 @@ struct IgemmArgs {
   int out_mode, epilogue;
   float scale;
   int tiles_m, tiles_n;
+  int splits, nk_per;      // split-K: blockIdx.y owns k-tiles [y*nk_per, (y+1)*nk_per)
+  float* split_ws;         // f32 [splits][M][n_packed] partial sums (NULL: single pass)
 };
 
 template <typename T, int NT, bool TR>
@@ -94,8 +96,14 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
   const int taps = a.kh * a.kw;
   const int hlog = a.hin << a.up, wlog = a.win << a.up;
   // running (tap, chunk-in-tap) of this thread's chunk slot
-  int cc = slot, tap = 0, ky = 0, kx = 0;
-  while (cc >= cpt) { cc -= cpt; ++tap; if (++kx == a.kw) { kx = 0; ++ky; } }
+  const int kt_begin = blockIdx.y * a.nk_per;
+  const int kt_end = min(a.nk, kt_begin + a.nk_per);
+  int cc, tap, ky, kx;
+  {
+    const int c0 = 2 * kt_begin + slot;
+    tap = c0 / cpt; cc = c0 - tap * cpt;
+    ky = tap / a.kw; kx = tap - ky * a.kw;
+  }
 
   u32x4 xr[4], wr[NT];
 
@@ -155,12 +163,14 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
 
   const int r16 = lane & 15, g4 = lane >> 4;
 
-  load_tile(0);
-  store_tile(0);
+  if (kt_begin < kt_end) {
+    load_tile(kt_begin);
+    store_tile(0);
+  }
   __syncthreads();
   int buf = 0;
-  for (int kt = 0; kt < a.nk; ++kt) {
-    const bool more = kt + 1 < a.nk;
+  for (int kt = kt_begin; kt < kt_end; ++kt) {
+    const bool more = kt + 1 < kt_end;
     if (more) load_tile(kt + 1);
     const unsigned char* xb = lds + buf * X_TILE + (wm * 64 + r16) * 128;
     const unsigned char* wb = lds + 2 * X_TILE + buf * W_TILE + (wn * WAVE_N + r16) * 128;
@@ -222,7 +232,21 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
 
     const int mp0 = mw0 + pass * 32;         // first row of this pass
     if (!TR) {
-      if (a.epilogue == MOBI_EPI_GEGLU) {
+      if (a.split_ws) {
+        // split-K: raw fp32 partial sums, finished by igemm_splitk_reduce_kernel
+        constexpr int TPR = WAVE_N / 8;
+        float* __restrict__ wsp = a.split_ws + (long long)blockIdx.y * a.M * a.n_packed;
+        for (int task = lane; task < 32 * TPR; task += 64) {
+          const int row = task / TPR, cg = task - row * TPR;
+          const int m = mp0 + row;
+          const int n = nw0 + cg * 8;
+          if (m >= a.M || n >= a.n_packed) continue;
+          const float* sp = stage + row * STAGE_STRIDE + cg * 8;
+          float* d = wsp + (long long)m * a.n_packed + n;
+          *reinterpret_cast<f32x4*>(d) = *reinterpret_cast<const f32x4*>(sp);
+          *reinterpret_cast<f32x4*>(d + 4) = *reinterpret_cast<const f32x4*>(sp + 4);
+        }
+      } else if (a.epilogue == MOBI_EPI_GEGLU) {
         constexpr int HALF = WAVE_N / 2;     // a | gate split of the wave's packed columns
         constexpr int TPR = HALF / 8;
         const int unit = nw0 / WAVE_N;
@@ -313,11 +337,57 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
   }
 }
 
+// split-K finish: sum the partial slabs, then the ordinary epilogue (bias, per-image vector, residual)
+template <typename T>
+__global__ __launch_bounds__(256) void igemm_splitk_reduce_kernel(const IgemmArgs a) {
+  const int vpr = a.cout >> 3;
+  const long long total = (long long)a.M * vpr;
+  T* __restrict__ outT = reinterpret_cast<T*>(a.out);
+  float* __restrict__ outF = reinterpret_cast<float*>(a.out);
+  const T* __restrict__ resid = reinterpret_cast<const T*>(a.residual);
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int m = (int)(i / vpr);
+    const int n = (int)(i - (long long)m * vpr) * 8;
+    float o[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = 0.f;
+    for (int s = 0; s < a.splits; ++s) {
+      const float* p = a.split_ws + ((long long)s * a.M + m) * a.n_packed + n;
+      const f32x4 v0 = *reinterpret_cast<const f32x4*>(p), v1 = *reinterpret_cast<const f32x4*>(p + 4);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { o[j] += v0[j]; o[4 + j] += v1[j]; }
+    }
+    const int img = m / a.hw_out, rem = m - img * a.hw_out;
+    if (a.bias) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] += a.bias[n + j];
+    }
+    if (a.rowvec) {
+      const float* rv = a.rowvec + (long long)img * a.rowvec_stride + n;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] += rv[j];
+    }
+    if (resid) {
+      float rf[8];
+      unpack8<T>(ld16(resid + (long long)img * a.res_img_stride + (long long)rem * a.cout + n), rf);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] += rf[j];
+    }
+    const long long off = (long long)img * a.out_img_stride + (long long)rem * a.cout + n;
+    if (a.out_mode == MOBI_OUT_ROWS_F32) {
+      *reinterpret_cast<f32x4*>(outF + off) = f32x4{o[0], o[1], o[2], o[3]};
+      *reinterpret_cast<f32x4*>(outF + off + 4) = f32x4{o[4], o[5], o[6], o[7]};
+    } else {
+      st16(outT + off, pack8<T>(o));
+    }
+  }
+}
+
 template <typename T>
 static int launch_igemm(const mobi_igemm_params* p, const IgemmArgs& a, int groups, hipStream_t st) {
   const bool tr = p->out_mode == MOBI_OUT_TRANSPOSED;
   const bool nt5 = (a.n_packed % 160) == 0;
-  dim3 grid(a.tiles_m * a.tiles_n, 1, groups), block(256);
+  dim3 grid(a.tiles_m * a.tiles_n, a.splits, groups), block(256);
   if (nt5) {
     if (tr) hipLaunchKernelGGL((igemm_kernel<T, 5, true>), grid, block, 0, st, a);
     else    hipLaunchKernelGGL((igemm_kernel<T, 5, false>), grid, block, 0, st, a);
@@ -326,10 +396,38 @@ static int launch_igemm(const mobi_igemm_params* p, const IgemmArgs& a, int grou
     else    hipLaunchKernelGGL((igemm_kernel<T, 4, false>), grid, block, 0, st, a);
   }
   MOBI_CHECK_LAUNCH();
+  if (a.split_ws) {
+    long long blocks = ((long long)a.M * (a.cout >> 3) + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL((igemm_splitk_reduce_kernel<T>), dim3((unsigned)blocks), dim3(256), 0, st, a);
+    MOBI_CHECK_LAUNCH();
+  }
   return MOBI_OK;
 }
 
+// split-K plan: only when the tile grid cannot fill the chip and k is long
+static int plan_splits(long long M, int n_packed, int ktot) {
+  const int bn = (n_packed % 160) == 0 ? 160 : 128;
+  const long long tiles = ((M + 127) / 128) * ((n_packed + bn - 1) / bn);
+  const int nk = (ktot + 63) / 64;
+  if (tiles >= 384 || nk < 16) return 1;
+  long long s = (512 + tiles - 1) / tiles;
+  if (s > 8) s = 8;
+  if (s > nk / 8) s = nk / 8;
+  return s < 2 ? 1 : (int)s;
+}
+
 }  // namespace mobi
+
+extern "C" int mobi_igemm_plan_splits(const mobi_igemm_params* p) {
+  if (!p || p->groups != 1 || p->epilogue != MOBI_EPI_NONE || p->out_mode == MOBI_OUT_TRANSPOSED) return 1;
+  return mobi::plan_splits((long long)p->batch * p->hout * p->wout, p->n_packed, p->kh * p->kw * (p->c0 + p->c1));
+}
+
+extern "C" size_t mobi_igemm_workspace_bytes(const mobi_igemm_params* p, int32_t splits) {
+  if (!p || splits <= 1) return 0;
+  return (size_t)splits * p->batch * p->hout * p->wout * p->n_packed * sizeof(float);
+}
 
 extern "C" int mobi_igemm(const mobi_igemm_params* p, void* stream) {
   using namespace mobi;
@@ -378,6 +476,14 @@ extern "C" int mobi_igemm(const mobi_igemm_params* p, void* stream) {
   a.tiles_m = (a.M + 127) / 128;
   a.tiles_n = (p->n_packed + bn - 1) / bn;
   if ((long long)a.tiles_m * a.tiles_n > 0x7fffffffLL) return MOBI_ERR_UNSUPPORTED;
+  a.splits = 1; a.nk_per = a.nk; a.split_ws = nullptr;
+  if (p->split_k > 1) {
+    if (!p->ws || p->groups != 1 || geglu || p->out_mode == MOBI_OUT_TRANSPOSED || p->split_k > 64) return MOBI_ERR_UNSUPPORTED;
+    if (reinterpret_cast<uintptr_t>(p->ws) & 15) return MOBI_ERR_ALIGN;
+    a.splits = p->split_k;
+    a.nk_per = (a.nk + a.splits - 1) / a.splits;
+    a.split_ws = reinterpret_cast<float*>(p->ws);
+  }
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   return p->dtype == MOBI_F16 ? launch_igemm<f16_t>(p, a, p->groups, st) : launch_igemm<bf16_t>(p, a, p->groups, st);
 }

@@ -81,7 +81,10 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const GnArgs a) {
 
 template <typename T>
 __global__ __launch_bounds__(256) void gn_apply_kernel(const GnArgs a) {
+  // per-channel scale / shift of this image, built once per block:  y = x * sc[c] + sh[c]
   __shared__ float s_mean[32], s_rstd[32];
+  __shared__ __attribute__((aligned(16))) float s_sc[2560];
+  __shared__ __attribute__((aligned(16))) float s_sh[2560];
   const int tid = threadIdx.x;
   const int img = blockIdx.y;
   if (tid < 32) {
@@ -96,12 +99,21 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const GnArgs a) {
     s_rstd[tid] = (float)(1.0 / sqrt(var + (double)a.eps));
   }
   __syncthreads();
-  const int V = a.C >> 3;
   const int cpg = a.C / 32;
+  for (int c = tid; c < a.C; c += 256) {
+    const int g = c / cpg;
+    const float sc = s_rstd[g] * a.gamma[c];
+    s_sc[c] = sc;
+    s_sh[c] = a.beta[c] - s_mean[g] * sc;
+  }
+  __syncthreads();
+  const int V = a.C >> 3;
   const long long total = (long long)a.hw * V;
   const T* __restrict__ s0 = reinterpret_cast<const T*>(a.src0) + (long long)img * a.hw * a.c0;
   const T* __restrict__ s1 = a.src1 ? reinterpret_cast<const T*>(a.src1) + (long long)img * a.hw * a.c1 : nullptr;
   T* __restrict__ out = reinterpret_cast<T*>(a.out) + (long long)img * a.hw * a.C;
+  // each thread keeps its 8-channel column while it strides over pixels when 256 % V == 0 or V % 256 == 0;
+  // otherwise the column changes per iteration (still one 16-byte access per iteration)
   for (long long i = (long long)blockIdx.x * 256 + tid; i < total; i += (long long)gridDim.x * 256) {
     const int p = (int)(i / V);
     const int c = (int)(i - (long long)p * V) * 8;
@@ -109,13 +121,16 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const GnArgs a) {
     const T* src = second ? s1 + (long long)p * a.c1 + (c - a.c0) : s0 + (long long)p * a.c0 + c;
     float f[8];
     unpack8<T>(ld16(src), f);
+    const f32x4 sc0 = *reinterpret_cast<const f32x4*>(s_sc + c), sc1 = *reinterpret_cast<const f32x4*>(s_sc + c + 4);
+    const f32x4 sh0 = *reinterpret_cast<const f32x4*>(s_sh + c), sh1 = *reinterpret_cast<const f32x4*>(s_sh + c + 4);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int g = (c + j) / cpg;
-      const float sc = s_rstd[g] * a.gamma[c + j];
-      float y = (f[j] - s_mean[g]) * sc + a.beta[c + j];
-      if (a.silu) y = silu_f(y);
-      f[j] = y;
+    for (int j = 0; j < 4; ++j) {
+      f[j] = f[j] * sc0[j] + sh0[j];
+      f[4 + j] = f[4 + j] * sc1[j] + sh1[j];
+    }
+    if (a.silu) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) f[j] = silu_f(f[j]);
     }
     st16(out + (long long)p * a.C + c, pack8<T>(f));
   }

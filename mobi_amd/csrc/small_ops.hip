@@ -266,6 +266,31 @@ __global__ void nhwc_to_nchw_kernel(const T* src, float* out, int batch, int c, 
   }
 }
 
+// up to 3 fp32 NCHW sources concatenated on channels -> T channels-last, zero-padded to c_pad channels
+template <typename T>
+__global__ __launch_bounds__(256) void pack_sources_kernel(const float* s0, const float* s1, const float* s2, int c0,
+                                                           int c1, int c2, int batch, int hw, int c_pad, T* out) {
+  const long long total = (long long)batch * hw * (c_pad >> 3);
+  const int vpp = c_pad >> 3;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int v = (int)(i % vpp);
+    const long long pix = i / vpp;
+    const int b = (int)(pix / hw);
+    const int p = (int)(pix - (long long)b * hw);
+    float f[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int c = v * 8 + j;
+      float val = 0.f;
+      if (c < c0) val = s0[((long long)b * c0 + c) * hw + p];
+      else if (c < c0 + c1) val = s1[((long long)b * c1 + (c - c0)) * hw + p];
+      else if (c < c0 + c1 + c2) val = s2[((long long)b * c2 + (c - c0 - c1)) * hw + p];
+      f[j] = val;
+    }
+    st16(out + i * 8, pack8<T>(f));
+  }
+}
+
 static inline unsigned grid_for(long long total, int block, long long cap = 65536) {
   long long g = (total + block - 1) / block;
   if (g > cap) g = cap;
@@ -345,6 +370,19 @@ extern "C" int mobi_conv_small_cout(const mobi_conv_small_cout_params* p, void* 
   const unsigned blocks = (unsigned)((pixels + 3) / 4);
   if (p->dtype == MOBI_F16) hipLaunchKernelGGL((conv_small_cout_kernel<f16_t>), dim3(blocks), dim3(256), 0, ST(stream), *p);
   else hipLaunchKernelGGL((conv_small_cout_kernel<bf16_t>), dim3(blocks), dim3(256), 0, ST(stream), *p);
+  MOBI_CHECK_LAUNCH();
+  return MOBI_OK;
+}
+
+extern "C" int mobi_pack_nchw_sources(const float* s0, const float* s1, const float* s2, int32_t c0, int32_t c1,
+                                      int32_t c2, int32_t batch, int32_t hw, int32_t c_pad, void* out, int32_t dtype,
+                                      void* stream) {
+  if (!s0 || !out || c0 <= 0 || c1 < 0 || c2 < 0 || (c1 > 0 && !s1) || (c2 > 0 && !s2)) return MOBI_ERR_ARG;
+  if (batch <= 0 || hw <= 0 || !DT_OK(dtype)) return MOBI_ERR_ARG;
+  if ((c_pad & 7) || c_pad < c0 + c1 + c2) return MOBI_ERR_UNSUPPORTED;
+  const unsigned g = grid_for((long long)batch * hw * (c_pad >> 3), 256, 8192);
+  if (dtype == MOBI_F16) hipLaunchKernelGGL((pack_sources_kernel<f16_t>), dim3(g), dim3(256), 0, ST(stream), s0, s1, s2, c0, c1, c2, batch, hw, c_pad, (f16_t*)out);
+  else hipLaunchKernelGGL((pack_sources_kernel<bf16_t>), dim3(g), dim3(256), 0, ST(stream), s0, s1, s2, c0, c1, c2, batch, hw, c_pad, (bf16_t*)out);
   MOBI_CHECK_LAUNCH();
   return MOBI_OK;
 }

@@ -148,9 +148,7 @@ class Encoder(nn.Module):
     def forward(self, x):
         """x: fp32 NCHW image / range view -> fp32 NCHW [B, 2*z, h, w]."""
         cin = self.conv_in_lidar if self.lidar_adapter else self.conv_in
-        w, b = cin.packed_f32()
-        h = ops.conv_small_cin([x.float().contiguous()], w, b, cin.kernel_size[0], cin.kernel_size[1], cin.padding,
-                               engine_dtype())
+        h = ops.igemm(ops.pack_sources([x.float().contiguous()], engine_dtype()), cin.packed_thin(), pad=cin.padding)
         if self.lidar_adapter:
             h = self.res_block_lidar2(self.res_block_lidar1(h))
         for i_level in range(self.num_resolutions):
@@ -208,8 +206,7 @@ class Decoder(nn.Module):
     def forward(self, z, clamp=None):
         """z: fp32 NCHW latent -> fp32 NCHW image; `clamp=(lo, hi)` fuses the torch.clamp the
         harness applies to every decode (ddpm.py:1476,1504)."""
-        w, b = self.conv_in.packed_f32()
-        h = ops.conv_small_cin([z.float().contiguous()], w, b, 3, 3, (1, 1), engine_dtype())
+        h = ops.igemm(ops.pack_sources([z.float().contiguous()], engine_dtype()), self.conv_in.packed_thin(), pad=(1, 1))
         h = self.mid.block_2(self.mid.attn_1(self.mid.block_1(h)))
         for i_level in reversed(range(self.num_resolutions)):
             for i_block in range(self.num_res_blocks + 1):

@@ -46,9 +46,8 @@ def _plain_conv(conv, x):
     """A bare Conv2d inside a TimestepEmbedSequential (input_blocks.0)."""
     if isinstance(x, (list, tuple)) or (x.dtype == torch.float32 and conv.in_channels <= 16):
         srcs = list(x) if isinstance(x, (list, tuple)) else [x]
-        w, b = conv.packed_f32()
-        return ops.conv_small_cin([s.float().contiguous() for s in srcs], w, b, conv.kernel_size[0],
-                                  conv.kernel_size[1], conv.padding, engine_dtype())
+        packed = ops.pack_sources([s.float().contiguous() for s in srcs], engine_dtype())
+        return ops.igemm(packed, conv.packed_thin(), stride=conv.stride, pad=conv.padding)
     x, ext = enter(x)
     return leave(ops.igemm(x, conv.packed(), stride=conv.stride, pad=conv.padding), ext)
 

@@ -128,6 +128,11 @@ class Conv2d(_Holder):
         """T [O][kh*kw*I] for the matrix-core / small-cout kernels."""
         return self._cached("mfma", lambda: ops.pack_conv(self.weight, self.bias, engine_dtype(), self.weight.device))
 
+    def packed_thin(self):
+        """as packed(), with the (< 32) input channels zero-padded to 32 for ops.pack_sources inputs."""
+        return self._cached("thin", lambda: ops.pack_conv_padded_cin(self.weight, self.bias, engine_dtype(),
+                                                                     self.weight.device))
+
     def packed_f32(self):
         """fp32 [O][I*kh*kw] (OIHW flattened) for the small-cin direct kernel."""
         return self._cached("f32", lambda: (self.weight.detach().float().reshape(self.out_channels, -1).contiguous(),

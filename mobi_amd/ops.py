@@ -99,6 +99,15 @@ def pack_conv(weight, bias, dtype, device):
     return Packed(w.to(dtype).contiguous(), b, kh, kw, i, o, o)
 
 
+def pack_conv_padded_cin(weight, bias, dtype, device, cin_pad=32):
+    """Thin-input convs (9, 4, 3, 2 input channels): zero-pad the input-channel axis to `cin_pad` so the
+    matrix-core kernel can run them on sources packed by `pack_sources`."""
+    o, i, kh, kw = weight.shape
+    w = torch.zeros((o, cin_pad, kh, kw), dtype=torch.float32, device=device)
+    w[:, :i] = weight.detach().to(device=device, dtype=torch.float32)
+    return pack_conv(w, bias, dtype, device)
+
+
 def pack_linear(weight, bias, dtype, device):
     return pack_conv(weight[:, :, None, None], bias, dtype, device)
 
@@ -139,7 +148,8 @@ def pack_geglu(weight, bias, dtype, device):
 # matrix-core ops
 # --------------------------------------------------------------------------------------
 def igemm(x, pw: Packed, *, x2=None, stride=1, pad=None, upsample=False, hout=None, wout=None, rowvec=None,
-          residual=None, out=None, out_mode=OUT_ROWS, scale=1.0, weight_per_image=False, w_group_stride=0):
+          residual=None, out=None, out_mode=OUT_ROWS, scale=1.0, weight_per_image=False, w_group_stride=0,
+          split_k=None):
     """x: [N,H,W,C0] (tokens: [N,T,1,C]); x2: optional second source concatenated on channels."""
     lib = _lib.load()
     n, hin, win, c0 = x.shape
@@ -184,6 +194,10 @@ def igemm(x, pw: Packed, *, x2=None, stride=1, pad=None, upsample=False, hout=No
     p.epilogue = EPI_GEGLU if pw.geglu else EPI_NONE
     p.scale = scale
     p.dtype = _dt(x.dtype)
+    splits = split_k if split_k is not None else lib.mobi_igemm_plan_splits(C.byref(p))
+    if splits > 1:
+        ws = torch.empty(lib.mobi_igemm_workspace_bytes(C.byref(p), splits), device=x.device, dtype=torch.uint8)
+        p.split_k, p.ws = splits, _ptr(ws)
     flops = 2.0 * n * hout * wout * (pw.n_packed if pw.geglu else pw.cout) * pw.kh * pw.kw * pw.cin
     with _Timed("igemm", flops):
         _lib.check(lib.mobi_igemm(C.byref(p), _stream()), "mobi_igemm")
@@ -346,6 +360,20 @@ def conv_small_cout(x, pw: Packed, pad=None, clamp=None):
         p.clamp, p.clamp_lo, p.clamp_hi = 1, clamp[0], clamp[1]
     p.in_scale, p.dtype = 1.0, _dt(x.dtype)
     _lib.check(lib.mobi_conv_small_cout(C.byref(p), _stream()), "mobi_conv_small_cout")
+    return out
+
+
+def pack_sources(srcs, dtype, c_pad=32):
+    """fp32 NCHW sources (<= 3), concatenated on channels -> T [N,H,W,c_pad] (zero padded)."""
+    lib = _lib.load()
+    n, _, h, w = srcs[0].shape
+    for s_ in srcs:
+        assert s_.dtype == torch.float32 and s_.is_contiguous() and s_.shape[0] == n and s_.shape[2:] == (h, w)
+    ss = list(srcs) + [None] * (3 - len(srcs))
+    cs = [0 if s_ is None else s_.shape[1] for s_ in ss]
+    out = torch.empty((n, h, w, c_pad), device=srcs[0].device, dtype=dtype)
+    _lib.check(lib.mobi_pack_nchw_sources(_ptr(ss[0]), _ptr(ss[1]), _ptr(ss[2]), cs[0], cs[1], cs[2], n, h * w,
+                                          c_pad, _ptr(out), _dt(dtype), _stream()), "mobi_pack_nchw_sources")
     return out
 
 

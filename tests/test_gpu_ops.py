@@ -346,3 +346,26 @@ def test_error_codes_on_device(ops):
     q = torch.zeros(1, 4, 24, dtype=torch.float16, device="cuda")
     with pytest.raises(_lib.EngineError):
         ops.attention(q, q, q.permute(0, 2, 1).contiguous(), 2, 1.0)                       # dh = 12
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("split", [None, 2, 5, 8])
+def test_igemm_split_k(ops, dtype, split):
+    """Small-m / long-k convolution (the 8x8 UNet level): k cut over workgroups, fp32 slabs, reduce launch
+    with bias + per-image vector + residual.  split=None exercises the library's own plan."""
+    xf, xd = rnd("sk.x", (2, 8, 8, 640), dtype)
+    x1f, x1d = rnd("sk.x1", (2, 8, 8, 320), dtype)
+    rf, rd = rnd("sk.res", (2, 8, 8, 320), dtype)
+    wf = torch.from_numpy(W.synth_param("sk.weight", (320, 960, 3, 3))).to(dtype).float()
+    bias = torch.from_numpy(W.synth_param("sk.bias", (320,)))
+    rv = W.synth_input("sk.rowvec", (2, 320))
+    pw = ops.pack_conv(wf, bias, dtype, "cuda")
+    ref = _conv_ref(torch.cat([xf, x1f], 3), wf, bias) + rv[:, None, None, :] + rf
+    y = ops.igemm(xd, pw, x2=x1d, rowvec=rv.cuda(), residual=rd, split_k=split)
+    assert rel(y.float(), ref) < TOL[dtype] * 0.5
+    if split is None:
+        from mobi_amd import _lib
+        import ctypes as C
+        p = _lib.IgemmParams()
+        p.batch, p.hout, p.wout, p.n_packed, p.kh, p.kw, p.c0, p.groups = 2, 8, 8, 320, 3, 3, 960, 1
+        assert _lib.load().mobi_igemm_plan_splits(C.byref(p)) > 1
