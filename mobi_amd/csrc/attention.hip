@@ -119,6 +119,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnArgs a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
   float m_run = -INFINITY, l_run = 0.f;
+  const float cexp = a.scale * 1.4426950408889634f;
 
   const int ntiles = (a.tk + 63) / 64;
   load_tile(0);
@@ -143,35 +144,48 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnArgs a) {
       }
     }
     // ---- online softmax (one query column per lane) -----------------------------
+    // p = exp2(s * c - m * c), c = scale * log2(e): one FMA + one v_exp per score; the running max is
+    // kept in the raw score domain (scale > 0).  Masking only on the ragged last tile; O / l are rescaled
+    // only when some lane's max actually moved (wave-uniform branch).
     float mx = -INFINITY;
+    if (key0 + 64 <= a.tk) {
 #pragma unroll
-    for (int kt = 0; kt < 2; ++kt)
+      for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int key = key0 + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-        float v = s[kt][r] * a.scale;
-        v = key < a.tk ? v : -INFINITY;
-        s[kt][r] = v;
-        mx = fmaxf(mx, v);
-      }
+        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kt][r]);
+    } else {
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = key0 + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+          const float v = key < a.tk ? s[kt][r] : -INFINITY;
+          s[kt][r] = v;
+          mx = fmaxf(mx, v);
+        }
+    }
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
     const float m_new = fmaxf(m_run, mx);
-    const float alpha = __expf(m_run - m_new);       // first tile: exp(-inf) = 0
+    if (!__all(m_new == m_run)) {
+      const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * cexp);   // first tile: exp2(-inf) = 0
+      l_run *= alpha;
+#pragma unroll
+      for (int d = 0; d < DT; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
+      m_run = m_new;
+    }
+    const float mc = m_run * cexp;
     float psum = 0.f;
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float p = __expf(s[kt][r] - m_new);
+        const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kt][r], cexp, -mc));
         s[kt][r] = p;
         psum += p;
       }
-    l_run = l_run * alpha + psum;
-    m_run = m_new;
-#pragma unroll
-    for (int d = 0; d < DT; ++d)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
+    l_run += psum;
 
     // ---- O^T += V^T . P^T --------------------------------------------------------
 #pragma unroll

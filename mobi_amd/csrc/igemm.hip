@@ -40,7 +40,7 @@ struct IgemmArgs {
 };
 
 template <typename T, int NT, bool TR>
-__global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
+__global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs a) {
   typedef typename Vec8<T>::type frag_t;
   constexpr int WAVE_N = NT * 16;
   constexpr int BN = 2 * WAVE_N;
@@ -105,53 +105,59 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
     ky = tap / a.kw; kx = tap - ky * a.kw;
   }
 
-  u32x4 xr[4], wr[NT];
+  // Two register sets: the loads of k-tile t+2 are in flight while tile t is multiplied and tile t+1
+  // (loaded one step earlier) is written to LDS.  Every load is issued UNCONDITIONALLY (invalid pieces read
+  // a safe address and are zeroed from a validity mask when written to LDS) so that the compiler can count
+  // them and wait with vmcnt(N) for the older tile only, instead of draining with vmcnt(0).
+  u32x4 xr0[4], wr0[NT], xr1[4], wr1[NT];
+  unsigned ok0 = 0, ok1 = 0;
 
-  auto load_tile = [&](int kt) {
-    // activations
-    const bool chunk_ok = tap < taps;
+  auto load_tile = [&](int kt, u32x4 (&xr)[4], u32x4 (&wr)[NT], unsigned& okm) {
+    const bool chunk_ok = (tap < taps) && (kt < kt_end);
     const int ch = cc * 32 + sub;
     const bool second = ch >= a.c0;
     const T* __restrict__ base = second ? src1 : src0;
     const int cs = second ? a.c1 : a.c0;
     const int chs = second ? ch - a.c0 : ch;
     const long long istr = second ? a.src_img_stride1 : a.src_img_stride0;
+    unsigned m = 0;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int hi = x_h[i] + ky, wi = x_w[i] + kx;
       const bool ok = chunk_ok && x_ok[i] && hi >= 0 && hi < hlog && wi >= 0 && wi < wlog;
-      u32x4 v = {0u, 0u, 0u, 0u};
-      if (ok) {
-        const int hs = hi >> a.up, ws = wi >> a.up;
-        v = ld16(base + x_img[i] * istr + (long long)(hs * a.win + ws) * cs + chs);
-      }
-      xr[i] = v;
+      const int hs = hi >> a.up, ws = wi >> a.up;
+      const T* ptr = ok ? base + x_img[i] * istr + (long long)(hs * a.win + ws) * cs + chs : src0;
+      xr[i] = ld16(ptr);
+      m |= ok ? (1u << i) : 0u;
     }
-    // weights
     const int kk = kt * 64 + seg * 8;
+    const bool kok = (kk < a.ktot) && (kt < kt_end);
 #pragma unroll
     for (int i = 0; i < NT; ++i) {
       const int n = n0 + row_b + 32 * i;
-      u32x4 v = {0u, 0u, 0u, 0u};
-      if (n < a.n_packed && kk < a.ktot) v = ld16(wgt + (long long)n * a.ktot + kk);
-      wr[i] = v;
+      const bool ok = kok && n < a.n_packed;
+      const T* ptr = ok ? wgt + (long long)n * a.ktot + kk : wgt;
+      wr[i] = ld16(ptr);
+      m |= ok ? (16u << i) : 0u;
     }
+    okm = m;
     // advance this thread's chunk by one k-tile (two chunks)
     cc += 2;
     while (cc >= cpt) { cc -= cpt; ++tap; if (++kx == a.kw) { kx = 0; ++ky; } }
   };
-  auto store_tile = [&](int buf) {
+  auto store_tile = [&](int buf, const u32x4 (&xr)[4], const u32x4 (&wr)[NT], unsigned okm) {
     unsigned char* xb = lds + buf * X_TILE;
     unsigned char* wb = lds + 2 * X_TILE + buf * W_TILE;
+    const u32x4 zero = {0u, 0u, 0u, 0u};
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int r = row_b + 32 * i;
-      st16(xb + r * 128 + ((seg ^ (r & 7)) << 4), xr[i]);
+      st16(xb + r * 128 + ((seg ^ (r & 7)) << 4), (okm >> i) & 1u ? xr[i] : zero);
     }
 #pragma unroll
     for (int i = 0; i < NT; ++i) {
       const int r = row_b + 32 * i;
-      st16(wb + r * 128 + ((seg ^ (r & 7)) << 4), wr[i]);
+      st16(wb + r * 128 + ((seg ^ (r & 7)) << 4), (okm >> (4 + i)) & 1u ? wr[i] : zero);
     }
   };
 
@@ -163,15 +169,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
 
   const int r16 = lane & 15, g4 = lane >> 4;
 
-  if (kt_begin < kt_end) {
-    load_tile(kt_begin);
-    store_tile(0);
-  }
-  __syncthreads();
-  int buf = 0;
-  for (int kt = kt_begin; kt < kt_end; ++kt) {
-    const bool more = kt + 1 < kt_end;
-    if (more) load_tile(kt + 1);
+  auto compute_tile = [&](int buf) {
     const unsigned char* xb = lds + buf * X_TILE + (wm * 64 + r16) * 128;
     const unsigned char* wb = lds + 2 * X_TILE + buf * W_TILE + (wn * WAVE_N + r16) * 128;
 #pragma unroll
@@ -188,9 +186,31 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
         for (int mi = 0; mi < 4; ++mi)
           acc[ni][mi] = TR ? mfma16(xf[mi], wf[ni], acc[ni][mi]) : mfma16(wf[ni], xf[mi], acc[ni][mi]);
     }
-    if (more) store_tile(buf ^ 1);
+  };
+
+  // prologue: tile kt_begin -> LDS[0], tile kt_begin+1 -> set 1 (loads past kt_end are harmless no-ops)
+  load_tile(kt_begin, xr0, wr0, ok0);
+  store_tile(0, xr0, wr0, ok0);
+  load_tile(kt_begin + 1, xr1, wr1, ok1);
+  __syncthreads();
+#pragma clang loop unroll(disable)
+  for (int kt = kt_begin; kt < kt_end; kt += 2) {
+    // even step: tile kt in LDS[0]; tile kt+1 waits in set 1; tile kt+2 -> set 0
+    load_tile(kt + 2, xr0, wr0, ok0);
+    __builtin_amdgcn_sched_barrier(0);
+    compute_tile(0);
+    __builtin_amdgcn_sched_barrier(0);
+    store_tile(1, xr1, wr1, ok1);
     __syncthreads();
-    buf ^= 1;
+    __builtin_amdgcn_sched_barrier(0);
+    // odd step: tile kt+1 in LDS[1]; tile kt+2 waits in set 0; tile kt+3 -> set 1
+    load_tile(kt + 3, xr1, wr1, ok1);
+    __builtin_amdgcn_sched_barrier(0);
+    if (kt + 1 < kt_end) compute_tile(1);
+    __builtin_amdgcn_sched_barrier(0);
+    store_tile(0, xr0, wr0, ok0);
+    __syncthreads();
+    __builtin_amdgcn_sched_barrier(0);
   }
 
   // ---- epilogue -----------------------------------------------------------
