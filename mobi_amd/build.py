@@ -50,6 +50,7 @@ def build(force=False, verbose=True):
     os.makedirs(OBJ, exist_ok=True)
     cc = hipcc()
     common = [cc, f"--offload-arch={ARCH}", "-O3", "-fPIC", "-std=c++17", "-Wno-unused-result"]
+    common += os.environ.get("MOBI_HIPCC_FLAGS", "").split()
 
     def compile_one(src):
         obj = os.path.join(OBJ, src.replace(".hip", ".o"))

@@ -17,6 +17,13 @@
 // per-image vector, residual and GEGLU are applied on coalesced 16-byte rows.
 #include "common.h"
 
+// A/B switch (build with -DMOBI_IGEMM_FENCE=1): pin the load / MFMA / LDS-write phases of a k step
+#if defined(MOBI_IGEMM_FENCE) && MOBI_IGEMM_FENCE
+#define MOBI_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#else
+#define MOBI_SCHED_FENCE() ((void)0)
+#endif
+
 namespace mobi {
 
 struct IgemmArgs {
@@ -24,7 +31,7 @@ struct IgemmArgs {
   int c0, c1, C;
   int hin, win, up, hout, wout, hw_out;
   int kh, kw, stride, pad_h, pad_w;
-  long long src_img_stride0, src_img_stride1;
+  int img_pix_stride;      // pixels between images of the sources (elements / channels)
   const void* weight; long long w_group_stride;
   int n_packed, cout, ktot, nk;
   int M;                 // rows per group
@@ -76,22 +83,37 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs a) {
   const int sub = (seg & 3) * 8;         // channel offset inside the chunk
   const int row_b = tid >> 3;            // 0..31
 
-  long long x_img[4];
-  int x_h[4], x_w[4];
-  bool x_ok[4];
+  // per output row (fixed for the whole k loop): pixel index of the image origin, window origin
+  int x_gp[4], x_h[4], x_w[4];
+  unsigned x_okm = 0;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int m = m0 + row_b + 32 * i;
-    x_ok[i] = m < a.M;
-    const int mm = x_ok[i] ? m : 0;
+    const bool ok = m < a.M;
+    x_okm |= ok ? (1u << i) : 0u;
+    const int mm = ok ? m : 0;
     const int img = mm / a.hw_out;
     const int rem = mm - img * a.hw_out;
     const int ho = rem / a.wout;
     const int wo = rem - ho * a.wout;
-    x_img[i] = (long long)(group * a.imgs_per_group + img);
+    x_gp[i] = (group * a.imgs_per_group + img) * a.img_pix_stride;
     x_h[i] = ho * a.stride - a.pad_h;
     x_w[i] = wo * a.stride - a.pad_w;
   }
+  // per weight row: pointer to its k = 0 element, validity
+  const T* w_ptr[NT];
+  unsigned w_okm = 0;
+#pragma unroll
+  for (int i = 0; i < NT; ++i) {
+    const int n = n0 + row_b + 32 * i;
+    const bool ok = n < a.n_packed;
+    w_okm |= ok ? (1u << i) : 0u;
+    w_ptr[i] = wgt + (long long)(ok ? n : 0) * a.ktot;
+  }
+  // per filter tap (changes every C/64 k-tiles): source pixel of each row and its validity
+  int t_pix[4] = {0, 0, 0, 0};
+  unsigned t_okm = 0;
+  int t_tap = -1;
   const int cpt = a.C >> 5;              // 32-channel chunks per tap
   const int taps = a.kh * a.kw;
   const int hlog = a.hin << a.up, wlog = a.win << a.up;
@@ -113,34 +135,40 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs a) {
   unsigned ok0 = 0, ok1 = 0;
 
   auto load_tile = [&](int kt, u32x4 (&xr)[4], u32x4 (&wr)[NT], unsigned& okm) {
+    if (tap != t_tap) {                       // no loads inside this branch
+      t_tap = tap;
+      t_okm = 0;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int hi = x_h[i] + ky, wi = x_w[i] + kx;
+        const bool ok = hi >= 0 && hi < hlog && wi >= 0 && wi < wlog;
+        t_okm |= ok ? (1u << i) : 0u;
+        t_pix[i] = (hi >> a.up) * a.win + (wi >> a.up);
+      }
+      t_okm &= x_okm;
+    }
     const bool chunk_ok = (tap < taps) && (kt < kt_end);
     const int ch = cc * 32 + sub;
     const bool second = ch >= a.c0;
     const T* __restrict__ base = second ? src1 : src0;
-    const int cs = second ? a.c1 : a.c0;
-    const int chs = second ? ch - a.c0 : ch;
-    const long long istr = second ? a.src_img_stride1 : a.src_img_stride0;
-    unsigned m = 0;
+    const unsigned cs = second ? a.c1 : a.c0;
+    const unsigned chs = second ? ch - a.c0 : ch;
+    const unsigned xm = chunk_ok ? t_okm : 0u;
+    unsigned m = xm;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int hi = x_h[i] + ky, wi = x_w[i] + kx;
-      const bool ok = chunk_ok && x_ok[i] && hi >= 0 && hi < hlog && wi >= 0 && wi < wlog;
-      const int hs = hi >> a.up, ws = wi >> a.up;
-      const T* ptr = ok ? base + x_img[i] * istr + (long long)(hs * a.win + ws) * cs + chs : src0;
+      const unsigned long long off = (unsigned long long)(unsigned)(x_gp[i] + t_pix[i]) * cs + chs;
+      const T* ptr = ((xm >> i) & 1u) ? base + off : src0;
       xr[i] = ld16(ptr);
-      m |= ok ? (1u << i) : 0u;
     }
     const int kk = kt * 64 + seg * 8;
-    const bool kok = (kk < a.ktot) && (kt < kt_end);
+    const unsigned wm = ((kk < a.ktot) && (kt < kt_end)) ? w_okm : 0u;
 #pragma unroll
     for (int i = 0; i < NT; ++i) {
-      const int n = n0 + row_b + 32 * i;
-      const bool ok = kok && n < a.n_packed;
-      const T* ptr = ok ? wgt + (long long)n * a.ktot + kk : wgt;
+      const T* ptr = ((wm >> i) & 1u) ? w_ptr[i] + kk : wgt;
       wr[i] = ld16(ptr);
-      m |= ok ? (16u << i) : 0u;
     }
-    okm = m;
+    okm = m | (wm << 4);
     // advance this thread's chunk by one k-tile (two chunks)
     cc += 2;
     while (cc >= cpt) { cc -= cpt; ++tap; if (++kx == a.kw) { kx = 0; ++ky; } }
@@ -197,20 +225,20 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs a) {
   for (int kt = kt_begin; kt < kt_end; kt += 2) {
     // even step: tile kt in LDS[0]; tile kt+1 waits in set 1; tile kt+2 -> set 0
     load_tile(kt + 2, xr0, wr0, ok0);
-    __builtin_amdgcn_sched_barrier(0);
+    MOBI_SCHED_FENCE();
     compute_tile(0);
-    __builtin_amdgcn_sched_barrier(0);
+    MOBI_SCHED_FENCE();
     store_tile(1, xr1, wr1, ok1);
     __syncthreads();
-    __builtin_amdgcn_sched_barrier(0);
+    MOBI_SCHED_FENCE();
     // odd step: tile kt+1 in LDS[1]; tile kt+2 waits in set 0; tile kt+3 -> set 1
     load_tile(kt + 3, xr1, wr1, ok1);
-    __builtin_amdgcn_sched_barrier(0);
+    MOBI_SCHED_FENCE();
     if (kt + 1 < kt_end) compute_tile(1);
-    __builtin_amdgcn_sched_barrier(0);
+    MOBI_SCHED_FENCE();
     store_tile(0, xr0, wr0, ok0);
     __syncthreads();
-    __builtin_amdgcn_sched_barrier(0);
+    MOBI_SCHED_FENCE();
   }
 
   // ---- epilogue -----------------------------------------------------------
@@ -477,9 +505,10 @@ extern "C" int mobi_igemm(const mobi_igemm_params* p, void* stream) {
   a.hout = p->hout; a.wout = p->wout; a.hw_out = p->hout * p->wout;
   a.kh = p->kh; a.kw = p->kw; a.stride = p->stride; a.pad_h = p->pad_h; a.pad_w = p->pad_w;
   const long long hw_in = (long long)p->hin * p->win;
-  a.src_img_stride0 = p->src_img_stride ? p->src_img_stride : hw_in * p->c0;
-  a.src_img_stride1 = p->src_img_stride ? p->src_img_stride : hw_in * p->c1;
-  if (p->src_img_stride && p->c1) return MOBI_ERR_UNSUPPORTED;
+  if (p->src_img_stride && (p->c1 || p->src_img_stride % p->c0)) return MOBI_ERR_UNSUPPORTED;
+  const long long ips = p->src_img_stride ? p->src_img_stride / p->c0 : hw_in;
+  if (ips * p->batch > 0x7fffffffLL) return MOBI_ERR_UNSUPPORTED;
+  a.img_pix_stride = (int)ips;
   a.weight = p->weight; a.w_group_stride = p->groups > 1 ? p->w_group_stride : 0;
   a.n_packed = p->n_packed; a.cout = p->cout;
   a.ktot = p->kh * p->kw * a.C;
