@@ -26,12 +26,14 @@ struct AttnArgs {
   float scale;
 };
 
-template <typename T, int KS>
-__global__ __launch_bounds__(256) void attention_kernel(const AttnArgs a) {
+// VVEC: every V^T row start is 16-byte aligned (tk % 8 == 0 rows), the production case; the generic
+// variant loads ragged V^T rows element-wise.  WPS = waves per SIMD the register budget is held to.
+template <typename T, int KS, bool VVEC, int WPS>
+__global__ __launch_bounds__(256, WPS) void attention_kernel(const AttnArgs a) {
   typedef typename Vec8<T>::type frag_t;
   constexpr int DT = (KS + 1) / 2;                 // 32-row tiles of the head dim for P.V
   constexpr int KSTR = KS * 32 + 16;               // bytes per K row in LDS (odd multiple of 16)
-  constexpr int VSTR = 136;                        // bytes per V^T row in LDS (odd multiple of 8)
+  constexpr int VSTR = 144;                        // bytes per V^T row in LDS (odd multiple of 16)
   constexpr int K_BYTES = 64 * KSTR;
   constexpr int V_BYTES = DT * 32 * VSTR;
   constexpr int KP = (64 * KS * 2 + 255) / 256;    // 16-byte K pieces per thread
@@ -64,51 +66,61 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnArgs a) {
     }
   }
 
-  const bool v_vec = ((a.vt_row & 7) == 0) && ((reinterpret_cast<uintptr_t>(vp) & 15) == 0);
+  // K / V^T staging.  Loads are unconditional (invalid pieces read a safe address and are zeroed through a
+  // validity mask when written to LDS) so that they can be counted by vmcnt.
+  // V^T keys are stored PERMUTED inside every group of 16 (key 8a+4b+c -> position 8b+4a+c): the 8 keys a lane
+  // needs for one k-step of P.V (the accumulator's key order) are then 16 contiguous bytes.
   u32x4 kr[KP], vr[VP];
+  unsigned kmask = 0, vmask = 0;
   auto load_tile = [&](int key0) {
+    kmask = 0; vmask = 0;
 #pragma unroll
     for (int i = 0; i < KP; ++i) {
       const int p = tid + 256 * i;
       const int row = p / (KS * 2), pc = p - row * (KS * 2);
-      u32x4 v = {0u, 0u, 0u, 0u};
-      if (row < 64 && key0 + row < a.tk && pc * 8 < dh) v = ld16(kp + (long long)(key0 + row) * a.k_row + pc * 8);
-      kr[i] = v;
+      const bool ok = row < 64 && key0 + row < a.tk && pc * 8 < dh;
+      const T* src = ok ? kp + (long long)(key0 + row) * a.k_row + pc * 8 : kp;
+      kr[i] = ld16(src);
+      kmask |= ok ? (1u << i) : 0u;
     }
 #pragma unroll
     for (int i = 0; i < VP; ++i) {
       const int p = tid + 256 * i;
       const int row = p >> 3, pc = p & 7;
-      u32x4 v = {0u, 0u, 0u, 0u};
-      if (row < dh) {
-        const T* src = vp + (long long)row * a.vt_row + key0 + pc * 8;
-        if (v_vec && key0 + pc * 8 + 8 <= a.tk) {
-          v = ld16(src);
-        } else {
-          typename Vec8<T>::type e;
+      if (VVEC) {
+        const bool ok = row < dh && key0 + pc * 8 < a.tk;       // tk % 8 == 0: a piece is all-in or all-out
+        const T* src = ok ? vp + (long long)row * a.vt_row + key0 + pc * 8 : vp;
+        vr[i] = ld16(src);
+        vmask |= ok ? (1u << i) : 0u;
+      } else {
+        typename Vec8<T>::type e;
 #pragma unroll
-          for (int j = 0; j < 8; ++j) e[j] = (key0 + pc * 8 + j < a.tk) ? src[j] : (T)0.0f;
-          v = __builtin_bit_cast(u32x4, e);
+        for (int j = 0; j < 8; ++j) {
+          const bool ok = row < dh && key0 + pc * 8 + j < a.tk;
+          e[j] = ok ? vp[(long long)row * a.vt_row + key0 + pc * 8 + j] : (T)0.0f;
         }
+        vr[i] = __builtin_bit_cast(u32x4, e);
+        vmask |= 1u << i;
       }
-      vr[i] = v;
     }
   };
   auto store_tile = [&]() {
+    const u32x4 zero = {0u, 0u, 0u, 0u};
 #pragma unroll
     for (int i = 0; i < KP; ++i) {
       const int p = tid + 256 * i;
       const int row = p / (KS * 2), pc = p - row * (KS * 2);
-      if (row < 64) st16(ldsK + row * KSTR + pc * 16, kr[i]);
+      if (row < 64) st16(ldsK + row * KSTR + pc * 16, (kmask >> i) & 1u ? kr[i] : zero);
     }
 #pragma unroll
     for (int i = 0; i < VP; ++i) {
       const int p = tid + 256 * i;
       const int row = p >> 3, pc = p & 7;
       if (row < DT * 32) {
-        u32x2* d = reinterpret_cast<u32x2*>(ldsV + row * VSTR + pc * 16);
-        d[0] = u32x2{vr[i][0], vr[i][1]};
-        d[1] = u32x2{vr[i][2], vr[i][3]};
+        const u32x4 v = (vmask >> i) & 1u ? vr[i] : zero;
+        unsigned char* d = ldsV + row * VSTR + (pc >> 1) * 32 + (pc & 1) * 8;
+        *reinterpret_cast<u32x2*>(d) = u32x2{v[0], v[1]};             // keys 8a + (0..3)     -> pos 4a + ..
+        *reinterpret_cast<u32x2*>(d + 16) = u32x2{v[2], v[3]};        // keys 8a + 4 + (0..3) -> pos 8 + 4a + ..
       }
     }
   };
@@ -195,12 +207,10 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnArgs a) {
         frag_t pf;
 #pragma unroll
         for (int j = 0; j < 8; ++j) pf[j] = (T)s[kt][st * 8 + j];
-        const unsigned char* vb = ldsV + ql * VSTR + (kt * 32 + st * 16 + half * 4) * 2;
+        const unsigned char* vb = ldsV + ql * VSTR + (kt * 32 + st * 16 + half * 8) * 2;
 #pragma unroll
         for (int d = 0; d < DT; ++d) {
-          const u32x2 lo = *reinterpret_cast<const u32x2*>(vb + d * 32 * VSTR);
-          const u32x2 hi = *reinterpret_cast<const u32x2*>(vb + d * 32 * VSTR + 16);
-          frag_t vf = __builtin_bit_cast(frag_t, u32x4{lo[0], lo[1], hi[0], hi[1]});
+          frag_t vf = __builtin_bit_cast(frag_t, ld16(vb + d * 32 * VSTR));
           o[d] = mfma32(vf, pf, o[d]);
         }
       }
@@ -232,23 +242,30 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnArgs a) {
   }
 }
 
-template <typename T>
-static int launch_attention(const mobi_attention_params* p, const AttnArgs& a, hipStream_t st) {
+template <typename T, bool VVEC>
+static int launch_attention_v(const mobi_attention_params* p, const AttnArgs& a, hipStream_t st) {
   dim3 grid((p->tq + 127) / 128, p->heads, p->images), block(256);
   const int ks = (p->dh + 15) / 16;
-#define MOBI_ATTN_CASE(KS_) hipLaunchKernelGGL((attention_kernel<T, KS_>), grid, block, 0, st, a)
-  if (ks <= 1) MOBI_ATTN_CASE(1);
-  else if (ks == 2) MOBI_ATTN_CASE(2);
-  else if (ks == 3) MOBI_ATTN_CASE(3);
-  else if (ks == 4) MOBI_ATTN_CASE(4);
-  else if (ks == 5) MOBI_ATTN_CASE(5);
-  else if (ks == 6) MOBI_ATTN_CASE(6);
-  else if (ks <= 8) MOBI_ATTN_CASE(8);
-  else if (ks <= 10) MOBI_ATTN_CASE(10);
+#define MOBI_ATTN_CASE(KS_, WPS_) hipLaunchKernelGGL((attention_kernel<T, KS_, VVEC, WPS_>), grid, block, 0, st, a)
+  if (ks <= 1) MOBI_ATTN_CASE(1, 2);
+  else if (ks == 2) MOBI_ATTN_CASE(2, 2);
+  else if (ks == 3) MOBI_ATTN_CASE(3, 2);
+  else if (ks == 4) MOBI_ATTN_CASE(4, 2);
+  else if (ks == 5) MOBI_ATTN_CASE(5, 2);
+  else if (ks == 6) MOBI_ATTN_CASE(6, 2);
+  else if (ks <= 8) MOBI_ATTN_CASE(8, 1);
+  else if (ks <= 10) MOBI_ATTN_CASE(10, 1);
   else return MOBI_ERR_UNSUPPORTED;
 #undef MOBI_ATTN_CASE
   MOBI_CHECK_LAUNCH();
   return MOBI_OK;
+}
+
+template <typename T>
+static int launch_attention(const mobi_attention_params* p, const AttnArgs& a, hipStream_t st) {
+  const bool vvec = (p->vt_row_stride % 8 == 0) && (p->vt_img_stride % 8 == 0) && (p->tk % 8 == 0) &&
+                    ((reinterpret_cast<uintptr_t>(p->vt) & 15) == 0);
+  return vvec ? launch_attention_v<T, true>(p, a, st) : launch_attention_v<T, false>(p, a, st);
 }
 
 }  // namespace mobi

@@ -46,6 +46,12 @@ struct IgemmArgs {
   float* split_ws;         // f32 [splits][M][n_packed] partial sums (NULL: single pass)
 };
 
+// 8 consecutive floats through two 16-byte accesses (LDS stage rows, bias, per-image vectors)
+__device__ __forceinline__ void ld8f(const float* p, float (&f)[8]) {
+  const f32x4 a = *reinterpret_cast<const f32x4*>(p), b = *reinterpret_cast<const f32x4*>(p + 4);
+  f[0] = a[0]; f[1] = a[1]; f[2] = a[2]; f[3] = a[3]; f[4] = b[0]; f[5] = b[1]; f[6] = b[2]; f[7] = b[3];
+}
+
 template <typename T, int NT, bool TR>
 __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs a) {
   typedef typename Vec8<T>::type frag_t;
@@ -304,13 +310,18 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs a) {
           const int oc = unit * HALF + cg * 8;
           if (m >= a.M || oc >= a.cout) continue;
           const float* sp = stage + row * STAGE_STRIDE + cg * 8;
-          float o[8];
+          float av[8], gv[8], o[8];
+          ld8f(sp, av);
+          ld8f(sp + HALF, gv);
+          if (a.bias) {
+            float ba[8], bg[8];
+            ld8f(a.bias + nw0 + cg * 8, ba);
+            ld8f(a.bias + nw0 + HALF + cg * 8, bg);
 #pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            float av = sp[j], gv = sp[HALF + j];
-            if (a.bias) { av += a.bias[nw0 + cg * 8 + j]; gv += a.bias[nw0 + HALF + cg * 8 + j]; }
-            o[j] = av * gelu_erf_f(gv);
+            for (int j = 0; j < 8; ++j) { av[j] += ba[j]; gv[j] += bg[j]; }
           }
+#pragma unroll
+          for (int j = 0; j < 8; ++j) o[j] = av[j] * gelu_erf_f(gv[j]);
           const int img = m / a.hw_out, rem = m - img * a.hw_out;
           const long long gi = (long long)(group * a.imgs_per_group + img);
           st16(outT + gi * a.out_img_stride + (long long)rem * a.cout + oc, pack8<T>(o));
@@ -324,16 +335,18 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs a) {
           if (m >= a.M || n >= a.cout) continue;
           const float* sp = stage + row * STAGE_STRIDE + cg * 8;
           float o[8];
-#pragma unroll
-          for (int j = 0; j < 8; ++j) o[j] = sp[j];
+          ld8f(sp, o);
           const int img = m / a.hw_out, rem = m - img * a.hw_out;
           const long long gi = (long long)(group * a.imgs_per_group + img);
           if (a.bias) {
+            float bb[8];
+            ld8f(a.bias + n, bb);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) o[j] += a.bias[n + j];
+            for (int j = 0; j < 8; ++j) o[j] += bb[j];
           }
           if (a.rowvec) {
-            const float* rv = a.rowvec + gi * a.rowvec_stride + n;
+            float rv[8];
+            ld8f(a.rowvec + gi * a.rowvec_stride + n, rv);
 #pragma unroll
             for (int j = 0; j < 8; ++j) o[j] += rv[j];
           }
@@ -407,11 +420,14 @@ __global__ __launch_bounds__(256) void igemm_splitk_reduce_kernel(const IgemmArg
     }
     const int img = m / a.hw_out, rem = m - img * a.hw_out;
     if (a.bias) {
+      float bb[8];
+      ld8f(a.bias + n, bb);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) o[j] += a.bias[n + j];
+      for (int j = 0; j < 8; ++j) o[j] += bb[j];
     }
     if (a.rowvec) {
-      const float* rv = a.rowvec + (long long)img * a.rowvec_stride + n;
+      float rv[8];
+      ld8f(a.rowvec + (long long)img * a.rowvec_stride + n, rv);
 #pragma unroll
       for (int j = 0; j < 8; ++j) o[j] += rv[j];
     }
@@ -494,6 +510,8 @@ extern "C" int mobi_igemm(const mobi_igemm_params* p, void* stream) {
   if (geglu && (p->out_mode != MOBI_OUT_ROWS || p->rowvec || p->residual)) return MOBI_ERR_UNSUPPORTED;
   if (!geglu && p->n_packed != p->cout) return MOBI_ERR_ARG;
   if (p->out_mode == MOBI_OUT_TRANSPOSED && (p->rowvec || p->residual)) return MOBI_ERR_UNSUPPORTED;
+  if ((reinterpret_cast<uintptr_t>(p->bias) | reinterpret_cast<uintptr_t>(p->rowvec)) & 15) return MOBI_ERR_ALIGN;
+  if (p->rowvec && (p->rowvec_stride & 3)) return MOBI_ERR_ALIGN;
   if ((reinterpret_cast<uintptr_t>(p->src0) | reinterpret_cast<uintptr_t>(p->src1) |
        reinterpret_cast<uintptr_t>(p->weight) | reinterpret_cast<uintptr_t>(p->out) |
        reinterpret_cast<uintptr_t>(p->residual)) & 15) return MOBI_ERR_ALIGN;
