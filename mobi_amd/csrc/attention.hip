@@ -47,6 +47,10 @@ __global__ __launch_bounds__(256, WPS) void attention_kernel(const AttnArgs a) {
   const int head = blockIdx.y, img = blockIdx.z;
   const int q0 = blockIdx.x * 128 + wave * 32;
   const int dh = a.dh;
+  // When the head dim leaves a padded row in the P.V tile (dh < 32*DT: dh = 40, 80, ...; not 64, 160) that
+  // row of V^T is filled with ones, so the matrix core accumulates the softmax denominator
+  // l[q] = sum_k P[k][q] for free (row dh of O^T) instead of 32 VALU adds per key tile.
+  const bool ONES = dh < DT * 32;
 
   const T* __restrict__ qp = reinterpret_cast<const T*>(a.q) + img * a.q_img + head * dh;
   const T* __restrict__ kp = reinterpret_cast<const T*>(a.k) + img * a.k_img + head * dh;
@@ -92,12 +96,20 @@ __global__ __launch_bounds__(256, WPS) void attention_kernel(const AttnArgs a) {
         const T* src = ok ? vp + (long long)row * a.vt_row + key0 + pc * 8 : vp;
         vr[i] = ld16(src);
         vmask |= ok ? (1u << i) : 0u;
+        if (ONES && row == dh && key0 + pc * 8 < a.tk) {         // the row-sum row (see below)
+          typename Vec8<T>::type e;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) e[j] = (T)1.0f;
+          vr[i] = __builtin_bit_cast(u32x4, e);
+          vmask |= 1u << i;
+        }
       } else {
         typename Vec8<T>::type e;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           const bool ok = row < dh && key0 + pc * 8 + j < a.tk;
           e[j] = ok ? vp[(long long)row * a.vt_row + key0 + pc * 8 + j] : (T)0.0f;
+          if (ONES && row == dh && key0 + pc * 8 + j < a.tk) e[j] = (T)1.0f;
         }
         vr[i] = __builtin_bit_cast(u32x4, e);
         vmask |= 1u << i;
@@ -188,16 +200,18 @@ __global__ __launch_bounds__(256, WPS) void attention_kernel(const AttnArgs a) {
       m_run = m_new;
     }
     const float mc = m_run * cexp;
-    float psum = 0.f;
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kt][r], cexp, -mc));
-        s[kt][r] = p;
-        psum += p;
-      }
-    l_run += psum;
+      for (int r = 0; r < 16; ++r) s[kt][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kt][r], cexp, -mc));
+    if (!ONES) {
+      float psum = 0.f;
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) psum += s[kt][r];
+      l_run += psum;
+    }
 
     // ---- O^T += V^T . P^T --------------------------------------------------------
 #pragma unroll
@@ -222,6 +236,15 @@ __global__ __launch_bounds__(256, WPS) void attention_kernel(const AttnArgs a) {
   }
 
   // ---- normalise and store: lane holds O^T[d][q] for d = 32 dt + 8 g + 4 half + (0..3) -------
+  if (ONES) {      // row dh of O^T sits in lane-half 0, register (dh % 32) / 2 of tile dh / 32
+    float lsum = 0.f;
+#pragma unroll
+    for (int d = 0; d < DT; ++d)
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        if (d * 32 + g * 8 == dh) lsum = o[d][g * 4];
+    l_run = half == 0 ? lsum : 0.f;
+  }
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
   const float inv = 1.0f / l_tot;
   const int qrow = q0 + ql;

@@ -12,7 +12,7 @@ Launch sequence of one transformer block (all HIP, include/mobi_engine.h):
   attn2      one key => softmax == 1: to_out(to_v(ref token)) is a per-image vector,
              two skinny_linear calls, added in attn1's epilogue (exact)
   adapter    layernorm -> igemm to_q -> skinny k/v -> ctx_attention -> igemm to_out
-             -> igemm connector (+ residual)
+             -> igemm [connector . to_out folded] (+ residual)
   cross-modal (camera then lidar, in place on the interleaved batch)
              layernorm(x[::2]) -> igemm to_q ; igemm to_k / to_v(T) on x[1::2] -> attention
              -> igemm to_out -> igemm connector (+ residual, written back into x[::2]); then
@@ -117,6 +117,16 @@ class CrossAttention(nn.Module):
         wo, bo = self.to_out[0].skinny()
         return ops.skinny_linear(ops.skinny_linear(token, wv), wo, bo)
 
+    def attend(self, x, context=None):
+        """Attention output BEFORE `to_out` (the caller applies to_out, possibly folded with a connector)."""
+        if context is None:
+            return self.self_attention(x)
+        if context.dtype == torch.float32:
+            if context.shape[1] > 8:
+                raise NotImplementedError("fp32 contexts with more than 8 tokens")
+            return self.few_token_attention(x, context.contiguous())
+        return self.token_attention(x, context)
+
     def forward(self, x, context=None, mask=None):
         """Reference-compatible call (attention.py:171-194); x: engine tokens [N,T,C];
         context: None (self-attention), fp32 [N,tk<=8,Cc], or engine tokens."""
@@ -164,6 +174,23 @@ class BasicTransformerBlock(nn.Module):
             self.cross_modal_connector_lidar = zero_module(Linear(dim, dim))
         self.checkpoint = checkpoint
 
+    def _folded(self, attn, connector, tag):
+        """`connector(attn.to_out(a))` is two Linear layers with nothing in between
+        (attention.py:237-243, 249-261): W = Wc Wo, b = Wc bo + bc, folded once in fp32.  Exact algebra;
+        saves one [T, C] x [C, C] GEMM and one activation round trip per adapter."""
+        lo, lc = attn.to_out[0], connector
+        key = (tag, lo.weight._version, lo.bias._version, lc.weight._version, lc.bias._version,
+               lo.weight.data_ptr(), lo.packed().w.dtype)
+        cache = self.__dict__.setdefault("_fold_cache", {})
+        hit = cache.get(tag)
+        if hit is None or hit[0] != key:
+            wc, wo = lc.weight.detach().double(), lo.weight.detach().double()
+            w = (wc @ wo).float()
+            b = (wc @ lo.bias.detach().double() + lc.bias.detach().double()).float()
+            hit = (key, ops.pack_linear(w, b, lo.packed().w.dtype, w.device))
+            cache[tag] = hit
+        return hit[1]
+
     @staticmethod
     def _ln(norm, x):
         g, b = norm.affine()
@@ -181,17 +208,20 @@ class BasicTransformerBlock(nn.Module):
         x = ops.linear(a, self.attn1.to_out[0].packed(), residual=x, rowvec=ref_vec)
 
         if self.bbox_cond:
-            a = self.cond_adapter_attn(self._ln(self.cond_adapter_norm, x), context=ctx)
-            x = ops.linear(a, self.cond_adapter_connector.packed(), residual=x)
+            a = self.cond_adapter_attn.attend(self._ln(self.cond_adapter_norm, x), context=ctx)
+            x = ops.linear(a, self._folded(self.cond_adapter_attn, self.cond_adapter_connector, "adapter"),
+                           residual=x)
 
         if self.multimodal:
             if x.shape[0] % 2:
                 raise ValueError("multimodal blocks need camera/lidar samples interleaved on an even batch")
             xc, xl = x[::2], x[1::2]
-            a = self.cross_modal_attn_camera(self._ln(self.cross_modal_norm_camera, xc), context=xl)
-            ops.linear(a, self.cross_modal_connector_camera.packed(), residual=xc, out=xc)
-            a = self.cross_modal_attn_lidar(self._ln(self.cross_modal_norm_lidar, xl), context=xc)
-            ops.linear(a, self.cross_modal_connector_lidar.packed(), residual=xl, out=xl)
+            a = self.cross_modal_attn_camera.attend(self._ln(self.cross_modal_norm_camera, xc), context=xl)
+            ops.linear(a, self._folded(self.cross_modal_attn_camera, self.cross_modal_connector_camera, "cam"),
+                       residual=xc, out=xc)
+            a = self.cross_modal_attn_lidar.attend(self._ln(self.cross_modal_norm_lidar, xl), context=xc)
+            ops.linear(a, self._folded(self.cross_modal_attn_lidar, self.cross_modal_connector_lidar, "lidar"),
+                       residual=xl, out=xl)
 
         return self.ff(self._ln(self.norm3, x), residual=x)
 
