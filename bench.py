@@ -38,39 +38,24 @@ WORKLOADS = {  # BASELINE.json configs[2] / configs[1]
 PEAK_TFLOPS = 2500.0          # dense bf16/fp16 MFMA, /opt/skills/guides/MI355X_MICROARCH.md
 
 
-def build_unet(device, seed=0):
-    from mobi_amd.ldm.modules.diffusionmodules.openaimodel import UNetModel
-    net = UNetModel(image_size=64, in_channels=9, out_channels=4, model_channels=320,
-                    attention_resolutions=[4, 2, 1], num_res_blocks=2, channel_mult=[1, 2, 4, 4], num_heads=8,
-                    use_spatial_transformer=True, transformer_depth=1, context_dim=768, legacy=False,
-                    bbox_cond=True, use_camera=True, use_lidar=True)
+def build_model(workload, seed=0):
+    """LatentDiffusion (UNet + camera VAE + lidar VAE) from configs/mobi_nusc_512.yaml with random-init
+    weights of the real architecture (also overwrites the zero-initialised layers)."""
+    from mobi_amd.ldm.util import instantiate_from_config, load_config
+    wl = WORKLOADS[workload]
+    cfg = load_config(os.path.join(ROOT, "configs", "mobi_nusc_512.yaml"),
+                      [f"latent_size={wl['latent']}", f"image_height={wl['latent'] * 8}"])
+    model = instantiate_from_config(cfg["model"])
     g = torch.Generator().manual_seed(seed)
     with torch.no_grad():
-        for name, p in net.named_parameters():          # also overwrites the zero-initialised layers
+        for name, p in model.named_parameters():
             if p.dim() >= 2:
                 p.normal_(0.0, 1.0 / math.sqrt(p[0].numel()), generator=g)
             elif name.endswith("weight"):
                 p.copy_(1.0 + 0.1 * torch.randn(p.shape, generator=g))
             else:
                 p.normal_(0.0, 0.05, generator=g)
-    return net.eval()
-
-
-class SamplerModel:
-    """What DDIMSampler needs from LatentDiffusion (schedule buffers + apply_model)."""
-
-    def __init__(self, net, device):
-        from mobi_amd.ldm.modules.diffusionmodules.util import make_beta_schedule
-        import numpy as np
-        betas = make_beta_schedule("linear", 1000, linear_start=0.00085, linear_end=0.012)
-        ac = np.cumprod(1.0 - betas)
-        f = lambda a: torch.tensor(a, dtype=torch.float32, device=device)
-        self.betas, self.alphas_cumprod = f(betas), f(ac)
-        self.alphas_cumprod_prev = f(np.append(1.0, ac[:-1]))
-        self.num_timesteps, self.device, self.net = 1000, device, net
-
-    def apply_model(self, x, t, c):
-        return self.net(x, t, context=c)
+    return model.eval()
 
 
 def main():
@@ -87,6 +72,7 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--dump-launches", default=None, help="write per-launch (kind, GFLOP, us) records of one step")
     ap.add_argument("--cpu-threads", type=int, default=32, help="threads for the CPU-oracle baseline leg")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end objects/s pass")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -113,8 +99,8 @@ def main():
     cfg = args.cfg_scale != 1.0
     elems = N * (2 if cfg else 1)
 
-    net = build_unet(device).to(device)
-    model = SamplerModel(net, device)
+    model = build_model(args.workload).to(device)
+    net = model.model.diffusion_model
     sampler = DDIMSampler(model)
     sampler.make_schedule(args.ddim_steps, ddim_eta=0.0, verbose=False)
     g = torch.Generator(device="cpu").manual_seed(1234 + rank)
@@ -156,6 +142,53 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
     finite = bool(torch.isfinite(x).all())
+
+    # ---- end-to-end: VAE encodes -> DDIM -> decode_sample -> VAE decodes (+clamp) -> all-gather -------------
+    objects_per_s = None
+    if not args.no_e2e:
+        from mobi_amd import dist as mdist
+        from mobi_amd.ldm.util import cat_interleave
+        R = side * 8
+        gi = torch.Generator(device="cpu").manual_seed(99 + rank)
+        u = lambda *s_: (torch.rand(*s_, generator=gi) * 2 - 1).to(device)
+        img_gt, rng_gt = u(B, 3, R, R), u(B, 2, R, R)
+        hole = torch.ones(B, 1, R, R)
+        hole[:, :, R // 4: 3 * R // 4, R // 4: 3 * R // 4] = 0
+        hole = hole.to(device)
+        nz = {k: torch.randn(B, 4, side, side, generator=gi).to(device)
+              for k in ("cam_gt", "cam_inpaint", "lidar_gt", "lidar_inpaint")}
+        x_T = mk(N, 4, side, side)
+
+        def e2e():
+            z_img, z_lid = model.encode_all_stages(img_gt, img_gt * hole, hole, rng_gt, rng_gt * hole, hole, noises=nz)
+            z = cat_interleave([z_img, z_lid])
+            smp, _ = sampler.sample(S=args.ddim_steps, batch_size=N, shape=[4, side, side], conditioning=cond,
+                                    verbose=False, eta=0.0, x_T=x_T, unconditional_guidance_scale=args.cfg_scale,
+                                    unconditional_conditioning=uc if cfg else None,
+                                    test_model_kwargs={"inpaint_image": z[:, 4:8].contiguous(),
+                                                       "inpaint_mask": z[:, 8:9].contiguous()})
+            h_cam, h_lid = model.decode_sample(smp, z_lid[:, :4])
+            log, _ = model.log_data(None, None, h_cam.contiguous(), h_lid.contiguous())
+            return mdist.gather_decoded(log, B * world)                 # the one collective of the path
+
+        with torch.no_grad():
+            if args.warmup > 0:
+                sampler_steps = args.ddim_steps
+                args.ddim_steps = 2
+                e2e()                                                   # short warm-up pass (VAE packs, allocator)
+                args.ddim_steps = sampler_steps
+            barrier()
+            t0 = time.perf_counter()
+            out = e2e()
+            barrier()
+            e2e_dt = time.perf_counter() - t0
+        if world > 1:
+            tmax = torch.tensor([e2e_dt], device=device)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            e2e_dt = float(tmax.item())
+        assert out["image_sample"].shape == (B * world, 3, R, R) and out["lidar_sample"].shape == (B * world, 2, R, R)
+        objects_per_s = B * world / e2e_dt
+        sampler.make_schedule(args.ddim_steps, ddim_eta=0.0, verbose=False)
 
     roofline = None
     kinds = {}
@@ -226,6 +259,10 @@ def main():
             "model_frac_of_peak": round(value * useful_gf / 1e3 / world / PEAK_TFLOPS, 4),
             "finite": finite,
         }
+        if objects_per_s is not None:
+            out["objects_per_s"] = round(objects_per_s, 4)
+            out["e2e"] = (f"{B} objects/GPU: 4 VAE encodes + DDIM-{args.ddim_steps} + 2 VAE decodes (+clamp) per object, "
+                          f"all-gather of decoded images; conditioning tokens supplied (SURVEY 8(f) row 1)")
         if roofline:
             out["roofline"] = roofline
         if cpu_baseline:

@@ -145,3 +145,21 @@ def test_every_product_module_imports():
                 if rel.endswith(".__init__"):
                     rel = rel[:-9]
                 importlib.import_module(rel)
+
+
+@pytest.mark.skipif(not os.path.exists("/root/reference/configs/mobi_nusc_512.yaml"), reason="reference tree not present")
+def test_reference_yaml_drops_in():
+    """The reference's own config file resolves (incl. ${} interpolation) and its `ldm.` targets map onto the
+    engine's classes; the engine's restated YAML describes the same UNet / VAEs."""
+    from mobi_amd.ldm.util import get_obj_from_str, load_config
+    ref = load_config("/root/reference/configs/mobi_nusc_512.yaml", ["use_lidar=True"])
+    mine = load_config(os.path.join(ROOT, "configs", "mobi_nusc_512.yaml"))
+    rp, mp_ = ref["model"]["params"], mine["model"]["params"]
+    assert rp["unet_config"]["params"] == mp_["unet_config"]["params"]
+    for k in ("first_stage_config", "lidar_stage_config"):
+        assert rp[k]["params"]["ddconfig"] == mp_[k]["params"]["ddconfig"]
+        assert get_obj_from_str(rp[k]["target"]).__module__ == "mobi_amd.ldm.models.autoencoder"
+    for k in ("linear_start", "linear_end", "timesteps", "scale_factor", "lidar_scale_factor", "image_size", "channels",
+              "cond_stage_key", "first_stage_key", "conditioning_key", "use_ema"):
+        assert rp[k] == mp_[k], k
+    assert get_obj_from_str(ref["model"]["target"]).__module__ == "mobi_amd.ldm.models.diffusion.ddpm"

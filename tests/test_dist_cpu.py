@@ -1,0 +1,60 @@
+"""CPU: the N>1 path (object sharding + the one all-gather per batch) with world_size 2 and 3 on gloo."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, n_objects, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from mobi_amd import dist as md
+    full = {"image": {"GT": torch.arange(n_objects * 3 * 4 * 4, dtype=torch.float32).reshape(n_objects, 3, 4, 4),
+                      "meta": "kept"},
+            "lidar": {"range_data": -torch.arange(n_objects * 2 * 4 * 4, dtype=torch.float32).reshape(n_objects, 2, 4, 4)}}
+    mine = md.shard_batch(full, n_objects)
+    lo, hi = md.shard_range(n_objects, rank, world)
+    assert mine["image"]["GT"].shape[0] == hi - lo and mine["image"]["meta"] == "kept"
+    assert torch.equal(mine["image"]["GT"], full["image"]["GT"][lo:hi])
+    # stand-in for sampling + decoding on this rank's objects: any per-object function
+    decoded = {"image_sample": mine["image"]["GT"] * 2 + 1, "lidar_sample": mine["lidar"]["range_data"] - 3}
+    out = md.gather_decoded(decoded, n_objects)
+    ok = torch.equal(out["image_sample"], full["image"]["GT"] * 2 + 1) and \
+        torch.equal(out["lidar_sample"], full["lidar"]["range_data"] - 3)
+    q.put((rank, bool(ok), tuple(out["image_sample"].shape)))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n_objects", [(2, 8), (2, 5), (3, 7)])
+def test_shard_and_gather_gloo(world, n_objects):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_objects, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok, _ in res), res
+    assert all(shape[0] == n_objects for _, _, shape in res)
+
+
+def test_shard_ranges_cover_exactly():
+    from mobi_amd.dist import shard_range
+    for n in (1, 5, 8, 64, 65):
+        for w in (1, 2, 3, 8):
+            spans = [shard_range(n, r, w) for r in range(w)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(w - 1))
+            assert max(h - l for l, h in spans) - min(h - l for l, h in spans) <= 1
