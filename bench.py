@@ -201,13 +201,14 @@ def main():
         ops.set_profiler(None)
         if args.dump_launches:
             with open(args.dump_launches, "w") as f:
-                for kind, flops, e0, e1 in sink:
-                    f.write(f"{kind}\t{flops / 1e9:.4f}\t{e0.elapsed_time(e1) * 1e3:.2f}\n")
-        for kind, flops, e0, e1 in sink:
-            k = kinds.setdefault(kind, dict(launches=0, flops=0.0, ms=0.0))
+                for kind, flops, e0, e1, nb in sink:
+                    f.write(f"{kind}\t{flops / 1e9:.4f}\t{e0.elapsed_time(e1) * 1e3:.2f}\t{nb / 1e6:.3f}\n")
+        for kind, flops, e0, e1, nb in sink:
+            k = kinds.setdefault(kind, dict(launches=0, flops=0.0, ms=0.0, bytes=0.0))
             k["launches"] += 1
             k["flops"] += flops
             k["ms"] += e0.elapsed_time(e1)
+            k["bytes"] += nb
         ig = kinds["igemm"]
         ach = ig["flops"] / (ig["ms"] * 1e-3) / 1e12
         roofline = {"bound": "mfma", "kernel": "igemm_kernel", "achieved": round(ach, 2), "peak": PEAK_TFLOPS,
@@ -216,6 +217,12 @@ def main():
                     "avg_launch_us": round(ig["ms"] * 1e3 / ig["launches"], 2),
                     "gflop_per_launch": round(ig["flops"] / ig["launches"] / 1e9, 3),
                     "note": "event-bracketed launches of one extra step; algorithmic 2*M*N*K of every conv/linear"}
+        roofline["algorithmic_mb_per_launch"] = round(ig["bytes"] / ig["launches"] / 1e6, 2)
+        pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+        if os.path.exists(pmc):            # HBM bytes per launch from the committed rocprofv3 --pmc passes
+            with open(pmc) as f:
+                roofline["traffic"] = round(json.load(f)["igemm_kernel"]["hbm_bytes_per_launch_corrected"])
+            roofline["traffic_source"] = "profiles/r01_pmc_traffic.json (FETCH_SIZE x2 + WRITE_SIZE, separate --pmc passes)"
         if "attention" in kinds:
             at = kinds["attention"]
             roofline["attention_tflops"] = round(at["flops"] / (at["ms"] * 1e-3) / 1e12, 2)

@@ -176,7 +176,7 @@ int mobi_ctx_attention(const mobi_ctx_attention_params* p, void* stream);
 int mobi_softmax_rows(const float* src, void* out, int64_t rows, int32_t cols, int32_t dtype, void* stream);
 
 /* ---------------------------------------------------------------------------
- * Small dense layers on fp32 vectors (m <= 64 rows):
+ * Small dense layers on fp32 vectors (m <= 16 rows per call):
  *   out[m][n] = post( sum_k W[n][k] * pre(x[m][k]) + b[n] )
  * time_embed MLP and every ResBlock emb_layers (openaimodel.py:627-631,
  * 219-225, 874-875), attn2's to_v/to_out on the reference token

@@ -6,49 +6,79 @@
 namespace mobi {
 
 // ---------------------------------------------------------------------------------------
-// skinny linear: one wave per output column, all m <= 64 rows; weights T read 16 B per lane
+// skinny linear (m <= 16 rows of fp32 activations against a tall T weight matrix): the weights are the only
+// real traffic (read once, 16 B per lane); x is staged in LDS per 512-wide k chunk (optionally through SiLU)
+// and shared by the block's 16 output columns; each wave owns 4 columns, two at a time.
 // ---------------------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void skinny_linear_kernel(const mobi_skinny_linear_params a) {
-  const int lane = threadIdx.x & 63;
-  const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (n >= a.n) return;
-  const T* __restrict__ w = reinterpret_cast<const T*>(a.weight) + (long long)n * a.k;
-  const int V = a.k >> 3;
-  for (int m0 = 0; m0 < a.m; m0 += 8) {
-    float acc[8];
+  constexpr int KC = 512, MMAX = 16, PAIRS = 2;
+  __shared__ __attribute__((aligned(16))) float xs[MMAX * KC];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n_base = blockIdx.x * (8 * PAIRS) + wave * (2 * PAIRS);
+  const T* __restrict__ wbase = reinterpret_cast<const T*>(a.weight);
+  float acc[PAIRS][2][MMAX];        // [pair][column of pair][row]  -- fully unrolled below
 #pragma unroll
-    for (int i = 0; i < 8; ++i) acc[i] = 0.f;
-    for (int v = lane; v < V; v += 64) {
-      float wf[8];
-      unpack8<T>(ld16(w + v * 8), wf);
+  for (int p = 0; p < PAIRS; ++p)
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const int m = m0 + i;
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int m = 0; m < MMAX; ++m) acc[p][c][m] = 0.f;
+  for (int k0 = 0; k0 < a.k; k0 += KC) {
+    __syncthreads();
+    for (int i = tid; i < a.m * (KC / 4); i += 256) {
+      const int m = i / (KC / 4), kq = (i - m * (KC / 4)) * 4;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (k0 + kq < a.k) v = *reinterpret_cast<const f32x4*>(a.x + (long long)m * a.x_row_stride + k0 + kq);
+      if (a.pre_act == MOBI_ACT_SILU) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = silu_f(v[j]);
+      }
+      *reinterpret_cast<f32x4*>(xs + m * KC + kq) = v;
+    }
+    __syncthreads();
+    const int kk = lane * 8;                       // this lane's 8 k values of the chunk
+    const bool kok = k0 + kk < a.k;
+#pragma unroll
+    for (int p = 0; p < PAIRS; ++p) {
+      float w0[8], w1[8];
+      const int n0 = n_base + 2 * p, n1 = n0 + 1;
+      u32x4 r0 = {0u, 0u, 0u, 0u}, r1 = {0u, 0u, 0u, 0u};
+      if (kok && n0 < a.n) r0 = ld16(wbase + (long long)n0 * a.k + k0 + kk);
+      if (kok && n1 < a.n) r1 = ld16(wbase + (long long)n1 * a.k + k0 + kk);
+      unpack8<T>(r0, w0);
+      unpack8<T>(r1, w1);
+#pragma unroll
+      for (int m = 0; m < MMAX; ++m) {
         if (m < a.m) {
-          const float* xp = a.x + (long long)m * a.x_row_stride + v * 8;
-          const f32x4 x0 = *reinterpret_cast<const f32x4*>(xp);
-          const f32x4 x1 = *reinterpret_cast<const f32x4*>(xp + 4);
-          float xf[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
+          const f32x4 xa = *reinterpret_cast<const f32x4*>(xs + m * KC + kk);
+          const f32x4 xb = *reinterpret_cast<const f32x4*>(xs + m * KC + kk + 4);
 #pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            const float xv = a.pre_act == MOBI_ACT_SILU ? silu_f(xf[j]) : xf[j];
-            acc[i] += wf[j] * xv;
+          for (int j = 0; j < 4; ++j) {
+            acc[p][0][m] += w0[j] * xa[j] + w0[4 + j] * xb[j];
+            acc[p][1][m] += w1[j] * xa[j] + w1[4 + j] * xb[j];
           }
         }
       }
     }
+  }
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const float s = wave_sum(acc[i]);
-      const int m = m0 + i;
-      if (lane == 0 && m < a.m) {
-        float o = s + (a.bias ? a.bias[n] : 0.f);
-        if (a.post_act == MOBI_ACT_SILU) o = silu_f(o);
-        a.out[(long long)m * a.out_row_stride + n] = o;
+  for (int p = 0; p < PAIRS; ++p)
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const int n = n_base + 2 * p + c;
+#pragma unroll
+      for (int m = 0; m < MMAX; ++m) {
+        if (m < a.m) {
+          const float s = wave_sum(acc[p][c][m]);
+          if (lane == 0 && n < a.n) {
+            float o = s + (a.bias ? a.bias[n] : 0.f);
+            if (a.post_act == MOBI_ACT_SILU) o = silu_f(o);
+            a.out[(long long)m * a.out_row_stride + n] = o;
+          }
+        }
       }
     }
-  }
 }
 
 __global__ void timestep_embedding_kernel(const int64_t* t, const float* freqs, float* out, int n, int half) {
@@ -306,10 +336,10 @@ using namespace mobi;
 
 extern "C" int mobi_skinny_linear(const mobi_skinny_linear_params* p, void* stream) {
   if (!p || !p->x || !p->weight || !p->out) return MOBI_ERR_ARG;
-  if (!DT_OK(p->dtype) || p->m <= 0 || p->m > 64 || p->n <= 0 || p->k <= 0) return MOBI_ERR_ARG;
+  if (!DT_OK(p->dtype) || p->m <= 0 || p->m > 16 || p->n <= 0 || p->k <= 0) return MOBI_ERR_ARG;
   if ((p->k & 7) || (p->x_row_stride & 3)) return MOBI_ERR_UNSUPPORTED;
   if ((reinterpret_cast<uintptr_t>(p->x) | reinterpret_cast<uintptr_t>(p->weight)) & 15) return MOBI_ERR_ALIGN;
-  const unsigned blocks = (unsigned)((p->n + 3) / 4);
+  const unsigned blocks = (unsigned)((p->n + 15) / 16);
   if (p->dtype == MOBI_F16) hipLaunchKernelGGL((skinny_linear_kernel<f16_t>), dim3(blocks), dim3(256), 0, ST(stream), *p);
   else hipLaunchKernelGGL((skinny_linear_kernel<bf16_t>), dim3(blocks), dim3(256), 0, ST(stream), *p);
   MOBI_CHECK_LAUNCH();

@@ -184,10 +184,10 @@ class BasicTransformerBlock(nn.Module):
         cache = self.__dict__.setdefault("_fold_cache", {})
         hit = cache.get(tag)
         if hit is None or hit[0] != key:
-            wc, wo = lc.weight.detach().double(), lo.weight.detach().double()
+            wc, wo = lc.weight.detach().double().cpu(), lo.weight.detach().double().cpu()      # load-time, host
             w = (wc @ wo).float()
-            b = (wc @ lo.bias.detach().double() + lc.bias.detach().double()).float()
-            hit = (key, ops.pack_linear(w, b, lo.packed().w.dtype, w.device))
+            b = (wc @ lo.bias.detach().double().cpu() + lc.bias.detach().double().cpu()).float()
+            hit = (key, ops.pack_linear(w, b, lo.packed().w.dtype, lo.weight.device))
             cache[tag] = hit
         return hit[1]
 

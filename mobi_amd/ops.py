@@ -30,8 +30,8 @@ def set_profiler(sink):
 class _Timed:
     """Brackets one launch with events on the launch stream when a profiler is installed."""
 
-    def __init__(self, kind, flops):
-        self.kind, self.flops = kind, flops
+    def __init__(self, kind, flops, nbytes=0.0):
+        self.kind, self.flops, self.nbytes = kind, flops, nbytes
 
     def __enter__(self):
         if _PROFILE is not None:
@@ -42,7 +42,7 @@ class _Timed:
     def __exit__(self, *exc):
         if _PROFILE is not None:
             self.e1.record()
-            _PROFILE.append((self.kind, self.flops, self.e0, self.e1))
+            _PROFILE.append((self.kind, self.flops, self.e0, self.e1, self.nbytes))
         return False
 
 
@@ -199,7 +199,9 @@ def igemm(x, pw: Packed, *, x2=None, stride=1, pad=None, upsample=False, hout=No
         ws = torch.empty(lib.mobi_igemm_workspace_bytes(C.byref(p), splits), device=x.device, dtype=torch.uint8)
         p.split_k, p.ws = splits, _ptr(ws)
     flops = 2.0 * n * hout * wout * (pw.n_packed if pw.geglu else pw.cout) * pw.kh * pw.kw * pw.cin
-    with _Timed("igemm", flops):
+    nbytes = (x.numel() + (0 if x2 is None else x2.numel())) * 2 + pw.w.numel() * 2 * (n if weight_per_image else 1) \
+        + out.numel() * out.element_size() + (0 if residual is None else residual.numel() * 2)
+    with _Timed("igemm", flops, nbytes):
         _lib.check(lib.mobi_igemm(C.byref(p), _stream()), "mobi_igemm")
     return out
 
@@ -304,8 +306,8 @@ def skinny_linear(x, w, bias=None, pre_act=ACT_NONE, post_act=ACT_NONE, out=None
     assert x.dtype == torch.float32 and x.stride(1) == 1 and w.is_contiguous()
     if out is None:
         out = torch.empty((m, n), device=x.device, dtype=torch.float32)
-    for m0 in range(0, m, 64):                      # the kernel handles up to 64 rows per launch
-        xs, os_ = x[m0:m0 + 64], out[m0:m0 + 64]
+    for m0 in range(0, m, 16):                      # the kernel handles up to 16 rows per launch
+        xs, os_ = x[m0:m0 + 16], out[m0:m0 + 16]
         p = _lib.SkinnyLinearParams()
         p.x, p.m, p.k, p.x_row_stride = _ptr(xs), xs.shape[0], k, x.stride(0)
         p.weight, p.bias, p.out, p.n, p.out_row_stride = _ptr(w), _ptr(bias), _ptr(os_), n, out.stride(0)
