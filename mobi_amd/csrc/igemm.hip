@@ -26,6 +26,10 @@
 
 namespace mobi {
 
+// 16 zero bytes in the code object: the source of every padded / out-of-range 16-byte piece of an operand tile
+// (a plain load from here instead of a load + select; the library allocates nothing).
+__device__ __attribute__((aligned(16))) unsigned int g_zero16[4] = {0u, 0u, 0u, 0u};
+
 struct IgemmArgs {
   const void* src0; const void* src1;
   int c0, c1, C;
@@ -135,10 +139,11 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs a) {
 
   // Two register sets: the loads of k-tile t+2 are in flight while tile t is multiplied and tile t+1
   // (loaded one step earlier) is written to LDS.  Every load is issued UNCONDITIONALLY (invalid pieces read
-  // a safe address and are zeroed from a validity mask when written to LDS) so that the compiler can count
-  // them and wait with vmcnt(N) for the older tile only, instead of draining with vmcnt(0).
+  // the zero block g_zero16) so that the compiler can count them and wait with vmcnt(N) for the older
+  // tile only, instead of draining with vmcnt(0).
   u32x4 xr0[4], wr0[NT], xr1[4], wr1[NT];
   unsigned ok0 = 0, ok1 = 0;
+  const T* const zsrc = reinterpret_cast<const T*>(g_zero16);
 
   auto load_tile = [&](int kt, u32x4 (&xr)[4], u32x4 (&wr)[NT], unsigned& okm) {
     if (tap != t_tap) {                       // no loads inside this branch
@@ -164,14 +169,14 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs a) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const unsigned long long off = (unsigned long long)(unsigned)(x_gp[i] + t_pix[i]) * cs + chs;
-      const T* ptr = ((xm >> i) & 1u) ? base + off : src0;
+      const T* ptr = ((xm >> i) & 1u) ? base + off : zsrc;
       xr[i] = ld16(ptr);
     }
     const int kk = kt * 64 + seg * 8;
     const unsigned wm = ((kk < a.ktot) && (kt < kt_end)) ? w_okm : 0u;
 #pragma unroll
     for (int i = 0; i < NT; ++i) {
-      const T* ptr = ((wm >> i) & 1u) ? w_ptr[i] + kk : wgt;
+      const T* ptr = ((wm >> i) & 1u) ? w_ptr[i] + kk : zsrc;
       wr[i] = ld16(ptr);
     }
     okm = m | (wm << 4);
@@ -182,16 +187,16 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs a) {
   auto store_tile = [&](int buf, const u32x4 (&xr)[4], const u32x4 (&wr)[NT], unsigned okm) {
     unsigned char* xb = lds + buf * X_TILE;
     unsigned char* wb = lds + 2 * X_TILE + buf * W_TILE;
-    const u32x4 zero = {0u, 0u, 0u, 0u};
+    (void)okm;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int r = row_b + 32 * i;
-      st16(xb + r * 128 + ((seg ^ (r & 7)) << 4), (okm >> i) & 1u ? xr[i] : zero);
+      st16(xb + r * 128 + ((seg ^ (r & 7)) << 4), xr[i]);
     }
 #pragma unroll
     for (int i = 0; i < NT; ++i) {
       const int r = row_b + 32 * i;
-      st16(wb + r * 128 + ((seg ^ (r & 7)) << 4), (okm >> (4 + i)) & 1u ? wr[i] : zero);
+      st16(wb + r * 128 + ((seg ^ (r & 7)) << 4), wr[i]);
     }
   };
 
