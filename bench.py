@@ -78,12 +78,17 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # MOBI_BENCH_BACKEND=gloo + MOBI_BENCH_ONE_DEVICE=1 let the multi-rank logic be exercised on a 1-GPU box
+    backend = os.environ.get("MOBI_BENCH_BACKEND", "nccl")
+    if os.environ.get("MOBI_BENCH_ONE_DEVICE") == "1":
+        local_rank = 0
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         import torch.distributed as dist
-        dist.init_process_group(backend="nccl")          # "nccl" is RCCL on ROCm
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+        dist.init_process_group(backend=backend)         # "nccl" is RCCL on ROCm
+    red_dev = device if backend == "nccl" else torch.device("cpu")
 
     import mobi_amd
     from mobi_amd import build, ops
@@ -138,7 +143,7 @@ def main():
         barrier()
         dt = time.perf_counter() - t0
     if world > 1:
-        tmax = torch.tensor([dt], device=device)
+        tmax = torch.tensor([dt], device=red_dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
     finite = bool(torch.isfinite(x).all())
@@ -169,6 +174,8 @@ def main():
                                                        "inpaint_mask": z[:, 8:9].contiguous()})
             h_cam, h_lid = model.decode_sample(smp, z_lid[:, :4])
             log, _ = model.log_data(None, None, h_cam.contiguous(), h_lid.contiguous())
+            if backend != "nccl":
+                log = {k: v.cpu() for k, v in log.items()}
             return mdist.gather_decoded(log, B * world)                 # the one collective of the path
 
         with torch.no_grad():
@@ -183,7 +190,7 @@ def main():
             barrier()
             e2e_dt = time.perf_counter() - t0
         if world > 1:
-            tmax = torch.tensor([e2e_dt], device=device)
+            tmax = torch.tensor([e2e_dt], device=red_dev)
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             e2e_dt = float(tmax.item())
         assert out["image_sample"].shape == (B * world, 3, R, R) and out["lidar_sample"].shape == (B * world, 2, R, R)
