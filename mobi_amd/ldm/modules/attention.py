@@ -82,16 +82,16 @@ class CrossAttention(nn.Module):
     def self_attention(self, xn):
         """xn: normed tokens [N,T,C] -> attention output before to_out."""
         c = self.inner_dim
-        qk = ops.linear(xn, self._qk_packed())
-        vt = ops.linear(xn, self.to_v.packed(), out_mode=OUT_TRANSPOSED)
+        qk, vt = ops.concurrently(lambda: ops.linear(xn, self._qk_packed()),
+                                  lambda: ops.linear(xn, self.to_v.packed(), out_mode=OUT_TRANSPOSED))
         return ops.attention(qk[..., :c], qk[..., c:], vt, self.heads, self.scale)
 
     def token_attention(self, xn, ctx):
         """Many queries against another token stream `ctx` [N,Tk,Cc] (engine tensor, may be a
         batch-strided view)."""
-        q = ops.linear(xn, self.to_q.packed())
-        k = ops.linear(ctx, self.to_k.packed())
-        vt = ops.linear(ctx, self.to_v.packed(), out_mode=OUT_TRANSPOSED)
+        q, k, vt = ops.concurrently(lambda: ops.linear(xn, self.to_q.packed()),
+                                    lambda: ops.linear(ctx, self.to_k.packed()),
+                                    lambda: ops.linear(ctx, self.to_v.packed(), out_mode=OUT_TRANSPOSED))
         return ops.attention(q, k, vt, self.heads, self.scale)
 
     def context_kv(self, context):
@@ -106,8 +106,7 @@ class CrossAttention(nn.Module):
 
     def few_token_attention(self, xn, context):
         """Queries against <= 8 fp32 context tokens."""
-        q = ops.linear(xn, self.to_q.packed())
-        k, v = self.context_kv(context)
+        q, (k, v) = ops.concurrently(lambda: ops.linear(xn, self.to_q.packed()), lambda: self.context_kv(context))
         return ops.ctx_attention(q, k, v, self.heads, self.scale)
 
     def single_token_vector(self, token):
@@ -203,8 +202,8 @@ class BasicTransformerBlock(nn.Module):
         """x: engine tokens [N,T,C]; context: fp32 [N, n_ctx, context_dim]."""
         ctx = context.float().contiguous()
         # attn1 (self) + attn2 (reference token; norm2 / to_q cancel out of a one-key softmax)
-        a = self.attn1.self_attention(self._ln(self.norm1, x))
-        ref_vec = self.attn2.single_token_vector(ctx[:, 0])
+        a, ref_vec = ops.concurrently(lambda: self.attn1.self_attention(self._ln(self.norm1, x)),
+                                      lambda: self.attn2.single_token_vector(ctx[:, 0]))
         x = ops.linear(a, self.attn1.to_out[0].packed(), residual=x, rowvec=ref_vec)
 
         if self.bbox_cond:

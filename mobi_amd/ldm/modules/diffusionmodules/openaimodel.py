@@ -114,16 +114,19 @@ class ResBlock(TimestepBlock):
             w, b = self.emb_layers[1].skinny()
             emb_out = ops.skinny_linear(emb.float().contiguous(), w, b, pre_act=ACT_SILU)
         n1, n2 = self.in_layers[0], self.out_layers[0]
-        g, b = n1.affine()
-        h = ops.groupnorm(x, g, b, n1.eps, silu=True, x2=skip)
-        h = ops.igemm(h, self.in_layers[2].packed(), rowvec=emb_out)
-        g, b = n2.affine()
-        h = ops.groupnorm(h, g, b, n2.eps, silu=True)
-        if isinstance(self.skip_connection, Conv2d):
-            xs = ops.igemm(x, self.skip_connection.packed(), x2=skip)
+
+        def main_path():
+            g, b = n1.affine()
+            h = ops.groupnorm(x, g, b, n1.eps, silu=True, x2=skip)
+            h = ops.igemm(h, self.in_layers[2].packed(), rowvec=emb_out)
+            g, b = n2.affine()
+            return ops.groupnorm(h, g, b, n2.eps, silu=True)
+
+        if isinstance(self.skip_connection, Conv2d):       # the 1x1 skip conv is independent of the main path
+            h, xs = ops.concurrently(main_path, lambda: ops.igemm(x, self.skip_connection.packed(), x2=skip))
         else:
             assert skip is None
-            xs = x
+            h, xs = main_path(), x
         return leave(ops.igemm(h, self.out_layers[3].packed(), residual=xs), ext)
 
 

@@ -8,6 +8,7 @@ is not on a ROCm device -- there is no CPU path.
 """
 import ctypes as C
 import math
+import os
 from dataclasses import dataclass
 from typing import Optional
 
@@ -44,6 +45,43 @@ class _Timed:
             self.e1.record()
             _PROFILE.append((self.kind, self.flops, self.e0, self.e1, self.nbytes))
         return False
+
+
+# --------------------------------------------------------------------------------------
+# stream-level concurrency: independent launches of one block (e.g. the q / k / v projections) run on
+# side HIP streams so that their latency-bound prologues / epilogues overlap; fork waits on the caller's
+# stream, join makes the caller's stream wait on every side stream.  Graph-capture safe (events only).
+# --------------------------------------------------------------------------------------
+_SIDE = {}
+_CONCURRENT = os.environ.get("MOBI_CONCURRENCY", "1") != "0"
+
+
+def set_concurrency(flag):
+    global _CONCURRENT
+    _CONCURRENT = bool(flag)
+
+
+def concurrently(*fns):
+    """Run independent launch sequences concurrently; returns their results in order."""
+    if not _CONCURRENT or _PROFILE is not None or len(fns) == 1:
+        return [f() for f in fns]
+    main = torch.cuda.current_stream()
+    key = (main.device, main.cuda_stream)
+    pool = _SIDE.setdefault(key, [])
+    while len(pool) < len(fns) - 1:
+        pool.append(torch.cuda.Stream(device=main.device))
+    start = torch.cuda.Event()
+    start.record(main)
+    results = [None] * len(fns)
+    for i, f in enumerate(fns[1:]):
+        side = pool[i]
+        side.wait_event(start)
+        with torch.cuda.stream(side):
+            results[i + 1] = f()
+    results[0] = fns[0]()
+    for i in range(len(fns) - 1):
+        main.wait_stream(pool[i])
+    return results
 
 
 def _dt(t):
