@@ -15,6 +15,8 @@
 // two sources never materialise an im2col, an upsampled or a concatenated tensor.
 // Epilogue: accumulators go through a per-wave fp32 LDS tile so that bias,
 // per-image vector, residual and GEGLU are applied on coalesced 16-byte rows.
+#include <stdlib.h>
+
 #include "common.h"
 
 // A/B switch (build with -DMOBI_IGEMM_FENCE=1): pin the load / MFMA / LDS-write phases of a k step
@@ -46,6 +48,7 @@ struct IgemmArgs {
   int out_mode, epilogue;
   float scale;
   int tiles_m, tiles_n;
+  int wm;                  // waves along the pixel axis (2 or 4): block tile = 64*wm pixels
   int splits, nk_per;      // split-K: blockIdx.y owns k-tiles [y*nk_per, (y+1)*nk_per)
   float* split_ws;         // f32 [splits][M][n_packed] partial sums (NULL: single pass)
 };
@@ -56,31 +59,39 @@ __device__ __forceinline__ void ld8f(const float* p, float (&f)[8]) {
   f[0] = a[0]; f[1] = a[1]; f[2] = a[2]; f[3] = a[3]; f[4] = b[0]; f[5] = b[1]; f[6] = b[2]; f[7] = b[3];
 }
 
-template <typename T, int NT, bool TR>
-__global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs a) {
+// WM = waves along the pixel axis: 2 -> 128-pixel tile, 4 waves, two blocks per CU;
+//                                  4 -> 256-pixel tile, 8 waves, one block per CU (weight tile shared by
+//                                       twice the pixels: fewer LDS writes and L2 reads per FLOP).
+template <typename T, int NT, bool TR, int WM>
+__global__ __launch_bounds__(128 * WM, 2) void igemm_kernel(const IgemmArgs a) {
   typedef typename Vec8<T>::type frag_t;
+  constexpr int NTHREADS = 128 * WM;
+  constexpr int NWAVES = 2 * WM;
+  constexpr int BM = 64 * WM;
+  constexpr int RP = NTHREADS / 8;               // tile rows staged per pass of the block
   constexpr int WAVE_N = NT * 16;
   constexpr int BN = 2 * WAVE_N;
-  constexpr int X_TILE = 128 * 128;              // bytes per buffer
+  constexpr int WP = (BN + RP - 1) / RP;         // weight pieces per thread and k-tile
+  constexpr int X_TILE = BM * 128;               // bytes per buffer
   constexpr int W_TILE = BN * 128;
   constexpr int STAGE_STRIDE = TR ? 36 : (WAVE_N + 4);      // floats
   constexpr int STAGE_ROWS = TR ? WAVE_N : 32;
   constexpr int STAGE_BYTES = STAGE_ROWS * STAGE_STRIDE * 4;
   constexpr int MAIN_BYTES = 2 * X_TILE + 2 * W_TILE;
-  constexpr int LDS_BYTES = MAIN_BYTES > 4 * STAGE_BYTES ? MAIN_BYTES : 4 * STAGE_BYTES;
+  constexpr int LDS_BYTES = MAIN_BYTES > NWAVES * STAGE_BYTES ? MAIN_BYTES : NWAVES * STAGE_BYTES;
   __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
-  const int wm = wave & 1, wn = wave >> 1;
+  const int wm = wave % WM, wn = wave / WM;
   const int group = blockIdx.z;
 
   const int nblk = a.tiles_m * a.tiles_n;
   const int L = xcd_remap(blockIdx.x, nblk);
   const int tile_n = L % a.tiles_n;
   const int tile_m = L / a.tiles_n;
-  const int m0 = tile_m * 128;
+  const int m0 = tile_m * BM;
   const int n0 = tile_n * BN;
 
   const T* __restrict__ src0 = reinterpret_cast<const T*>(a.src0);
@@ -91,14 +102,14 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs a) {
   const int seg = tid & 7;               // 16-byte piece of the 128-byte k row
   const int slot = seg >> 2;             // which 32-channel chunk of the k-tile
   const int sub = (seg & 3) * 8;         // channel offset inside the chunk
-  const int row_b = tid >> 3;            // 0..31
+  const int row_b = tid >> 3;            // 0..RP-1
 
   // per output row (fixed for the whole k loop): pixel index of the image origin, window origin
   int x_gp[4], x_h[4], x_w[4];
   unsigned x_okm = 0;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const int m = m0 + row_b + 32 * i;
+    const int m = m0 + row_b + RP * i;
     const bool ok = m < a.M;
     x_okm |= ok ? (1u << i) : 0u;
     const int mm = ok ? m : 0;
@@ -111,12 +122,12 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs a) {
     x_w[i] = wo * a.stride - a.pad_w;
   }
   // per weight row: pointer to its k = 0 element, validity
-  const T* w_ptr[NT];
+  const T* w_ptr[WP];
   unsigned w_okm = 0;
 #pragma unroll
-  for (int i = 0; i < NT; ++i) {
-    const int n = n0 + row_b + 32 * i;
-    const bool ok = n < a.n_packed;
+  for (int i = 0; i < WP; ++i) {
+    const int n = n0 + row_b + RP * i;
+    const bool ok = (row_b + RP * i < BN) && n < a.n_packed;
     w_okm |= ok ? (1u << i) : 0u;
     w_ptr[i] = wgt + (long long)(ok ? n : 0) * a.ktot;
   }
@@ -141,11 +152,11 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs a) {
   // (loaded one step earlier) is written to LDS.  Every load is issued UNCONDITIONALLY (invalid pieces read
   // the zero block g_zero16) so that the compiler can count them and wait with vmcnt(N) for the older
   // tile only, instead of draining with vmcnt(0).
-  u32x4 xr0[4], wr0[NT], xr1[4], wr1[NT];
+  u32x4 xr0[4], wr0[WP], xr1[4], wr1[WP];
   unsigned ok0 = 0, ok1 = 0;
   const T* const zsrc = reinterpret_cast<const T*>(g_zero16);
 
-  auto load_tile = [&](int kt, u32x4 (&xr)[4], u32x4 (&wr)[NT], unsigned& okm) {
+  auto load_tile = [&](int kt, u32x4 (&xr)[4], u32x4 (&wr)[WP], unsigned& okm) {
     if (tap != t_tap) {                       // no loads inside this branch
       t_tap = tap;
       t_okm = 0;
@@ -173,30 +184,30 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs a) {
       xr[i] = ld16(ptr);
     }
     const int kk = kt * 64 + seg * 8;
-    const unsigned wm = ((kk < a.ktot) && (kt < kt_end)) ? w_okm : 0u;
+    const unsigned wmask = ((kk < a.ktot) && (kt < kt_end)) ? w_okm : 0u;
 #pragma unroll
-    for (int i = 0; i < NT; ++i) {
-      const T* ptr = ((wm >> i) & 1u) ? w_ptr[i] + kk : zsrc;
+    for (int i = 0; i < WP; ++i) {
+      const T* ptr = ((wmask >> i) & 1u) ? w_ptr[i] + kk : zsrc;
       wr[i] = ld16(ptr);
     }
-    okm = m | (wm << 4);
+    okm = m | (wmask << 4);
     // advance this thread's chunk by one k-tile (two chunks)
     cc += 2;
     while (cc >= cpt) { cc -= cpt; ++tap; if (++kx == a.kw) { kx = 0; ++ky; } }
   };
-  auto store_tile = [&](int buf, const u32x4 (&xr)[4], const u32x4 (&wr)[NT], unsigned okm) {
+  auto store_tile = [&](int buf, const u32x4 (&xr)[4], const u32x4 (&wr)[WP], unsigned okm) {
     unsigned char* xb = lds + buf * X_TILE;
     unsigned char* wb = lds + 2 * X_TILE + buf * W_TILE;
     (void)okm;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int r = row_b + 32 * i;
+      const int r = row_b + RP * i;
       st16(xb + r * 128 + ((seg ^ (r & 7)) << 4), xr[i]);
     }
 #pragma unroll
-    for (int i = 0; i < NT; ++i) {
-      const int r = row_b + 32 * i;
-      st16(wb + r * 128 + ((seg ^ (r & 7)) << 4), wr[i]);
+    for (int i = 0; i < WP; ++i) {
+      const int r = row_b + RP * i;
+      if (r < BN) st16(wb + r * 128 + ((seg ^ (r & 7)) << 4), wr[i]);
     }
   };
 
@@ -456,13 +467,25 @@ template <typename T>
 static int launch_igemm(const mobi_igemm_params* p, const IgemmArgs& a, int groups, hipStream_t st) {
   const bool tr = p->out_mode == MOBI_OUT_TRANSPOSED;
   const bool nt5 = (a.n_packed % 160) == 0;
-  dim3 grid(a.tiles_m * a.tiles_n, a.splits, groups), block(256);
-  if (nt5) {
-    if (tr) hipLaunchKernelGGL((igemm_kernel<T, 5, true>), grid, block, 0, st, a);
-    else    hipLaunchKernelGGL((igemm_kernel<T, 5, false>), grid, block, 0, st, a);
+  dim3 grid(a.tiles_m * a.tiles_n, a.splits, groups);
+  if (a.wm == 4) {
+    dim3 block(512);
+    if (nt5) {
+      if (tr) hipLaunchKernelGGL((igemm_kernel<T, 5, true, 4>), grid, block, 0, st, a);
+      else    hipLaunchKernelGGL((igemm_kernel<T, 5, false, 4>), grid, block, 0, st, a);
+    } else {
+      if (tr) hipLaunchKernelGGL((igemm_kernel<T, 4, true, 4>), grid, block, 0, st, a);
+      else    hipLaunchKernelGGL((igemm_kernel<T, 4, false, 4>), grid, block, 0, st, a);
+    }
   } else {
-    if (tr) hipLaunchKernelGGL((igemm_kernel<T, 4, true>), grid, block, 0, st, a);
-    else    hipLaunchKernelGGL((igemm_kernel<T, 4, false>), grid, block, 0, st, a);
+    dim3 block(256);
+    if (nt5) {
+      if (tr) hipLaunchKernelGGL((igemm_kernel<T, 5, true, 2>), grid, block, 0, st, a);
+      else    hipLaunchKernelGGL((igemm_kernel<T, 5, false, 2>), grid, block, 0, st, a);
+    } else {
+      if (tr) hipLaunchKernelGGL((igemm_kernel<T, 4, true, 2>), grid, block, 0, st, a);
+      else    hipLaunchKernelGGL((igemm_kernel<T, 4, false, 2>), grid, block, 0, st, a);
+    }
   }
   MOBI_CHECK_LAUNCH();
   if (a.split_ws) {
@@ -545,7 +568,13 @@ extern "C" int mobi_igemm(const mobi_igemm_params* p, void* stream) {
   a.out_img_stride = p->out_img_stride ? p->out_img_stride : (long long)a.hw_out * p->cout;
   a.out_mode = p->out_mode; a.epilogue = p->epilogue; a.scale = p->scale;
   const int bn = (p->n_packed % 160) == 0 ? 160 : 128;
-  a.tiles_m = (a.M + 127) / 128;
+  // 256-pixel tiles (8 waves, one block per CU) when that still gives every CU a block; MOBI_IGEMM_WM overrides
+  {
+    const long long tiles256 = ((a.M + 255) / 256) * (long long)((p->n_packed + bn - 1) / bn);
+    a.wm = tiles256 >= 256 ? 4 : 2;
+    if (const char* e = getenv("MOBI_IGEMM_WM")) { if (e[0] == '2') a.wm = 2; else if (e[0] == '4') a.wm = 4; }
+  }
+  a.tiles_m = (a.M + 64 * a.wm - 1) / (64 * a.wm);
   a.tiles_n = (p->n_packed + bn - 1) / bn;
   if ((long long)a.tiles_m * a.tiles_n > 0x7fffffffLL) return MOBI_ERR_UNSUPPORTED;
   a.splits = 1; a.nk_per = a.nk; a.split_ws = nullptr;

@@ -53,7 +53,7 @@ class _Timed:
 # stream, join makes the caller's stream wait on every side stream.  Graph-capture safe (events only).
 # --------------------------------------------------------------------------------------
 _SIDE = {}
-_CONCURRENT = os.environ.get("MOBI_CONCURRENCY", "1") != "0"
+_CONCURRENT = os.environ.get("MOBI_CONCURRENCY", "0") == "1"     # measured: no gain on MI355X (kernels already fill the chip)
 
 
 def set_concurrency(flag):

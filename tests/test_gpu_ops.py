@@ -369,3 +369,33 @@ def test_igemm_split_k(ops, dtype, split):
         p = _lib.IgemmParams()
         p.batch, p.hout, p.wout, p.n_packed, p.kh, p.kw, p.c0, p.groups = 2, 8, 8, 320, 3, 3, 960, 1
         assert _lib.load().mobi_igemm_plan_splits(C.byref(p)) > 1
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("wm", ["2", "4"])
+def test_igemm_block_heights(ops, dtype, wm, monkeypatch):
+    """Both block shapes of the implicit-GEMM kernel (4 waves x 128 pixels, 8 waves x 256 pixels) on the same
+    convolutions, incl. ragged pixel counts, two sources, GEGLU and the transposed epilogue."""
+    from mobi_amd._lib import OUT_TRANSPOSED
+    monkeypatch.setenv("MOBI_IGEMM_WM", wm)
+    for name, cin, cout, kh, kw, h, w, stride, up, asym in IGEMM_CASES[:7]:
+        xf, xd = rnd("x." + name, (3, h, w, cin), dtype)
+        wf = torch.from_numpy(W.synth_param(name + ".weight", (cout, cin, kh, kw))).to(dtype).float()
+        bias = torch.from_numpy(W.synth_param(name + ".bias", (cout,)))
+        pw = ops.pack_conv(wf, bias, dtype, "cuda")
+        pad = (kh // 2, kw // 2)
+        if asym:
+            y = ops.igemm(xd, pw, stride=2, pad=(0, 0), hout=(h + 1 - 3) // 2 + 1, wout=(w + 1 - 3) // 2 + 1)
+        else:
+            y = ops.igemm(xd, pw, stride=stride, pad=pad, upsample=up)
+        assert rel(y.float(), _conv_ref(xf, wf, bias, stride, pad, up, asym)) < TOL[dtype] * 0.5, name
+    xf, xd = rnd("bh.x", (2, 300, 320), dtype)
+    wf = torch.from_numpy(W.synth_param("bh.g.weight", (2560, 320))).to(dtype).float()
+    bf = torch.from_numpy(W.synth_param("bh.g.bias", (2560,)))
+    y = ops.linear(xd, ops.pack_geglu(wf, bf, dtype, "cuda"))
+    a, gate = F.linear(xf, wf, bf).chunk(2, dim=-1)
+    assert rel(y.float(), a * F.gelu(gate)) < TOL[dtype]
+    wv = torch.from_numpy(W.synth_param("bh.v.weight", (320, 320))).to(dtype).float()
+    xs_f, xs_d = rnd("bh.xs", (2, 304, 320), dtype)
+    yt = ops.linear(xs_d, ops.pack_linear(wv, None, dtype, "cuda"), out_mode=OUT_TRANSPOSED)
+    assert rel(yt.float(), F.linear(xs_f, wv).permute(0, 2, 1)) < TOL[dtype] * 0.5
