@@ -48,6 +48,7 @@ struct IgemmArgs {
   int out_mode, epilogue;
   float scale;
   int tiles_m, tiles_n;
+  int src0_bytes, src1_bytes, w_bytes, fast;   // buffer extents for the FAST path's descriptors
   int wm;                  // waves along the pixel axis (2 or 4): block tile = 64*wm pixels
   int splits, nk_per;      // split-K: blockIdx.y owns k-tiles [y*nk_per, (y+1)*nk_per)
   float* split_ws;         // f32 [splits][M][n_packed] partial sums (NULL: single pass)
@@ -62,7 +63,11 @@ __device__ __forceinline__ void ld8f(const float* p, float (&f)[8]) {
 // WM = waves along the pixel axis: 2 -> 128-pixel tile, 4 waves, two blocks per CU;
 //                                  4 -> 256-pixel tile, 8 waves, one block per CU (weight tile shared by
 //                                       twice the pixels: fewer LDS writes and L2 reads per FLOP).
-template <typename T, int NT, bool TR, int WM>
+// FAST: channel counts are multiples of 64 (and the concat boundary too), so one k-tile lies inside one filter tap
+//       of one source.  Tap / source / channel bookkeeping is then wave-uniform (SALU), operands are fetched
+//       with buffer loads (SGPR descriptor + 32-bit offset, out-of-range offset = hardware zero fill), and the
+//       per-lane address work per k-tile drops to one add + one select per 16-byte piece.
+template <typename T, int NT, bool TR, int WM, bool FAST>
 __global__ __launch_bounds__(128 * WM, 2) void igemm_kernel(const IgemmArgs a) {
   typedef typename Vec8<T>::type frag_t;
   constexpr int NTHREADS = 128 * WM;
@@ -156,7 +161,54 @@ __global__ __launch_bounds__(128 * WM, 2) void igemm_kernel(const IgemmArgs a) {
   unsigned ok0 = 0, ok1 = 0;
   const T* const zsrc = reinterpret_cast<const T*>(g_zero16);
 
-  auto load_tile = [&](int kt, u32x4 (&xr)[4], u32x4 (&wr)[WP], unsigned& okm) {
+  // ---- FAST path state (all wave-uniform) ----------------------------------------------------------------
+  int u_tap = 0, u_ky = 0, u_kx = 0, u_c = 0;           // tap and channel offset (multiple of 64) of the next tile
+  unsigned f_row[4] = {0u, 0u, 0u, 0u};                 // byte offset of each row's pixel in the current source/tap
+  unsigned f_w[WP];                                     // byte offset of each weight row (out of range if invalid)
+  int f_tap = -1, f_src = -1;
+  if constexpr (FAST) {
+    const long long c_first = (long long)kt_begin * 64;
+    u_tap = (int)(c_first / a.C); u_c = (int)(c_first - (long long)u_tap * a.C);
+    u_ky = u_tap / a.kw; u_kx = u_tap - u_ky * a.kw;
+#pragma unroll
+    for (int i = 0; i < WP; ++i) {
+      const int n = n0 + row_b + RP * i;
+      const bool ok = (row_b + RP * i < BN) && n < a.n_packed;
+      f_w[i] = ok ? (unsigned)n * (unsigned)a.ktot * 2u + (unsigned)seg * 16u : 0x80000000u;
+    }
+  }
+  auto load_tile_fast = [&](int kt, u32x4 (&xr)[4], u32x4 (&wr)[WP]) {
+    const bool tile_ok = kt < kt_end;                         // uniform
+    const int src = u_c >= a.c0 ? 1 : 0;                       // uniform
+    if (u_tap != f_tap || src != f_src) {                      // uniform branch, no loads inside
+      f_tap = u_tap; f_src = src;
+      const unsigned cs2 = (unsigned)(src ? a.c1 : a.c0) * 2u;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int hi = x_h[i] + u_ky, wi = x_w[i] + u_kx;
+        const bool ok = ((x_okm >> i) & 1u) && hi >= 0 && hi < hlog && wi >= 0 && wi < wlog;
+        const unsigned pix = (unsigned)(x_gp[i] + (hi >> a.up) * a.win + (wi >> a.up));
+        f_row[i] = ok ? pix * cs2 + (unsigned)seg * 16u : 0x80000000u;
+      }
+    }
+    // descriptors are rebuilt from scalars every tile (a few SALU ops); a tile past the k range gets 0 records,
+    // i.e. every piece of it reads as zero
+    const void* xbase = src ? a.src1 : a.src0;
+    const int xbytes = tile_ok ? (src ? a.src1_bytes : a.src0_bytes) : 0;
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(xbase), 0, xbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(wgt), 0, tile_ok ? a.w_bytes : 0, 0x00020000);
+    const unsigned chb = (unsigned)(src ? u_c - a.c0 : u_c) * 2u;    // uniform channel byte offset
+#pragma unroll
+    for (int i = 0; i < 4; ++i) xr[i] = __builtin_amdgcn_raw_buffer_load_b128(rx, f_row[i] + chb, 0, 0);
+    const unsigned kb = (unsigned)kt * 128u;
+#pragma unroll
+    for (int i = 0; i < WP; ++i) wr[i] = __builtin_amdgcn_raw_buffer_load_b128(rw, f_w[i] + kb, 0, 0);
+    u_c += 64;
+    if (u_c >= a.C) { u_c = 0; ++u_tap; if (++u_kx == a.kw) { u_kx = 0; ++u_ky; } }
+  };
+
+  auto load_tile_generic = [&](int kt, u32x4 (&xr)[4], u32x4 (&wr)[WP], unsigned& okm) {
     if (tap != t_tap) {                       // no loads inside this branch
       t_tap = tap;
       t_okm = 0;
@@ -194,6 +246,10 @@ __global__ __launch_bounds__(128 * WM, 2) void igemm_kernel(const IgemmArgs a) {
     // advance this thread's chunk by one k-tile (two chunks)
     cc += 2;
     while (cc >= cpt) { cc -= cpt; ++tap; if (++kx == a.kw) { kx = 0; ++ky; } }
+  };
+  auto load_tile = [&](int kt, u32x4 (&xr)[4], u32x4 (&wr)[WP], unsigned& okm) {
+    if constexpr (FAST) load_tile_fast(kt, xr, wr);
+    else load_tile_generic(kt, xr, wr, okm);
   };
   auto store_tile = [&](int buf, const u32x4 (&xr)[4], const u32x4 (&wr)[WP], unsigned okm) {
     unsigned char* xb = lds + buf * X_TILE;
@@ -468,25 +524,17 @@ static int launch_igemm(const mobi_igemm_params* p, const IgemmArgs& a, int grou
   const bool tr = p->out_mode == MOBI_OUT_TRANSPOSED;
   const bool nt5 = (a.n_packed % 160) == 0;
   dim3 grid(a.tiles_m * a.tiles_n, a.splits, groups);
-  if (a.wm == 4) {
-    dim3 block(512);
-    if (nt5) {
-      if (tr) hipLaunchKernelGGL((igemm_kernel<T, 5, true, 4>), grid, block, 0, st, a);
-      else    hipLaunchKernelGGL((igemm_kernel<T, 5, false, 4>), grid, block, 0, st, a);
-    } else {
-      if (tr) hipLaunchKernelGGL((igemm_kernel<T, 4, true, 4>), grid, block, 0, st, a);
-      else    hipLaunchKernelGGL((igemm_kernel<T, 4, false, 4>), grid, block, 0, st, a);
-    }
-  } else {
-    dim3 block(256);
-    if (nt5) {
-      if (tr) hipLaunchKernelGGL((igemm_kernel<T, 5, true, 2>), grid, block, 0, st, a);
-      else    hipLaunchKernelGGL((igemm_kernel<T, 5, false, 2>), grid, block, 0, st, a);
-    } else {
-      if (tr) hipLaunchKernelGGL((igemm_kernel<T, 4, true, 2>), grid, block, 0, st, a);
-      else    hipLaunchKernelGGL((igemm_kernel<T, 4, false, 2>), grid, block, 0, st, a);
-    }
-  }
+#define MOBI_IGEMM_LAUNCH(NT_, TR_, WM_, FAST_) \
+  hipLaunchKernelGGL((igemm_kernel<T, NT_, TR_, WM_, FAST_>), grid, dim3(128 * WM_), 0, st, a)
+#define MOBI_IGEMM_BY_FAST(NT_, TR_, WM_) \
+  do { if (a.fast) MOBI_IGEMM_LAUNCH(NT_, TR_, WM_, true); else MOBI_IGEMM_LAUNCH(NT_, TR_, WM_, false); } while (0)
+#define MOBI_IGEMM_BY_TR(NT_, WM_) \
+  do { if (tr) MOBI_IGEMM_BY_FAST(NT_, true, WM_); else MOBI_IGEMM_BY_FAST(NT_, false, WM_); } while (0)
+  if (a.wm == 4) { if (nt5) MOBI_IGEMM_BY_TR(5, 4); else MOBI_IGEMM_BY_TR(4, 4); }
+  else           { if (nt5) MOBI_IGEMM_BY_TR(5, 2); else MOBI_IGEMM_BY_TR(4, 2); }
+#undef MOBI_IGEMM_BY_TR
+#undef MOBI_IGEMM_BY_FAST
+#undef MOBI_IGEMM_LAUNCH
   MOBI_CHECK_LAUNCH();
   if (a.split_ws) {
     long long blocks = ((long long)a.M * (a.cout >> 3) + 255) / 256;
@@ -575,6 +623,18 @@ extern "C" int mobi_igemm(const mobi_igemm_params* p, void* stream) {
     if (const char* e = getenv("MOBI_IGEMM_WM")) { if (e[0] == '2') a.wm = 2; else if (e[0] == '4') a.wm = 4; }
   }
   a.tiles_m = (a.M + 64 * a.wm - 1) / (64 * a.wm);
+  {
+    // FAST path: k-tiles never straddle a tap or a source, and every byte offset fits 31 bits
+    const long long ext0 = (((long long)p->batch - 1) * ips + hw_in) * p->c0 * 2;
+    const long long ext1 = p->c1 ? (((long long)p->batch - 1) * ips + hw_in) * p->c1 * 2 : 0;
+    const long long wext = (long long)p->n_packed * a.ktot * 2;
+    a.fast = (a.C % 64 == 0) && (p->c1 == 0 || p->c0 % 64 == 0) && ext0 < 0x7fffffffLL && ext1 < 0x7fffffffLL &&
+             wext < 0x7fffffffLL;
+    if (const char* e = getenv("MOBI_IGEMM_FAST")) a.fast = a.fast && e[0] != '0';
+    a.src0_bytes = (int)(ext0 < 0x7fffffffLL ? ext0 : 0);
+    a.src1_bytes = (int)(ext1 < 0x7fffffffLL ? ext1 : 0);
+    a.w_bytes = (int)(wext < 0x7fffffffLL ? wext : 0);
+  }
   a.tiles_n = (p->n_packed + bn - 1) / bn;
   if ((long long)a.tiles_m * a.tiles_n > 0x7fffffffLL) return MOBI_ERR_UNSUPPORTED;
   a.splits = 1; a.nk_per = a.nk; a.split_ws = nullptr;
