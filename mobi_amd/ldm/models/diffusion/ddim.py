@@ -114,7 +114,13 @@ class DDIMSampler(object):
         if unconditional_conditioning is None or unconditional_guidance_scale == 1.:
             return self.model.apply_model(parts, t, c), None
         parts2 = [torch.cat([p] * 2) for p in parts]
-        out = self.model.apply_model(parts2, torch.cat([t] * 2), torch.cat([unconditional_conditioning, c]))
+        # [uncond ; cond] tokens are the same tensor at every step of a run: build it once so that the UNet's
+        # per-context cache (attn2 vector, adapter k/v) hits
+        ck = (id(unconditional_conditioning), id(c), unconditional_conditioning._version, c._version)
+        if getattr(self, "_cfg_ctx_key", None) != ck:
+            self._cfg_ctx_key, self._cfg_ctx_refs = ck, (unconditional_conditioning, c)
+            self._cfg_ctx = torch.cat([unconditional_conditioning, c])
+        out = self.model.apply_model(parts2, torch.cat([t] * 2), self._cfg_ctx)
         e_uncond, e_cond = out.chunk(2)
         return e_cond.contiguous(), e_uncond.contiguous()
 

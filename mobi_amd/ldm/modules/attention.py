@@ -198,16 +198,35 @@ class BasicTransformerBlock(nn.Module):
     def forward(self, x, context=None):
         return self._forward(x, context)
 
+    def _context_terms(self, ctx):
+        """Everything that depends on the conditioning tokens only -- attn2's per-image vector and the bbox
+        adapter's keys / values -- is the same at every denoising step of a sampling run.  It is computed once
+        per context tensor (the cache holds a reference to the tensor, so its storage cannot be recycled, and
+        checks the tensor's version counter and the weights' versions) instead of once per UNet call."""
+        ws = [self.attn2.to_v.weight, self.attn2.to_out[0].weight, self.attn2.to_out[0].bias]
+        if self.bbox_cond:
+            ws += [self.cond_adapter_attn.to_k.weight, self.cond_adapter_attn.to_v.weight]
+        key = (id(ctx), ctx._version, ctx.data_ptr(), tuple(ctx.shape), tuple(w._version for w in ws),
+               ws[0].data_ptr(), self.attn2.to_v.skinny()[0].dtype)
+        c = self.__dict__.setdefault("_ctx_cache", {})
+        if c.get("key") != key:
+            c["key"], c["ctx"] = key, ctx
+            c["ref_vec"] = self.attn2.single_token_vector(ctx[:, 0])
+            c["kv"] = self.cond_adapter_attn.context_kv(ctx) if self.bbox_cond else None
+        return c["ref_vec"], c["kv"]
+
     def _forward(self, x, context=None):
         """x: engine tokens [N,T,C]; context: fp32 [N, n_ctx, context_dim]."""
         ctx = context.float().contiguous()
+        ref_vec, ctx_kv = self._context_terms(ctx)
         # attn1 (self) + attn2 (reference token; norm2 / to_q cancel out of a one-key softmax)
-        a, ref_vec = ops.concurrently(lambda: self.attn1.self_attention(self._ln(self.norm1, x)),
-                                      lambda: self.attn2.single_token_vector(ctx[:, 0]))
+        a = self.attn1.self_attention(self._ln(self.norm1, x))
         x = ops.linear(a, self.attn1.to_out[0].packed(), residual=x, rowvec=ref_vec)
 
         if self.bbox_cond:
-            a = self.cond_adapter_attn.attend(self._ln(self.cond_adapter_norm, x), context=ctx)
+            ca = self.cond_adapter_attn
+            q = ops.linear(self._ln(self.cond_adapter_norm, x), ca.to_q.packed())
+            a = ops.ctx_attention(q, ctx_kv[0], ctx_kv[1], ca.heads, ca.scale)
             x = ops.linear(a, self._folded(self.cond_adapter_attn, self.cond_adapter_connector, "adapter"),
                            residual=x)
 
