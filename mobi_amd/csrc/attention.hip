@@ -70,66 +70,90 @@ __global__ __launch_bounds__(256, WPS) void attention_kernel(const AttnArgs a) {
     }
   }
 
-  // K / V^T staging.  Loads are unconditional (invalid pieces read a safe address and are zeroed through a
-  // validity mask when written to LDS) so that they can be counted by vmcnt.
+  // K / V^T staging.
+  // VVEC (production) path: buffer loads with a per-block descriptor (SGPRs) and a 32-bit byte offset that is a
+  // per-thread constant plus a wave-uniform term for the key tile -- one VALU add per 16-byte piece; rows past
+  // the last key, padded head-dim columns and padded V^T rows fall outside the descriptor's extent (or carry an
+  // out-of-range constant) and read as zero in hardware.  Loads are unconditional, so vmcnt can count them.
   // V^T keys are stored PERMUTED inside every group of 16 (key 8a+4b+c -> position 8b+4a+c): the 8 keys a lane
   // needs for one k-step of P.V (the accumulator's key order) are then 16 contiguous bytes.
   u32x4 kr[KP], vr[VP];
-  unsigned kmask = 0, vmask = 0;
+  unsigned koff[KP], voff[VP];
+  unsigned ones_m = 0;                                  // pieces of the all-ones row (softmax denominator)
+  constexpr unsigned OOB = 0x80000000u;
+#pragma unroll
+  for (int i = 0; i < KP; ++i) {
+    const int p = tid + 256 * i;
+    const int row = p / (KS * 2), pc = p - row * (KS * 2);
+    koff[i] = (row < 64 && pc * 8 < dh) ? (unsigned)(row * a.k_row + pc * 8) * 2u : OOB;
+  }
+#pragma unroll
+  for (int i = 0; i < VP; ++i) {
+    const int p = tid + 256 * i;
+    const int row = p >> 3, pc = p & 7;
+    voff[i] = row < dh ? (unsigned)(row * a.vt_row + pc * 8) * 2u : OOB;
+    if (ONES && row == dh) ones_m |= 1u << i;
+  }
+  const int k_bytes = ((a.tk - 1) * a.k_row + dh) * 2;
+  const int v_bytes = ((dh - 1) * a.vt_row + a.tk) * 2;
   auto load_tile = [&](int key0) {
-    kmask = 0; vmask = 0;
+    if (VVEC) {
+      const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(kp), 0, k_bytes, 0x00020000);
+      const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(vp), 0, v_bytes, 0x00020000);
+      const unsigned ku = (unsigned)key0 * (unsigned)a.k_row * 2u, vu = (unsigned)key0 * 2u;    // wave-uniform
 #pragma unroll
-    for (int i = 0; i < KP; ++i) {
-      const int p = tid + 256 * i;
-      const int row = p / (KS * 2), pc = p - row * (KS * 2);
-      const bool ok = row < 64 && key0 + row < a.tk && pc * 8 < dh;
-      const T* src = ok ? kp + (long long)(key0 + row) * a.k_row + pc * 8 : kp;
-      kr[i] = ld16(src);
-      kmask |= ok ? (1u << i) : 0u;
-    }
+      for (int i = 0; i < KP; ++i) kr[i] = __builtin_amdgcn_raw_buffer_load_b128(rk, koff[i] + ku, 0, 0);
 #pragma unroll
-    for (int i = 0; i < VP; ++i) {
-      const int p = tid + 256 * i;
-      const int row = p >> 3, pc = p & 7;
-      if (VVEC) {
-        const bool ok = row < dh && key0 + pc * 8 < a.tk;       // tk % 8 == 0: a piece is all-in or all-out
-        const T* src = ok ? vp + (long long)row * a.vt_row + key0 + pc * 8 : vp;
-        vr[i] = ld16(src);
-        vmask |= ok ? (1u << i) : 0u;
-        if (ONES && row == dh && key0 + pc * 8 < a.tk) {         // the row-sum row (see below)
-          typename Vec8<T>::type e;
+      for (int i = 0; i < VP; ++i) vr[i] = __builtin_amdgcn_raw_buffer_load_b128(rv, voff[i] + vu, 0, 0);
+      if (key0 + 64 > a.tk) {             // ragged last tile: keys >= tk of a V^T row alias the next row -> zero them
 #pragma unroll
-          for (int j = 0; j < 8; ++j) e[j] = (T)1.0f;
-          vr[i] = __builtin_bit_cast(u32x4, e);
-          vmask |= 1u << i;
+        for (int i = 0; i < VP; ++i) {
+          const int pc = (tid + 256 * i) & 7;
+          if (key0 + pc * 8 >= a.tk) vr[i] = u32x4{0u, 0u, 0u, 0u};
         }
-      } else {
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < KP; ++i) {
+        const int p = tid + 256 * i;
+        const int row = p / (KS * 2), pc = p - row * (KS * 2);
+        const bool ok = row < 64 && key0 + row < a.tk && pc * 8 < dh;
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (ok) v = ld16(kp + (long long)(key0 + row) * a.k_row + pc * 8);
+        kr[i] = v;
+      }
+#pragma unroll
+      for (int i = 0; i < VP; ++i) {
+        const int p = tid + 256 * i;
+        const int row = p >> 3, pc = p & 7;
         typename Vec8<T>::type e;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           const bool ok = row < dh && key0 + pc * 8 + j < a.tk;
           e[j] = ok ? vp[(long long)row * a.vt_row + key0 + pc * 8 + j] : (T)0.0f;
-          if (ONES && row == dh && key0 + pc * 8 + j < a.tk) e[j] = (T)1.0f;
         }
         vr[i] = __builtin_bit_cast(u32x4, e);
-        vmask |= 1u << i;
       }
     }
   };
   auto store_tile = [&]() {
-    const u32x4 zero = {0u, 0u, 0u, 0u};
+    typename Vec8<T>::type one8;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) one8[j] = (T)1.0f;
+    const u32x4 ones = __builtin_bit_cast(u32x4, one8);
 #pragma unroll
     for (int i = 0; i < KP; ++i) {
       const int p = tid + 256 * i;
       const int row = p / (KS * 2), pc = p - row * (KS * 2);
-      if (row < 64) st16(ldsK + row * KSTR + pc * 16, (kmask >> i) & 1u ? kr[i] : zero);
+      if (row < 64) st16(ldsK + row * KSTR + pc * 16, kr[i]);
     }
 #pragma unroll
     for (int i = 0; i < VP; ++i) {
       const int p = tid + 256 * i;
       const int row = p >> 3, pc = p & 7;
       if (row < DT * 32) {
-        const u32x4 v = (vmask >> i) & 1u ? vr[i] : zero;
+        // the ones row may also cover keys >= tk: their P is exactly 0, so the denominator is unaffected
+        const u32x4 v = (ones_m >> i) & 1u ? ones : vr[i];
         unsigned char* d = ldsV + row * VSTR + (pc >> 1) * 32 + (pc & 1) * 8;
         *reinterpret_cast<u32x2*>(d) = u32x2{v[0], v[1]};             // keys 8a + (0..3)     -> pos 4a + ..
         *reinterpret_cast<u32x2*>(d + 16) = u32x2{v[2], v[3]};        // keys 8a + 4 + (0..3) -> pos 8 + 4a + ..
