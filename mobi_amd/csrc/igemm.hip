@@ -48,7 +48,7 @@ struct IgemmArgs {
   int out_mode, epilogue;
   float scale;
   int tiles_m, tiles_n;
-  int src0_bytes, src1_bytes, w_bytes, fast;   // buffer extents for the FAST path's descriptors
+  int src0_bytes, src1_bytes, w_bytes, fast, glds;   // buffer extents for the FAST path's descriptors
   int wm;                  // waves along the pixel axis (2 or 4): block tile = 64*wm pixels
   int splits, nk_per;      // split-K: blockIdx.y owns k-tiles [y*nk_per, (y+1)*nk_per)
   float* split_ws;         // f32 [splits][M][n_packed] partial sums (NULL: single pass)
@@ -58,6 +58,164 @@ struct IgemmArgs {
 __device__ __forceinline__ void ld8f(const float* p, float (&f)[8]) {
   const f32x4 a = *reinterpret_cast<const f32x4*>(p), b = *reinterpret_cast<const f32x4*>(p + 4);
   f[0] = a[0]; f[1] = a[1]; f[2] = a[2]; f[3] = a[3]; f[4] = b[0]; f[5] = b[1]; f[6] = b[2]; f[7] = b[3];
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Epilogue shared by both main-loop variants: accumulators -> per-wave fp32 LDS tile -> coalesced 16-byte rows
+// with scale / bias / per-image vector / residual / GEGLU, fp32 or transposed output, split-K partial slabs.
+// `stage` is this wave's private LDS area (the caller guarantees every wave is past its last fragment read).
+// ---------------------------------------------------------------------------------------------------------
+template <typename T, int NT, bool TR>
+__device__ __forceinline__ void igemm_epilogue(const IgemmArgs& a, float* stage, f32x4 (&acc)[NT][4], int lane,
+                                               int group, int nw0, int mw0) {
+  constexpr int WAVE_N = NT * 16;
+  constexpr int STAGE_STRIDE = TR ? 36 : (WAVE_N + 4);      // floats
+  const int r16 = lane & 15, g4 = lane >> 4;
+  const float scale = a.scale;
+  T* __restrict__ outT = reinterpret_cast<T*>(a.out);
+  float* __restrict__ outF = reinterpret_cast<float*>(a.out);
+  const T* __restrict__ resid = reinterpret_cast<const T*>(a.residual);
+
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {
+    // (the main loop's last barrier already ordered every wave's fragment reads
+    //  before these writes; passes of one wave are ordered by the waits below)
+    if (!TR) {
+      // D rows = channel (g4*4 + r), cols = pixel (r16): lane owns 4 consecutive channels
+#pragma unroll
+      for (int ml = 0; ml < 2; ++ml)
+#pragma unroll
+        for (int ni = 0; ni < NT; ++ni) {
+          f32x4 v = acc[ni][pass * 2 + ml];
+          v *= scale;
+          *reinterpret_cast<f32x4*>(stage + (ml * 16 + r16) * STAGE_STRIDE + ni * 16 + g4 * 4) = v;
+        }
+    } else {
+      // D rows = pixel (g4*4 + r), cols = channel (r16): lane owns 4 consecutive pixels
+#pragma unroll
+      for (int ml = 0; ml < 2; ++ml)
+#pragma unroll
+        for (int ni = 0; ni < NT; ++ni) {
+          f32x4 v = acc[ni][pass * 2 + ml];
+          v *= scale;
+          *reinterpret_cast<f32x4*>(stage + (ni * 16 + r16) * STAGE_STRIDE + ml * 16 + g4 * 4) = v;
+        }
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);      // lgkmcnt(0): this wave's LDS writes are done
+    __builtin_amdgcn_wave_barrier();
+
+    const int mp0 = mw0 + pass * 32;         // first row of this pass
+    if (!TR) {
+      if (a.split_ws) {
+        // split-K: raw fp32 partial sums, finished by igemm_splitk_reduce_kernel
+        constexpr int TPR = WAVE_N / 8;
+        float* __restrict__ wsp = a.split_ws + (long long)blockIdx.y * a.M * a.n_packed;
+        for (int task = lane; task < 32 * TPR; task += 64) {
+          const int row = task / TPR, cg = task - row * TPR;
+          const int m = mp0 + row;
+          const int n = nw0 + cg * 8;
+          if (m >= a.M || n >= a.n_packed) continue;
+          const float* sp = stage + row * STAGE_STRIDE + cg * 8;
+          float* d = wsp + (long long)m * a.n_packed + n;
+          *reinterpret_cast<f32x4*>(d) = *reinterpret_cast<const f32x4*>(sp);
+          *reinterpret_cast<f32x4*>(d + 4) = *reinterpret_cast<const f32x4*>(sp + 4);
+        }
+      } else if (a.epilogue == MOBI_EPI_GEGLU) {
+        constexpr int HALF = WAVE_N / 2;     // a | gate split of the wave's packed columns
+        constexpr int TPR = HALF / 8;
+        const int unit = nw0 / WAVE_N;
+        for (int task = lane; task < 32 * TPR; task += 64) {
+          const int row = task / TPR, cg = task - row * TPR;
+          const int m = mp0 + row;
+          const int oc = unit * HALF + cg * 8;
+          if (m >= a.M || oc >= a.cout) continue;
+          const float* sp = stage + row * STAGE_STRIDE + cg * 8;
+          float av[8], gv[8], o[8];
+          ld8f(sp, av);
+          ld8f(sp + HALF, gv);
+          if (a.bias) {
+            float ba[8], bg[8];
+            ld8f(a.bias + nw0 + cg * 8, ba);
+            ld8f(a.bias + nw0 + HALF + cg * 8, bg);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { av[j] += ba[j]; gv[j] += bg[j]; }
+          }
+#pragma unroll
+          for (int j = 0; j < 8; ++j) o[j] = av[j] * gelu_erf_f(gv[j]);
+          const int img = m / a.hw_out, rem = m - img * a.hw_out;
+          const long long gi = (long long)(group * a.imgs_per_group + img);
+          st16(outT + gi * a.out_img_stride + (long long)rem * a.cout + oc, pack8<T>(o));
+        }
+      } else {
+        constexpr int TPR = WAVE_N / 8;
+        for (int task = lane; task < 32 * TPR; task += 64) {
+          const int row = task / TPR, cg = task - row * TPR;
+          const int m = mp0 + row;
+          const int n = nw0 + cg * 8;
+          if (m >= a.M || n >= a.cout) continue;
+          const float* sp = stage + row * STAGE_STRIDE + cg * 8;
+          float o[8];
+          ld8f(sp, o);
+          const int img = m / a.hw_out, rem = m - img * a.hw_out;
+          const long long gi = (long long)(group * a.imgs_per_group + img);
+          if (a.bias) {
+            float bb[8];
+            ld8f(a.bias + n, bb);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] += bb[j];
+          }
+          if (a.rowvec) {
+            float rv[8];
+            ld8f(a.rowvec + gi * a.rowvec_stride + n, rv);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] += rv[j];
+          }
+          if (resid) {
+            float rf[8];
+            unpack8<T>(ld16(resid + gi * a.res_img_stride + (long long)rem * a.cout + n), rf);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] += rf[j];
+          }
+          const long long off = gi * a.out_img_stride + (long long)rem * a.cout + n;
+          if (a.out_mode == MOBI_OUT_ROWS_F32) {
+            *reinterpret_cast<f32x4*>(outF + off) = f32x4{o[0], o[1], o[2], o[3]};
+            *reinterpret_cast<f32x4*>(outF + off + 4) = f32x4{o[4], o[5], o[6], o[7]};
+          } else {
+            st16(outT + off, pack8<T>(o));
+          }
+        }
+      }
+    } else {
+      // transposed output [image][cout][hw]
+      const bool vec_ok = (a.hw_out & 7) == 0;
+      for (int task = lane; task < WAVE_N * 4; task += 64) {
+        const int crow = task >> 2, pg = task & 3;
+        const int n = nw0 + crow;
+        const int m = mp0 + pg * 8;
+        if (n >= a.cout || m >= a.M) continue;
+        const float* sp = stage + crow * STAGE_STRIDE + pg * 8;
+        float o[8];
+        const float bv = a.bias ? a.bias[n] : 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = sp[j] + bv;
+        if (vec_ok) {
+          const int img = m / a.hw_out, rem = m - img * a.hw_out;
+          const long long gi = (long long)(group * a.imgs_per_group + img);
+          st16(outT + gi * a.out_img_stride + (long long)n * a.hw_out + rem, pack8<T>(o));
+        } else {
+          for (int j = 0; j < 8; ++j) {
+            const int mj = m + j;
+            if (mj >= a.M) break;
+            const int img = mj / a.hw_out, rem = mj - img * a.hw_out;
+            const long long gi = (long long)(group * a.imgs_per_group + img);
+            outT[gi * a.out_img_stride + (long long)n * a.hw_out + rem] = from_f32<T>(o[j]);
+          }
+        }
+      }
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+  }
 }
 
 // WM = waves along the pixel axis: 2 -> 128-pixel tile, 4 waves, two blocks per CU;
@@ -321,153 +479,161 @@ __global__ __launch_bounds__(128 * WM, 2) void igemm_kernel(const IgemmArgs a) {
 
   // ---- epilogue -----------------------------------------------------------
   float* stage = reinterpret_cast<float*>(lds) + wave * (STAGE_BYTES / 4);
-  const float scale = a.scale;
-  const int nw0 = n0 + wn * WAVE_N;          // first packed column of this wave
-  const int mw0 = m0 + wm * 64;              // first row of this wave
-  T* __restrict__ outT = reinterpret_cast<T*>(a.out);
-  float* __restrict__ outF = reinterpret_cast<float*>(a.out);
-  const T* __restrict__ resid = reinterpret_cast<const T*>(a.residual);
+  igemm_epilogue<T, NT, TR>(a, stage, acc, lane, group, n0 + wn * WAVE_N, m0 + wm * 64);
+}
 
-#pragma unroll
-  for (int pass = 0; pass < 2; ++pass) {
-    // (the main loop's last barrier already ordered every wave's fragment reads
-    //  before these writes; passes of one wave are ordered by the waits below)
-    if (!TR) {
-      // D rows = channel (g4*4 + r), cols = pixel (r16): lane owns 4 consecutive channels
-#pragma unroll
-      for (int ml = 0; ml < 2; ++ml)
-#pragma unroll
-        for (int ni = 0; ni < NT; ++ni) {
-          f32x4 v = acc[ni][pass * 2 + ml];
-          v *= scale;
-          *reinterpret_cast<f32x4*>(stage + (ml * 16 + r16) * STAGE_STRIDE + ni * 16 + g4 * 4) = v;
-        }
-    } else {
-      // D rows = pixel (g4*4 + r), cols = channel (r16): lane owns 4 consecutive pixels
-#pragma unroll
-      for (int ml = 0; ml < 2; ++ml)
-#pragma unroll
-        for (int ni = 0; ni < NT; ++ni) {
-          f32x4 v = acc[ni][pass * 2 + ml];
-          v *= scale;
-          *reinterpret_cast<f32x4*>(stage + (ni * 16 + r16) * STAGE_STRIDE + ml * 16 + g4 * 4) = v;
-        }
-    }
-    __builtin_amdgcn_s_waitcnt(0xc07f);      // lgkmcnt(0): this wave's LDS writes are done
-    __builtin_amdgcn_wave_barrier();
+// =========================================================================================================
+// Direct-to-LDS main loop (FAST shapes only):  256 pixels x (2 * WAVE_N) channels, 8 waves (4 x 2), THREE LDS
+// stages filled by global_load_lds_dwordx4 (no VGPR staging, no ds_write), one raw s_barrier per k-tile and a
+// COUNTED s_waitcnt vmcnt: the tile being multiplied is complete while the next tile's DMA stays in flight.
+//   iteration t:  wait(tile t landed) ; barrier ; issue DMA of tile t+2 into stage (t+2)%3 ; multiply stage t%3
+// The barrier also proves every wave finished reading stage (t-1)%3 == (t+2)%3 before it is overwritten.
+// LDS image = [row][8 x 16 B], lane-linear per wave instruction (8 rows = 1 KiB); the XOR swizzle is applied on
+// the SOURCE side: the lane that fills slot s of row r fetches piece s ^ (r & 7).  Padded / out-of-range pieces
+// are fetched from the 16-byte zero block.
+// =========================================================================================================
+template <typename T, int NT, bool TR>
+__global__ __launch_bounds__(512, 2) void igemm_glds_kernel(const IgemmArgs a) {
+  typedef typename Vec8<T>::type frag_t;
+  constexpr int BM = 256;
+  constexpr int WAVE_N = NT * 16;
+  constexpr int BN = 2 * WAVE_N;
+  constexpr int X_TILE = BM * 128, W_TILE = BN * 128;
+  constexpr int STAGE = X_TILE + W_TILE;
+  constexpr int WJ = (BN + 63) / 64;                         // weight DMA instructions per thread and tile
+  constexpr int PIECES = 4 + WJ;                             // DMA instructions per thread and tile
+  constexpr int STAGE_STRIDE = TR ? 36 : (WAVE_N + 4);
+  constexpr int STAGE_ROWS = TR ? WAVE_N : 32;
+  constexpr int EPI_BYTES = 8 * STAGE_ROWS * STAGE_STRIDE * 4;
+  constexpr int LDS_BYTES = 3 * STAGE > EPI_BYTES ? 3 * STAGE : EPI_BYTES;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
+  typedef __attribute__((address_space(3))) void* lds_ptr_t;
+  typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
 
-    const int mp0 = mw0 + pass * 32;         // first row of this pass
-    if (!TR) {
-      if (a.split_ws) {
-        // split-K: raw fp32 partial sums, finished by igemm_splitk_reduce_kernel
-        constexpr int TPR = WAVE_N / 8;
-        float* __restrict__ wsp = a.split_ws + (long long)blockIdx.y * a.M * a.n_packed;
-        for (int task = lane; task < 32 * TPR; task += 64) {
-          const int row = task / TPR, cg = task - row * TPR;
-          const int m = mp0 + row;
-          const int n = nw0 + cg * 8;
-          if (m >= a.M || n >= a.n_packed) continue;
-          const float* sp = stage + row * STAGE_STRIDE + cg * 8;
-          float* d = wsp + (long long)m * a.n_packed + n;
-          *reinterpret_cast<f32x4*>(d) = *reinterpret_cast<const f32x4*>(sp);
-          *reinterpret_cast<f32x4*>(d + 4) = *reinterpret_cast<const f32x4*>(sp + 4);
-        }
-      } else if (a.epilogue == MOBI_EPI_GEGLU) {
-        constexpr int HALF = WAVE_N / 2;     // a | gate split of the wave's packed columns
-        constexpr int TPR = HALF / 8;
-        const int unit = nw0 / WAVE_N;
-        for (int task = lane; task < 32 * TPR; task += 64) {
-          const int row = task / TPR, cg = task - row * TPR;
-          const int m = mp0 + row;
-          const int oc = unit * HALF + cg * 8;
-          if (m >= a.M || oc >= a.cout) continue;
-          const float* sp = stage + row * STAGE_STRIDE + cg * 8;
-          float av[8], gv[8], o[8];
-          ld8f(sp, av);
-          ld8f(sp + HALF, gv);
-          if (a.bias) {
-            float ba[8], bg[8];
-            ld8f(a.bias + nw0 + cg * 8, ba);
-            ld8f(a.bias + nw0 + HALF + cg * 8, bg);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave & 3, wn = wave >> 2;
+  const int group = blockIdx.z;
+  const int nblk = a.tiles_m * a.tiles_n;
+  const int L = xcd_remap(blockIdx.x, nblk);
+  const int tile_n = L % a.tiles_n, tile_m = L / a.tiles_n;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const T* __restrict__ wgt = reinterpret_cast<const T*>(a.weight) + (long long)group * a.w_group_stride;
+  const unsigned char* const zsrc = reinterpret_cast<const unsigned char*>(g_zero16);
+
+  const int rloc = lane >> 3;                                // row inside the wave's 8-row DMA piece
+  const int sg = (lane & 7) ^ rloc;                          // source piece that lands in this lane's slot
+  // activation rows of this thread: row_j = 8 * wave + rloc + 64 j
+  int x_gp[4], x_h[4], x_w[4];
+  unsigned x_okm = 0;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) { av[j] += ba[j]; gv[j] += bg[j]; }
-          }
-#pragma unroll
-          for (int j = 0; j < 8; ++j) o[j] = av[j] * gelu_erf_f(gv[j]);
-          const int img = m / a.hw_out, rem = m - img * a.hw_out;
-          const long long gi = (long long)(group * a.imgs_per_group + img);
-          st16(outT + gi * a.out_img_stride + (long long)rem * a.cout + oc, pack8<T>(o));
-        }
-      } else {
-        constexpr int TPR = WAVE_N / 8;
-        for (int task = lane; task < 32 * TPR; task += 64) {
-          const int row = task / TPR, cg = task - row * TPR;
-          const int m = mp0 + row;
-          const int n = nw0 + cg * 8;
-          if (m >= a.M || n >= a.cout) continue;
-          const float* sp = stage + row * STAGE_STRIDE + cg * 8;
-          float o[8];
-          ld8f(sp, o);
-          const int img = m / a.hw_out, rem = m - img * a.hw_out;
-          const long long gi = (long long)(group * a.imgs_per_group + img);
-          if (a.bias) {
-            float bb[8];
-            ld8f(a.bias + n, bb);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) o[j] += bb[j];
-          }
-          if (a.rowvec) {
-            float rv[8];
-            ld8f(a.rowvec + gi * a.rowvec_stride + n, rv);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) o[j] += rv[j];
-          }
-          if (resid) {
-            float rf[8];
-            unpack8<T>(ld16(resid + gi * a.res_img_stride + (long long)rem * a.cout + n), rf);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) o[j] += rf[j];
-          }
-          const long long off = gi * a.out_img_stride + (long long)rem * a.cout + n;
-          if (a.out_mode == MOBI_OUT_ROWS_F32) {
-            *reinterpret_cast<f32x4*>(outF + off) = f32x4{o[0], o[1], o[2], o[3]};
-            *reinterpret_cast<f32x4*>(outF + off + 4) = f32x4{o[4], o[5], o[6], o[7]};
-          } else {
-            st16(outT + off, pack8<T>(o));
-          }
-        }
-      }
-    } else {
-      // transposed output [image][cout][hw]
-      const bool vec_ok = (a.hw_out & 7) == 0;
-      for (int task = lane; task < WAVE_N * 4; task += 64) {
-        const int crow = task >> 2, pg = task & 3;
-        const int n = nw0 + crow;
-        const int m = mp0 + pg * 8;
-        if (n >= a.cout || m >= a.M) continue;
-        const float* sp = stage + crow * STAGE_STRIDE + pg * 8;
-        float o[8];
-        const float bv = a.bias ? a.bias[n] : 0.f;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) o[j] = sp[j] + bv;
-        if (vec_ok) {
-          const int img = m / a.hw_out, rem = m - img * a.hw_out;
-          const long long gi = (long long)(group * a.imgs_per_group + img);
-          st16(outT + gi * a.out_img_stride + (long long)n * a.hw_out + rem, pack8<T>(o));
-        } else {
-          for (int j = 0; j < 8; ++j) {
-            const int mj = m + j;
-            if (mj >= a.M) break;
-            const int img = mj / a.hw_out, rem = mj - img * a.hw_out;
-            const long long gi = (long long)(group * a.imgs_per_group + img);
-            outT[gi * a.out_img_stride + (long long)n * a.hw_out + rem] = from_f32<T>(o[j]);
-          }
-        }
-      }
-    }
-    __builtin_amdgcn_s_waitcnt(0xc07f);
-    __builtin_amdgcn_wave_barrier();
+  for (int j = 0; j < 4; ++j) {
+    const int m = m0 + 8 * wave + rloc + 64 * j;
+    const bool ok = m < a.M;
+    x_okm |= ok ? (1u << j) : 0u;
+    const int mm = ok ? m : 0;
+    const int img = mm / a.hw_out, rem = mm - img * a.hw_out;
+    const int ho = rem / a.wout, wo = rem - ho * a.wout;
+    x_gp[j] = (group * a.imgs_per_group + img) * a.img_pix_stride;
+    x_h[j] = ho * a.stride - a.pad_h;
+    x_w[j] = wo * a.stride - a.pad_w;
   }
+  // weight rows: j < WJ-1 (or all, when BN % 64 == 0): 8 * wave + rloc + 64 j; the last partial group of 32 rows is
+  // fetched by waves 0-3 and (identically, benign duplicate) by waves 4-7 so that every wave issues PIECES DMAs
+  const unsigned char* w_src[WJ];
+  int w_lds[WJ];
+#pragma unroll
+  for (int j = 0; j < WJ; ++j) {
+    const bool partial = (BN % 64 != 0) && (j == WJ - 1);
+    const int r = partial ? 64 * j + 8 * (wave & 3) + rloc : 64 * j + 8 * wave + rloc;
+    const int n = n0 + r;
+    w_lds[j] = (partial ? 64 * j + 8 * (wave & 3) : 64 * j + 8 * wave) * 128;
+    w_src[j] = n < a.n_packed ? reinterpret_cast<const unsigned char*>(wgt + (long long)n * a.ktot) + sg * 16 : nullptr;
+  }
+  const int kt_begin = blockIdx.y * a.nk_per;
+  const int kt_end = min(a.nk, kt_begin + a.nk_per);
+  const int hlog = a.hin << a.up, wlog = a.win << a.up;
+  // wave-uniform tile state
+  int u_tap, u_ky, u_kx, u_c;
+  {
+    const long long c_first = (long long)kt_begin * 64;
+    u_tap = (int)(c_first / a.C); u_c = (int)(c_first - (long long)u_tap * a.C);
+    u_ky = u_tap / a.kw; u_kx = u_tap - u_ky * a.kw;
+  }
+  unsigned f_row[4] = {0u, 0u, 0u, 0u};
+  unsigned f_okm = 0;
+  int f_tap = -1, f_src = -1;
+
+  auto issue_tile = [&](int kt) {                            // kt < kt_end guaranteed by the caller
+    unsigned char* st = lds + ((kt - kt_begin) % 3) * STAGE;
+    const int src = u_c >= a.c0 ? 1 : 0;
+    if (u_tap != f_tap || src != f_src) {
+      f_tap = u_tap; f_src = src; f_okm = 0;
+      const unsigned cs2 = (unsigned)(src ? a.c1 : a.c0) * 2u;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int hi = x_h[j] + u_ky, wi = x_w[j] + u_kx;
+        const bool ok = ((x_okm >> j) & 1u) && hi >= 0 && hi < hlog && wi >= 0 && wi < wlog;
+        f_okm |= ok ? (1u << j) : 0u;
+        f_row[j] = (unsigned)(x_gp[j] + (hi >> a.up) * a.win + (wi >> a.up)) * cs2 + (unsigned)sg * 16u;
+      }
+    }
+    const unsigned char* xbase = reinterpret_cast<const unsigned char*>(src ? a.src1 : a.src0) +
+                                 (unsigned)(src ? u_c - a.c0 : u_c) * 2u;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const unsigned char* g = ((f_okm >> j) & 1u) ? xbase + f_row[j] : zsrc;
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)g, (lds_ptr_t)(st + (8 * wave + 64 * j) * 128), 16, 0, 0);
+    }
+    const unsigned kb = (unsigned)kt * 128u;
+#pragma unroll
+    for (int j = 0; j < WJ; ++j) {
+      const unsigned char* g = w_src[j] ? w_src[j] + kb : zsrc;
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)g, (lds_ptr_t)(st + X_TILE + w_lds[j]), 16, 0, 0);
+    }
+    u_c += 64;
+    if (u_c >= a.C) { u_c = 0; ++u_tap; if (++u_kx == a.kw) { u_kx = 0; ++u_ky; } }
+  };
+
+  f32x4 acc[NT][4];
+#pragma unroll
+  for (int i = 0; i < NT; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int r16 = lane & 15, g4 = lane >> 4;
+
+  if (kt_begin < kt_end) issue_tile(kt_begin);
+  if (kt_begin + 1 < kt_end) issue_tile(kt_begin + 1);
+  for (int kt = kt_begin; kt < kt_end; ++kt) {
+    // tile kt has landed once at most ONE younger tile's DMAs (PIECES per thread) are still outstanding
+    if (kt + 1 < kt_end) {
+      if constexpr (PIECES == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    if (kt + 2 < kt_end) issue_tile(kt + 2);
+    const unsigned char* st = lds + ((kt - kt_begin) % 3) * STAGE;
+    const unsigned char* xb = st + (wm * 64 + r16) * 128;
+    const unsigned char* wb = st + X_TILE + (wn * WAVE_N + r16) * 128;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int sw = ((ks * 4 + g4) ^ (r16 & 7)) << 4;
+      frag_t xf[4], wf[NT];
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi) xf[mi] = __builtin_bit_cast(frag_t, ld16(xb + mi * 16 * 128 + sw));
+#pragma unroll
+      for (int ni = 0; ni < NT; ++ni) wf[ni] = __builtin_bit_cast(frag_t, ld16(wb + ni * 16 * 128 + sw));
+#pragma unroll
+      for (int ni = 0; ni < NT; ++ni)
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+          acc[ni][mi] = TR ? mfma16(xf[mi], wf[ni], acc[ni][mi]) : mfma16(wf[ni], xf[mi], acc[ni][mi]);
+    }
+  }
+  __syncthreads();                                           // every wave is past its last fragment read
+  float* stage = reinterpret_cast<float*>(lds) + wave * (STAGE_ROWS * STAGE_STRIDE);
+  igemm_epilogue<T, NT, TR>(a, stage, acc, lane, group, n0 + wn * WAVE_N, m0 + wm * 64);
 }
 
 // split-K finish: sum the partial slabs, then the ordinary epilogue (bias, per-image vector, residual)
@@ -530,8 +696,15 @@ static int launch_igemm(const mobi_igemm_params* p, const IgemmArgs& a, int grou
   do { if (a.fast) MOBI_IGEMM_LAUNCH(NT_, TR_, WM_, true); else MOBI_IGEMM_LAUNCH(NT_, TR_, WM_, false); } while (0)
 #define MOBI_IGEMM_BY_TR(NT_, WM_) \
   do { if (tr) MOBI_IGEMM_BY_FAST(NT_, true, WM_); else MOBI_IGEMM_BY_FAST(NT_, false, WM_); } while (0)
-  if (a.wm == 4) { if (nt5) MOBI_IGEMM_BY_TR(5, 4); else MOBI_IGEMM_BY_TR(4, 4); }
-  else           { if (nt5) MOBI_IGEMM_BY_TR(5, 2); else MOBI_IGEMM_BY_TR(4, 2); }
+  if (a.wm == 4 && a.fast && a.glds) {
+    dim3 block(512);
+    if (nt5) { if (tr) hipLaunchKernelGGL((igemm_glds_kernel<T, 5, true>), grid, block, 0, st, a);
+               else    hipLaunchKernelGGL((igemm_glds_kernel<T, 5, false>), grid, block, 0, st, a); }
+    else     { if (tr) hipLaunchKernelGGL((igemm_glds_kernel<T, 4, true>), grid, block, 0, st, a);
+               else    hipLaunchKernelGGL((igemm_glds_kernel<T, 4, false>), grid, block, 0, st, a); }
+  }
+  else if (a.wm == 4) { if (nt5) MOBI_IGEMM_BY_TR(5, 4); else MOBI_IGEMM_BY_TR(4, 4); }
+  else                { if (nt5) MOBI_IGEMM_BY_TR(5, 2); else MOBI_IGEMM_BY_TR(4, 2); }
 #undef MOBI_IGEMM_BY_TR
 #undef MOBI_IGEMM_BY_FAST
 #undef MOBI_IGEMM_LAUNCH
@@ -631,6 +804,8 @@ extern "C" int mobi_igemm(const mobi_igemm_params* p, void* stream) {
     a.fast = (a.C % 64 == 0) && (p->c1 == 0 || p->c0 % 64 == 0) && ext0 < 0x7fffffffLL && ext1 < 0x7fffffffLL &&
              wext < 0x7fffffffLL;
     if (const char* e = getenv("MOBI_IGEMM_FAST")) a.fast = a.fast && e[0] != '0';
+    a.glds = 1;
+    if (const char* e = getenv("MOBI_IGEMM_GLDS")) a.glds = e[0] != '0';
     a.src0_bytes = (int)(ext0 < 0x7fffffffLL ? ext0 : 0);
     a.src1_bytes = (int)(ext1 < 0x7fffffffLL ? ext1 : 0);
     a.w_bytes = (int)(wext < 0x7fffffffLL ? wext : 0);
