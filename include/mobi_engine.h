@@ -98,6 +98,10 @@ typedef struct mobi_igemm_params {
                             sums them and applies the epilogue.  Not with GEGLU / transposed /
                             per-image weights.                                              */
   void* ws;              /* mobi_igemm_workspace_bytes(p, split_k) bytes, 16-byte aligned  */
+  int32_t k_order;       /* layout of W's k axis.  0: k = tap*C + c.  1: k = (c/64)*taps*64 + tap*64
+                            + c%64 -- the taps of one 64-channel slice are consecutive k-tiles, so the
+                            9 reads of a 3x3 window's pixels hit L2 instead of being re-fetched per
+                            tap.  Needs C % 64 == 0 (and c0 % 64 == 0 with two sources).        */
 } mobi_igemm_params;
 
 int mobi_igemm(const mobi_igemm_params* p, void* stream);

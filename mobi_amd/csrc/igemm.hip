@@ -48,7 +48,8 @@ struct IgemmArgs {
   int out_mode, epilogue;
   float scale;
   int tiles_m, tiles_n;
-  int src0_bytes, src1_bytes, w_bytes, fast, glds;   // buffer extents for the FAST path's descriptors
+  int src0_bytes, src1_bytes, w_bytes, fast, glds;
+  int k_order;             // 0: k = tap*C + c;  1: k = (c/64)*taps*64 + tap*64 + c%64 (FAST shapes only)   // buffer extents for the FAST path's descriptors
   int wm;                  // waves along the pixel axis (2 or 4): block tile = 64*wm pixels
   int splits, nk_per;      // split-K: blockIdx.y owns k-tiles [y*nk_per, (y+1)*nk_per)
   float* split_ws;         // f32 [splits][M][n_packed] partial sums (NULL: single pass)
@@ -326,7 +327,13 @@ __global__ __launch_bounds__(128 * WM, 2) void igemm_kernel(const IgemmArgs a) {
   int f_tap = -1, f_src = -1;
   if constexpr (FAST) {
     const long long c_first = (long long)kt_begin * 64;
-    u_tap = (int)(c_first / a.C); u_c = (int)(c_first - (long long)u_tap * a.C);
+    if (a.k_order) {                       // channel-chunk-major k: tile = (64-channel chunk, tap), taps innermost
+      const int taps_ = a.kh * a.kw;
+      const int cc = kt_begin / taps_;
+      u_tap = kt_begin - cc * taps_; u_c = cc * 64;
+    } else {                               // tap-major k: tile = (tap, 64-channel chunk)
+      u_tap = (int)(c_first / a.C); u_c = (int)(c_first - (long long)u_tap * a.C);
+    }
     u_ky = u_tap / a.kw; u_kx = u_tap - u_ky * a.kw;
 #pragma unroll
     for (int i = 0; i < WP; ++i) {
@@ -362,8 +369,13 @@ __global__ __launch_bounds__(128 * WM, 2) void igemm_kernel(const IgemmArgs a) {
     const unsigned kb = (unsigned)kt * 128u;
 #pragma unroll
     for (int i = 0; i < WP; ++i) wr[i] = __builtin_amdgcn_raw_buffer_load_b128(rw, f_w[i] + kb, 0, 0);
-    u_c += 64;
-    if (u_c >= a.C) { u_c = 0; ++u_tap; if (++u_kx == a.kw) { u_kx = 0; ++u_ky; } }
+    if (a.k_order) {
+      ++u_tap;
+      if (++u_kx == a.kw) { u_kx = 0; if (++u_ky == a.kh) { u_ky = 0; u_tap = 0; u_c += 64; } }
+    } else {
+      u_c += 64;
+      if (u_c >= a.C) { u_c = 0; ++u_tap; if (++u_kx == a.kw) { u_kx = 0; ++u_ky; } }
+    }
   };
 
   auto load_tile_generic = [&](int kt, u32x4 (&xr)[4], u32x4 (&wr)[WP], unsigned& okm) {
@@ -556,7 +568,13 @@ __global__ __launch_bounds__(512, 2) void igemm_glds_kernel(const IgemmArgs a) {
   int u_tap, u_ky, u_kx, u_c;
   {
     const long long c_first = (long long)kt_begin * 64;
-    u_tap = (int)(c_first / a.C); u_c = (int)(c_first - (long long)u_tap * a.C);
+    if (a.k_order) {                       // channel-chunk-major k: tile = (64-channel chunk, tap), taps innermost
+      const int taps_ = a.kh * a.kw;
+      const int cc = kt_begin / taps_;
+      u_tap = kt_begin - cc * taps_; u_c = cc * 64;
+    } else {                               // tap-major k: tile = (tap, 64-channel chunk)
+      u_tap = (int)(c_first / a.C); u_c = (int)(c_first - (long long)u_tap * a.C);
+    }
     u_ky = u_tap / a.kw; u_kx = u_tap - u_ky * a.kw;
   }
   unsigned f_row[4] = {0u, 0u, 0u, 0u};
@@ -590,8 +608,13 @@ __global__ __launch_bounds__(512, 2) void igemm_glds_kernel(const IgemmArgs a) {
       const unsigned char* g = w_src[j] ? w_src[j] + kb : zsrc;
       __builtin_amdgcn_global_load_lds((gbl_ptr_t)g, (lds_ptr_t)(st + X_TILE + w_lds[j]), 16, 0, 0);
     }
-    u_c += 64;
-    if (u_c >= a.C) { u_c = 0; ++u_tap; if (++u_kx == a.kw) { u_kx = 0; ++u_ky; } }
+    if (a.k_order) {
+      ++u_tap;
+      if (++u_kx == a.kw) { u_kx = 0; if (++u_ky == a.kh) { u_ky = 0; u_tap = 0; u_c += 64; } }
+    } else {
+      u_c += 64;
+      if (u_c >= a.C) { u_c = 0; ++u_tap; if (++u_kx == a.kw) { u_kx = 0; ++u_ky; } }
+    }
   };
 
   f32x4 acc[NT][4];
@@ -804,6 +827,9 @@ extern "C" int mobi_igemm(const mobi_igemm_params* p, void* stream) {
     a.fast = (a.C % 64 == 0) && (p->c1 == 0 || p->c0 % 64 == 0) && ext0 < 0x7fffffffLL && ext1 < 0x7fffffffLL &&
              wext < 0x7fffffffLL;
     if (const char* e = getenv("MOBI_IGEMM_FAST")) a.fast = a.fast && e[0] != '0';
+    a.k_order = p->k_order;
+    if (p->k_order != 0 && p->k_order != 1) return MOBI_ERR_ARG;
+    if (p->k_order == 1 && !a.fast) return MOBI_ERR_UNSUPPORTED;      // the generic gather walks k tap-major only
     a.glds = 1;
     if (const char* e = getenv("MOBI_IGEMM_GLDS")) a.glds = e[0] != '0';
     a.src0_bytes = (int)(ext0 < 0x7fffffffLL ? ext0 : 0);

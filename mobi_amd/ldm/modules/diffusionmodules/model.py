@@ -158,7 +158,7 @@ class Encoder(nn.Module):
                 h = self.down[i_level].downsample(h)
         h = self.mid.block_2(self.mid.attn_1(self.mid.block_1(h)))
         h = _gn_swish(self.norm_out, h)
-        return ops.conv_small_cout(h, self.conv_out.packed(), pad=self.conv_out.padding)
+        return ops.conv_small_cout(h, self.conv_out.packed_tap_major(), pad=self.conv_out.padding)
 
 
 class Decoder(nn.Module):
@@ -220,4 +220,4 @@ class Decoder(nn.Module):
         else:
             h = _gn_swish(self.norm_out, h)
             cout = self.conv_out
-        return ops.conv_small_cout(h, cout.packed(), pad=cout.padding, clamp=clamp)
+        return ops.conv_small_cout(h, cout.packed_tap_major(), pad=cout.padding, clamp=clamp)

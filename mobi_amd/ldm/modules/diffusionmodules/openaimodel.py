@@ -250,4 +250,4 @@ class UNetModel(nn.Module):
         n0 = self.out[0]
         g, b = n0.affine()
         h = ops.groupnorm(h, g, b, n0.eps, silu=True)
-        return ops.conv_small_cout(h, self.out[2].packed(), pad=self.out[2].padding)
+        return ops.conv_small_cout(h, self.out[2].packed_tap_major(), pad=self.out[2].padding)

@@ -93,6 +93,11 @@ def zero_module(module):
 # --------------------------------------------------------------------------------------
 # parameter holders
 # --------------------------------------------------------------------------------------
+import os as _os
+
+_CHUNK_MAJOR = _os.environ.get("MOBI_CHUNK_MAJOR", "1") != "0"
+
+
 class _Holder(nn.Module):
     """Caches device-side packed copies keyed on (dtype, device, parameter versions)."""
 
@@ -126,7 +131,13 @@ class Conv2d(_Holder):
 
     def packed(self):
         """T [O][kh*kw*I] for the matrix-core / small-cout kernels."""
-        return self._cached("mfma", lambda: ops.pack_conv(self.weight, self.bias, engine_dtype(), self.weight.device))
+        return self._cached("mfma", lambda: ops.pack_conv(self.weight, self.bias, engine_dtype(), self.weight.device,
+                                                          chunk_major=_CHUNK_MAJOR))
+
+    def packed_tap_major(self):
+        """k = tap*C + c order (the small-cout direct kernel)."""
+        return self._cached("tapmajor", lambda: ops.pack_conv(self.weight, self.bias, engine_dtype(),
+                                                              self.weight.device))
 
     def packed_thin(self):
         """as packed(), with the (< 32) input channels zero-padded to 32 for ops.pack_sources inputs."""

@@ -127,13 +127,20 @@ class Packed:
     cout: int
     n_packed: int
     geglu: bool = False
+    k_order: int = 0                # 0: k = tap*C + c; 1: 64-channel-chunk major (mobi_igemm_params.k_order)
 
 
-def pack_conv(weight, bias, dtype, device):
-    """OIHW fp32 -> [O][kh*kw*I] (k = tap*C + c), the layout mobi_igemm / conv_small_cout read."""
+def pack_conv(weight, bias, dtype, device, chunk_major=False):
+    """OIHW fp32 -> [O][kh*kw*I], the layout mobi_igemm / conv_small_cout read.
+    Default k = tap*C + c.  chunk_major (igemm only, I % 64 == 0, more than one tap): k runs over
+    (64-channel chunk, tap, channel in chunk) so that consecutive k-tiles revisit the same pixels (L2 reuse)."""
     o, i, kh, kw = weight.shape
-    w = weight.detach().to(device=device, dtype=torch.float32).permute(0, 2, 3, 1).reshape(o, kh * kw * i)
+    w = weight.detach().to(device=device, dtype=torch.float32)
     b = None if bias is None else bias.detach().to(device=device, dtype=torch.float32).contiguous()
+    if chunk_major and i % 64 == 0 and kh * kw > 1:
+        w = w.reshape(o, i // 64, 64, kh, kw).permute(0, 1, 3, 4, 2).reshape(o, kh * kw * i)
+        return Packed(w.to(dtype).contiguous(), b, kh, kw, i, o, o, k_order=1)
+    w = w.permute(0, 2, 3, 1).reshape(o, kh * kw * i)
     return Packed(w.to(dtype).contiguous(), b, kh, kw, i, o, o)
 
 
@@ -231,6 +238,9 @@ def igemm(x, pw: Packed, *, x2=None, stride=1, pad=None, upsample=False, hout=No
     p.out_mode = out_mode
     p.epilogue = EPI_GEGLU if pw.geglu else EPI_NONE
     p.scale = scale
+    p.k_order = pw.k_order
+    if pw.k_order and (c0 % 64 or (c1 and c1 % 64)):
+        raise ValueError("chunk-major weights need 64-channel-aligned sources")
     p.dtype = _dt(x.dtype)
     splits = split_k if split_k is not None else lib.mobi_igemm_plan_splits(C.byref(p))
     if splits > 1:
@@ -389,7 +399,7 @@ def conv_small_cout(x, pw: Packed, pad=None, clamp=None):
     """x: T [N,H,W,Cin] -> fp32 NCHW [N,cout,H,W]."""
     lib = _lib.load()
     n, h, w, cin = x.shape
-    assert x.is_contiguous() and cin == pw.cin
+    assert x.is_contiguous() and cin == pw.cin and pw.k_order == 0
     out = torch.empty((n, pw.cout, h, w), device=x.device, dtype=torch.float32)
     p = _lib.ConvSmallCoutParams()
     ph, pw_ = (pw.kh // 2, pw.kw // 2) if pad is None else pad

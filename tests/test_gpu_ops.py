@@ -359,10 +359,11 @@ def test_igemm_split_k(ops, dtype, split):
     wf = torch.from_numpy(W.synth_param("sk.weight", (320, 960, 3, 3))).to(dtype).float()
     bias = torch.from_numpy(W.synth_param("sk.bias", (320,)))
     rv = W.synth_input("sk.rowvec", (2, 320))
-    pw = ops.pack_conv(wf, bias, dtype, "cuda")
     ref = _conv_ref(torch.cat([xf, x1f], 3), wf, bias) + rv[:, None, None, :] + rf
-    y = ops.igemm(xd, pw, x2=x1d, rowvec=rv.cuda(), residual=rd, split_k=split)
-    assert rel(y.float(), ref) < TOL[dtype] * 0.5
+    for chunk_major in (False, True):
+        pw = ops.pack_conv(wf, bias, dtype, "cuda", chunk_major=chunk_major)
+        y = ops.igemm(xd, pw, x2=x1d, rowvec=rv.cuda(), residual=rd, split_k=split)
+        assert rel(y.float(), ref) < TOL[dtype] * 0.5, chunk_major
     if split is None:
         from mobi_amd import _lib
         import ctypes as C
@@ -382,13 +383,14 @@ def test_igemm_block_heights(ops, dtype, wm, monkeypatch):
         xf, xd = rnd("x." + name, (3, h, w, cin), dtype)
         wf = torch.from_numpy(W.synth_param(name + ".weight", (cout, cin, kh, kw))).to(dtype).float()
         bias = torch.from_numpy(W.synth_param(name + ".bias", (cout,)))
-        pw = ops.pack_conv(wf, bias, dtype, "cuda")
         pad = (kh // 2, kw // 2)
-        if asym:
-            y = ops.igemm(xd, pw, stride=2, pad=(0, 0), hout=(h + 1 - 3) // 2 + 1, wout=(w + 1 - 3) // 2 + 1)
-        else:
-            y = ops.igemm(xd, pw, stride=stride, pad=pad, upsample=up)
-        assert rel(y.float(), _conv_ref(xf, wf, bias, stride, pad, up, asym)) < TOL[dtype] * 0.5, name
+        for chunk_major in (False, True):            # both k orders of the packed weights
+            pw = ops.pack_conv(wf, bias, dtype, "cuda", chunk_major=chunk_major)
+            if asym:
+                y = ops.igemm(xd, pw, stride=2, pad=(0, 0), hout=(h + 1 - 3) // 2 + 1, wout=(w + 1 - 3) // 2 + 1)
+            else:
+                y = ops.igemm(xd, pw, stride=stride, pad=pad, upsample=up)
+            assert rel(y.float(), _conv_ref(xf, wf, bias, stride, pad, up, asym)) < TOL[dtype] * 0.5, (name, chunk_major)
     xf, xd = rnd("bh.x", (2, 300, 320), dtype)
     wf = torch.from_numpy(W.synth_param("bh.g.weight", (2560, 320))).to(dtype).float()
     bf = torch.from_numpy(W.synth_param("bh.g.bias", (2560,)))
