@@ -95,7 +95,9 @@ def zero_module(module):
 # --------------------------------------------------------------------------------------
 import os as _os
 
-_CHUNK_MAJOR = _os.environ.get("MOBI_CHUNK_MAJOR", "1") != "0"
+# measured on MI355X (tools/kbench.py): the chunk-major k order is 10-15 % SLOWER than tap-major for the UNet's 3x3
+# convolutions (per-tile re-derivation of the tap window outweighs the L2 reuse) -> off by default, kept for study
+_CHUNK_MAJOR = _os.environ.get("MOBI_CHUNK_MAJOR", "0") == "1"
 
 
 class _Holder(nn.Module):
