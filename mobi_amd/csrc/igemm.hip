@@ -20,6 +20,12 @@
 #include "common.h"
 
 // A/B switch (build with -DMOBI_IGEMM_FENCE=1): pin the load / MFMA / LDS-write phases of a k step
+#ifndef MOBI_FRAG2
+#define MOBI_FRAG2 0
+#endif
+#ifndef MOBI_DMA_KS
+#define MOBI_DMA_KS 1      // k-step of a tile in front of which the next-but-one tile's DMA is issued (A/B: 0 | 1)
+#endif
 #if defined(MOBI_IGEMM_FENCE) && MOBI_IGEMM_FENCE
 #define MOBI_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 #else
@@ -635,12 +641,37 @@ __global__ __launch_bounds__(512, 2) void igemm_glds_kernel(const IgemmArgs a) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __builtin_amdgcn_s_barrier();
-    if (kt + 2 < kt_end) issue_tile(kt + 2);
     const unsigned char* st = lds + ((kt - kt_begin) % 3) * STAGE;
     const unsigned char* xb = st + (wm * 64 + r16) * 128;
     const unsigned char* wb = st + X_TILE + (wn * WAVE_N + r16) * 128;
+#if MOBI_FRAG2
+    {
+      // all fragments of the tile are requested up front (two register sets): one exposed LDS latency per tile
+      frag_t xf[2][4], wf[2][NT];
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const int sw = ((ks * 4 + g4) ^ (r16 & 7)) << 4;
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) xf[ks][mi] = __builtin_bit_cast(frag_t, ld16(xb + mi * 16 * 128 + sw));
+#pragma unroll
+        for (int ni = 0; ni < NT; ++ni) wf[ks][ni] = __builtin_bit_cast(frag_t, ld16(wb + ni * 16 * 128 + sw));
+      }
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        if (ks == MOBI_DMA_KS && kt + 2 < kt_end) issue_tile(kt + 2);
+#pragma unroll
+        for (int ni = 0; ni < NT; ++ni)
+#pragma unroll
+          for (int mi = 0; mi < 4; ++mi)
+            acc[ni][mi] = TR ? mfma16(xf[ks][mi], wf[ks][ni], acc[ni][mi]) : mfma16(wf[ks][ni], xf[ks][mi], acc[ni][mi]);
+      }
+    }
+#else
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
+      // the DMA of tile kt+2 is issued between the two k-steps: its (expensive) issue slots then sit in the
+      // shadow of the first k-step's MFMAs instead of delaying the first fragment reads after the barrier
+      if (ks == MOBI_DMA_KS && kt + 2 < kt_end) issue_tile(kt + 2);
       const int sw = ((ks * 4 + g4) ^ (r16 & 7)) << 4;
       frag_t xf[4], wf[NT];
 #pragma unroll
@@ -653,6 +684,7 @@ __global__ __launch_bounds__(512, 2) void igemm_glds_kernel(const IgemmArgs a) {
         for (int mi = 0; mi < 4; ++mi)
           acc[ni][mi] = TR ? mfma16(xf[mi], wf[ni], acc[ni][mi]) : mfma16(wf[ni], xf[mi], acc[ni][mi]);
     }
+#endif
   }
   __syncthreads();                                           // every wave is past its last fragment read
   float* stage = reinterpret_cast<float*>(lds) + wave * (STAGE_ROWS * STAGE_STRIDE);

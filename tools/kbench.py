@@ -50,7 +50,7 @@ def main():
     ap.add_argument("--residual", action="store_true")
     ap.add_argument("--geglu", action="store_true")
     ap.add_argument("--split", type=int, default=None)
-    ap.add_argument("--tap-major", action="store_true")
+    ap.add_argument("--chunk-major", action="store_true")
     ap.add_argument("--c", type=int, default=320)
     a = ap.parse_args()
     from mobi_amd import build, ops
@@ -70,7 +70,7 @@ def main():
         x = rn(a.images, a.hw, a.hw, a.cin)
         x2 = rn(a.images, a.hw, a.hw, a.cin2) if a.cin2 else None
         w = torch.randn(a.cout, a.cin + a.cin2, a.k, a.k, generator=g) / (a.k * (a.cin + a.cin2) ** 0.5)
-        pw = ops.pack_conv(w, torch.zeros(a.cout), dt, dev, chunk_major=not a.tap_major)
+        pw = ops.pack_conv(w, torch.zeros(a.cout), dt, dev, chunk_major=a.chunk_major)
         fn = lambda: ops.igemm(x, pw, x2=x2, stride=a.stride, upsample=a.up, split_k=a.split)
         us = timeit(fn, a.iters)
         y = fn()
