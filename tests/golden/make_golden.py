@@ -33,6 +33,8 @@ from oracle import weights as W                      # noqa: E402
 
 def install_stubs():
     import torch.nn as nn
+    import transformers  # noqa: F401  (must be imported before torchvision is stubbed: its availability probe)
+    from transformers import CLIPVisionModel  # noqa: F401
 
     def mod(name, **attrs):
         m = types.ModuleType(name)
@@ -341,6 +343,29 @@ def main():
          n_cam_gt=noises[0], n_cam_inp=noises[1], n_lid_gt=noises[2], n_lid_inp=noises[3],
          z_image=z_image, z_lidar=z_lidar, sample=sample, h_cam=h_cam, h_lid=h_lid,
          cat_interleave=R.lu.cat_interleave([torch.arange(6.).reshape(3, 2), -torch.arange(6.).reshape(3, 2)]))
+
+    # ---- 7. conditioning producer: CLIP tower (tiny depth, real width) + mapper + bbox MLP ----
+    import transformers
+    import ldm.modules.encoders.modules as em
+    clip_cfg = dict(COND_CLIP_CFG)
+    orig = transformers.CLIPVisionModel.from_pretrained
+    em.CLIPVisionModel.from_pretrained = classmethod(
+        lambda cls, *a, **k: transformers.CLIPVisionModel(transformers.CLIPVisionConfig(**clip_cfg)))
+    try:
+        enc = em.FrozenCLIPImageEmbedder(conditions=["ref_image", "ref_bbox"]).eval()
+    finally:
+        em.CLIPVisionModel.from_pretrained = orig
+    W.fill_module_(enc, seed=13)
+    ref_image = W.synth_input("cond.ref_image", (2, 3, 28, 28))
+    ref_bbox = W.synth_input("cond.ref_bbox", (2, 8, 3), kind="uniform") * 0.5 + 0.5
+    out = enc.encode({"ref_image": ref_image, "ref_bbox": ref_bbox})
+    save("cond_producer", ref_image=ref_image, ref_bbox=ref_bbox, ref_image_token=out["ref_image_token"],
+         ref_bbox_token=out["ref_bbox_token"])
+
+
+# real ViT-L width (the reference hard-codes 1024 for the mapper), reduced depth / resolution
+COND_CLIP_CFG = dict(hidden_size=1024, intermediate_size=256, num_hidden_layers=1, num_attention_heads=16,
+                     image_size=28, patch_size=14, projection_dim=64, hidden_act="quick_gelu")
 
 
 if __name__ == "__main__":
