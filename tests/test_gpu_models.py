@@ -261,3 +261,69 @@ def test_latent_diffusion_plumbing(dtype):
     got = ld.decode_first_stage(h_lid, module_name="lidar_stage_model", clamp=(-1., 1.))
     assert rel_l2(got.cpu(), ref) < TOL_NET[dtype]
     assert float(got.max()) <= 1.0 and float(got.min()) >= -1.0
+
+
+def test_harness_flow_with_conditioning_producer():
+    """The call sequence of scripts/inference_test_bench.py:403-464 on the engine: get_input (VAE encodes +
+    CLIP/bbox conditioning + lidar alignment + interleave) -> DDIMSampler.sample with CFG -> decode_sample ->
+    log_data (decode + clamp).  Conditioning tokens are checked against a CPU evaluation of the same modules."""
+    _set(torch.float16)
+    import copy
+    import torch.nn.functional as F
+    from mobi_amd.ldm.models.diffusion.ddim import DDIMSampler
+    from mobi_amd.ldm.util import instantiate_from_config, load_config
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg = load_config(os.path.join(root, "configs", "mobi_nusc_512.yaml"), ["latent_size=8", "image_height=64"])
+    mp = cfg["model"]["params"]
+    mp["unet_config"]["params"]["model_channels"] = 64
+    for k in ("first_stage_config", "lidar_stage_config"):
+        mp[k]["params"]["ddconfig"]["ch"] = 32
+    mp["cond_stage_config"] = {"target": "ldm.modules.encoders.modules.FrozenCLIPImageEmbedder",
+                               "params": {"conditions": ["ref_image", "ref_bbox"],
+                                          "clip_config": dict(hidden_size=1024, intermediate_size=256,
+                                                              num_hidden_layers=1, num_attention_heads=16,
+                                                              image_size=28, patch_size=14, projection_dim=64,
+                                                              hidden_act="quick_gelu")}}
+    model = instantiate_from_config(cfg["model"])
+    W.fill_module_(model, seed=17)
+    cond_cpu = copy.deepcopy(model.cond_stage_model)
+    proj_w, proj_b = model.proj_out.weight.detach().clone(), model.proj_out.bias.detach().clone()
+    model = model.cuda().eval()
+    B = 2
+    batch = {"image": {"GT": W.synth_input("hf.img", (B, 3, 64, 64), kind="uniform"),
+                       "inpaint_mask": torch.ones(B, 1, 64, 64),
+                       "cond": {"ref_image": W.synth_input("hf.ref", (B, 3, 28, 28)),
+                                "ref_bbox": W.synth_input("hf.bbox", (B, 8, 3), kind="uniform") * 0.5 + 0.5}},
+             "lidar": {"range_data": W.synth_input("hf.rng", (B, 2, 64, 64), kind="uniform"),
+                       "range_mask": torch.ones(B, 1, 64, 64),
+                       "cond": {"ref_image": W.synth_input("hf.ref", (B, 3, 28, 28)),
+                                "ref_bbox": W.synth_input("hf.bbox2", (B, 8, 3), kind="uniform") * 0.5 + 0.5}}}
+    batch["image"]["inpaint_mask"][:, :, 16:48, 16:48] = 0
+    batch["lidar"]["range_mask"][:, :, 16:48, 16:48] = 0
+    batch["image"]["inpaint_image"] = batch["image"]["GT"] * batch["image"]["inpaint_mask"]
+    batch["lidar"]["range_data_inpaint"] = batch["lidar"]["range_data"] * batch["lidar"]["range_mask"]
+    to_dev = lambda d: {k: to_dev(v) if isinstance(v, dict) else v.cuda() for k, v in d.items()}
+    data = model.get_input(to_dev(batch), "inpaint", force_c_encode=True, return_vae_rec=True)
+    assert data["z"].shape == (2 * B, 9, 8, 8) and data["cond"].shape == (2 * B, 2, 768)
+    assert data["image_rec"].shape == (B, 3, 64, 64) and data["lidar_rec"].shape == (B, 2, 64, 64)
+    # conditioning tokens vs CPU: [proj_out(CLIP->mapper->LN), bbox token], camera/lidar interleaved
+    with torch.no_grad():
+        ref = []
+        for mod in ("image", "lidar"):
+            c = cond_cpu.encode({k: batch[mod]["cond"][k].clone() for k in ("ref_image", "ref_bbox")})
+            ref.append(torch.cat([F.linear(c["ref_image_token"], proj_w, proj_b), c["ref_bbox_token"]], dim=1))
+        ref = torch.stack(ref, dim=1).reshape(2 * B, 2, 768)
+    assert rel_l2(data["cond"].cpu(), ref) < 5e-3
+    uc = torch.cat([model.learnable_vector, model.bbox_uncond_vector], dim=1).repeat(2 * B, 1, 1)
+    z = data["z"]
+    samples, _ = DDIMSampler(model).sample(S=3, batch_size=2 * B, shape=[4, 8, 8], conditioning=data["cond"],
+                                           verbose=False, eta=0.0, unconditional_guidance_scale=5.0,
+                                           unconditional_conditioning=uc, x_T=W.synth_input("hf.xT", (2 * B, 4, 8, 8)).cuda(),
+                                           test_model_kwargs={"inpaint_image": z[:, 4:8].contiguous(),
+                                                              "inpaint_mask": z[:, 8:9].contiguous()})
+    h_cam, h_lid = model.decode_sample(samples, data["z_lidar"])
+    log, _ = model.log_data(batch, data, h_cam.contiguous(), h_lid.contiguous())
+    for k, ch in (("image_sample", 3), ("lidar_sample", 2)):
+        assert log[k].shape == (B, ch, 64, 64) and bool(torch.isfinite(log[k]).all())
+        assert float(log[k].abs().max()) <= 1.0
