@@ -317,7 +317,7 @@ def test_harness_flow_with_conditioning_producer():
     assert rel_l2(data["cond"].cpu(), ref) < 5e-3
     uc = torch.cat([model.learnable_vector, model.bbox_uncond_vector], dim=1).repeat(2 * B, 1, 1)
     z = data["z"]
-    samples, _ = DDIMSampler(model).sample(S=3, batch_size=2 * B, shape=[4, 8, 8], conditioning=data["cond"],
+    samples, _ = DDIMSampler(model).sample(S=4, batch_size=2 * B, shape=[4, 8, 8], conditioning=data["cond"],
                                            verbose=False, eta=0.0, unconditional_guidance_scale=5.0,
                                            unconditional_conditioning=uc, x_T=W.synth_input("hf.xT", (2 * B, 4, 8, 8)).cuda(),
                                            test_model_kwargs={"inpaint_image": z[:, 4:8].contiguous(),
