@@ -33,11 +33,11 @@ class DDIMSampler(object):
         self.register_buffer("betas", to_torch(self.model.betas))
         self.register_buffer("alphas_cumprod", to_torch(alphas_cumprod))
         self.register_buffer("alphas_cumprod_prev", to_torch(self.model.alphas_cumprod_prev))
-        self.register_buffer("sqrt_alphas_cumprod", to_torch(np.sqrt(ac)))
-        self.register_buffer("sqrt_one_minus_alphas_cumprod", to_torch(np.sqrt(1. - ac)))
-        self.register_buffer("log_one_minus_alphas_cumprod", to_torch(np.log(1. - ac)))
-        self.register_buffer("sqrt_recip_alphas_cumprod", to_torch(np.sqrt(1. / ac)))
-        self.register_buffer("sqrt_recipm1_alphas_cumprod", to_torch(np.sqrt(1. / ac - 1)))
+        self.register_buffer("sqrt_alphas_cumprod", to_torch(torch.sqrt(ac)))
+        self.register_buffer("sqrt_one_minus_alphas_cumprod", to_torch(torch.sqrt(1. - ac)))
+        self.register_buffer("log_one_minus_alphas_cumprod", to_torch(torch.log(1. - ac)))
+        self.register_buffer("sqrt_recip_alphas_cumprod", to_torch(torch.sqrt(1. / ac)))
+        self.register_buffer("sqrt_recipm1_alphas_cumprod", to_torch(torch.sqrt(1. / ac - 1)))
         sig, a, a_prev = make_ddim_sampling_parameters(alphacums=ac, ddim_timesteps=self.ddim_timesteps,
                                                        eta=ddim_eta, verbose=verbose)
         self.ddim_sigmas, self.ddim_alphas, self.ddim_alphas_prev = sig, a, a_prev
