@@ -208,9 +208,9 @@ def main():
         ops.set_profiler(None)
         if args.dump_launches:
             with open(args.dump_launches, "w") as f:
-                for kind, flops, e0, e1, nb in sink:
-                    f.write(f"{kind}\t{flops / 1e9:.4f}\t{e0.elapsed_time(e1) * 1e3:.2f}\t{nb / 1e6:.3f}\n")
-        for kind, flops, e0, e1, nb in sink:
+                for kind, flops, e0, e1, nb, tag in sink:
+                    f.write(f"{kind}\t{flops / 1e9:.4f}\t{e0.elapsed_time(e1) * 1e3:.2f}\t{nb / 1e6:.3f}\t{tag}\n")
+        for kind, flops, e0, e1, nb, tag in sink:
             k = kinds.setdefault(kind, dict(launches=0, flops=0.0, ms=0.0, bytes=0.0))
             k["launches"] += 1
             k["flops"] += flops

@@ -78,8 +78,8 @@ typedef struct mobi_igemm_params {
   const void* weight;    /* T [groups][n_packed][kh*kw*(c0+c1)], k contiguous, k = tap*C + c */
   int32_t groups;        /* 1: one weight matrix; == batch: one weight matrix per image  */
   int64_t w_group_stride;/* elements between the per-group weight matrices              */
-  int32_t n_packed;      /* rows of W; GEGLU: units of u value rows then u gate rows,
-                            u = 40 if n_packed % 160 == 0 else 32 (zero-padded)          */
+  int32_t n_packed;      /* rows of W; GEGLU: n_packed = 2 * cout, every 16 rows = 8 value rows
+                            then the 8 gate rows of the same 8 outputs (cout % 8 == 0)    */
   int32_t cout;          /* logical output columns                                       */
   const float* bias;     /* [cout] or NULL (GEGLU: [n_packed], packed like the rows)     */
   const float* rowvec;   /* f32 [batch][cout] or NULL: per-image additive vector         */

@@ -32,7 +32,39 @@
 #define MOBI_SCHED_FENCE() ((void)0)
 #endif
 
+#ifndef MOBI_STAMP
+#define MOBI_STAMP 0       // 1: in-kernel phase stamps of the direct-to-LDS kernel (tools/stamp_igemm.py), never in a release build
+#endif
+
 namespace mobi {
+
+#if MOBI_STAMP
+__device__ unsigned long long* g_stamps = nullptr;      // [block][8]: entry, first tile landed, loop end, epilogue end, hw id, nk
+#define MOBI_STAMP_AT(slot)                                                                          \
+  do {                                                                                               \
+    if (g_stamps && threadIdx.x == 0)                                                                \
+      g_stamps[(size_t)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) * 8 + (slot)] = \
+          __builtin_amdgcn_s_memrealtime();                                                          \
+  } while (0)
+#else
+#define MOBI_STAMP_AT(slot) ((void)0)
+#endif
+#if MOBI_STAMP == 2
+// per wave: accumulated 10-ns ticks of the five phases of a k-tile step (wait, barrier, k-step 0, DMA issue,
+// k-step 1) + the number of steps; [block][wave][8]
+__device__ unsigned long long* g_phase = nullptr;
+#define MOBI_PHASE_DECL unsigned long long ph_t[6]; unsigned ph_acc[5] = {0u, 0u, 0u, 0u, 0u}; unsigned ph_n = 0
+#define MOBI_PHASE(i) ph_t[i] = __builtin_amdgcn_s_memrealtime()
+#define MOBI_PHASE_ACC()                                                                  \
+  do {                                                                                    \
+    for (int i_ = 0; i_ < 5; ++i_) ph_acc[i_] += (unsigned)(ph_t[i_ + 1] - ph_t[i_]);     \
+    ++ph_n;                                                                               \
+  } while (0)
+#else
+#define MOBI_PHASE_DECL ((void)0)
+#define MOBI_PHASE(i) ((void)0)
+#define MOBI_PHASE_ACC() ((void)0)
+#endif
 
 // 16 zero bytes in the code object: the source of every padded / out-of-range 16-byte piece of an operand tile
 // (a plain load from here instead of a load + select; the library allocates nothing).
@@ -59,6 +91,7 @@ struct IgemmArgs {
   int wm;                  // waves along the pixel axis (2 or 4): block tile = 64*wm pixels
   int splits, nk_per;      // split-K: blockIdx.y owns k-tiles [y*nk_per, (y+1)*nk_per)
   float* split_ws;         // f32 [splits][M][n_packed] partial sums (NULL: single pass)
+  int epi_direct;          // direct-to-LDS kernel: register epilogue (full tiles, row-major T output, no per-image vector)
 };
 
 // 8 consecutive floats through two 16-byte accesses (LDS stage rows, bias, per-image vectors)
@@ -71,55 +104,120 @@ __device__ __forceinline__ void ld8f(const float* p, float (&f)[8]) {
 // Epilogue shared by both main-loop variants: accumulators -> per-wave fp32 LDS tile -> coalesced 16-byte rows
 // with scale / bias / per-image vector / residual / GEGLU, fp32 or transposed output, split-K partial slabs.
 // `stage` is this wave's private LDS area (the caller guarantees every wave is past its last fragment read).
+// RPP = pixel rows of the wave's 64 x WAVE_N tile that go through the stage per pass (32: 2 passes, 16: 4 passes;
+// the direct-to-LDS kernel uses 16 so that all eight stages fit the one k-stage that is free at that point).
+// Latency: the bias is added in the accumulator domain from registers loaded before anything else, and the
+// residual rows of ALL passes are requested up front, so no global load sits between an LDS read and a store.
 // ---------------------------------------------------------------------------------------------------------
-template <typename T, int NT, bool TR>
+template <int RPP, bool TR, int NT>
+struct EpiGeom {
+  static constexpr int WAVE_N = NT * 16;
+  static constexpr int STRIDE = TR ? (RPP + 4) : (WAVE_N + 4);      // floats
+  static constexpr int ROWS = TR ? WAVE_N : RPP;
+  static constexpr int BYTES = ROWS * STRIDE * 4;                   // per wave
+};
+
+template <typename T, int NT, bool TR, int RPP>
 __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& a, float* stage, f32x4 (&acc)[NT][4], int lane,
                                                int group, int nw0, int mw0) {
   constexpr int WAVE_N = NT * 16;
-  constexpr int STAGE_STRIDE = TR ? 36 : (WAVE_N + 4);      // floats
+  constexpr int STAGE_STRIDE = EpiGeom<RPP, TR, NT>::STRIDE;
+  constexpr int MT = RPP / 16;                 // 16-pixel MFMA tiles per pass
+  constexpr int NPASS = 4 / MT;
   const int r16 = lane & 15, g4 = lane >> 4;
   const float scale = a.scale;
   T* __restrict__ outT = reinterpret_cast<T*>(a.out);
   float* __restrict__ outF = reinterpret_cast<float*>(a.out);
   const T* __restrict__ resid = reinterpret_cast<const T*>(a.residual);
+  const bool plain = !TR && !a.split_ws && a.epilogue != MOBI_EPI_GEGLU;
+  const bool use_bias = a.bias != nullptr && !a.split_ws;
+
+  // image / in-image index of the wave's first row (wave-uniform); rows of a task are found by a short walk
+  const int mw0c = mw0 < a.M ? mw0 : 0;
+  const int img0 = __builtin_amdgcn_readfirstlane(mw0c / a.hw_out);
+  const int rem0 = mw0c - img0 * a.hw_out;
+  auto locate = [&](int row_in_tile, int& img, int& rem) {
+    img = img0; rem = rem0 + row_in_tile;
+    while (rem >= a.hw_out) { rem -= a.hw_out; ++img; }
+  };
+
+  // ---- bias in the accumulator domain ----------------------------------------------------------------------
+  f32x4 bias4[NT];
+#pragma unroll
+  for (int ni = 0; ni < NT; ++ni) {
+    bias4[ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (use_bias) {
+      if (!TR) {
+        const int n = nw0 + ni * 16 + g4 * 4;                  // D rows = channel: 4 consecutive channels per lane
+        if (n < a.n_packed) bias4[ni] = *reinterpret_cast<const f32x4*>(a.bias + n);
+      } else {
+        const int n = nw0 + ni * 16 + r16;                     // D cols = channel: one channel per lane
+        const float b = n < a.cout ? a.bias[n] : 0.f;
+        bias4[ni] = f32x4{b, b, b, b};
+      }
+    }
+  }
+
+  // ---- residual rows of every pass (plain path) --------------------------------------------------------------
+  constexpr int TPR_P = WAVE_N / 8;
+  constexpr int NIT_P = (RPP * TPR_P + 63) / 64;
+  u32x4 rres[NPASS][NIT_P];
+  if (plain && resid) {
+#pragma unroll
+    for (int pass = 0; pass < NPASS; ++pass)
+#pragma unroll
+      for (int it = 0; it < NIT_P; ++it) {
+        rres[pass][it] = u32x4{0u, 0u, 0u, 0u};
+        const int task = lane + 64 * it;
+        const int row = task / TPR_P, cg = task - row * TPR_P;
+        const int rt = pass * RPP + row;
+        const int n = nw0 + cg * 8;
+        if (task < RPP * TPR_P && mw0 + rt < a.M && n < a.cout) {
+          int img, rem;
+          locate(rt, img, rem);
+          const long long gi = (long long)(group * a.imgs_per_group + img);
+          rres[pass][it] = ld16(resid + gi * a.res_img_stride + (long long)rem * a.cout + n);
+        }
+      }
+  }
 
 #pragma unroll
-  for (int pass = 0; pass < 2; ++pass) {
-    // (the main loop's last barrier already ordered every wave's fragment reads
-    //  before these writes; passes of one wave are ordered by the waits below)
+  for (int pass = 0; pass < NPASS; ++pass) {
+    // (the caller's last barrier ordered every wave's fragment reads before these writes; the passes of one
+    //  wave are ordered by the waits below)
     if (!TR) {
       // D rows = channel (g4*4 + r), cols = pixel (r16): lane owns 4 consecutive channels
 #pragma unroll
-      for (int ml = 0; ml < 2; ++ml)
+      for (int ml = 0; ml < MT; ++ml)
 #pragma unroll
         for (int ni = 0; ni < NT; ++ni) {
-          f32x4 v = acc[ni][pass * 2 + ml];
-          v *= scale;
+          f32x4 v = acc[ni][pass * MT + ml];
+          v = v * scale + bias4[ni];
           *reinterpret_cast<f32x4*>(stage + (ml * 16 + r16) * STAGE_STRIDE + ni * 16 + g4 * 4) = v;
         }
     } else {
       // D rows = pixel (g4*4 + r), cols = channel (r16): lane owns 4 consecutive pixels
 #pragma unroll
-      for (int ml = 0; ml < 2; ++ml)
+      for (int ml = 0; ml < MT; ++ml)
 #pragma unroll
         for (int ni = 0; ni < NT; ++ni) {
-          f32x4 v = acc[ni][pass * 2 + ml];
-          v *= scale;
+          f32x4 v = acc[ni][pass * MT + ml];
+          v = v * scale + bias4[ni];
           *reinterpret_cast<f32x4*>(stage + (ni * 16 + r16) * STAGE_STRIDE + ml * 16 + g4 * 4) = v;
         }
     }
     __builtin_amdgcn_s_waitcnt(0xc07f);      // lgkmcnt(0): this wave's LDS writes are done
     __builtin_amdgcn_wave_barrier();
 
-    const int mp0 = mw0 + pass * 32;         // first row of this pass
+    const int rp0 = pass * RPP;              // first row (inside the wave tile) of this pass
     if (!TR) {
       if (a.split_ws) {
         // split-K: raw fp32 partial sums, finished by igemm_splitk_reduce_kernel
         constexpr int TPR = WAVE_N / 8;
         float* __restrict__ wsp = a.split_ws + (long long)blockIdx.y * a.M * a.n_packed;
-        for (int task = lane; task < 32 * TPR; task += 64) {
+        for (int task = lane; task < RPP * TPR; task += 64) {
           const int row = task / TPR, cg = task - row * TPR;
-          const int m = mp0 + row;
+          const int m = mw0 + rp0 + row;
           const int n = nw0 + cg * 8;
           if (m >= a.M || n >= a.n_packed) continue;
           const float* sp = stage + row * STAGE_STRIDE + cg * 8;
@@ -128,49 +226,38 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& a, float* stage,
           *reinterpret_cast<f32x4*>(d + 4) = *reinterpret_cast<const f32x4*>(sp + 4);
         }
       } else if (a.epilogue == MOBI_EPI_GEGLU) {
-        constexpr int HALF = WAVE_N / 2;     // a | gate split of the wave's packed columns
-        constexpr int TPR = HALF / 8;
-        const int unit = nw0 / WAVE_N;
-        for (int task = lane; task < 32 * TPR; task += 64) {
-          const int row = task / TPR, cg = task - row * TPR;
-          const int m = mp0 + row;
-          const int oc = unit * HALF + cg * 8;
+        // packed columns: per 16-column MFMA tile, 8 value columns then the 8 gate columns of the same outputs
+        constexpr int TPR = WAVE_N / 16;
+        for (int task = lane; task < RPP * TPR; task += 64) {
+          const int row = task / TPR, t = task - row * TPR;
+          const int m = mw0 + rp0 + row;
+          const int oc = (nw0 >> 1) + t * 8;
           if (m >= a.M || oc >= a.cout) continue;
-          const float* sp = stage + row * STAGE_STRIDE + cg * 8;
+          const float* sp = stage + row * STAGE_STRIDE + t * 16;
           float av[8], gv[8], o[8];
           ld8f(sp, av);
-          ld8f(sp + HALF, gv);
-          if (a.bias) {
-            float ba[8], bg[8];
-            ld8f(a.bias + nw0 + cg * 8, ba);
-            ld8f(a.bias + nw0 + HALF + cg * 8, bg);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) { av[j] += ba[j]; gv[j] += bg[j]; }
-          }
+          ld8f(sp + 8, gv);
 #pragma unroll
           for (int j = 0; j < 8; ++j) o[j] = av[j] * gelu_erf_f(gv[j]);
-          const int img = m / a.hw_out, rem = m - img * a.hw_out;
+          int img, rem;
+          locate(rp0 + row, img, rem);
           const long long gi = (long long)(group * a.imgs_per_group + img);
           st16(outT + gi * a.out_img_stride + (long long)rem * a.cout + oc, pack8<T>(o));
         }
       } else {
-        constexpr int TPR = WAVE_N / 8;
-        for (int task = lane; task < 32 * TPR; task += 64) {
-          const int row = task / TPR, cg = task - row * TPR;
-          const int m = mp0 + row;
+#pragma unroll
+        for (int it = 0; it < NIT_P; ++it) {
+          const int task = lane + 64 * it;
+          const int row = task / TPR_P, cg = task - row * TPR_P;
+          const int m = mw0 + rp0 + row;
           const int n = nw0 + cg * 8;
-          if (m >= a.M || n >= a.cout) continue;
+          if (task >= RPP * TPR_P || m >= a.M || n >= a.cout) continue;
           const float* sp = stage + row * STAGE_STRIDE + cg * 8;
           float o[8];
           ld8f(sp, o);
-          const int img = m / a.hw_out, rem = m - img * a.hw_out;
+          int img, rem;
+          locate(rp0 + row, img, rem);
           const long long gi = (long long)(group * a.imgs_per_group + img);
-          if (a.bias) {
-            float bb[8];
-            ld8f(a.bias + n, bb);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) o[j] += bb[j];
-          }
           if (a.rowvec) {
             float rv[8];
             ld8f(a.rowvec + gi * a.rowvec_stride + n, rv);
@@ -179,7 +266,7 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& a, float* stage,
           }
           if (resid) {
             float rf[8];
-            unpack8<T>(ld16(resid + gi * a.res_img_stride + (long long)rem * a.cout + n), rf);
+            unpack8<T>(rres[pass][it], rf);
 #pragma unroll
             for (int j = 0; j < 8; ++j) o[j] += rf[j];
           }
@@ -194,19 +281,19 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& a, float* stage,
       }
     } else {
       // transposed output [image][cout][hw]
+      constexpr int PG = RPP / 8;            // 8-pixel groups per staged row
       const bool vec_ok = (a.hw_out & 7) == 0;
-      for (int task = lane; task < WAVE_N * 4; task += 64) {
-        const int crow = task >> 2, pg = task & 3;
+      for (int task = lane; task < WAVE_N * PG; task += 64) {
+        const int crow = task / PG, pg = task - crow * PG;
         const int n = nw0 + crow;
-        const int m = mp0 + pg * 8;
+        const int m = mw0 + rp0 + pg * 8;
         if (n >= a.cout || m >= a.M) continue;
         const float* sp = stage + crow * STAGE_STRIDE + pg * 8;
         float o[8];
-        const float bv = a.bias ? a.bias[n] : 0.f;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) o[j] = sp[j] + bv;
+        ld8f(sp, o);
         if (vec_ok) {
-          const int img = m / a.hw_out, rem = m - img * a.hw_out;
+          int img, rem;
+          locate(rp0 + pg * 8, img, rem);
           const long long gi = (long long)(group * a.imgs_per_group + img);
           st16(outT + gi * a.out_img_stride + (long long)n * a.hw_out + rem, pack8<T>(o));
         } else {
@@ -223,6 +310,133 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& a, float* stage,
     __builtin_amdgcn_s_waitcnt(0xc07f);
     __builtin_amdgcn_wave_barrier();
   }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Register epilogue of the direct-to-LDS kernel (full tiles, row-major T output, no per-image vector, no split):
+// no LDS, no barrier.  A lane-row exchange (v_permlane16_swap / v_permlane32_swap, gfx950) turns the MFMA
+// accumulator layout (4 consecutive channels of one pixel per lane and tile) into 8 consecutive channels of one
+// pixel per lane (plain: one 16-byte store per lane and tile pair) or pairs every value with its gate (GEGLU:
+// 4 outputs per lane, one 8-byte store).  Bias and residual rows were requested at the START of the output tile's
+// k loop by explicit loads the compiler does not track; the kernel counts every vector-memory instruction it
+// issues, so all waits are exact s_waitcnt vmcnt(N) immediates and never drain the DMA of the next k-tiles.
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ u32x4 vm_load16(const void* p) {
+  u32x4 r;
+  asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(r) : "v"(p) : "memory");
+  return r;
+}
+__device__ __forceinline__ void vm_store16(void* p, const u32x4& v) {
+  asm volatile("global_store_dwordx4 %0, %1, off" : : "v"(p), "v"(v) : "memory");
+}
+__device__ __forceinline__ void vm_store8(void* p, const u32x2& v) {
+  asm volatile("global_store_dwordx2 %0, %1, off" : : "v"(p), "v"(v) : "memory");
+}
+// wait until at most n (wave-uniform; rounded DOWN to an encoded value, which only waits longer) vector-memory
+// operations of this wave are outstanding
+__device__ __forceinline__ void wait_vmcnt_le(int n) {
+#define MOBI_VMW(k) else if (n >= k) asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory")
+  if (n >= 37) asm volatile("s_waitcnt vmcnt(37)" ::: "memory");
+  MOBI_VMW(32); MOBI_VMW(27); MOBI_VMW(26); MOBI_VMW(22); MOBI_VMW(18); MOBI_VMW(17); MOBI_VMW(14); MOBI_VMW(12);
+  MOBI_VMW(10); MOBI_VMW(8); MOBI_VMW(7); MOBI_VMW(6); MOBI_VMW(5); MOBI_VMW(4);
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#undef MOBI_VMW
+}
+
+template <int NT>
+struct DirectEpiRegs {
+  u32x4 bias[NT];          // f32 x 4: channels 16 ni + 4 g4 + (0..3) of the wave's columns
+  u32x4 res[NT][2];        // T x 8: the lane's 8 output channels of its pixel in tile pair p
+};
+
+// request bias / residual of output tile (mw0, nw0); returns the number of vector-memory instructions issued
+template <typename T, int NT>
+__device__ __forceinline__ int direct_epilogue_request(const IgemmArgs& a, DirectEpiRegs<NT>& q, int lane, int group,
+                                                       int nw0, int mw0) {
+  const int r16 = lane & 15, g4 = lane >> 4;
+  int n_issued = 0;
+  if (a.bias) {
+#pragma unroll
+    for (int ni = 0; ni < NT; ++ni) q.bias[ni] = vm_load16(a.bias + nw0 + ni * 16 + g4 * 4);
+    n_issued += NT;
+  }
+  if (a.residual) {                                            // plain epilogue only (checked on the host)
+    const T* __restrict__ resid = reinterpret_cast<const T*>(a.residual);
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      const int m = mw0 + (2 * p + (g4 & 1)) * 16 + r16;
+      const int img = m / a.hw_out, rem = m - img * a.hw_out;
+      const T* rowp = resid + (long long)(group * a.imgs_per_group + img) * a.res_img_stride + (long long)rem * a.cout +
+                      nw0 + 8 * (g4 >> 1);
+#pragma unroll
+      for (int ni = 0; ni < NT; ++ni) q.res[ni][p] = vm_load16(rowp + ni * 16);
+    }
+    n_issued += 2 * NT;
+  }
+  return n_issued;
+}
+
+// returns the number of vector-memory instructions issued (stores)
+template <typename T, int NT, bool GEGLU>
+__device__ __forceinline__ int direct_epilogue(const IgemmArgs& a, f32x4 (&acc)[NT][4], DirectEpiRegs<NT>& q, int lane,
+                                               int group, int nw0, int mw0) {
+  const int r16 = lane & 15, g4 = lane >> 4;
+  const float scale = a.scale;
+  T* __restrict__ outT = reinterpret_cast<T*>(a.out);
+  // the requested registers are complete (caller waited): pin their uses behind that wait
+  if (a.bias) {
+#pragma unroll
+    for (int ni = 0; ni < NT; ++ni) asm volatile("" : "+v"(q.bias[ni]));
+  }
+  if (a.residual) {
+#pragma unroll
+    for (int ni = 0; ni < NT; ++ni) { asm volatile("" : "+v"(q.res[ni][0])); asm volatile("" : "+v"(q.res[ni][1])); }
+  }
+  constexpr bool geglu = GEGLU;
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    // plain: after the 16-lane-row swap a lane holds pixel tile 2p + (g4 & 1), channels 16 ni + 8 (g4 >> 1) + 0..7
+    // GEGLU: after the 32-lane swap a lane holds pixel tile 2p + (g4 >> 1), outputs 8 ni + 4 (g4 & 1) + 0..3
+    const int mi = geglu ? 2 * p + (g4 >> 1) : 2 * p + (g4 & 1);
+    const int m = mw0 + mi * 16 + r16;
+    const int img = m / a.hw_out, rem = m - img * a.hw_out;
+    T* rowp = outT + (long long)(group * a.imgs_per_group + img) * a.out_img_stride + (long long)rem * a.cout;
+#pragma unroll
+    for (int ni = 0; ni < NT; ++ni) {
+      f32x4 x = acc[ni][2 * p] * scale, y = acc[ni][2 * p + 1] * scale;
+      if (a.bias) {
+        const f32x4 b = __builtin_bit_cast(f32x4, q.bias[ni]);
+        x += b; y += b;
+      }
+      // (inline asm: hipcc 7.2 merges the four __builtin_amdgcn_permlane*_swap calls of a tile into one and
+      //  broadcasts its result; the s_nops cover the VALU-write -> permlane-swap -> VALU-read hazard slots the
+      //  compiler would otherwise insert itself)
+      float xs[4], ys[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float xv = x[r], yv = y[r];
+        if constexpr (geglu) asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(xv), "+v"(yv));
+        else asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(xv), "+v"(yv));
+        xs[r] = xv; ys[r] = yv;
+      }
+      if constexpr (geglu) {
+        float o[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = xs[r] * gelu_erf_f(ys[r]);
+        vm_store8(rowp + (nw0 >> 1) + ni * 8 + 4 * (g4 & 1), pack4<T>(o));
+      } else {
+        float o[8] = {xs[0], xs[1], xs[2], xs[3], ys[0], ys[1], ys[2], ys[3]};
+        if (a.residual) {
+          float rf[8];
+          unpack8<T>(q.res[ni][p], rf);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) o[j] += rf[j];
+        }
+        vm_store16(rowp + nw0 + ni * 16 + 8 * (g4 >> 1), pack8<T>(o));
+      }
+    }
+  }
+  return 2 * NT;
 }
 
 // WM = waves along the pixel axis: 2 -> 128-pixel tile, 4 waves, two blocks per CU;
@@ -497,22 +711,32 @@ __global__ __launch_bounds__(128 * WM, 2) void igemm_kernel(const IgemmArgs a) {
 
   // ---- epilogue -----------------------------------------------------------
   float* stage = reinterpret_cast<float*>(lds) + wave * (STAGE_BYTES / 4);
-  igemm_epilogue<T, NT, TR>(a, stage, acc, lane, group, n0 + wn * WAVE_N, m0 + wm * 64);
+  igemm_epilogue<T, NT, TR, 32>(a, stage, acc, lane, group, n0 + wn * WAVE_N, m0 + wm * 64);
 }
 
 // =========================================================================================================
 // Direct-to-LDS main loop (FAST shapes only):  256 pixels x (2 * WAVE_N) channels, 8 waves (4 x 2), THREE LDS
 // stages filled by global_load_lds_dwordx4 (no VGPR staging, no ds_write), one raw s_barrier per k-tile and a
 // COUNTED s_waitcnt vmcnt: the tile being multiplied is complete while the next tile's DMA stays in flight.
-//   iteration t:  wait(tile t landed) ; barrier ; issue DMA of tile t+2 into stage (t+2)%3 ; multiply stage t%3
-// The barrier also proves every wave finished reading stage (t-1)%3 == (t+2)%3 before it is overwritten.
+//   step i:  wait(k-tile i landed) ; barrier ; issue DMA of k-tile i+2 into stage (i+2)%3 ; multiply stage i%3
+// The barrier also proves every wave finished reading stage (i-1)%3 == (i+2)%3 before it is overwritten.
+//
+// PERSISTENT: one block per CU walks output tiles blockIdx.x, +gridDim.x, ...; the k-tile sequence runs on
+// ACROSS output tiles, so the first two k-tiles of the next output tile are already in flight while this tile's
+// epilogue runs (measured per output tile before: 3.1 us entry-to-first-tile + 1.2 us block turnaround, every
+// tile; now once per block).  The epilogue stages through the LDS stage of the tile's LAST k-tile, the only one
+// that is free at that point (the other two are DMA targets).
 // LDS image = [row][8 x 16 B], lane-linear per wave instruction (8 rows = 1 KiB); the XOR swizzle is applied on
 // the SOURCE side: the lane that fills slot s of row r fetches piece s ^ (r & 7).  Padded / out-of-range pieces
 // are fetched from the 16-byte zero block.
 // =========================================================================================================
-template <typename T, int NT, bool TR>
+// MODE 0: LDS-staged epilogue, row-major output    1: LDS-staged epilogue, transposed output
+//      2: register epilogue (plain)                  3: register epilogue (GEGLU)
+template <typename T, int NT, int MODE>
 __global__ __launch_bounds__(512, 2) void igemm_glds_kernel(const IgemmArgs a) {
   typedef typename Vec8<T>::type frag_t;
+  constexpr bool TR = MODE == 1;
+  constexpr bool DIRECT = MODE >= 2;
   constexpr int BM = 256;
   constexpr int WAVE_N = NT * 16;
   constexpr int BN = 2 * WAVE_N;
@@ -520,11 +744,11 @@ __global__ __launch_bounds__(512, 2) void igemm_glds_kernel(const IgemmArgs a) {
   constexpr int STAGE = X_TILE + W_TILE;
   constexpr int WJ = (BN + 63) / 64;                         // weight DMA instructions per thread and tile
   constexpr int PIECES = 4 + WJ;                             // DMA instructions per thread and tile
-  constexpr int STAGE_STRIDE = TR ? 36 : (WAVE_N + 4);
-  constexpr int STAGE_ROWS = TR ? WAVE_N : 32;
-  constexpr int EPI_BYTES = 8 * STAGE_ROWS * STAGE_STRIDE * 4;
-  constexpr int LDS_BYTES = 3 * STAGE > EPI_BYTES ? 3 * STAGE : EPI_BYTES;
-  __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
+  constexpr int RPP = 16;                                    // epilogue rows per pass: 8 wave stages fit one k-stage
+  constexpr int EPI_WAVE = EpiGeom<RPP, TR, NT>::BYTES;
+  static_assert(8 * EPI_WAVE <= STAGE, "the epilogue must fit the one free k-stage");
+  static_assert(PIECES == 6 || PIECES == 7, "vmcnt immediates below");
+  __shared__ __attribute__((aligned(16))) unsigned char lds[3 * STAGE];
   typedef __attribute__((address_space(3))) void* lds_ptr_t;
   typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
 
@@ -532,47 +756,56 @@ __global__ __launch_bounds__(512, 2) void igemm_glds_kernel(const IgemmArgs a) {
   const int wm = wave & 3, wn = wave >> 2;
   const int group = blockIdx.z;
   const int nblk = a.tiles_m * a.tiles_n;
-  const int L = xcd_remap(blockIdx.x, nblk);
-  const int tile_n = L % a.tiles_n, tile_m = L / a.tiles_n;
-  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  MOBI_STAMP_AT(0);
   const T* __restrict__ wgt = reinterpret_cast<const T*>(a.weight) + (long long)group * a.w_group_stride;
   const unsigned char* const zsrc = reinterpret_cast<const unsigned char*>(g_zero16);
 
   const int rloc = lane >> 3;                                // row inside the wave's 8-row DMA piece
   const int sg = (lane & 7) ^ rloc;                          // source piece that lands in this lane's slot
-  // activation rows of this thread: row_j = 8 * wave + rloc + 64 j
-  int x_gp[4], x_h[4], x_w[4];
-  unsigned x_okm = 0;
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int m = m0 + 8 * wave + rloc + 64 * j;
-    const bool ok = m < a.M;
-    x_okm |= ok ? (1u << j) : 0u;
-    const int mm = ok ? m : 0;
-    const int img = mm / a.hw_out, rem = mm - img * a.hw_out;
-    const int ho = rem / a.wout, wo = rem - ho * a.wout;
-    x_gp[j] = (group * a.imgs_per_group + img) * a.img_pix_stride;
-    x_h[j] = ho * a.stride - a.pad_h;
-    x_w[j] = wo * a.stride - a.pad_w;
-  }
-  // weight rows: j < WJ-1 (or all, when BN % 64 == 0): 8 * wave + rloc + 64 j; the last partial group of 32 rows is
-  // fetched by waves 0-3 and (identically, benign duplicate) by waves 4-7 so that every wave issues PIECES DMAs
-  const unsigned char* w_src[WJ];
-  int w_lds[WJ];
-#pragma unroll
-  for (int j = 0; j < WJ; ++j) {
-    const bool partial = (BN % 64 != 0) && (j == WJ - 1);
-    const int r = partial ? 64 * j + 8 * (wave & 3) + rloc : 64 * j + 8 * wave + rloc;
-    const int n = n0 + r;
-    w_lds[j] = (partial ? 64 * j + 8 * (wave & 3) : 64 * j + 8 * wave) * 128;
-    w_src[j] = n < a.n_packed ? reinterpret_cast<const unsigned char*>(wgt + (long long)n * a.ktot) + sg * 16 : nullptr;
-  }
   const int kt_begin = blockIdx.y * a.nk_per;
   const int kt_end = min(a.nk, kt_begin + a.nk_per);
   const int hlog = a.hin << a.up, wlog = a.win << a.up;
-  // wave-uniform tile state
-  int u_tap, u_ky, u_kx, u_c;
-  {
+
+  // ---- fetch side: state of the output tile whose k-tiles are being requested --------------------------------
+  int f_bid = blockIdx.x;                                    // output tile being fetched (>= nblk: nothing left)
+  int f_kt = kt_begin;                                       // its next k-tile
+  int f_slot = 0;                                            // LDS stage of the next request (0, 1, 2, 0, ...)
+  int x_gp[4], x_h[4], x_w[4];                               // activation rows of this thread: 8 * wave + rloc + 64 j
+  unsigned x_okm = 0;
+  const unsigned char* w_src[WJ];
+  int w_lds[WJ];
+  int u_tap = 0, u_ky = 0, u_kx = 0, u_c = 0;                // wave-uniform (tap, channel offset) of the next k-tile
+  unsigned f_row[4] = {0u, 0u, 0u, 0u};
+  unsigned f_okm = 0;
+  int f_tap = -1, f_src = -1;
+
+  auto set_fetch_tile = [&]() {
+    const int L = xcd_remap(f_bid, nblk);
+    const int tile_n = L % a.tiles_n, tile_m = L / a.tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    x_okm = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int m = m0 + 8 * wave + rloc + 64 * j;
+      const bool ok = m < a.M;
+      x_okm |= ok ? (1u << j) : 0u;
+      const int mm = ok ? m : 0;
+      const int img = mm / a.hw_out, rem = mm - img * a.hw_out;
+      const int ho = rem / a.wout, wo = rem - ho * a.wout;
+      x_gp[j] = (group * a.imgs_per_group + img) * a.img_pix_stride;
+      x_h[j] = ho * a.stride - a.pad_h;
+      x_w[j] = wo * a.stride - a.pad_w;
+    }
+    // weight rows: j < WJ-1 (or all, when BN % 64 == 0): 8 * wave + rloc + 64 j; the last partial group of 32 rows
+    // is fetched by waves 0-3 and (identically, benign duplicate) by waves 4-7 so that every wave issues PIECES DMAs
+#pragma unroll
+    for (int j = 0; j < WJ; ++j) {
+      const bool partial = (BN % 64 != 0) && (j == WJ - 1);
+      const int r = partial ? 64 * j + 8 * (wave & 3) + rloc : 64 * j + 8 * wave + rloc;
+      const int n = n0 + r;
+      w_lds[j] = (partial ? 64 * j + 8 * (wave & 3) : 64 * j + 8 * wave) * 128;
+      w_src[j] = n < a.n_packed ? reinterpret_cast<const unsigned char*>(wgt + (long long)n * a.ktot) + sg * 16 : nullptr;
+    }
     const long long c_first = (long long)kt_begin * 64;
     if (a.k_order) {                       // channel-chunk-major k: tile = (64-channel chunk, tap), taps innermost
       const int taps_ = a.kh * a.kw;
@@ -582,13 +815,16 @@ __global__ __launch_bounds__(512, 2) void igemm_glds_kernel(const IgemmArgs a) {
       u_tap = (int)(c_first / a.C); u_c = (int)(c_first - (long long)u_tap * a.C);
     }
     u_ky = u_tap / a.kw; u_kx = u_tap - u_ky * a.kw;
-  }
-  unsigned f_row[4] = {0u, 0u, 0u, 0u};
-  unsigned f_okm = 0;
-  int f_tap = -1, f_src = -1;
+    f_tap = -1; f_src = -1;
+  };
 
-  auto issue_tile = [&](int kt) {                            // kt < kt_end guaranteed by the caller
-    unsigned char* st = lds + ((kt - kt_begin) % 3) * STAGE;
+  // request the next k-tile of the sequence (caller checked f_bid < nblk) and advance the sequence
+  // every vector-memory instruction this wave issues is counted (wave-uniform); mk0 / mk1 / mk2 = the count right
+  // after the requests of the oldest / next / youngest k-tile that has not been multiplied yet
+  int vm_issued = 0, mk0 = 0, mk1 = 0, mk2 = 0;
+  auto issue_next = [&]() {
+    unsigned char* st = lds + f_slot * STAGE;
+    f_slot = f_slot == 2 ? 0 : f_slot + 1;
     const int src = u_c >= a.c0 ? 1 : 0;
     if (u_tap != f_tap || src != f_src) {
       f_tap = u_tap; f_src = src; f_okm = 0;
@@ -608,13 +844,18 @@ __global__ __launch_bounds__(512, 2) void igemm_glds_kernel(const IgemmArgs a) {
       const unsigned char* g = ((f_okm >> j) & 1u) ? xbase + f_row[j] : zsrc;
       __builtin_amdgcn_global_load_lds((gbl_ptr_t)g, (lds_ptr_t)(st + (8 * wave + 64 * j) * 128), 16, 0, 0);
     }
-    const unsigned kb = (unsigned)kt * 128u;
+    const unsigned kb = (unsigned)f_kt * 128u;
 #pragma unroll
     for (int j = 0; j < WJ; ++j) {
       const unsigned char* g = w_src[j] ? w_src[j] + kb : zsrc;
       __builtin_amdgcn_global_load_lds((gbl_ptr_t)g, (lds_ptr_t)(st + X_TILE + w_lds[j]), 16, 0, 0);
     }
-    if (a.k_order) {
+    vm_issued += PIECES;
+    if (++f_kt == kt_end) {                                  // the sequence moves on to this block's next output tile
+      f_kt = kt_begin;
+      f_bid += gridDim.x;
+      if (f_bid < nblk) set_fetch_tile();
+    } else if (a.k_order) {
       ++u_tap;
       if (++u_kx == a.kw) { u_kx = 0; if (++u_ky == a.kh) { u_ky = 0; u_tap = 0; u_c += 64; } }
     } else {
@@ -623,72 +864,110 @@ __global__ __launch_bounds__(512, 2) void igemm_glds_kernel(const IgemmArgs a) {
     }
   };
 
-  f32x4 acc[NT][4];
-#pragma unroll
-  for (int i = 0; i < NT; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   const int r16 = lane & 15, g4 = lane >> 4;
+  f32x4 acc[NT][4];
 
-  if (kt_begin < kt_end) issue_tile(kt_begin);
-  if (kt_begin + 1 < kt_end) issue_tile(kt_begin + 1);
-  for (int kt = kt_begin; kt < kt_end; ++kt) {
-    // tile kt has landed once at most ONE younger tile's DMAs (PIECES per thread) are still outstanding
-    if (kt + 1 < kt_end) {
-      if constexpr (PIECES == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    } else {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (kt_begin >= kt_end) return;                            // never launched: the host trims empty split-K ranges
+
+  set_fetch_tile();
+  int ahead = 0;                                             // requested k-tiles not yet multiplied
+  int c_slot = 0;                                            // LDS stage of the k-tile to multiply next
+  issue_next(); ++ahead; mk0 = vm_issued;
+  if (f_bid < nblk) { issue_next(); ++ahead; mk1 = vm_issued; }
+  DirectEpiRegs<DIRECT ? NT : 1> dq;
+  MOBI_PHASE_DECL;
+
+  for (int bid = blockIdx.x; bid < nblk; bid += gridDim.x) {
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int L = xcd_remap(bid, nblk);
+    const int nw0 = (L % a.tiles_n) * BN + wn * WAVE_N, mw0 = (L / a.tiles_n) * BM + wm * 64;
+    int mk_req = 0;
+    if constexpr (DIRECT) {                                  // bias / residual rows of this output tile: in flight
+      vm_issued += direct_epilogue_request<T, NT>(a, dq, lane, group, nw0, mw0);      // for the whole k loop
+      mk_req = vm_issued;
     }
-    __builtin_amdgcn_s_barrier();
-    const unsigned char* st = lds + ((kt - kt_begin) % 3) * STAGE;
-    const unsigned char* xb = st + (wm * 64 + r16) * 128;
-    const unsigned char* wb = st + X_TILE + (wn * WAVE_N + r16) * 128;
-#if MOBI_FRAG2
-    {
-      // all fragments of the tile are requested up front (two register sets): one exposed LDS latency per tile
-      frag_t xf[2][4], wf[2][NT];
+
+    for (int kt = kt_begin; kt < kt_end; ++kt) {
+      // the oldest requested k-tile has landed once only operations issued AFTER its requests are outstanding
+      // (vector-memory operations retire in issue order).  LDS-staged epilogues issue loads / stores that are not
+      // counted: under-counting only makes the wait stricter.
+      MOBI_PHASE(0);
+      wait_vmcnt_le(vm_issued - mk0);
+      MOBI_PHASE(1);
+      __builtin_amdgcn_s_barrier();
+      MOBI_PHASE(2);
+#if MOBI_STAMP
+      if (kt == kt_begin && bid == (int)blockIdx.x) MOBI_STAMP_AT(1);
+#endif
+      const unsigned char* st = lds + c_slot * STAGE;
+      const unsigned char* xb = st + (wm * 64 + r16) * 128;
+      const unsigned char* wb = st + X_TILE + (wn * WAVE_N + r16) * 128;
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
+        // the DMA of the k-tile two steps ahead is issued between the two k-steps: its (expensive) issue slots
+        // then sit in the shadow of the first k-step's MFMAs instead of delaying the first fragment reads
+        if (ks == MOBI_DMA_KS) MOBI_PHASE(3);
+        if (ks == MOBI_DMA_KS && f_bid < nblk) {
+          issue_next(); ++ahead;
+          if (ahead == 2) mk1 = vm_issued; else mk2 = vm_issued;
+        }
+        if (ks == MOBI_DMA_KS) MOBI_PHASE(4);
         const int sw = ((ks * 4 + g4) ^ (r16 & 7)) << 4;
+        frag_t xf[4], wf[NT];
 #pragma unroll
-        for (int mi = 0; mi < 4; ++mi) xf[ks][mi] = __builtin_bit_cast(frag_t, ld16(xb + mi * 16 * 128 + sw));
+        for (int mi = 0; mi < 4; ++mi) xf[mi] = __builtin_bit_cast(frag_t, ld16(xb + mi * 16 * 128 + sw));
 #pragma unroll
-        for (int ni = 0; ni < NT; ++ni) wf[ks][ni] = __builtin_bit_cast(frag_t, ld16(wb + ni * 16 * 128 + sw));
-      }
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        if (ks == MOBI_DMA_KS && kt + 2 < kt_end) issue_tile(kt + 2);
+        for (int ni = 0; ni < NT; ++ni) wf[ni] = __builtin_bit_cast(frag_t, ld16(wb + ni * 16 * 128 + sw));
 #pragma unroll
         for (int ni = 0; ni < NT; ++ni)
 #pragma unroll
           for (int mi = 0; mi < 4; ++mi)
-            acc[ni][mi] = TR ? mfma16(xf[ks][mi], wf[ks][ni], acc[ni][mi]) : mfma16(wf[ks][ni], xf[ks][mi], acc[ni][mi]);
+            acc[ni][mi] = TR ? mfma16(xf[mi], wf[ni], acc[ni][mi]) : mfma16(wf[ni], xf[mi], acc[ni][mi]);
       }
+      MOBI_PHASE(5);
+      MOBI_PHASE_ACC();
+      --ahead; mk0 = mk1; mk1 = mk2;
+      if (kt + 1 < kt_end) c_slot = c_slot == 2 ? 0 : c_slot + 1;
     }
-#else
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      // the DMA of tile kt+2 is issued between the two k-steps: its (expensive) issue slots then sit in the
-      // shadow of the first k-step's MFMAs instead of delaying the first fragment reads after the barrier
-      if (ks == MOBI_DMA_KS && kt + 2 < kt_end) issue_tile(kt + 2);
-      const int sw = ((ks * 4 + g4) ^ (r16 & 7)) << 4;
-      frag_t xf[4], wf[NT];
-#pragma unroll
-      for (int mi = 0; mi < 4; ++mi) xf[mi] = __builtin_bit_cast(frag_t, ld16(xb + mi * 16 * 128 + sw));
-#pragma unroll
-      for (int ni = 0; ni < NT; ++ni) wf[ni] = __builtin_bit_cast(frag_t, ld16(wb + ni * 16 * 128 + sw));
-#pragma unroll
-      for (int ni = 0; ni < NT; ++ni)
-#pragma unroll
-        for (int mi = 0; mi < 4; ++mi)
-          acc[ni][mi] = TR ? mfma16(xf[mi], wf[ni], acc[ni][mi]) : mfma16(wf[ni], xf[mi], acc[ni][mi]);
+    if constexpr (DIRECT) {
+      // registers only: no barrier, the waves drift by at most one epilogue until the next k-tile's barrier
+      MOBI_STAMP_AT(2);
+      wait_vmcnt_le(vm_issued - mk_req);                     // bias / residual registers are complete
+      vm_issued += direct_epilogue<T, NT, MODE == 3>(a, acc, dq, lane, group, nw0, mw0);
+    } else {
+      // every wave is past its last fragment read of stage c_slot: it is free until the k-tile three steps on is
+      // requested, which happens after the next barrier, i.e. after every wave has left this epilogue
+      __syncthreads();
+      MOBI_STAMP_AT(2);
+      float* stage = reinterpret_cast<float*>(lds + c_slot * STAGE) + wave * (EPI_WAVE / 4);
+      igemm_epilogue<T, NT, TR, RPP>(a, stage, acc, lane, group, nw0, mw0);
     }
-#endif
+    c_slot = c_slot == 2 ? 0 : c_slot + 1;
   }
-  __syncthreads();                                           // every wave is past its last fragment read
-  float* stage = reinterpret_cast<float*>(lds) + wave * (STAGE_ROWS * STAGE_STRIDE);
-  igemm_epilogue<T, NT, TR>(a, stage, acc, lane, group, n0 + wn * WAVE_N, m0 + wm * 64);
+#if MOBI_STAMP
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // the stamp then covers this wave's stores too
+  MOBI_STAMP_AT(3);
+  if (g_stamps && threadIdx.x == 0) {
+    unsigned hw, xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    unsigned long long* d = g_stamps + (size_t)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) * 8;
+    d[4] = ((unsigned long long)xcc << 32) | hw;
+    d[5] = (unsigned long long)(kt_end - kt_begin);
+    d[6] = (unsigned long long)((nblk - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x);
+  }
+#if MOBI_STAMP == 2
+  if (g_phase && lane == 0) {
+    unsigned long long* d = g_phase + ((size_t)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) * 8 + wave) * 8;
+    for (int i = 0; i < 5; ++i) d[i] = ph_acc[i];
+    d[5] = ph_n;
+  }
+#endif
+#endif
 }
 
 // split-K finish: sum the partial slabs, then the ordinary epilogue (bias, per-image vector, residual)
@@ -740,6 +1019,21 @@ __global__ __launch_bounds__(256) void igemm_splitk_reduce_kernel(const IgemmArg
   }
 }
 
+// CUs of the current device (cached per device ordinal); 256 on MI355X.  MOBI_IGEMM_PERSIST_BLOCKS overrides the
+// persistent grid size (tests: few blocks walk many output tiles).
+static int compute_units() {
+  if (const char* e = getenv("MOBI_IGEMM_PERSIST_BLOCKS")) { const int v = atoi(e); if (v > 0) return v; }
+  static int cached[64] = {0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+  if (!cached[dev]) {
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    cached[dev] = n;
+  }
+  return cached[dev];
+}
+
 template <typename T>
 static int launch_igemm(const mobi_igemm_params* p, const IgemmArgs& a, int groups, hipStream_t st) {
   const bool tr = p->out_mode == MOBI_OUT_TRANSPOSED;
@@ -752,11 +1046,17 @@ static int launch_igemm(const mobi_igemm_params* p, const IgemmArgs& a, int grou
 #define MOBI_IGEMM_BY_TR(NT_, WM_) \
   do { if (tr) MOBI_IGEMM_BY_FAST(NT_, true, WM_); else MOBI_IGEMM_BY_FAST(NT_, false, WM_); } while (0)
   if (a.wm == 4 && a.fast && a.glds) {
+    // persistent: one 156-KB-LDS block per CU walks the output tiles
     dim3 block(512);
-    if (nt5) { if (tr) hipLaunchKernelGGL((igemm_glds_kernel<T, 5, true>), grid, block, 0, st, a);
-               else    hipLaunchKernelGGL((igemm_glds_kernel<T, 5, false>), grid, block, 0, st, a); }
-    else     { if (tr) hipLaunchKernelGGL((igemm_glds_kernel<T, 4, true>), grid, block, 0, st, a);
-               else    hipLaunchKernelGGL((igemm_glds_kernel<T, 4, false>), grid, block, 0, st, a); }
+    dim3 pgrid(grid.x < (unsigned)compute_units() ? grid.x : (unsigned)compute_units(), grid.y, grid.z);
+    const int mode = tr ? 1 : (a.epi_direct ? (a.epilogue == MOBI_EPI_GEGLU ? 3 : 2) : 0);
+#define MOBI_GLDS_LAUNCH(NT_, MODE_) hipLaunchKernelGGL((igemm_glds_kernel<T, NT_, MODE_>), pgrid, block, 0, st, a)
+#define MOBI_GLDS_BY_MODE(NT_)                                                                     \
+  do { switch (mode) { case 0: MOBI_GLDS_LAUNCH(NT_, 0); break; case 1: MOBI_GLDS_LAUNCH(NT_, 1); break; \
+                       case 2: MOBI_GLDS_LAUNCH(NT_, 2); break; default: MOBI_GLDS_LAUNCH(NT_, 3); break; } } while (0)
+    if (nt5) MOBI_GLDS_BY_MODE(5); else MOBI_GLDS_BY_MODE(4);
+#undef MOBI_GLDS_BY_MODE
+#undef MOBI_GLDS_LAUNCH
   }
   else if (a.wm == 4) { if (nt5) MOBI_IGEMM_BY_TR(5, 4); else MOBI_IGEMM_BY_TR(4, 4); }
   else                { if (nt5) MOBI_IGEMM_BY_TR(5, 2); else MOBI_IGEMM_BY_TR(4, 2); }
@@ -779,6 +1079,7 @@ static int plan_splits(long long M, int n_packed, int ktot) {
   const long long tiles = ((M + 127) / 128) * ((n_packed + bn - 1) / bn);
   const int nk = (ktot + 63) / 64;
   if (tiles >= 384 || nk < 16) return 1;
+  if (tiles >= 256 && nk < 40) return 1;        // measured (tools/sweep_split.py): one full wave of blocks, short k
   long long s = (512 + tiles - 1) / tiles;
   if (s > 8) s = 8;
   if (s > nk / 8) s = nk / 8;
@@ -786,6 +1087,17 @@ static int plan_splits(long long M, int n_packed, int ktot) {
 }
 
 }  // namespace mobi
+
+#if MOBI_STAMP
+extern "C" int mobi_debug_set_stamps(void* buf) {
+  return hipMemcpyToSymbol(HIP_SYMBOL(mobi::g_stamps), &buf, sizeof(void*)) == hipSuccess ? MOBI_OK : MOBI_ERR_LAUNCH;
+}
+#endif
+#if MOBI_STAMP == 2
+extern "C" int mobi_debug_set_phases(void* buf) {
+  return hipMemcpyToSymbol(HIP_SYMBOL(mobi::g_phase), &buf, sizeof(void*)) == hipSuccess ? MOBI_OK : MOBI_ERR_LAUNCH;
+}
+#endif
 
 extern "C" int mobi_igemm_plan_splits(const mobi_igemm_params* p) {
   if (!p || p->groups != 1 || p->epilogue != MOBI_EPI_NONE || p->out_mode == MOBI_OUT_TRANSPOSED) return 1;
@@ -813,6 +1125,7 @@ extern "C" int mobi_igemm(const mobi_igemm_params* p, void* stream) {
   if (p->out_mode != MOBI_OUT_TRANSPOSED && (p->cout & 7)) return MOBI_ERR_UNSUPPORTED;
   if (geglu && (p->out_mode != MOBI_OUT_ROWS || p->rowvec || p->residual)) return MOBI_ERR_UNSUPPORTED;
   if (!geglu && p->n_packed != p->cout) return MOBI_ERR_ARG;
+  if (geglu && p->n_packed != 2 * p->cout) return MOBI_ERR_ARG;
   if (p->out_mode == MOBI_OUT_TRANSPOSED && (p->rowvec || p->residual)) return MOBI_ERR_UNSUPPORTED;
   if ((reinterpret_cast<uintptr_t>(p->bias) | reinterpret_cast<uintptr_t>(p->rowvec)) & 15) return MOBI_ERR_ALIGN;
   if (p->rowvec && (p->rowvec_stride & 3)) return MOBI_ERR_ALIGN;
@@ -874,10 +1187,14 @@ extern "C" int mobi_igemm(const mobi_igemm_params* p, void* stream) {
   if (p->split_k > 1) {
     if (!p->ws || p->groups != 1 || geglu || p->out_mode == MOBI_OUT_TRANSPOSED || p->split_k > 64) return MOBI_ERR_UNSUPPORTED;
     if (reinterpret_cast<uintptr_t>(p->ws) & 15) return MOBI_ERR_ALIGN;
-    a.splits = p->split_k;
-    a.nk_per = (a.nk + a.splits - 1) / a.splits;
+    a.nk_per = (a.nk + p->split_k - 1) / p->split_k;
+    a.splits = (a.nk + a.nk_per - 1) / a.nk_per;            // no empty k ranges: every slab that is summed is written
     a.split_ws = reinterpret_cast<float*>(p->ws);
   }
+  // register epilogue of the direct-to-LDS kernel: every tile full, row-major T output, no per-image vector
+  a.epi_direct = a.wm == 4 && a.fast && a.glds && p->out_mode == MOBI_OUT_ROWS && !p->rowvec && !a.split_ws &&
+                 a.M % 256 == 0 && p->n_packed % bn == 0 && a.nk_per >= 3;
+  if (const char* e = getenv("MOBI_IGEMM_EPI_DIRECT")) a.epi_direct = a.epi_direct && e[0] != '0';
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   return p->dtype == MOBI_F16 ? launch_igemm<f16_t>(p, a, p->groups, st) : launch_igemm<bf16_t>(p, a, p->groups, st);
 }

@@ -31,8 +31,8 @@ def set_profiler(sink):
 class _Timed:
     """Brackets one launch with events on the launch stream when a profiler is installed."""
 
-    def __init__(self, kind, flops, nbytes=0.0):
-        self.kind, self.flops, self.nbytes = kind, flops, nbytes
+    def __init__(self, kind, flops, nbytes=0.0, tag=""):
+        self.kind, self.flops, self.nbytes, self.tag = kind, flops, nbytes, tag
 
     def __enter__(self):
         if _PROFILE is not None:
@@ -43,7 +43,7 @@ class _Timed:
     def __exit__(self, *exc):
         if _PROFILE is not None:
             self.e1.record()
-            _PROFILE.append((self.kind, self.flops, self.e0, self.e1, self.nbytes))
+            _PROFILE.append((self.kind, self.flops, self.e0, self.e1, self.nbytes, self.tag))
         return False
 
 
@@ -158,16 +158,12 @@ def pack_linear(weight, bias, dtype, device):
 
 
 def geglu_layout(inner):
-    """(unit, n_packed) of the packed GEGLU projection: rows are grouped in units of
-    `unit` value columns followed by `unit` gate columns; unit = 40 when the igemm runs its
-    80-column wave tile (n_packed % 160 == 0), else 32 with a 64-column wave tile."""
-    if inner % 40 == 0 and (2 * inner) % 160 == 0:
-        return 40, 2 * inner
-    units = (inner + 31) // 32
-    n_packed = units * 64
-    if n_packed % 160 == 0:            # keep the kernel on its 64-column wave tile
-        n_packed += 64
-    return 32, n_packed
+    """(unit, n_packed) of the packed GEGLU projection: every 16-row MFMA tile of the packed matrix holds
+    `unit` = 8 value rows followed by the 8 gate rows of the same outputs, so that a value and its gate sit in
+    lanes 32 apart of one accumulator tile (one v_permlane32_swap pairs them in the register epilogue)."""
+    if inner % 8:
+        raise ValueError("GEGLU inner width must be a multiple of 8")
+    return 8, 2 * inner
 
 
 def pack_geglu(weight, bias, dtype, device):
@@ -177,15 +173,9 @@ def pack_geglu(weight, bias, dtype, device):
     unit, n_packed = geglu_layout(inner)
     w = weight.detach().to(device=device, dtype=torch.float32)
     b = bias.detach().to(device=device, dtype=torch.float32)
-    wp = torch.zeros(n_packed, cin, device=device, dtype=torch.float32)
-    bp = torch.zeros(n_packed, device=device, dtype=torch.float32)
-    for u in range((inner + unit - 1) // unit):
-        lo, hi = u * unit, min(inner, (u + 1) * unit)
-        n = hi - lo
-        wp[2 * u * unit: 2 * u * unit + n] = w[lo:hi]
-        wp[2 * u * unit + unit: 2 * u * unit + unit + n] = w[inner + lo: inner + hi]
-        bp[2 * u * unit: 2 * u * unit + n] = b[lo:hi]
-        bp[2 * u * unit + unit: 2 * u * unit + unit + n] = b[inner + lo: inner + hi]
+    t = inner // unit
+    wp = torch.stack([w[:inner].reshape(t, unit, cin), w[inner:].reshape(t, unit, cin)], dim=1).reshape(n_packed, cin)
+    bp = torch.stack([b[:inner].reshape(t, unit), b[inner:].reshape(t, unit)], dim=1).reshape(n_packed)
     return Packed(wp.to(dtype).contiguous(), bp.contiguous(), 1, 1, cin, inner, n_packed, geglu=True)
 
 
@@ -249,7 +239,9 @@ def igemm(x, pw: Packed, *, x2=None, stride=1, pad=None, upsample=False, hout=No
     flops = 2.0 * n * hout * wout * (pw.n_packed if pw.geglu else pw.cout) * pw.kh * pw.kw * pw.cin
     nbytes = (x.numel() + (0 if x2 is None else x2.numel())) * 2 + pw.w.numel() * 2 * (n if weight_per_image else 1) \
         + out.numel() * out.element_size() + (0 if residual is None else residual.numel() * 2)
-    with _Timed("igemm", flops, nbytes):
+    tag = f"m={n * hout * wout} n={pw.n_packed} k={pw.kh * pw.kw * pw.cin} tap={pw.kh}x{pw.kw} split={splits} mode={out_mode}" \
+        if _PROFILE is not None else ""
+    with _Timed("igemm", flops, nbytes, tag):
         _lib.check(lib.mobi_igemm(C.byref(p), _stream()), "mobi_igemm")
     return out
 
@@ -316,7 +308,7 @@ def attention(q, k, vt, heads, scale):
     for t_ in (q, k, vt):
         assert t_.shape[2] == 1 or t_.stride(2) == 1
     p.images, p.heads, p.dh, p.tq, p.tk, p.scale, p.dtype = n, heads, dh, tq, tk, scale, _dt(q.dtype)
-    with _Timed("attention", 4.0 * n * heads * tq * tk * dh):
+    with _Timed("attention", 4.0 * n * heads * tq * tk * dh, 0.0, f"n={n} heads={heads} tq={tq} tk={tk} dh={dh}"):
         _lib.check(lib.mobi_attention(C.byref(p), _stream()), "mobi_attention")
     return out
 

@@ -401,3 +401,47 @@ def test_igemm_block_heights(ops, dtype, wm, monkeypatch):
     xs_f, xs_d = rnd("bh.xs", (2, 304, 320), dtype)
     yt = ops.linear(xs_d, ops.pack_linear(wv, None, dtype, "cuda"), out_mode=OUT_TRANSPOSED)
     assert rel(yt.float(), F.linear(xs_f, wv).permute(0, 2, 1)) < TOL[dtype] * 0.5
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("blocks", [None, "3"])
+def test_igemm_persistent_register_epilogue(ops, dtype, blocks, monkeypatch):
+    """The persistent direct-to-LDS kernel on full 256-pixel tiles: register epilogue (lane-row exchange, counted
+    vector-memory waits) vs the LDS-staged epilogue of the same kernel, both against the fp32 reference.
+    1x1 + bias + residual (80- and 64-column wave tiles), 3x3 over two sources, GEGLU.
+    blocks="3": three persistent blocks walk all output tiles, so the k-tile sequence rolls across many tiles."""
+    monkeypatch.setenv("MOBI_IGEMM_WM", "4")
+    if blocks:
+        monkeypatch.setenv("MOBI_IGEMM_PERSIST_BLOCKS", blocks)
+    xf, xd = rnd("pd.x", (4, 32, 32, 320), dtype)
+    rf, rd = rnd("pd.r", (4, 32, 32, 320), dtype)
+    r2f, r2d = rnd("pd.r2", (4, 32, 32, 128), dtype)
+    x1f, x1d = rnd("pd.x1", (4, 32, 32, 64), dtype)
+    w1 = torch.from_numpy(W.synth_param("pd.w1", (320, 320, 1, 1))).to(dtype).float()
+    b1 = torch.from_numpy(W.synth_param("pd.b1", (320,)))
+    w2 = torch.from_numpy(W.synth_param("pd.w2", (128, 320, 1, 1))).to(dtype).float()
+    w3 = torch.from_numpy(W.synth_param("pd.w3", (320, 384, 3, 3))).to(dtype).float()
+    b3 = torch.from_numpy(W.synth_param("pd.b3", (320,)))
+    wg = torch.from_numpy(W.synth_param("pd.wg", (2560, 320))).to(dtype).float()
+    bg = torch.from_numpy(W.synth_param("pd.bg", (2560,)))
+    ref1 = _conv_ref(xf, w1, b1, pad=(0, 0)) * 0.5 + 0.5 * b1 + rf          # scale applies before the bias
+    ref2 = _conv_ref(xf, w2, None, pad=(0, 0)) + r2f
+    ref3 = _conv_ref(torch.cat([xf, x1f], 3), w3, b3)
+    a, gate = F.linear(xf.reshape(4, 1024, 320), wg, bg).chunk(2, dim=-1)
+    refg = a * F.gelu(gate)
+    p1, p2 = ops.pack_conv(w1, b1, dtype, "cuda"), ops.pack_conv(w2, None, dtype, "cuda")
+    p3, pg = ops.pack_conv(w3, b3, dtype, "cuda"), ops.pack_geglu(wg, bg, dtype, "cuda")
+    outs = {}
+    for direct in ("1", "0"):
+        monkeypatch.setenv("MOBI_IGEMM_EPI_DIRECT", direct)
+        y1 = ops.igemm(xd, p1, residual=rd, scale=0.5)
+        y2 = ops.igemm(xd, p2, residual=r2d)
+        y3 = ops.igemm(xd, p3, x2=x1d)
+        yg = ops.linear(xd.view(4, 1024, 320), pg)
+        assert rel(y1.float(), ref1) < TOL[dtype] * 0.5, direct
+        assert rel(y2.float(), ref2) < TOL[dtype] * 0.5, direct
+        assert rel(y3.float(), ref3) < TOL[dtype] * 0.5, direct
+        assert rel(yg.float(), refg) < TOL[dtype], direct
+        outs[direct] = (y1, y2, y3, yg)
+    for ya, yb in zip(outs["1"], outs["0"]):                      # same fp32 arithmetic, one rounding: near-identical
+        assert rel(ya.float(), yb.float()) < 2e-3

@@ -1,0 +1,71 @@
+#!/usr/bin/env python3
+"""Split-K plan sweep: times the step's small-m igemm shapes at several split factors (one process, same box).
+
+    python tools/sweep_split.py [--dtype bf16] [--iters 30]
+"""
+import argparse
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+SHAPES = [  # (images, hw, cin, cout, k)
+    (16, 16, 1280, 1280, 1), (8, 16, 1280, 1280, 1), (16, 8, 1280, 1280, 1), (8, 8, 1280, 1280, 1),
+    (16, 16, 5120, 1280, 1), (16, 16, 2560, 1280, 1), (16, 8, 2560, 1280, 1), (16, 8, 5120, 1280, 1),
+    (16, 16, 1280, 1280, 3), (16, 16, 2560, 1280, 3), (16, 8, 1280, 1280, 3), (16, 8, 2560, 1280, 3),
+    (16, 16, 640, 1280, 3), (16, 32, 320, 640, 3), (16, 32, 640, 640, 1), (8, 32, 640, 640, 1),
+    (16, 32, 640, 640, 3), (16, 32, 1280, 640, 3),
+]
+
+
+def timeit(fn, iters, warm=6):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e3 / iters
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--dtype", default="bf16")
+    ap.add_argument("--iters", type=int, default=30)
+    a = ap.parse_args()
+    from mobi_amd import build, ops
+    build.build(verbose=False)
+    dt = torch.bfloat16 if a.dtype == "bf16" else torch.float16
+    g = torch.Generator().manual_seed(0)
+    for images, hw, cin, cout, k in SHAPES:
+        x = torch.randn(images, hw, hw, cin, generator=g).cuda().to(dt)
+        w = torch.randn(cout, cin, k, k, generator=g) / (k * cin ** 0.5)
+        pw = ops.pack_conv(w, torch.zeros(cout), dt, "cuda")
+        res = torch.randn(images, hw, hw, cout, generator=g).cuda().to(dt)
+        nk = k * k * cin // 64
+        fl = 2.0 * images * hw * hw * cout * cin * k * k
+        line = f"m={images * hw * hw:6d} n={cout:5d} k={k * k * cin:6d} nk={nk:4d} planned={'-':>2s}:"
+        cells = []
+        planned = timeit(lambda: ops.igemm(x, pw, residual=res), a.iters)
+        planned = timeit(lambda: ops.igemm(x, pw, residual=res), a.iters)
+        for wm in ("2", "4"):
+            os.environ["MOBI_IGEMM_WM"] = wm
+            for s in (1, 2, 3, 4, 6, 8, 12, 16):
+                if s > 1 and nk // s < 4:
+                    continue
+                us = timeit(lambda: ops.igemm(x, pw, residual=res, split_k=s), a.iters)
+                cells.append((us, s, wm))
+        os.environ.pop("MOBI_IGEMM_WM", None)
+        best = min(cells)
+        print(f"m={images * hw * hw:6d} n={cout:5d} k={k * k * cin:6d} nk={nk:4d} plan={planned:7.1f}us | " +
+              " ".join(f"{'r' if wm == '2' else 'g'}{s}={us:5.1f}" for us, s, wm in cells) +
+              f" | best {'reg128' if best[2] == '2' else 'glds256'} s{best[1]} {best[0]:6.1f}us {fl / best[0] / 1e6:6.0f} TF", flush=True)
+
+
+if __name__ == "__main__":
+    main()
