@@ -157,11 +157,14 @@ int mobi_layernorm(const mobi_layernorm_params* p, void* stream);
 typedef struct mobi_attention_params {
   const void* q;  int64_t q_img_stride;  int32_t q_row_stride;    /* T [image][tq][...], head h at column h*dh */
   const void* k;  int64_t k_img_stride;  int32_t k_row_stride;    /* T [image][tk][...]                         */
-  const void* vt; int64_t vt_img_stride; int32_t vt_row_stride;   /* T [image][heads*dh][tk...]                 */
+  const void* vt; int64_t vt_img_stride; int32_t vt_row_stride;   /* v_layout 0: T [image][heads*dh][tk...] (V^T)
+                                                                     v_layout 1: T [image][tk][...] (V rows, head
+                                                                     h at column h*dh, like k)                  */
   void* out;      int64_t out_img_stride; int32_t out_row_stride; /* T [image][tq][heads*dh]                    */
   int32_t images, heads, dh, tq, tk;
   float scale;
   int32_t dtype;
+  int32_t v_layout;      /* 0: vt holds V transposed; 1: vt holds V row-major (q|k|v stacked projections)       */
 } mobi_attention_params;
 int mobi_attention(const mobi_attention_params* p, void* stream);
 

@@ -52,7 +52,7 @@ class AttentionParams(C.Structure):
                 ("vt", vp), ("vt_img_stride", i64), ("vt_row_stride", i32),
                 ("out", vp), ("out_img_stride", i64), ("out_row_stride", i32),
                 ("images", i32), ("heads", i32), ("dh", i32), ("tq", i32), ("tk", i32), ("scale", f32),
-                ("dtype", i32)]
+                ("dtype", i32), ("v_layout", i32)]
 
 
 class CtxAttentionParams(C.Structure):

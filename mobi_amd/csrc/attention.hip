@@ -8,10 +8,15 @@
 // are per-lane scalars and the only cross-lane step is one xor-32 shuffle.
 //   O^T[d][q]   += V^T[d][key] . P^T[key][q]
 // P^T is the S^T accumulator itself, converted to T in registers and fed straight back
-// as the B operand (no LDS round trip); V arrives already transposed ([channel][token],
-// written by the V projection's transposed epilogue), so its A fragments are two
-// 8-byte LDS reads in the accumulator's permuted key order
+// as the B operand (no LDS round trip), so the A fragments of V^T must follow the accumulator's
+// permuted key order
 //   key(j, half) = 16 s + 8 (j >> 2) + 4 half + (j & 3).
+// Two V layouts:
+//   v_layout 1 (production): V row-major [token][channel], e.g. the v columns of a stacked q|k|v projection.
+//     The tile is staged like K ([key][d] rows) and the A fragments come from gfx950's transposing LDS read
+//     ds_read_b64_tr_b16 (a 4-key x 16-channel block per 16 lanes, delivered channel-major).
+//   v_layout 0: V already transposed [channel][token] (written by a projection's transposed epilogue); the LDS
+//     image is key-permuted so that a fragment is one 16-byte read.
 // LDS row strides are odd multiples of the access width (bank-conflict free reads).
 #include "common.h"
 
@@ -20,7 +25,7 @@ namespace mobi {
 struct AttnArgs {
   const void* q; long long q_img; int q_row;
   const void* k; long long k_img; int k_row;
-  const void* vt; long long vt_img; int vt_row;
+  const void* vt; long long vt_img; int vt_row;      // v_layout 1: V rows [tk][vt_row]; 0: V^T rows [C][vt_row]
   void* out; long long out_img; int out_row;
   int heads, dh, tq, tk;
   float scale;
@@ -28,16 +33,22 @@ struct AttnArgs {
 
 // VVEC: every V^T row start is 16-byte aligned (tk % 8 == 0 rows), the production case; the generic
 // variant loads ragged V^T rows element-wise.  WPS = waves per SIMD the register budget is held to.
-template <typename T, int KS, bool VVEC, int WPS>
+// VMODE 0: V^T, generic (ragged rows, element loads)   1: V^T, 16-byte aligned rows   2: V row-major (tr reads)
+template <typename T, int KS, int VMODE, int WPS>
 __global__ __launch_bounds__(256, WPS) void attention_kernel(const AttnArgs a) {
   typedef typename Vec8<T>::type frag_t;
+  constexpr bool VVEC = VMODE == 1;
+  constexpr bool VROWS = VMODE == 2;
   constexpr int DT = (KS + 1) / 2;                 // 32-row tiles of the head dim for P.V
   constexpr int KSTR = KS * 32 + 16;               // bytes per K row in LDS (odd multiple of 16)
-  constexpr int VSTR = 144;                        // bytes per V^T row in LDS (odd multiple of 16)
+  // V^T image: 144-byte rows of 64 permuted keys.  V-rows image: [key][DT*32 channels], row stride an odd
+  // multiple of 64 bytes: the 4 key rows x 64 bytes a 32-lane half reads per ds_read_b64_tr_b16 then cover all
+  // 64 banks exactly once.
+  constexpr int VSTR = VROWS ? ((DT & 1) ? DT * 64 : DT * 64 + 64) : 144;
   constexpr int K_BYTES = 64 * KSTR;
-  constexpr int V_BYTES = DT * 32 * VSTR;
+  constexpr int V_BYTES = VROWS ? 64 * VSTR : DT * 32 * VSTR;
   constexpr int KP = (64 * KS * 2 + 255) / 256;    // 16-byte K pieces per thread
-  constexpr int VP = (DT * 32 * 8 + 255) / 256;    // 16-byte V^T pieces per thread
+  constexpr int VP = VROWS ? KP : (DT * 32 * 8 + 255) / 256;    // 16-byte V pieces per thread
   __shared__ __attribute__((aligned(16))) unsigned char lds[K_BYTES + V_BYTES];
   unsigned char* ldsK = lds;
   unsigned char* ldsV = lds + K_BYTES;
@@ -54,7 +65,8 @@ __global__ __launch_bounds__(256, WPS) void attention_kernel(const AttnArgs a) {
 
   const T* __restrict__ qp = reinterpret_cast<const T*>(a.q) + img * a.q_img + head * dh;
   const T* __restrict__ kp = reinterpret_cast<const T*>(a.k) + img * a.k_img + head * dh;
-  const T* __restrict__ vp = reinterpret_cast<const T*>(a.vt) + img * a.vt_img + (long long)head * dh * a.vt_row;
+  const T* __restrict__ vp = reinterpret_cast<const T*>(a.vt) + img * a.vt_img +
+                             (VROWS ? (long long)head * dh : (long long)head * dh * a.vt_row);
   T* __restrict__ op = reinterpret_cast<T*>(a.out) + img * a.out_img + head * dh;
 
   // Q fragments: lane (q = ql, half) holds Q[q][ks*16 + 8*half .. +8)
@@ -90,14 +102,41 @@ __global__ __launch_bounds__(256, WPS) void attention_kernel(const AttnArgs a) {
 #pragma unroll
   for (int i = 0; i < VP; ++i) {
     const int p = tid + 256 * i;
-    const int row = p >> 3, pc = p & 7;
-    voff[i] = row < dh ? (unsigned)(row * a.vt_row + pc * 8) * 2u : OOB;
-    if (ONES && row == dh) ones_m |= 1u << i;
+    if (VROWS) {                                        // same piece map as K: (key row, 8 channels)
+      const int row = p / (KS * 2), pc = p - row * (KS * 2);
+      voff[i] = (row < 64 && pc * 8 < dh) ? (unsigned)(row * a.vt_row + pc * 8) * 2u : OOB;
+    } else {
+      const int row = p >> 3, pc = p & 7;
+      voff[i] = row < dh ? (unsigned)(row * a.vt_row + pc * 8) * 2u : OOB;
+      if (ONES && row == dh) ones_m |= 1u << i;
+    }
   }
   const int k_bytes = ((a.tk - 1) * a.k_row + dh) * 2;
-  const int v_bytes = ((dh - 1) * a.vt_row + a.tk) * 2;
+  const int v_bytes = VROWS ? ((a.tk - 1) * a.vt_row + dh) * 2 : ((dh - 1) * a.vt_row + a.tk) * 2;
+  if (VROWS) {
+    // channels [dh, DT*32) of every key row are written ONCE: zero, except channel dh = 1.0 (the denominator
+    // column); the tile stores below only touch channels < dh
+    for (int p = tid; p < 64 * DT * 4; p += 256) {
+      const int row = p / (DT * 4), pc = p - row * (DT * 4);
+      if (pc * 8 >= dh) {
+        typename Vec8<T>::type e;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) e[j] = (T)0.0f;
+        if (pc * 8 == dh) e[0] = (T)1.0f;
+        st16(ldsV + row * VSTR + pc * 16, __builtin_bit_cast(u32x4, e));
+      }
+    }
+  }
   auto load_tile = [&](int key0) {
-    if (VVEC) {
+    if (VROWS) {
+      const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(kp), 0, k_bytes, 0x00020000);
+      const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(vp), 0, v_bytes, 0x00020000);
+      const unsigned ku = (unsigned)key0 * (unsigned)a.k_row * 2u, vu = (unsigned)key0 * (unsigned)a.vt_row * 2u;
+#pragma unroll
+      for (int i = 0; i < KP; ++i) kr[i] = __builtin_amdgcn_raw_buffer_load_b128(rk, koff[i] + ku, 0, 0);
+#pragma unroll
+      for (int i = 0; i < VP; ++i) vr[i] = __builtin_amdgcn_raw_buffer_load_b128(rv, voff[i] + vu, 0, 0);
+    } else if (VVEC) {
       const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(kp), 0, k_bytes, 0x00020000);
       const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(vp), 0, v_bytes, 0x00020000);
       const unsigned ku = (unsigned)key0 * (unsigned)a.k_row * 2u, vu = (unsigned)key0 * 2u;    // wave-uniform
@@ -146,6 +185,15 @@ __global__ __launch_bounds__(256, WPS) void attention_kernel(const AttnArgs a) {
       const int p = tid + 256 * i;
       const int row = p / (KS * 2), pc = p - row * (KS * 2);
       if (row < 64) st16(ldsK + row * KSTR + pc * 16, kr[i]);
+    }
+    if (VROWS) {
+#pragma unroll
+      for (int i = 0; i < VP; ++i) {
+        const int p = tid + 256 * i;
+        const int row = p / (KS * 2), pc = p - row * (KS * 2);
+        if (row < 64 && pc * 8 < dh) st16(ldsV + row * VSTR + pc * 16, vr[i]);
+      }
+      return;
     }
 #pragma unroll
     for (int i = 0; i < VP; ++i) {
@@ -245,11 +293,28 @@ __global__ __launch_bounds__(256, WPS) void attention_kernel(const AttnArgs a) {
         frag_t pf;
 #pragma unroll
         for (int j = 0; j < 8; ++j) pf[j] = (T)s[kt][st * 8 + j];
-        const unsigned char* vb = ldsV + ql * VSTR + (kt * 32 + st * 16 + half * 8) * 2;
+        if constexpr (VROWS) {
+          // lane 4q+p of each 16-lane group addresses key row q, channels 4p..4p+3 of the group's 16-channel block
+          // (block = channels 32 d + 16 (group & 1)); it receives channel (lane & 15) of the 4 keys.  Two reads:
+          // keys base + 4 half + (0..3) and + 8, the accumulator's key order.
+          typedef __attribute__((address_space(3))) s16x4* lds4_t;
+          const int l16 = lane & 15, grp = lane >> 4;
+          const unsigned char* vb = ldsV + (kt * 32 + st * 16 + 4 * half + (l16 >> 2)) * VSTR +
+                                    (16 * (grp & 1) + 4 * (l16 & 3)) * 2;
 #pragma unroll
-        for (int d = 0; d < DT; ++d) {
-          frag_t vf = __builtin_bit_cast(frag_t, ld16(vb + d * 32 * VSTR));
-          o[d] = mfma32(vf, pf, o[d]);
+          for (int d = 0; d < DT; ++d) {
+            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4_t)(vb + d * 64));
+            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4_t)(vb + d * 64 + 8 * VSTR));
+            const s16x8 both = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+            o[d] = mfma32(__builtin_bit_cast(frag_t, both), pf, o[d]);
+          }
+        } else {
+          const unsigned char* vb = ldsV + ql * VSTR + (kt * 32 + st * 16 + half * 8) * 2;
+#pragma unroll
+          for (int d = 0; d < DT; ++d) {
+            frag_t vf = __builtin_bit_cast(frag_t, ld16(vb + d * 32 * VSTR));
+            o[d] = mfma32(vf, pf, o[d]);
+          }
         }
       }
     __syncthreads();                  // every wave is done with this tile's LDS image
@@ -289,7 +354,7 @@ __global__ __launch_bounds__(256, WPS) void attention_kernel(const AttnArgs a) {
   }
 }
 
-template <typename T, bool VVEC>
+template <typename T, int VVEC>
 static int launch_attention_v(const mobi_attention_params* p, const AttnArgs& a, hipStream_t st) {
   dim3 grid((p->tq + 127) / 128, p->heads, p->images), block(256);
   const int ks = (p->dh + 15) / 16;
@@ -310,9 +375,10 @@ static int launch_attention_v(const mobi_attention_params* p, const AttnArgs& a,
 
 template <typename T>
 static int launch_attention(const mobi_attention_params* p, const AttnArgs& a, hipStream_t st) {
+  if (p->v_layout == 1) return launch_attention_v<T, 2>(p, a, st);
   const bool vvec = (p->vt_row_stride % 8 == 0) && (p->vt_img_stride % 8 == 0) && (p->tk % 8 == 0) &&
                     ((reinterpret_cast<uintptr_t>(p->vt) & 15) == 0);
-  return vvec ? launch_attention_v<T, true>(p, a, st) : launch_attention_v<T, false>(p, a, st);
+  return vvec ? launch_attention_v<T, 1>(p, a, st) : launch_attention_v<T, 0>(p, a, st);
 }
 
 }  // namespace mobi
@@ -323,6 +389,9 @@ extern "C" int mobi_attention(const mobi_attention_params* p, void* stream) {
   if (p->dtype != MOBI_F16 && p->dtype != MOBI_BF16) return MOBI_ERR_ARG;
   if (p->images <= 0 || p->heads <= 0 || p->tq <= 0 || p->tk <= 0 || p->dh <= 0) return MOBI_ERR_ARG;
   if ((p->dh & 7) || p->dh > 160) return MOBI_ERR_UNSUPPORTED;
+  if (p->v_layout != 0 && p->v_layout != 1) return MOBI_ERR_ARG;
+  if (p->v_layout == 1 && ((p->vt_row_stride & 7) || (p->vt_img_stride & 7) ||
+                           (reinterpret_cast<uintptr_t>(p->vt) & 15))) return MOBI_ERR_ALIGN;
   if ((p->q_row_stride & 7) || (p->k_row_stride & 7) || (p->out_row_stride & 3)) return MOBI_ERR_ALIGN;
   if ((p->q_img_stride & 7) || (p->k_img_stride & 7) || (p->out_img_stride & 3)) return MOBI_ERR_ALIGN;
   if ((reinterpret_cast<uintptr_t>(p->q) | reinterpret_cast<uintptr_t>(p->k) |

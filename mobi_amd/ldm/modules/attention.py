@@ -23,7 +23,7 @@ import torch
 import torch.nn as nn
 
 from ... import ops
-from ..._lib import ACT_NONE, OUT_TRANSPOSED
+from ..._lib import ACT_NONE
 from .diffusionmodules.util import Conv2d, GroupNorm32, LayerNorm, Linear, Marker, enter, leave, zero_module
 
 
@@ -67,32 +67,34 @@ class CrossAttention(nn.Module):
         self.to_out = nn.Sequential(Linear(inner_dim, query_dim), Marker())
 
     # -- packed projections ---------------------------------------------------------------
-    def _qk_packed(self):
-        def build():
-            w = torch.cat([self.to_q.weight.detach(), self.to_k.weight.detach()], dim=0)
-            return ops.pack_linear(w, None, self.to_q.packed().w.dtype, w.device)
-        key = ("qk", self.to_q.weight._version, self.to_k.weight._version, self.to_q.weight.data_ptr(),
-               self.to_q.packed().w.dtype)
-        c = self.__dict__.setdefault("_qk_cache", {})
-        if c.get("key") != key:
-            c["key"], c["val"] = key, build()
-        return c["val"]
+    def _stacked(self, names):
+        """One packed matrix for several projections of the same input (rows stacked in `names` order): the input
+        is read once and the launch count drops; attention reads q / k / v as column ranges of the result."""
+        mods = [getattr(self, n) for n in names]
+        dtype = mods[0].packed().w.dtype
+        key = (names, dtype) + tuple(v for m in mods for v in (m.weight._version, m.weight.data_ptr()))
+        c = self.__dict__.setdefault("_stack_cache", {})
+        hit = c.get(names)
+        if hit is None or hit[0] != key:
+            w = torch.cat([m.weight.detach() for m in mods], dim=0)
+            hit = (key, ops.pack_linear(w, None, dtype, w.device))
+            c[names] = hit
+        return hit[1]
 
     # -- forms of attention ------------------------------------------------------------------
     def self_attention(self, xn):
         """xn: normed tokens [N,T,C] -> attention output before to_out."""
         c = self.inner_dim
-        qk, vt = ops.concurrently(lambda: ops.linear(xn, self._qk_packed()),
-                                  lambda: ops.linear(xn, self.to_v.packed(), out_mode=OUT_TRANSPOSED))
-        return ops.attention(qk[..., :c], qk[..., c:], vt, self.heads, self.scale)
+        qkv = ops.linear(xn, self._stacked(("to_q", "to_k", "to_v")))
+        return ops.attention(qkv[..., :c], qkv[..., c:2 * c], qkv[..., 2 * c:], self.heads, self.scale, v_rows=True)
 
     def token_attention(self, xn, ctx):
         """Many queries against another token stream `ctx` [N,Tk,Cc] (engine tensor, may be a
         batch-strided view)."""
-        q, k, vt = ops.concurrently(lambda: ops.linear(xn, self.to_q.packed()),
-                                    lambda: ops.linear(ctx, self.to_k.packed()),
-                                    lambda: ops.linear(ctx, self.to_v.packed(), out_mode=OUT_TRANSPOSED))
-        return ops.attention(q, k, vt, self.heads, self.scale)
+        c = self.inner_dim
+        q, kv = ops.concurrently(lambda: ops.linear(xn, self.to_q.packed()),
+                                 lambda: ops.linear(ctx, self._stacked(("to_k", "to_v"))))
+        return ops.attention(q, kv[..., :c], kv[..., c:], self.heads, self.scale, v_rows=True)
 
     def context_kv(self, context):
         """fp32 context [N,tk,Cc] -> (k, v) fp32 [N,tk,C]."""

@@ -291,21 +291,22 @@ def layernorm(x, gamma, beta, eps=1e-5):
     return out
 
 
-def attention(q, k, vt, heads, scale):
-    """q: [N, Tq, >=C] view (row stride may exceed C: fused projections), k: [N, Tk, ...],
-    vt: [N, C, Tk] -> out [N, Tq, C]."""
+def attention(q, k, v, heads, scale, v_rows=False):
+    """q: [N, Tq, >=C] view (row stride may exceed C: stacked projections), k: [N, Tk, ...];
+    v_rows=False: v is V^T [N, C, Tk];  v_rows=True: v is [N, Tk, >=C] row-major like k.  -> out [N, Tq, C]."""
     lib = _lib.load()
     n, tq = q.shape[0], q.shape[1]
     tk = k.shape[1]
-    c = vt.shape[1]
+    c = v.shape[2] if v_rows else v.shape[1]
     dh = c // heads
     out = torch.empty((n, tq, c), device=q.device, dtype=q.dtype)
     p = _lib.AttentionParams()
     p.q, p.q_img_stride, p.q_row_stride = _ptr(q), q.stride(0), q.stride(1)
     p.k, p.k_img_stride, p.k_row_stride = _ptr(k), k.stride(0), k.stride(1)
-    p.vt, p.vt_img_stride, p.vt_row_stride = _ptr(vt), vt.stride(0), vt.stride(1)
+    p.vt, p.vt_img_stride, p.vt_row_stride = _ptr(v), v.stride(0), v.stride(1)
+    p.v_layout = 1 if v_rows else 0
     p.out, p.out_img_stride, p.out_row_stride = _ptr(out), out.stride(0), out.stride(1)
-    for t_ in (q, k, vt):
+    for t_ in (q, k, v):
         assert t_.shape[2] == 1 or t_.stride(2) == 1
     p.images, p.heads, p.dh, p.tq, p.tk, p.scale, p.dtype = n, heads, dh, tq, tk, scale, _dt(q.dtype)
     with _Timed("attention", 4.0 * n * heads * tq * tk * dh, 0.0, f"n={n} heads={heads} tq={tq} tk={tk} dh={dh}"):

@@ -197,14 +197,16 @@ ATTN_CASES = [(8, 8, 64, 64), (8, 16, 100, 100), (8, 40, 256, 256), (8, 80, 64, 
 
 
 @pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("v_rows", [True, False], ids=["v_rows", "v_transposed"])
 @pytest.mark.parametrize("heads,dh,tq,tk", ATTN_CASES)
-def test_attention(ops, dtype, heads, dh, tq, tk):
+def test_attention(ops, dtype, heads, dh, tq, tk, v_rows):
+    """both V layouts of the C ABI: row-major V (transposing LDS reads) and pre-transposed V^T."""
     n, c = 2, heads * dh
     qf, qd = rnd(f"a.q{dh}.{tq}", (n, tq, c), dtype, 1.5)
     kf, kd = rnd(f"a.k{dh}.{tk}", (n, tk, c), dtype, 1.5)
     vf, vd = rnd(f"a.v{dh}.{tk}", (n, tk, c), dtype)
-    vt = vd.permute(0, 2, 1).contiguous()
-    y = ops.attention(qd, kd, vt, heads, dh ** -0.5)
+    vt = vd if v_rows else vd.permute(0, 2, 1).contiguous()
+    y = ops.attention(qd, kd, vt, heads, dh ** -0.5, v_rows=v_rows)
     sp = lambda t: t.reshape(n, -1, heads, dh).permute(0, 2, 1, 3)
     sim = torch.einsum("bhid,bhjd->bhij", sp(qf), sp(kf)) * dh ** -0.5
     ref = torch.einsum("bhij,bhjd->bhid", sim.softmax(-1), sp(vf)).permute(0, 2, 1, 3).reshape(n, tq, c)
@@ -229,6 +231,10 @@ def test_attention_strided_partner_and_spike(ops, dtype):
     sim = torch.einsum("bhid,bhjd->bhij", sp(xf[::2, :, :c]), sp(xf[1::2, :, c:])) * dh ** -0.5
     ref = torch.einsum("bhij,bhjd->bhid", sim.softmax(-1), sp(vf[1::2])).permute(0, 2, 1, 3).reshape(2, t, c)
     assert rel(y.float(), ref) < TOL[dtype]
+    # the same with V row-major inside a stacked k|v tensor of the partner half (the production call)
+    kvd = torch.cat([xd[:, :, c:], vd], dim=2)
+    y2 = ops.attention(xd[::2, :, :c], kvd[1::2, :, :c], kvd[1::2, :, c:], heads, dh ** -0.5, v_rows=True)
+    assert rel(y2.float(), ref) < TOL[dtype]
 
 
 @pytest.mark.parametrize("dtype", DT)

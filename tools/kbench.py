@@ -51,6 +51,7 @@ def main():
     ap.add_argument("--geglu", action="store_true")
     ap.add_argument("--split", type=int, default=None)
     ap.add_argument("--chunk-major", action="store_true")
+    ap.add_argument("--v-rows", action="store_true", help="attn: V row-major inside a stacked q|k|v tensor")
     ap.add_argument("--c", type=int, default=320)
     a = ap.parse_args()
     from mobi_amd import build, ops
@@ -61,9 +62,13 @@ def main():
     rn = lambda *s: torch.randn(*s, generator=g).to(dev).to(dt)
     if a.kind == "attn":
         c = a.heads * a.dh
-        q, k = rn(a.images, a.t, c), rn(a.images, a.t, c)
-        vt = rn(a.images, c, a.t)
-        us = timeit(lambda: ops.attention(q, k, vt, a.heads, a.dh ** -0.5), a.iters)
+        if a.v_rows:
+            qkv = rn(a.images, a.t, 3 * c)
+            q, k, vt = qkv[..., :c], qkv[..., c:2 * c], qkv[..., 2 * c:]
+        else:
+            q, k = rn(a.images, a.t, c), rn(a.images, a.t, c)
+            vt = rn(a.images, c, a.t)
+        us = timeit(lambda: ops.attention(q, k, vt, a.heads, a.dh ** -0.5, v_rows=a.v_rows), a.iters)
         fl = 4.0 * a.images * a.heads * a.t * a.t * a.dh
         print(f"attention heads={a.heads} dh={a.dh} T={a.t} images={a.images}: {us:.1f} us  {fl / us / 1e6:.1f} TFLOP/s")
     elif a.kind == "conv":
