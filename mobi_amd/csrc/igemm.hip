@@ -91,6 +91,7 @@ struct IgemmArgs {
   int wm;                  // waves along the pixel axis (2 or 4): block tile = 64*wm pixels
   int splits, nk_per;      // split-K: blockIdx.y owns k-tiles [y*nk_per, (y+1)*nk_per)
   float* split_ws;         // f32 [splits][M][n_packed] partial sums (NULL: single pass)
+  int lin_window;          // direct-to-LDS kernel: window pixels are linear in the tap (no upsampling, <= 16 taps)
   int epi_direct;          // direct-to-LDS kernel: register epilogue (full tiles, row-major T output, no per-image vector)
 };
 
@@ -778,6 +779,14 @@ __global__ __launch_bounds__(512, 2) void igemm_glds_kernel(const IgemmArgs a) {
   unsigned f_row[4] = {0u, 0u, 0u, 0u};
   unsigned f_okm = 0;
   int f_tap = -1, f_src = -1;
+  // linear window (no upsampling, <= 16 taps): pixel(tap) = x_pix0[j] + ky * win + kx, so a tap change costs one
+  // wave-uniform offset and a mask shift instead of re-deriving four windows (what made the taps-innermost k order
+  // slower than it had to be)
+  const bool lin = a.lin_window != 0;
+  int x_pix0[4] = {0, 0, 0, 0};                              // x_gp + x_h * win + x_w (may be "negative": only used when valid)
+  unsigned long long x_tapok = 0;                            // bit 4 * tap + j: row j's window pixel of that tap is inside
+  unsigned f_rowbase[4] = {0u, 0u, 0u, 0u};
+  unsigned f_tapoff = 0;
 
   auto set_fetch_tile = [&]() {
     const int L = xcd_remap(f_bid, nblk);
@@ -795,6 +804,20 @@ __global__ __launch_bounds__(512, 2) void igemm_glds_kernel(const IgemmArgs a) {
       x_gp[j] = (group * a.imgs_per_group + img) * a.img_pix_stride;
       x_h[j] = ho * a.stride - a.pad_h;
       x_w[j] = wo * a.stride - a.pad_w;
+    }
+    if (lin) {
+      x_tapok = 0;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        x_pix0[j] = x_gp[j] + x_h[j] * a.win + x_w[j];
+        if ((x_okm >> j) & 1u) {
+          for (int ky = 0; ky < a.kh; ++ky)
+            for (int kx = 0; kx < a.kw; ++kx) {
+              const int hi = x_h[j] + ky, wi = x_w[j] + kx;
+              if (hi >= 0 && hi < hlog && wi >= 0 && wi < wlog) x_tapok |= 1ull << ((ky * a.kw + kx) * 4 + j);
+            }
+        }
+      }
     }
     // weight rows: j < WJ-1 (or all, when BN % 64 == 0): 8 * wave + rloc + 64 j; the last partial group of 32 rows
     // is fetched by waves 0-3 and (identically, benign duplicate) by waves 4-7 so that every wave issues PIECES DMAs
@@ -826,7 +849,22 @@ __global__ __launch_bounds__(512, 2) void igemm_glds_kernel(const IgemmArgs a) {
     unsigned char* st = lds + f_slot * STAGE;
     f_slot = f_slot == 2 ? 0 : f_slot + 1;
     const int src = u_c >= a.c0 ? 1 : 0;
-    if (u_tap != f_tap || src != f_src) {
+    if (lin) {
+      if (src != f_src) {
+        f_src = src;
+        const unsigned cs2 = (unsigned)(src ? a.c1 : a.c0) * 2u;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) f_rowbase[j] = (unsigned)x_pix0[j] * cs2 + (unsigned)sg * 16u;
+        f_tap = -1;
+      }
+      if (u_tap != f_tap) {
+        f_tap = u_tap;
+        f_tapoff = (unsigned)(u_ky * a.win + u_kx) * ((unsigned)(src ? a.c1 : a.c0) * 2u);     // wave-uniform
+        f_okm = (unsigned)(x_tapok >> (u_tap * 4)) & 15u;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) f_row[j] = f_rowbase[j] + f_tapoff;
+      }
+    } else if (u_tap != f_tap || src != f_src) {
       f_tap = u_tap; f_src = src; f_okm = 0;
       const unsigned cs2 = (unsigned)(src ? a.c1 : a.c0) * 2u;
 #pragma unroll
@@ -1191,6 +1229,10 @@ extern "C" int mobi_igemm(const mobi_igemm_params* p, void* stream) {
     a.splits = (a.nk + a.nk_per - 1) / a.nk_per;            // no empty k ranges: every slab that is summed is written
     a.split_ws = reinterpret_cast<float*>(p->ws);
   }
+  // (taps-innermost k order only: it changes tap every k-tile; measured 1.5-3 % slower than the window re-derivation
+  //  on tap-major k, where a tap lasts C/64 k-tiles -- tools/sweep_korder.py)
+  a.lin_window = p->k_order == 1 && p->upsample == 0 && p->kh * p->kw <= 16;
+  if (const char* e = getenv("MOBI_IGEMM_LIN")) a.lin_window = a.lin_window && e[0] != '0';
   // register epilogue of the direct-to-LDS kernel: every tile full, row-major T output, no per-image vector
   a.epi_direct = a.wm == 4 && a.fast && a.glds && p->out_mode == MOBI_OUT_ROWS && !p->rowvec && !a.split_ws &&
                  a.M % 256 == 0 && p->n_packed % bn == 0 && a.nk_per >= 3;
