@@ -94,6 +94,7 @@ SYMBOLS = {
     "mobi_struct_size": (C.c_size_t, [C.c_int]),
     "mobi_igemm": (C.c_int, [C.POINTER(IgemmParams), vp]),
     "mobi_igemm_plan_splits": (C.c_int, [C.POINTER(IgemmParams)]),
+    "mobi_igemm_kernel_variant": (C.c_int, [C.POINTER(IgemmParams)]),
     "mobi_igemm_workspace_bytes": (C.c_size_t, [C.POINTER(IgemmParams), i32]),
     "mobi_groupnorm_workspace_bytes": (C.c_size_t, [i32, i32]),
     "mobi_groupnorm": (C.c_int, [C.POINTER(GroupNormParams), vp]),

@@ -20,6 +20,10 @@
 // LDS row strides are odd multiples of the access width (bank-conflict free reads).
 #include "common.h"
 
+#ifndef MOBI_ATTN_DBUF
+#define MOBI_ATTN_DBUF 1   // two LDS images of the K / V tile: one barrier per key tile, the next tile is written while
+#endif                     // this one is still being multiplied (A/B: -DMOBI_ATTN_DBUF=0)
+
 namespace mobi {
 
 struct AttnArgs {
@@ -49,7 +53,9 @@ __global__ __launch_bounds__(256, WPS) void attention_kernel(const AttnArgs a) {
   constexpr int V_BYTES = VROWS ? 64 * VSTR : DT * 32 * VSTR;
   constexpr int KP = (64 * KS * 2 + 255) / 256;    // 16-byte K pieces per thread
   constexpr int VP = VROWS ? KP : (DT * 32 * 8 + 255) / 256;    // 16-byte V pieces per thread
-  __shared__ __attribute__((aligned(16))) unsigned char lds[K_BYTES + V_BYTES];
+  constexpr int NBUF = MOBI_ATTN_DBUF ? 2 : 1;
+  constexpr int IMG_BYTES = K_BYTES + V_BYTES;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[NBUF * IMG_BYTES];
   unsigned char* ldsK = lds;
   unsigned char* ldsV = lds + K_BYTES;
 
@@ -123,7 +129,8 @@ __global__ __launch_bounds__(256, WPS) void attention_kernel(const AttnArgs a) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) e[j] = (T)0.0f;
         if (pc * 8 == dh) e[0] = (T)1.0f;
-        st16(ldsV + row * VSTR + pc * 16, __builtin_bit_cast(u32x4, e));
+#pragma unroll
+        for (int b = 0; b < NBUF; ++b) st16(ldsV + b * IMG_BYTES + row * VSTR + pc * 16, __builtin_bit_cast(u32x4, e));
       }
     }
   }
@@ -175,7 +182,7 @@ __global__ __launch_bounds__(256, WPS) void attention_kernel(const AttnArgs a) {
       }
     }
   };
-  auto store_tile = [&]() {
+  auto store_tile = [&](int boff) {
     typename Vec8<T>::type one8;
 #pragma unroll
     for (int j = 0; j < 8; ++j) one8[j] = (T)1.0f;
@@ -184,14 +191,14 @@ __global__ __launch_bounds__(256, WPS) void attention_kernel(const AttnArgs a) {
     for (int i = 0; i < KP; ++i) {
       const int p = tid + 256 * i;
       const int row = p / (KS * 2), pc = p - row * (KS * 2);
-      if (row < 64) st16(ldsK + row * KSTR + pc * 16, kr[i]);
+      if (row < 64) st16(ldsK + boff + row * KSTR + pc * 16, kr[i]);
     }
     if (VROWS) {
 #pragma unroll
       for (int i = 0; i < VP; ++i) {
         const int p = tid + 256 * i;
         const int row = p / (KS * 2), pc = p - row * (KS * 2);
-        if (row < 64 && pc * 8 < dh) st16(ldsV + row * VSTR + pc * 16, vr[i]);
+        if (row < 64 && pc * 8 < dh) st16(ldsV + boff + row * VSTR + pc * 16, vr[i]);
       }
       return;
     }
@@ -202,7 +209,7 @@ __global__ __launch_bounds__(256, WPS) void attention_kernel(const AttnArgs a) {
       if (row < DT * 32) {
         // the ones row may also cover keys >= tk: their P is exactly 0, so the denominator is unaffected
         const u32x4 v = (ones_m >> i) & 1u ? ones : vr[i];
-        unsigned char* d = ldsV + row * VSTR + (pc >> 1) * 32 + (pc & 1) * 8;
+        unsigned char* d = ldsV + boff + row * VSTR + (pc >> 1) * 32 + (pc & 1) * 8;
         *reinterpret_cast<u32x2*>(d) = u32x2{v[0], v[1]};             // keys 8a + (0..3)     -> pos 4a + ..
         *reinterpret_cast<u32x2*>(d + 16) = u32x2{v[2], v[3]};        // keys 8a + 4 + (0..3) -> pos 8 + 4a + ..
       }
@@ -219,11 +226,12 @@ __global__ __launch_bounds__(256, WPS) void attention_kernel(const AttnArgs a) {
 
   const int ntiles = (a.tk + 63) / 64;
   load_tile(0);
-  store_tile();
+  store_tile(0);
   __syncthreads();
   for (int t = 0; t < ntiles; ++t) {
     const int key0 = t * 64;
     const bool more = t + 1 < ntiles;
+    const int boff = MOBI_ATTN_DBUF ? (t & 1) * IMG_BYTES : 0;       // image of this tile
     if (more) load_tile(key0 + 64);
 
     // ---- S^T = K . Q^T for two 32-key sub-tiles --------------------------------
@@ -232,7 +240,7 @@ __global__ __launch_bounds__(256, WPS) void attention_kernel(const AttnArgs a) {
     for (int kt = 0; kt < 2; ++kt) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) s[kt][r] = 0.f;
-      const unsigned char* kb = ldsK + (kt * 32 + ql) * KSTR + half * 16;
+      const unsigned char* kb = ldsK + boff + (kt * 32 + ql) * KSTR + half * 16;
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
         frag_t kf = __builtin_bit_cast(frag_t, ld16(kb + ks * 32));
@@ -285,6 +293,11 @@ __global__ __launch_bounds__(256, WPS) void attention_kernel(const AttnArgs a) {
       l_run += psum;
     }
 
+#if MOBI_ATTN_DBUF
+    // the next tile goes into the OTHER image: every wave left it at the barrier that ended the previous step, and
+    // its loads were issued a whole S / softmax phase ago
+    if (more) store_tile(IMG_BYTES - boff);
+#endif
     // ---- O^T += V^T . P^T --------------------------------------------------------
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt)
@@ -299,7 +312,7 @@ __global__ __launch_bounds__(256, WPS) void attention_kernel(const AttnArgs a) {
           // keys base + 4 half + (0..3) and + 8, the accumulator's key order.
           typedef __attribute__((address_space(3))) s16x4* lds4_t;
           const int l16 = lane & 15, grp = lane >> 4;
-          const unsigned char* vb = ldsV + (kt * 32 + st * 16 + 4 * half + (l16 >> 2)) * VSTR +
+          const unsigned char* vb = ldsV + boff + (kt * 32 + st * 16 + 4 * half + (l16 >> 2)) * VSTR +
                                     (16 * (grp & 1) + 4 * (l16 & 3)) * 2;
 #pragma unroll
           for (int d = 0; d < DT; ++d) {
@@ -309,7 +322,7 @@ __global__ __launch_bounds__(256, WPS) void attention_kernel(const AttnArgs a) {
             o[d] = mfma32(__builtin_bit_cast(frag_t, both), pf, o[d]);
           }
         } else {
-          const unsigned char* vb = ldsV + ql * VSTR + (kt * 32 + st * 16 + half * 8) * 2;
+          const unsigned char* vb = ldsV + boff + ql * VSTR + (kt * 32 + st * 16 + half * 8) * 2;
 #pragma unroll
           for (int d = 0; d < DT; ++d) {
             frag_t vf = __builtin_bit_cast(frag_t, ld16(vb + d * 32 * VSTR));
@@ -317,11 +330,13 @@ __global__ __launch_bounds__(256, WPS) void attention_kernel(const AttnArgs a) {
           }
         }
       }
-    __syncthreads();                  // every wave is done with this tile's LDS image
+    __syncthreads();                  // every wave is done with this tile's LDS image (and wrote the next one)
+#if !MOBI_ATTN_DBUF
     if (more) {
-      store_tile();
+      store_tile(0);
       __syncthreads();
     }
+#endif
   }
 
   // ---- normalise and store: lane holds O^T[d][q] for d = 32 dt + 8 g + 4 half + (0..3) -------

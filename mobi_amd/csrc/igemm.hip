@@ -1147,7 +1147,8 @@ extern "C" size_t mobi_igemm_workspace_bytes(const mobi_igemm_params* p, int32_t
   return (size_t)splits * p->batch * p->hout * p->wout * p->n_packed * sizeof(float);
 }
 
-extern "C" int mobi_igemm(const mobi_igemm_params* p, void* stream) {
+// argument checks + launch plan (tile height, addressing path, main-loop variant, split-K ranges, epilogue kind)
+static int igemm_prepare(const mobi_igemm_params* p, mobi::IgemmArgs& a) {
   using namespace mobi;
   if (!p || !p->src0 || !p->weight || !p->out) return MOBI_ERR_ARG;
   if (p->dtype != MOBI_F16 && p->dtype != MOBI_BF16) return MOBI_ERR_ARG;
@@ -1171,7 +1172,6 @@ extern "C" int mobi_igemm(const mobi_igemm_params* p, void* stream) {
        reinterpret_cast<uintptr_t>(p->weight) | reinterpret_cast<uintptr_t>(p->out) |
        reinterpret_cast<uintptr_t>(p->residual)) & 15) return MOBI_ERR_ALIGN;
 
-  IgemmArgs a;
   a.src0 = p->src0; a.src1 = p->src1;
   a.c0 = p->c0; a.c1 = p->c1; a.C = p->c0 + p->c1;
   a.hin = p->hin; a.win = p->win; a.up = p->upsample;
@@ -1237,6 +1237,22 @@ extern "C" int mobi_igemm(const mobi_igemm_params* p, void* stream) {
   a.epi_direct = a.wm == 4 && a.fast && a.glds && p->out_mode == MOBI_OUT_ROWS && !p->rowvec && !a.split_ws &&
                  a.M % 256 == 0 && p->n_packed % bn == 0 && a.nk_per >= 3;
   if (const char* e = getenv("MOBI_IGEMM_EPI_DIRECT")) a.epi_direct = a.epi_direct && e[0] != '0';
+  return MOBI_OK;
+}
+
+extern "C" int mobi_igemm(const mobi_igemm_params* p, void* stream) {
+  using namespace mobi;
+  IgemmArgs a;
+  const int rc = igemm_prepare(p, a);
+  if (rc != MOBI_OK) return rc;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   return p->dtype == MOBI_F16 ? launch_igemm<f16_t>(p, a, p->groups, st) : launch_igemm<bf16_t>(p, a, p->groups, st);
+}
+
+extern "C" int mobi_igemm_kernel_variant(const mobi_igemm_params* p) {
+  mobi::IgemmArgs a;
+  const int rc = igemm_prepare(p, a);
+  if (rc != MOBI_OK) return rc;
+  if (a.wm == 4 && a.fast && a.glds) return MOBI_IGEMM_DIRECT_LDS;
+  return a.wm == 4 ? MOBI_IGEMM_STAGED_256 : MOBI_IGEMM_STAGED_128;
 }

@@ -239,8 +239,11 @@ def igemm(x, pw: Packed, *, x2=None, stride=1, pad=None, upsample=False, hout=No
     flops = 2.0 * n * hout * wout * (pw.n_packed if pw.geglu else pw.cout) * pw.kh * pw.kw * pw.cin
     nbytes = (x.numel() + (0 if x2 is None else x2.numel())) * 2 + pw.w.numel() * 2 * (n if weight_per_image else 1) \
         + out.numel() * out.element_size() + (0 if residual is None else residual.numel() * 2)
-    tag = f"m={n * hout * wout} n={pw.n_packed} k={pw.kh * pw.kw * pw.cin} tap={pw.kh}x{pw.kw} split={splits} mode={out_mode}" \
-        if _PROFILE is not None else ""
+    tag = ""
+    if _PROFILE is not None:
+        kern = ("staged128", "staged256", "direct_lds")[lib.mobi_igemm_kernel_variant(C.byref(p))]
+        tag = f"kern={kern} m={n * hout * wout} n={pw.n_packed} k={pw.kh * pw.kw * pw.cin} tap={pw.kh}x{pw.kw} " \
+              f"split={splits} mode={out_mode}"
     with _Timed("igemm", flops, nbytes, tag):
         _lib.check(lib.mobi_igemm(C.byref(p), _stream()), "mobi_igemm")
     return out

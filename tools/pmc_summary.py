@@ -1,0 +1,65 @@
+#!/usr/bin/env python3
+"""Fold rocprofv3 --pmc counter CSVs (one pass per counter) into profiles/<round>_pmc_traffic.json.
+
+    python tools/pmc_summary.py OUT.json FETCH_SIZE=<dir> WRITE_SIZE=<dir> [...]
+
+Per kernel family: launches, average counter value per launch; for the implicit-GEMM / attention kernels the HBM
+bytes per launch = FETCH_SIZE x 2 (gfx950: a 128-byte request is tallied as 64 B, MI355X_MICROARCH.md) + WRITE_SIZE,
+both reported in KB.
+"""
+import csv
+import glob
+import json
+import os
+import sys
+
+FAMILIES = ["igemm_glds_kernel", "igemm_kernel", "igemm_splitk_reduce_kernel", "attention_kernel", "gn_stats_kernel",
+            "gn_apply_kernel", "layernorm_kernel", "ctx_attention_kernel"]
+
+
+def family(name):
+    for f in FAMILIES:
+        if f in name:
+            return f
+    return None
+
+
+def fold(directory, counter):
+    acc = {}
+    for path in glob.glob(os.path.join(directory, "**", "*counter_collection.csv"), recursive=True):
+        with open(path) as f:
+            for row in csv.DictReader(f):
+                if row.get("Counter_Name") != counter:
+                    continue
+                fam = family(row["Kernel_Name"])
+                if fam is None:
+                    continue
+                a = acc.setdefault(fam, {"launches": 0, "sum": 0.0})
+                a["launches"] += 1
+                a["sum"] += float(row["Counter_Value"])
+    return {k: {"launches": v["launches"], "avg_per_launch": v["sum"] / v["launches"]} for k, v in acc.items()}
+
+
+def main():
+    out = sys.argv[1]
+    raw = {}
+    for spec in sys.argv[2:]:
+        counter, directory = spec.split("=", 1)
+        raw[counter] = fold(directory, counter)
+    res = {"command": "rocprofv3 --pmc <counter> (one pass per counter) -- python bench.py --steps 2 --warmup 1 "
+                      "--no-e2e --no-cpu-baseline --no-roofline",
+           "units": "FETCH_SIZE / WRITE_SIZE in KB per launch as reported; gfx950 correction (MI355X_MICROARCH.md, "
+                    "HBM): FETCH_SIZE tallies 64 B per 128-B request of wide coalesced reads -> doubled",
+           "raw": raw}
+    for fam in FAMILIES:
+        f, w = raw.get("FETCH_SIZE", {}).get(fam), raw.get("WRITE_SIZE", {}).get(fam)
+        if f and w:
+            res[fam] = {"launches": f["launches"], "fetch_kb_raw": f["avg_per_launch"], "write_kb": w["avg_per_launch"],
+                        "hbm_bytes_per_launch_corrected": (2 * f["avg_per_launch"] + w["avg_per_launch"]) * 1024}
+    with open(out, "w") as fh:
+        json.dump(res, fh, indent=1)
+    print(json.dumps({k: v for k, v in res.items() if k in FAMILIES}, indent=1))
+
+
+if __name__ == "__main__":
+    main()
