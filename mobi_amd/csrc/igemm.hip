@@ -32,6 +32,15 @@
 #define MOBI_SCHED_FENCE() ((void)0)
 #endif
 
+#ifndef MOBI_DBG_SKIP
+#define MOBI_DBG_SKIP 0    // diagnosis only (wrong results): bit 0 = no activation DMA, bit 1 = no weight DMA, bit 2 = no MFMA
+#endif
+#ifndef MOBI_PP_DMA_KS
+#define MOBI_PP_DMA_KS 1   // ping-pong kernel: LOAD phase (k-step) that carries the DMA requests
+#endif
+#ifndef MOBI_PP_PRIO
+#define MOBI_PP_PRIO 1     // ping-pong kernel: s_setprio of the MATRIX phase
+#endif
 #ifndef MOBI_STAMP
 #define MOBI_STAMP 0       // 1: in-kernel phase stamps of the direct-to-LDS kernel (tools/stamp_igemm.py), never in a release build
 #endif
@@ -49,7 +58,7 @@ __device__ unsigned long long* g_stamps = nullptr;      // [block][8]: entry, fi
 #else
 #define MOBI_STAMP_AT(slot) ((void)0)
 #endif
-#if MOBI_STAMP == 2
+#if MOBI_STAMP >= 2
 // per wave: accumulated 10-ns ticks of the five phases of a k-tile step (wait, barrier, k-step 0, DMA issue,
 // k-step 1) + the number of steps; [block][wave][8]
 __device__ unsigned long long* g_phase = nullptr;
@@ -92,7 +101,9 @@ struct IgemmArgs {
   int splits, nk_per;      // split-K: blockIdx.y owns k-tiles [y*nk_per, (y+1)*nk_per)
   float* split_ws;         // f32 [splits][M][n_packed] partial sums (NULL: single pass)
   int lin_window;          // direct-to-LDS kernel: window pixels are linear in the tap (no upsampling, <= 16 taps)
-  int epi_direct;          // direct-to-LDS kernel: register epilogue (full tiles, row-major T output, no per-image vector)
+  int epi_direct;          // direct-to-LDS kernel: register epilogue (full tiles, row-major T output)
+  int pp;                  // register-epilogue launch on the ping-pong kernel
+  int hw_shift, w_shift;   // log2(hw_out), log2(wout) when both are powers of two (ping-pong kernel), else -1
 };
 
 // 8 consecutive floats through two 16-byte accesses (LDS stage rows, bias, per-image vectors)
@@ -327,8 +338,11 @@ __device__ __forceinline__ u32x4 vm_load16(const void* p) {
   asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(r) : "v"(p) : "memory");
   return r;
 }
+// (the s_nop 1 is part of the statement: hipcc does not know that a 16-byte store reads its data registers for
+//  two more wave cycles and would let its next VALU instruction overwrite them -- seen as garbage in the first two
+//  of a lane's eight outputs, last four lanes of each 16-lane row)
 __device__ __forceinline__ void vm_store16(void* p, const u32x4& v) {
-  asm volatile("global_store_dwordx4 %0, %1, off" : : "v"(p), "v"(v) : "memory");
+  asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" : : "v"(p), "v"(v) : "memory");
 }
 __device__ __forceinline__ void vm_store8(void* p, const u32x2& v) {
   asm volatile("global_store_dwordx2 %0, %1, off" : : "v"(p), "v"(v) : "memory");
@@ -346,22 +360,28 @@ __device__ __forceinline__ void wait_vmcnt_le(int n) {
 
 template <int NT>
 struct DirectEpiRegs {
-  u32x4 bias[NT];          // f32 x 4: channels 16 ni + 4 g4 + (0..3) of the wave's columns
+  u32x4 bias[NT];          // f32 x 4: channels 16 ni + 4 g4 + (0..3) of the wave's columns (bias OR per-image vector)
   u32x4 res[NT][2];        // T x 8: the lane's 8 output channels of its pixel in tile pair p
 };
 
 // request bias / residual of output tile (mw0, nw0); returns the number of vector-memory instructions issued
-template <typename T, int NT>
+// VEC = false: the caller has put bias / per-image vector into the accumulators' initial value (ping-pong kernel)
+template <typename T, int NT, bool VEC = true, bool RES = true>
 __device__ __forceinline__ int direct_epilogue_request(const IgemmArgs& a, DirectEpiRegs<NT>& q, int lane, int group,
                                                        int nw0, int mw0) {
   const int r16 = lane & 15, g4 = lane >> 4;
   int n_issued = 0;
-  if (a.bias) {
+  if (VEC && (a.bias || a.rowvec)) {                                    // never both (checked on the host)
+    const float* vec = a.bias;
+    if (a.rowvec) {                                            // the wave's 64 pixels lie in one image: hw_out % 64 == 0
+      const int img = __builtin_amdgcn_readfirstlane(mw0 / a.hw_out);
+      vec = a.rowvec + (long long)(group * a.imgs_per_group + img) * a.rowvec_stride;
+    }
 #pragma unroll
-    for (int ni = 0; ni < NT; ++ni) q.bias[ni] = vm_load16(a.bias + nw0 + ni * 16 + g4 * 4);
+    for (int ni = 0; ni < NT; ++ni) q.bias[ni] = vm_load16(vec + nw0 + ni * 16 + g4 * 4);
     n_issued += NT;
   }
-  if (a.residual) {                                            // plain epilogue only (checked on the host)
+  if (RES && a.residual) {                                     // plain epilogue only (checked on the host)
     const T* __restrict__ resid = reinterpret_cast<const T*>(a.residual);
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
@@ -378,18 +398,19 @@ __device__ __forceinline__ int direct_epilogue_request(const IgemmArgs& a, Direc
 }
 
 // returns the number of vector-memory instructions issued (stores)
-template <typename T, int NT, bool GEGLU>
+template <typename T, int NT, bool GEGLU, bool VEC = true>
 __device__ __forceinline__ int direct_epilogue(const IgemmArgs& a, f32x4 (&acc)[NT][4], DirectEpiRegs<NT>& q, int lane,
                                                int group, int nw0, int mw0) {
   const int r16 = lane & 15, g4 = lane >> 4;
   const float scale = a.scale;
   T* __restrict__ outT = reinterpret_cast<T*>(a.out);
   // the requested registers are complete (caller waited): pin their uses behind that wait
-  if (a.bias) {
+  const bool has_vec = VEC && (a.bias || a.rowvec);
+  if (has_vec) {
 #pragma unroll
     for (int ni = 0; ni < NT; ++ni) asm volatile("" : "+v"(q.bias[ni]));
   }
-  if (a.residual) {
+  if (!GEGLU && a.residual) {
 #pragma unroll
     for (int ni = 0; ni < NT; ++ni) { asm volatile("" : "+v"(q.res[ni][0])); asm volatile("" : "+v"(q.res[ni][1])); }
   }
@@ -405,7 +426,7 @@ __device__ __forceinline__ int direct_epilogue(const IgemmArgs& a, f32x4 (&acc)[
 #pragma unroll
     for (int ni = 0; ni < NT; ++ni) {
       f32x4 x = acc[ni][2 * p] * scale, y = acc[ni][2 * p + 1] * scale;
-      if (a.bias) {
+      if (has_vec) {
         const f32x4 b = __builtin_bit_cast(f32x4, q.bias[ni]);
         x += b; y += b;
       }
@@ -877,18 +898,23 @@ __global__ __launch_bounds__(512, 2) void igemm_glds_kernel(const IgemmArgs a) {
     }
     const unsigned char* xbase = reinterpret_cast<const unsigned char*>(src ? a.src1 : a.src0) +
                                  (unsigned)(src ? u_c - a.c0 : u_c) * 2u;
+#if !(MOBI_DBG_SKIP & 1)
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const unsigned char* g = ((f_okm >> j) & 1u) ? xbase + f_row[j] : zsrc;
       __builtin_amdgcn_global_load_lds((gbl_ptr_t)g, (lds_ptr_t)(st + (8 * wave + 64 * j) * 128), 16, 0, 0);
     }
+    vm_issued += 4;
+#endif
     const unsigned kb = (unsigned)f_kt * 128u;
+#if !(MOBI_DBG_SKIP & 2)
 #pragma unroll
     for (int j = 0; j < WJ; ++j) {
       const unsigned char* g = w_src[j] ? w_src[j] + kb : zsrc;
       __builtin_amdgcn_global_load_lds((gbl_ptr_t)g, (lds_ptr_t)(st + X_TILE + w_lds[j]), 16, 0, 0);
     }
-    vm_issued += PIECES;
+    vm_issued += WJ;
+#endif
     if (++f_kt == kt_end) {                                  // the sequence moves on to this block's next output tile
       f_kt = kt_begin;
       f_bid += gridDim.x;
@@ -960,11 +986,18 @@ __global__ __launch_bounds__(512, 2) void igemm_glds_kernel(const IgemmArgs a) {
         for (int mi = 0; mi < 4; ++mi) xf[mi] = __builtin_bit_cast(frag_t, ld16(xb + mi * 16 * 128 + sw));
 #pragma unroll
         for (int ni = 0; ni < NT; ++ni) wf[ni] = __builtin_bit_cast(frag_t, ld16(wb + ni * 16 * 128 + sw));
+#if MOBI_DBG_SKIP & 4
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) asm volatile("" :: "v"(xf[mi]));
+#pragma unroll
+        for (int ni = 0; ni < NT; ++ni) asm volatile("" :: "v"(wf[ni]));
+#else
 #pragma unroll
         for (int ni = 0; ni < NT; ++ni)
 #pragma unroll
           for (int mi = 0; mi < 4; ++mi)
             acc[ni][mi] = TR ? mfma16(xf[mi], wf[ni], acc[ni][mi]) : mfma16(wf[ni], xf[mi], acc[ni][mi]);
+#endif
       }
       MOBI_PHASE(5);
       MOBI_PHASE_ACC();
@@ -1006,6 +1039,289 @@ __global__ __launch_bounds__(512, 2) void igemm_glds_kernel(const IgemmArgs a) {
   }
 #endif
 #endif
+}
+
+// =========================================================================================================
+// PING-PONG main loop (register-epilogue launches of the direct-to-LDS geometry: full 256 x (2 * WAVE_N) tiles,
+// row-major output, no split-K, window pixels linear in the tap).
+//
+// Why: with all eight waves in lockstep the three parts of a k-tile step ADD UP instead of overlapping (3x3,
+// 320 -> 320, 64x64 x 16, 173 us: LDS fragment reads + barriers alone 74 us, + DMA requests 122 us, MFMAs alone
+// 48 us at peak; tools/diag_ingest.sh).  The two waves of every SIMD (w and w + 4) run the same program, so both
+// wait for their fragments, then both queue on the one matrix pipe, then both stall in the DMA issue.
+//
+// Here every k-step is split into a LOAD phase (fragment reads LDS -> registers, DMA requests of the k-tile two
+// steps ahead, the previous output tile's epilogue stores) and a MATRIX phase (MFMAs only).  Every phase boundary
+// is one raw s_barrier of all eight waves, and waves 4-7 run ONE PHASE BEHIND waves 0-3: while one wave of a SIMD
+// multiplies, its partner reads / requests / stores.  The epilogue of an output tile is deferred into the first
+// LOAD phase of the next tile (registers only, so it needs no LDS), where it overlaps the partner's MATRIX phase.
+//
+//   phase g = 4 i + { 0: early LOAD(i, ks 0)  | late MATRIX(i-1, ks 1)
+//                     1: early MATRIX(i, ks 0) | late LOAD(i, ks 0)
+//                     2: early LOAD(i, ks 1)   | late MATRIX(i, ks 0)
+//                     3: early MATRIX(i, ks 1) | late LOAD(i, ks 1) }
+// LDS hazards (three stages, k-tile i in stage i % 3):
+//   RAW  k-tile i+1 is first read in phase 4(i+1) (early waves): every wave waits for ITS pieces of k-tile i+1 (a
+//        counted vmcnt; vector-memory operations retire in issue order) before the barrier that ends phase 4i+3.
+//   WAR  the DMA of k-tile i+2 overwrites stage (i-1) % 3, last read by the late waves in phase 4(i-1)+3; it is
+//        requested in LOAD(i, ks MOBI_PP_DMA_KS), i.e. in phase >= 4i, and every LOAD phase ends with lgkmcnt(0).
+// Operands arrive by buffer_load ... lds (SGPR descriptor + 32-bit lane offset): padded pieces use an offset
+// beyond the descriptor's range and the hardware writes zeros.
+// =========================================================================================================
+template <typename T, int NT, bool GEGLU>
+__global__ __launch_bounds__(512, 2) void igemm_pp_kernel(const IgemmArgs a) {
+  typedef typename Vec8<T>::type frag_t;
+  constexpr int BM = 256;
+  constexpr int WAVE_N = NT * 16;
+  constexpr int BN = 2 * WAVE_N;
+  constexpr int X_TILE = BM * 128, W_TILE = BN * 128;
+  constexpr int STAGE = X_TILE + W_TILE;
+  constexpr int WJ = (BN + 63) / 64;                         // weight DMA instructions per thread and tile
+  constexpr int PIECES = 4 + WJ;
+  constexpr unsigned OOB = 0x80000000u;                      // beyond every descriptor (extents < 2^31, host check)
+  __shared__ __attribute__((aligned(16))) unsigned char lds[3 * STAGE];
+  typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave & 3, wn = wave >> 2;
+  const bool late = wave >= 4;                               // the half that runs one phase behind
+  const int group = blockIdx.z;
+  const int nblk = a.tiles_m * a.tiles_n;
+  const int nk = a.nk;
+  const T* wgt = reinterpret_cast<const T*>(a.weight) + (long long)group * a.w_group_stride;
+  const __amdgpu_buffer_rsrc_t rx0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.src0), 0, a.src0_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rx1 =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.src1 ? a.src1 : a.src0), 0, a.src1 ? a.src1_bytes : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(wgt), 0, a.w_bytes, 0x00020000);
+
+  const int rloc = lane >> 3;                                // row inside the wave's 8-row DMA piece
+  const unsigned sg16 = (unsigned)((lane & 7) ^ rloc) * 16u; // source piece that lands in this lane's slot (swizzle)
+
+  // ---- fetch side ----------------------------------------------------------------------------------------------
+  int f_bid = blockIdx.x, f_kt = 0, f_slot = 0;
+  int x_hw[4];                                               // window origin of this lane's four rows:
+                                                             // (row << 16) | (column & 0xffff), both may be < 0
+  int x_img[4];                                              // first pixel of their images (wave-uniform: hw_out % 64 == 0)
+  unsigned f_row[4] = {OOB, OOB, OOB, OOB};                  // byte offsets of the current (tap, source)
+  unsigned w_off = 0;                                        // this lane's piece of weight row n0 + 8 * wave + rloc
+  int w_rowstep = 0;                                         // bytes between weight rows 64 apart (wave-uniform)
+  int u_tap = 0, u_ky = 0, u_kx = 0, u_c = 0, f_tap = -1, f_src = -1;
+
+  auto set_fetch_tile = [&]() {
+    const int L = xcd_remap(f_bid, nblk);
+    const int tile_n = L % a.tiles_n, tile_m = L / a.tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int m = m0 + 8 * wave + rloc + 64 * j;           // < M: every tile is full
+      const int rem = m & (a.hw_out - 1);                    // hw_out, wout: powers of two (host check)
+      const int ho = rem >> a.w_shift, wo = rem & (a.wout - 1);
+      const int h0 = ho * a.stride - a.pad_h, w0 = wo * a.stride - a.pad_w;
+      x_hw[j] = (int)(((unsigned)h0 << 16) | ((unsigned)w0 & 0xffffu));
+      x_img[j] = __builtin_amdgcn_readfirstlane((group * a.imgs_per_group + (m >> a.hw_shift)) * a.img_pix_stride);
+    }
+    w_off = (unsigned)(n0 + 8 * wave + rloc) * (unsigned)a.ktot * 2u + sg16;
+    w_rowstep = a.ktot * 128;
+    u_tap = 0; u_ky = 0; u_kx = 0; u_c = 0; f_tap = -1; f_src = -1;
+  };
+
+  // every vector-memory instruction this wave issues is counted (wave-uniform); mk1 / mk2 = the count right after
+  // the requests of the next / next-but-one k-tile
+  int vm_issued = 0, mk1 = 0, mk2 = 0;
+  auto issue_next = [&]() {
+    unsigned char* st = lds + f_slot * STAGE;
+    f_slot = f_slot == 2 ? 0 : f_slot + 1;
+    const int src = u_c >= a.c0 ? 1 : 0;
+    if (u_tap != f_tap || src != f_src) {
+      f_tap = u_tap; f_src = src;
+      const unsigned cs2 = (unsigned)(src ? a.c1 : a.c0) * 2u;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int hi = (x_hw[j] >> 16) + u_ky, wi = (int)(short)x_hw[j] + u_kx;
+        const bool ok = (unsigned)hi < (unsigned)a.hin && (unsigned)wi < (unsigned)a.win;
+        f_row[j] = ok ? (unsigned)(x_img[j] + hi * a.win + wi) * cs2 + sg16 : OOB;
+      }
+    }
+    const int soff = (src ? u_c - a.c0 : u_c) * 2;
+#if !(MOBI_DBG_SKIP & 1)
+    if (src) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rx1, (lds_ptr_t)(st + (8 * wave + 64 * j) * 128), 16, f_row[j], soff, 0, 0);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rx0, (lds_ptr_t)(st + (8 * wave + 64 * j) * 128), 16, f_row[j], soff, 0, 0);
+    }
+    vm_issued += 4;
+#endif
+#if !(MOBI_DBG_SKIP & 2)
+    const int kb = f_kt * 128;
+#pragma unroll
+    for (int j = 0; j < WJ; ++j) {
+      // rows 8 * wave + rloc + 64 j; the last partial group of 32 rows is fetched by waves 0-3 and (identically,
+      // benign duplicate) by waves 4-7 so that every wave issues PIECES requests
+      const bool partial = (BN % 64 != 0) && (j == WJ - 1);
+      const int wl = (partial ? 64 * j + 8 * (wave & 3) : 64 * j + 8 * wave) * 128;
+      const int so = kb + j * w_rowstep - (partial ? (wave >> 2) * (w_rowstep >> 1) : 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr_t)(st + X_TILE + wl), 16, w_off, so, 0, 0);
+    }
+    vm_issued += WJ;
+#endif
+    if (++f_kt == nk) {                                      // the sequence moves on to this block's next output tile
+      f_kt = 0;
+      f_bid += gridDim.x;
+      if (f_bid < nblk) set_fetch_tile();
+    } else if (a.k_order) {                                  // channel-chunk-major k: taps innermost
+      ++u_tap;
+      if (++u_kx == a.kw) { u_kx = 0; if (++u_ky == a.kh) { u_ky = 0; u_tap = 0; u_c += 64; } }
+    } else {                                                 // tap-major k
+      u_c += 64;
+      if (u_c >= a.C) { u_c = 0; ++u_tap; if (++u_kx == a.kw) { u_kx = 0; ++u_ky; } }
+    }
+  };
+
+#define MOBI_PP_BARRIER()                     \
+  do {                                        \
+    __builtin_amdgcn_sched_barrier(0);        \
+    __builtin_amdgcn_s_barrier();             \
+    __builtin_amdgcn_sched_barrier(0);        \
+  } while (0)
+
+  const int r16 = lane & 15, g4 = lane >> 4;
+  f32x4 acc[NT][4];
+  DirectEpiRegs<NT> dq;                                      // residual rows only: bias / per-image vector start the sums
+
+  // bias OR per-image vector (never both) of the wave tile at (mw0, nw0): f32 x 4 per 16-column MFMA tile, the
+  // accumulator layout.  Requested BEFORE anything else of the phase so that the latency hides behind the
+  // epilogue stores; lands in registers that are free at that point (no fragment is live at a tile boundary).
+  const bool has_vec = a.bias || a.rowvec;
+  auto request_vec = [&](u32x4 (&bv)[NT], int nw0, int mw0) {
+    const float* vec = a.bias;
+    if (a.rowvec) {                                          // the wave's 64 pixels lie in one image: hw_out % 64 == 0
+      const int img = __builtin_amdgcn_readfirstlane(mw0 / a.hw_out);
+      vec = a.rowvec + (long long)(group * a.imgs_per_group + img) * a.rowvec_stride;
+    }
+#pragma unroll
+    for (int ni = 0; ni < NT; ++ni) bv[ni] = vm_load16(vec + nw0 + ni * 16 + g4 * 4);
+  };
+  auto start_sums = [&](u32x4 (&bv)[NT]) {
+#pragma unroll
+    for (int ni = 0; ni < NT; ++ni) {
+      f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (has_vec) { asm volatile("" : "+v"(bv[ni])); v = __builtin_bit_cast(f32x4, bv[ni]); }
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi) acc[ni][mi] = v;
+    }
+  };
+
+  int ahead = 0;                                             // requested k-tiles not yet multiplied
+  {
+    const int L0 = xcd_remap(blockIdx.x, nblk);
+    const int nw0 = (L0 % a.tiles_n) * BN + wn * WAVE_N, mw0 = (L0 / a.tiles_n) * BM + wm * 64;
+    u32x4 bv[NT];
+    if (has_vec) { request_vec(bv, nw0, mw0); vm_issued += NT; }
+    set_fetch_tile();
+    issue_next(); ++ahead;
+    const int mk_first = vm_issued;
+    if (f_bid < nblk) { issue_next(); ++ahead; mk1 = vm_issued; }
+    wait_vmcnt_le(vm_issued - mk_first);                     // this wave's pieces of the first k-tile (and, older,
+    start_sums(bv);                                          // the vector) have landed
+    vm_issued += direct_epilogue_request<T, NT, false, !GEGLU>(a, dq, lane, group, nw0, mw0);
+  }
+  int mk_req = vm_issued;
+  int c_slot = 0;                                            // LDS stage of the k-tile to multiply next
+  if (late) MOBI_PP_BARRIER();
+
+  int p_nw0 = 0, p_mw0 = 0;
+#if MOBI_STAMP == 3
+  // per wave, in shader cycles: [ks][wait at the LOAD barrier, LOAD, wait at the MATRIX barrier, MATRIX issue]
+  unsigned pp_acc[2][4] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}}, pp_n = 0;
+  unsigned long long pp_t[5];
+#define MOBI_PP_T(i) pp_t[i] = __builtin_amdgcn_s_memtime()
+#else
+#define MOBI_PP_T(i) ((void)0)
+#endif
+  for (int bid = blockIdx.x; bid < nblk; bid += gridDim.x) {
+    const int L = xcd_remap(bid, nblk);
+    const int nw0 = (L % a.tiles_n) * BN + wn * WAVE_N, mw0 = (L / a.tiles_n) * BM + wm * 64;
+    for (int kt = 0; kt < nk; ++kt) {
+      const unsigned char* st = lds + c_slot * STAGE;
+      const unsigned char* xb = st + (wm * 64 + r16) * 128;
+      const unsigned char* wb = st + X_TILE + (wn * WAVE_N + r16) * 128;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        // ---- LOAD phase ----------------------------------------------------------------------------------------
+        MOBI_PP_T(0);
+        MOBI_PP_BARRIER();
+        MOBI_PP_T(1);
+        if (ks == 0 && kt == 0 && bid != (int)blockIdx.x) {  // tile boundary: previous tile's registers -> memory
+          u32x4 bv[NT];
+          if (has_vec) { request_vec(bv, nw0, mw0); vm_issued += NT; }
+          const int mk_vec = vm_issued;
+          wait_vmcnt_le(vm_issued - mk_req);                 // residual rows of the previous tile
+          vm_issued += direct_epilogue<T, NT, GEGLU, false>(a, acc, dq, lane, group, p_nw0, p_mw0);
+          wait_vmcnt_le(vm_issued - mk_vec);
+          start_sums(bv);
+          vm_issued += direct_epilogue_request<T, NT, false, !GEGLU>(a, dq, lane, group, nw0, mw0);
+          mk_req = vm_issued;
+        }
+        const int sw = ((ks * 4 + g4) ^ (r16 & 7)) << 4;
+        frag_t xf[4], wf[NT];
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) xf[mi] = __builtin_bit_cast(frag_t, ld16(xb + mi * 16 * 128 + sw));
+#pragma unroll
+        for (int ni = 0; ni < NT; ++ni) wf[ni] = __builtin_bit_cast(frag_t, ld16(wb + ni * 16 * 128 + sw));
+        if (ks == MOBI_PP_DMA_KS && f_bid < nblk) {          // k-tile two steps ahead, behind the reads' latency
+          issue_next(); ++ahead;
+          if (ahead == 2) mk1 = vm_issued; else mk2 = vm_issued;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the stage may be overwritten after two more barriers
+        if (ks == 1 && late && ahead >= 2) wait_vmcnt_le(vm_issued - mk1);      // RAW rule above, late waves
+        // ---- MATRIX phase --------------------------------------------------------------------------------------
+        MOBI_PP_T(2);
+        MOBI_PP_BARRIER();
+        MOBI_PP_T(3);
+        __builtin_amdgcn_s_setprio(MOBI_PP_PRIO);
+#if MOBI_DBG_SKIP & 4
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) asm volatile("" :: "v"(xf[mi]));
+#pragma unroll
+        for (int ni = 0; ni < NT; ++ni) asm volatile("" :: "v"(wf[ni]));
+#else
+#pragma unroll
+        for (int ni = 0; ni < NT; ++ni)
+#pragma unroll
+          for (int mi = 0; mi < 4; ++mi) acc[ni][mi] = mfma16(wf[ni], xf[mi], acc[ni][mi]);
+#endif
+        __builtin_amdgcn_s_setprio(0);
+        MOBI_PP_T(4);
+#if MOBI_STAMP == 3
+        if (kt != 0) {                                       // (tile boundaries excluded)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) pp_acc[ks][i] += (unsigned)(pp_t[i + 1] - pp_t[i]);
+          if (ks) ++pp_n;
+        }
+#endif
+        if (ks == 1 && !late && ahead >= 2) wait_vmcnt_le(vm_issued - mk1);     // RAW rule above, early waves
+      }
+      --ahead; mk1 = mk2;
+      c_slot = c_slot == 2 ? 0 : c_slot + 1;
+    }
+    p_nw0 = nw0; p_mw0 = mw0;
+  }
+  if (!late) MOBI_PP_BARRIER();                              // every wave has passed the same number of barriers
+  wait_vmcnt_le(vm_issued - mk_req);
+  direct_epilogue<T, NT, GEGLU, false>(a, acc, dq, lane, group, p_nw0, p_mw0);
+#if MOBI_STAMP == 3
+  if (g_phase && lane == 0) {
+    unsigned long long* d = g_phase + ((size_t)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) * 8 + wave) * 16;
+    for (int i = 0; i < 8; ++i) d[i] = pp_acc[i >> 2][i & 3];
+    d[8] = pp_n;
+  }
+#endif
+#undef MOBI_PP_T
+#undef MOBI_PP_BARRIER
 }
 
 // split-K finish: sum the partial slabs, then the ordinary epilogue (bias, per-image vector, residual)
@@ -1092,7 +1408,13 @@ static int launch_igemm(const mobi_igemm_params* p, const IgemmArgs& a, int grou
 #define MOBI_GLDS_BY_MODE(NT_)                                                                     \
   do { switch (mode) { case 0: MOBI_GLDS_LAUNCH(NT_, 0); break; case 1: MOBI_GLDS_LAUNCH(NT_, 1); break; \
                        case 2: MOBI_GLDS_LAUNCH(NT_, 2); break; default: MOBI_GLDS_LAUNCH(NT_, 3); break; } } while (0)
-    if (nt5) MOBI_GLDS_BY_MODE(5); else MOBI_GLDS_BY_MODE(4);
+    if (a.pp) {
+#define MOBI_PP_LAUNCH(NT_, G_) hipLaunchKernelGGL((igemm_pp_kernel<T, NT_, G_>), pgrid, block, 0, st, a)
+      if (mode == 3) { if (nt5) MOBI_PP_LAUNCH(5, true); else MOBI_PP_LAUNCH(4, true); }
+      else           { if (nt5) MOBI_PP_LAUNCH(5, false); else MOBI_PP_LAUNCH(4, false); }
+#undef MOBI_PP_LAUNCH
+    }
+    else if (nt5) MOBI_GLDS_BY_MODE(5); else MOBI_GLDS_BY_MODE(4);
 #undef MOBI_GLDS_BY_MODE
 #undef MOBI_GLDS_LAUNCH
   }
@@ -1131,7 +1453,7 @@ extern "C" int mobi_debug_set_stamps(void* buf) {
   return hipMemcpyToSymbol(HIP_SYMBOL(mobi::g_stamps), &buf, sizeof(void*)) == hipSuccess ? MOBI_OK : MOBI_ERR_LAUNCH;
 }
 #endif
-#if MOBI_STAMP == 2
+#if MOBI_STAMP >= 2
 extern "C" int mobi_debug_set_phases(void* buf) {
   return hipMemcpyToSymbol(HIP_SYMBOL(mobi::g_phase), &buf, sizeof(void*)) == hipSuccess ? MOBI_OK : MOBI_ERR_LAUNCH;
 }
@@ -1234,9 +1556,17 @@ static int igemm_prepare(const mobi_igemm_params* p, mobi::IgemmArgs& a) {
   a.lin_window = p->k_order == 1 && p->upsample == 0 && p->kh * p->kw <= 16;
   if (const char* e = getenv("MOBI_IGEMM_LIN")) a.lin_window = a.lin_window && e[0] != '0';
   // register epilogue of the direct-to-LDS kernel: every tile full, row-major T output, no per-image vector
-  a.epi_direct = a.wm == 4 && a.fast && a.glds && p->out_mode == MOBI_OUT_ROWS && !p->rowvec && !a.split_ws &&
-                 a.M % 256 == 0 && p->n_packed % bn == 0 && a.nk_per >= 3;
+  // (a per-image vector takes the bias registers: never both, and every wave's 64 pixels inside one image)
+  a.epi_direct = a.wm == 4 && a.fast && a.glds && p->out_mode == MOBI_OUT_ROWS && !a.split_ws &&
+                 (!p->rowvec || (!p->bias && a.hw_out % 64 == 0)) && a.M % 256 == 0 && p->n_packed % bn == 0 &&
+                 a.nk_per >= 3;
   if (const char* e = getenv("MOBI_IGEMM_EPI_DIRECT")) a.epi_direct = a.epi_direct && e[0] != '0';
+  // ping-pong kernel: window pixels linear in the tap (no upsampling, <= 16 taps), one k range
+  auto log2_exact = [](int v) { int s = 0; while ((1 << s) < v) ++s; return (1 << s) == v ? s : -1; };
+  a.hw_shift = log2_exact(a.hw_out); a.w_shift = log2_exact(a.wout);
+  a.pp = a.epi_direct && a.splits == 1 && p->upsample == 0 && p->scale == 1.0f && a.hw_shift >= 6 && a.w_shift >= 0 &&
+         a.hin < 32768 && a.win < 32768;
+  if (const char* e = getenv("MOBI_IGEMM_PP")) a.pp = a.pp && e[0] != '0';
   return MOBI_OK;
 }
 
@@ -1253,6 +1583,6 @@ extern "C" int mobi_igemm_kernel_variant(const mobi_igemm_params* p) {
   mobi::IgemmArgs a;
   const int rc = igemm_prepare(p, a);
   if (rc != MOBI_OK) return rc;
-  if (a.wm == 4 && a.fast && a.glds) return MOBI_IGEMM_DIRECT_LDS;
+  if (a.wm == 4 && a.fast && a.glds) return a.pp ? MOBI_IGEMM_PINGPONG : MOBI_IGEMM_DIRECT_LDS;
   return a.wm == 4 ? MOBI_IGEMM_STAGED_256 : MOBI_IGEMM_STAGED_128;
 }

@@ -111,11 +111,14 @@ class CrossAttention(nn.Module):
         q, (k, v) = ops.concurrently(lambda: ops.linear(xn, self.to_q.packed()), lambda: self.context_kv(context))
         return ops.ctx_attention(q, k, v, self.heads, self.scale)
 
-    def single_token_vector(self, token):
+    def single_token_vector(self, token, extra_bias=None):
         """One key => softmax == 1 => the output is to_out(to_v(token)) for every query.
-        token: fp32 [N, Cc] (row stride free) -> fp32 [N, query_dim]."""
+        token: fp32 [N, Cc] (row stride free) -> fp32 [N, query_dim].  extra_bias: a parameter vector added to
+        to_out's bias (the bias of the launch this per-image vector is added in)."""
         wv, _ = self.to_v.skinny()
         wo, bo = self.to_out[0].skinny()
+        if extra_bias is not None:
+            bo = bo + extra_bias.detach().float()
         return ops.skinny_linear(ops.skinny_linear(token, wv), wo, bo)
 
     def attend(self, x, context=None):
@@ -205,7 +208,7 @@ class BasicTransformerBlock(nn.Module):
         adapter's keys / values -- is the same at every denoising step of a sampling run.  It is computed once
         per context tensor (the cache holds a reference to the tensor, so its storage cannot be recycled, and
         checks the tensor's version counter and the weights' versions) instead of once per UNet call."""
-        ws = [self.attn2.to_v.weight, self.attn2.to_out[0].weight, self.attn2.to_out[0].bias]
+        ws = [self.attn2.to_v.weight, self.attn2.to_out[0].weight, self.attn2.to_out[0].bias, self.attn1.to_out[0].bias]
         if self.bbox_cond:
             ws += [self.cond_adapter_attn.to_k.weight, self.cond_adapter_attn.to_v.weight]
         key = (id(ctx), ctx._version, ctx.data_ptr(), tuple(ctx.shape), tuple(w._version for w in ws),
@@ -213,7 +216,8 @@ class BasicTransformerBlock(nn.Module):
         c = self.__dict__.setdefault("_ctx_cache", {})
         if c.get("key") != key:
             c["key"], c["ctx"] = key, ctx
-            c["ref_vec"] = self.attn2.single_token_vector(ctx[:, 0])
+            # (+ attn1.to_out's bias: the launch that adds this vector then passes no separate bias)
+            c["ref_vec"] = self.attn2.single_token_vector(ctx[:, 0], extra_bias=self.attn1.to_out[0].bias)
             c["kv"] = self.cond_adapter_attn.context_kv(ctx) if self.bbox_cond else None
         return c["ref_vec"], c["kv"]
 
@@ -223,7 +227,7 @@ class BasicTransformerBlock(nn.Module):
         ref_vec, ctx_kv = self._context_terms(ctx)
         # attn1 (self) + attn2 (reference token; norm2 / to_q cancel out of a one-key softmax)
         a = self.attn1.self_attention(self._ln(self.norm1, x))
-        x = ops.linear(a, self.attn1.to_out[0].packed(), residual=x, rowvec=ref_vec)
+        x = ops.linear(a, self.attn1.to_out[0].packed(), residual=x, rowvec=ref_vec, rowvec_has_bias=True)
 
         if self.bbox_cond:
             ca = self.cond_adapter_attn

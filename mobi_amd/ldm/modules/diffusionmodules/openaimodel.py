@@ -107,18 +107,21 @@ class ResBlock(TimestepBlock):
         x, ext = enter(x)
         if skip is not None:
             skip, _ = enter(skip)
+        # emb_out already carries conv1's bias (one fp32 add at pack time instead of one per pixel; the launch
+        # then needs only ONE per-image vector, which keeps it on the register-epilogue kernels)
         if isinstance(emb, dict):
             lo, hi = self._emb_slice
             emb_out = emb["proj"][:, lo:hi]
         else:
             w, b = self.emb_layers[1].skinny()
-            emb_out = ops.skinny_linear(emb.float().contiguous(), w, b, pre_act=ACT_SILU)
+            emb_out = ops.skinny_linear(emb.float().contiguous(), w, b + self.in_layers[2].bias.detach().float(),
+                                        pre_act=ACT_SILU)
         n1, n2 = self.in_layers[0], self.out_layers[0]
 
         def main_path():
             g, b = n1.affine()
             h = ops.groupnorm(x, g, b, n1.eps, silu=True, x2=skip)
-            h = ops.igemm(h, self.in_layers[2].packed(), rowvec=emb_out)
+            h = ops.igemm(h, self.in_layers[2].packed(), rowvec=emb_out, rowvec_has_bias=True)
             g, b = n2.affine()
             return ops.groupnorm(h, g, b, n2.eps, silu=True)
 
@@ -214,14 +217,18 @@ class UNetModel(nn.Module):
         self._emb_total = off
 
     def _emb_projection(self):
-        """(T weight [sum cout, 4*mc], fp32 bias) of all ResBlock emb_layers stacked."""
+        """(T weight [sum cout, 4*mc], fp32 bias) of all ResBlock emb_layers stacked; the bias also carries the
+        bias of the conv the projection is added to (`in_layers[2]`, openaimodel.py:262-270 of the reference:
+        `h = in_layers(x); h = h + emb_out`)."""
         lins = [rb.emb_layers[1] for rb in self._res_blocks]
+        convs = [rb.in_layers[2] for rb in self._res_blocks]
         key = (engine_dtype(), lins[0].weight.device, tuple(l.weight._version for l in lins),
-               tuple(l.bias._version for l in lins), lins[0].weight.data_ptr())
+               tuple(l.bias._version for l in lins), tuple(c.bias._version for c in convs), lins[0].weight.data_ptr())
         c = self.__dict__.setdefault("_embproj_cache", {})
         if c.get("key") != key:
             w = torch.cat([l.weight.detach() for l in lins], dim=0).to(engine_dtype()).contiguous()
-            b = torch.cat([l.bias.detach() for l in lins], dim=0).float().contiguous()
+            b = torch.cat([l.bias.detach().float() + c.bias.detach().float() for l, c in zip(lins, convs)],
+                          dim=0).contiguous()
             c["key"], c["val"] = key, (w, b)
         return c["val"]
 

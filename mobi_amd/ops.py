@@ -183,9 +183,11 @@ def pack_geglu(weight, bias, dtype, device):
 # matrix-core ops
 # --------------------------------------------------------------------------------------
 def igemm(x, pw: Packed, *, x2=None, stride=1, pad=None, upsample=False, hout=None, wout=None, rowvec=None,
-          residual=None, out=None, out_mode=OUT_ROWS, scale=1.0, weight_per_image=False, w_group_stride=0,
-          split_k=None):
-    """x: [N,H,W,C0] (tokens: [N,T,1,C]); x2: optional second source concatenated on channels."""
+          rowvec_has_bias=False, residual=None, out=None, out_mode=OUT_ROWS, scale=1.0, weight_per_image=False,
+          w_group_stride=0, split_k=None):
+    """x: [N,H,W,C0] (tokens: [N,T,1,C]); x2: optional second source concatenated on channels.
+    rowvec: fp32 [N, cout] added per image; rowvec_has_bias: its producer already added this layer's bias (the
+    launch then passes no bias, which keeps it on the register-epilogue kernels)."""
     lib = _lib.load()
     n, hin, win, c0 = x.shape
     c1 = 0 if x2 is None else x2.shape[3]
@@ -214,7 +216,8 @@ def igemm(x, pw: Packed, *, x2=None, stride=1, pad=None, upsample=False, hout=No
     p.groups = n if weight_per_image else 1
     p.w_group_stride = w_group_stride
     p.n_packed, p.cout = pw.n_packed, pw.cout
-    p.bias, p.rowvec, p.residual = _ptr(pw.bias), _ptr(rowvec), _ptr(residual)
+    assert rowvec is not None or not rowvec_has_bias
+    p.bias, p.rowvec, p.residual = (None if rowvec_has_bias else _ptr(pw.bias)), _ptr(rowvec), _ptr(residual)
     if rowvec is not None:
         assert rowvec.dtype == torch.float32 and rowvec.stride(1) == 1 and rowvec.shape == (n, pw.cout)
         p.rowvec_stride = rowvec.stride(0)
@@ -241,7 +244,7 @@ def igemm(x, pw: Packed, *, x2=None, stride=1, pad=None, upsample=False, hout=No
         + out.numel() * out.element_size() + (0 if residual is None else residual.numel() * 2)
     tag = ""
     if _PROFILE is not None:
-        kern = ("staged128", "staged256", "direct_lds")[lib.mobi_igemm_kernel_variant(C.byref(p))]
+        kern = ("staged128", "staged256", "direct_lds", "pingpong")[lib.mobi_igemm_kernel_variant(C.byref(p))]
         tag = f"kern={kern} m={n * hout * wout} n={pw.n_packed} k={pw.kh * pw.kw * pw.cin} tap={pw.kh}x{pw.kw} " \
               f"split={splits} mode={out_mode}"
     with _Timed("igemm", flops, nbytes, tag):
