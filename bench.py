@@ -219,18 +219,25 @@ def main():
             k["ms"] += e0.elapsed_time(e1)
             k["bytes"] += nb
         ig = kinds["igemm"]
-        # dominant kernel: the persistent direct-to-LDS implicit GEMM (igemm_glds_kernel<...> in the rocprofv3 summary)
-        dk = dict(launches=0, flops=0.0, ms=0.0, bytes=0.0)
+        # dominant kernel: the implicit-GEMM main loop that takes the most time of the step -- the library says which
+        # variant every launch runs (mobi_igemm_kernel_variant): igemm_pp_kernel<...> (persistent direct-to-LDS,
+        # ping-pong schedule), igemm_glds_kernel<...> (same geometry, lockstep) or igemm_kernel<...> (register-staged)
+        by_variant = {}
         for kind, flops, e0, e1, nb, tag in sink:
-            if kind == "igemm" and "kern=direct_lds" in tag:
-                dk["launches"] += 1
-                dk["flops"] += flops
-                dk["ms"] += e0.elapsed_time(e1)
-                dk["bytes"] += nb
-        if dk["launches"] == 0:
-            dk = ig
+            if kind != "igemm":
+                continue
+            var = tag.split(" ")[0].replace("kern=", "") if tag.startswith("kern=") else "igemm"
+            d = by_variant.setdefault(var, dict(launches=0, flops=0.0, ms=0.0, bytes=0.0))
+            d["launches"] += 1
+            d["flops"] += flops
+            d["ms"] += e0.elapsed_time(e1)
+            d["bytes"] += nb
+        dom = max(by_variant, key=lambda v: by_variant[v]["ms"]) if by_variant else "igemm"
+        dk = by_variant.get(dom, ig)
+        kname = {"pingpong": "igemm_pp_kernel", "direct_lds": "igemm_glds_kernel", "staged128": "igemm_kernel",
+                 "staged256": "igemm_kernel"}.get(dom, "igemm_kernel")
         ach = dk["flops"] / (dk["ms"] * 1e-3) / 1e12
-        roofline = {"bound": "mfma", "kernel": "igemm_glds_kernel", "achieved": round(ach, 2), "peak": PEAK_TFLOPS,
+        roofline = {"bound": "mfma", "kernel": kname, "achieved": round(ach, 2), "peak": PEAK_TFLOPS,
                     "unit": "TFLOP/s", "frac": round(ach / PEAK_TFLOPS, 4), "traffic": None,
                     "launches_per_step": dk["launches"],
                     "avg_launch_us": round(dk["ms"] * 1e3 / dk["launches"], 2),
@@ -239,10 +246,11 @@ def main():
                     "note": "HIP-event-bracketed launches (on the launch stream) of one extra step after the timed "
                             "region; algorithmic 2*M*N*K of every conv / linear the kernel ran"}
         roofline["algorithmic_mb_per_launch"] = round(dk["bytes"] / dk["launches"] / 1e6, 2)
+        roofline["igemm_ms_by_variant"] = {v: round(d["ms"], 3) for v, d in by_variant.items()}
         pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
         if os.path.exists(pmc):            # HBM bytes per launch from the committed rocprofv3 --pmc passes
             with open(pmc) as f:
-                rec = json.load(f).get("igemm_glds_kernel")
+                rec = json.load(f).get(kname)
             if rec:
                 roofline["traffic"] = round(rec["hbm_bytes_per_launch_corrected"])
                 roofline["traffic_source"] = "profiles/r01_pmc_traffic.json (FETCH_SIZE x2 + WRITE_SIZE, separate --pmc passes)"

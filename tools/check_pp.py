@@ -16,7 +16,8 @@ for (n, h, w, cin, cout, k, res, rowvec, blocks) in [
         (4, 32, 32, 320, 320, 3, True, False, 3), (4, 32, 32, 128, 128, 3, False, True, 5),
         (8, 8, 8, 128, 320, 3, True, True, 2), (2, 64, 64, 320, 640, 1, True, True, 7),
         (2, 64, 64, 320, 640, 1, False, False, 7), (2, 64, 64, 320, 640, 1, True, False, 0), (3, 16, 16, 192, 160, 1, False, False, 0),
-        (3, 16, 16, 64, 160, 3, True, False, 0), (3, 16, 16, 128, 160, 3, False, False, 0)]:
+        (3, 16, 16, 64, 160, 3, True, False, 0), (3, 16, 16, 128, 160, 3, False, False, 0),
+        (1, 128, 128, 128, 128, 3, True, False, 0), (1, 64, 64, 192, 320, 3, False, True, 5), (2, 16, 512, 64, 128, 3, False, False, 0)]:
     if blocks: os.environ["MOBI_IGEMM_PERSIST_BLOCKS"] = str(blocks)
     else: os.environ.pop("MOBI_IGEMM_PERSIST_BLOCKS", None)
     x = torch.randn(n, h, w, cin, generator=g).to(dt)

@@ -13,7 +13,7 @@ import json
 import os
 import sys
 
-FAMILIES = ["igemm_glds_kernel", "igemm_kernel", "igemm_splitk_reduce_kernel", "attention_kernel", "gn_stats_kernel",
+FAMILIES = ["igemm_pp_kernel", "igemm_halo_kernel", "igemm_glds_kernel", "igemm_kernel", "igemm_splitk_reduce_kernel", "attention_kernel", "gn_stats_kernel",
             "gn_apply_kernel", "layernorm_kernel", "ctx_attention_kernel"]
 
 
