@@ -52,7 +52,22 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const GnArgs a) {
       const bool second = c >= a.c0;
       const T* __restrict__ base = second ? s1 + (c - a.c0) : s0 + c;
       const int cs = second ? a.c1 : a.c0;
-      for (int p = p_begin + slot; p < p_end; p += rows) {
+      // four independent 16-byte loads in flight per thread (the loop is latency-bound otherwise: one load per
+      // thread and iteration keeps only ~32 KB per CU in flight)
+      int p = p_begin + slot;
+      for (; p + 3 * rows < p_end; p += 4 * rows) {
+        u32x4 r[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) r[u] = ld16(base + (long long)(p + u * rows) * cs);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          float f[8];
+          unpack8<T>(r[u], f);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) { sum[j] += f[j]; sq[j] += f[j] * f[j]; }
+        }
+      }
+      for (; p < p_end; p += rows) {
         float f[8];
         unpack8<T>(ld16(base + (long long)p * cs), f);
 #pragma unroll
@@ -108,19 +123,22 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const GnArgs a) {
   }
   __syncthreads();
   const int V = a.C >> 3;
-  const long long total = (long long)a.hw * V;
+  const int total = a.hw * V;                                // 16-byte items of one image (host: < 2^31)
   const T* __restrict__ s0 = reinterpret_cast<const T*>(a.src0) + (long long)img * a.hw * a.c0;
   const T* __restrict__ s1 = a.src1 ? reinterpret_cast<const T*>(a.src1) + (long long)img * a.hw * a.c1 : nullptr;
   T* __restrict__ out = reinterpret_cast<T*>(a.out) + (long long)img * a.hw * a.C;
-  // each thread keeps its 8-channel column while it strides over pixels when 256 % V == 0 or V % 256 == 0;
-  // otherwise the column changes per iteration (still one 16-byte access per iteration)
-  for (long long i = (long long)blockIdx.x * 256 + tid; i < total; i += (long long)gridDim.x * 256) {
-    const int p = (int)(i / V);
-    const int c = (int)(i - (long long)p * V) * 8;
-    const bool second = c >= a.c0;
-    const T* src = second ? s1 + (long long)p * a.c1 + (c - a.c0) : s0 + (long long)p * a.c0 + c;
+  // item i = pixel * V + column.  A thread walks i, i + S, i + 2 S, ... (S = threads of the grid row); (pixel, column)
+  // advance by (S / V, S % V) with one carry instead of a division per item, and two items are in flight.
+  const int S = (int)gridDim.x * 256;
+  const int dp = S / V, dv = S - dp * V;
+  int i = (int)blockIdx.x * 256 + tid;
+  int p = i / V, v = i - p * V;
+  auto src_of = [&](int pp, int c) -> const T* {
+    return c >= a.c0 ? s1 + (long long)pp * a.c1 + (c - a.c0) : s0 + (long long)pp * a.c0 + c;
+  };
+  auto finish = [&](const u32x4& raw, int pp, int c) {
     float f[8];
-    unpack8<T>(ld16(src), f);
+    unpack8<T>(raw, f);
     const f32x4 sc0 = *reinterpret_cast<const f32x4*>(s_sc + c), sc1 = *reinterpret_cast<const f32x4*>(s_sc + c + 4);
     const f32x4 sh0 = *reinterpret_cast<const f32x4*>(s_sh + c), sh1 = *reinterpret_cast<const f32x4*>(s_sh + c + 4);
 #pragma unroll
@@ -132,7 +150,20 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const GnArgs a) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) f[j] = silu_f(f[j]);
     }
-    st16(out + (long long)p * a.C + c, pack8<T>(f));
+    st16(out + (long long)pp * a.C + c, pack8<T>(f));
+  };
+  while (i < total) {
+    int p2 = p + dp, v2 = v + dv;
+    if (v2 >= V) { v2 -= V; ++p2; }
+    const bool two = i + S < total;
+    const u32x4 r0 = ld16(src_of(p, v * 8));
+    u32x4 r1 = r0;
+    if (two) r1 = ld16(src_of(p2, v2 * 8));
+    finish(r0, p, v * 8);
+    if (two) finish(r1, p2, v2 * 8);
+    i += 2 * S;
+    p = p2 + dp; v = v2 + dv;
+    if (v >= V) { v -= V; ++p; }
   }
 }
 
@@ -143,48 +174,80 @@ struct LnArgs {
   const float* gamma; const float* beta; float eps;
 };
 
-// one wave per token row; C <= 64*8*MAXV
+// one wave per LN_ROWS token rows (their loads are all issued before the first reduction: more bytes in flight per
+// wave than one 16-byte load per lane); C <= 64*8*MAXV
+template <int MAXV> struct LnRows { static constexpr int N = MAXV <= 2 ? 4 : 2; };
 template <typename T, int MAXV>
 __global__ __launch_bounds__(256) void layernorm_kernel(const LnArgs a) {
+  constexpr int MOBI_LN_ROWS = LnRows<MAXV>::N;
   const int lane = threadIdx.x & 63;
-  const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
   const long long total = (long long)a.images * a.rows;
-  if (row >= total) return;
-  const int img = (int)(row / a.rows);
-  const int r = (int)(row - (long long)img * a.rows);
-  const T* __restrict__ src = reinterpret_cast<const T*>(a.src) + img * a.src_img + (long long)r * a.C;
-  T* __restrict__ out = reinterpret_cast<T*>(a.out) + img * a.out_img + (long long)r * a.C;
+  const long long row0 = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * MOBI_LN_ROWS;
+  if (row0 >= total) return;
   const int V = a.C >> 3;
-  float f[MAXV][8];
-  float s = 0.f;
+  const T* src[MOBI_LN_ROWS];
+  T* out[MOBI_LN_ROWS];
+  bool ok[MOBI_LN_ROWS];
 #pragma unroll
-  for (int i = 0; i < MAXV; ++i) {
-    const int v = lane + 64 * i;
-    if (v < V) {
-      unpack8<T>(ld16(src + v * 8), f[i]);
-#pragma unroll
-      for (int j = 0; j < 8; ++j) s += f[i][j];
-    }
+  for (int r = 0; r < MOBI_LN_ROWS; ++r) {
+    const long long row = row0 + r;
+    ok[r] = row < total;
+    const long long rr = ok[r] ? row : row0;
+    const int img = (int)(rr / a.rows);
+    const int t = (int)(rr - (long long)img * a.rows);
+    src[r] = reinterpret_cast<const T*>(a.src) + img * a.src_img + (long long)t * a.C;
+    out[r] = reinterpret_cast<T*>(a.out) + img * a.out_img + (long long)t * a.C;
   }
-  const float mean = wave_sum(s) / (float)a.C;
-  float q = 0.f;
+  u32x4 raw[MOBI_LN_ROWS][MAXV];
 #pragma unroll
-  for (int i = 0; i < MAXV; ++i) {
-    const int v = lane + 64 * i;
-    if (v < V) {
+  for (int r = 0; r < MOBI_LN_ROWS; ++r)
 #pragma unroll
-      for (int j = 0; j < 8; ++j) { const float d = f[i][j] - mean; q += d * d; }
+    for (int i = 0; i < MAXV; ++i) {
+      const int v = lane + 64 * i;
+      raw[r][i] = u32x4{0u, 0u, 0u, 0u};
+      if (v < V) raw[r][i] = ld16(src[r] + v * 8);
     }
-  }
-  const float rstd = rsqrtf(wave_sum(q) / (float)a.C + a.eps);
+  float gam[MAXV][8], bet[MAXV][8];
 #pragma unroll
   for (int i = 0; i < MAXV; ++i) {
     const int v = lane + 64 * i;
-    if (v < V) {
-      float o[8];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) o[j] = (f[i][j] - mean) * rstd * a.gamma[v * 8 + j] + a.beta[v * 8 + j];
-      st16(out + v * 8, pack8<T>(o));
+    for (int j = 0; j < 8; ++j) { gam[i][j] = v < V ? a.gamma[v * 8 + j] : 0.f; bet[i][j] = v < V ? a.beta[v * 8 + j] : 0.f; }
+  }
+#pragma unroll
+  for (int r = 0; r < MOBI_LN_ROWS; ++r) {
+    __builtin_amdgcn_sched_barrier(0);                       // one row at a time (registers), the loads are all out
+    float f[1][MAXV][8];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+      unpack8<T>(raw[r][i], f[0][i]);
+      if (lane + 64 * i < V) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s += f[0][i][j];
+      }
+    }
+    const float mean = wave_sum(s) / (float)a.C;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+      if (lane + 64 * i < V) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const float d = f[0][i][j] - mean; q += d * d; }
+      }
+    }
+    const float rstd = rsqrtf(wave_sum(q) / (float)a.C + a.eps);
+    if (ok[r]) {
+#pragma unroll
+      for (int i = 0; i < MAXV; ++i) {
+        const int v = lane + 64 * i;
+        if (v < V) {
+          float o[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) o[j] = (f[0][i][j] - mean) * rstd * gam[i][j] + bet[i][j];
+          st16(out[r] + v * 8, pack8<T>(o));
+        }
+      }
     }
   }
 }
@@ -206,12 +269,12 @@ static int launch_gn(const GnArgs& a, int batch, hipStream_t st) {
 template <typename T>
 static int launch_ln(const LnArgs& a, hipStream_t st) {
   const long long total = (long long)a.images * a.rows;
-  const unsigned blocks = (unsigned)((total + 3) / 4);
   const int V = a.C >> 3;
-  if (V <= 64) hipLaunchKernelGGL((layernorm_kernel<T, 1>), dim3(blocks), dim3(256), 0, st, a);
-  else if (V <= 128) hipLaunchKernelGGL((layernorm_kernel<T, 2>), dim3(blocks), dim3(256), 0, st, a);
-  else if (V <= 192) hipLaunchKernelGGL((layernorm_kernel<T, 3>), dim3(blocks), dim3(256), 0, st, a);
-  else if (V <= 320) hipLaunchKernelGGL((layernorm_kernel<T, 5>), dim3(blocks), dim3(256), 0, st, a);
+  auto blocks = [&](int rows_per_wave) { return dim3((unsigned)((total + 4 * rows_per_wave - 1) / (4 * rows_per_wave))); };
+  if (V <= 64) hipLaunchKernelGGL((layernorm_kernel<T, 1>), blocks(LnRows<1>::N), dim3(256), 0, st, a);
+  else if (V <= 128) hipLaunchKernelGGL((layernorm_kernel<T, 2>), blocks(LnRows<2>::N), dim3(256), 0, st, a);
+  else if (V <= 192) hipLaunchKernelGGL((layernorm_kernel<T, 3>), blocks(LnRows<3>::N), dim3(256), 0, st, a);
+  else if (V <= 320) hipLaunchKernelGGL((layernorm_kernel<T, 5>), blocks(LnRows<5>::N), dim3(256), 0, st, a);
   else return MOBI_ERR_UNSUPPORTED;
   MOBI_CHECK_LAUNCH();
   return MOBI_OK;
@@ -231,7 +294,7 @@ extern "C" int mobi_groupnorm(const mobi_groupnorm_params* p, void* stream) {
   if (p->c0 <= 0 || (p->c0 & 31) || p->c1 < 0 || (p->c1 & 31) || (p->c1 > 0 && !p->src1)) return MOBI_ERR_UNSUPPORTED;
   if (p->batch <= 0 || p->hw <= 0 || p->batch > 65535) return MOBI_ERR_ARG;
   const int C = p->c0 + p->c1;
-  if (C > 2560) return MOBI_ERR_UNSUPPORTED;
+  if (C > 2560 || (long long)p->hw * (C >> 3) >= 0x7fffffffLL) return MOBI_ERR_UNSUPPORTED;
   if ((reinterpret_cast<uintptr_t>(p->src0) | reinterpret_cast<uintptr_t>(p->src1) |
        reinterpret_cast<uintptr_t>(p->out)) & 15) return MOBI_ERR_ALIGN;
   GnArgs a;

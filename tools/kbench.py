@@ -32,7 +32,7 @@ def timeit(fn, iters, warm=3):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("kind", choices=["attn", "conv", "linear", "gn"])
+    ap.add_argument("kind", choices=["attn", "conv", "linear", "gn", "ln"])
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--heads", type=int, default=8)
@@ -94,6 +94,12 @@ def main():
         by = 2.0 * a.rows * (a.cin + a.cout * (2 if a.residual else 1))
         print(f"linear {a.cin}->{a.cout} rows={a.rows} geglu={a.geglu} residual={a.residual}: {us:.1f} us  "
               f"{fl / us / 1e6:.1f} TFLOP/s  {by / us / 1e3:.0f} GB/s")
+    elif a.kind == "ln":
+        x = rn(a.images, a.hw, a.c)
+        gam, bet = torch.ones(a.c, device=dev), torch.zeros(a.c, device=dev)
+        us = timeit(lambda: ops.layernorm(x, gam, bet, 1e-5), a.iters)
+        by = 2.0 * x.numel() * 2
+        print(f"layernorm C={a.c} tokens={a.hw} images={a.images}: {us:.1f} us  {by / us / 1e3:.0f} GB/s (2 passes)")
     else:
         x = rn(a.images, 1, a.hw, a.c)
         gam, bet = torch.ones(a.c, device=dev), torch.zeros(a.c, device=dev)
