@@ -174,80 +174,48 @@ struct LnArgs {
   const float* gamma; const float* beta; float eps;
 };
 
-// one wave per LN_ROWS token rows (their loads are all issued before the first reduction: more bytes in flight per
-// wave than one 16-byte load per lane); C <= 64*8*MAXV
-template <int MAXV> struct LnRows { static constexpr int N = MAXV <= 2 ? 4 : 2; };
+// one wave per token row; C <= 64*8*MAXV
 template <typename T, int MAXV>
 __global__ __launch_bounds__(256) void layernorm_kernel(const LnArgs a) {
-  constexpr int MOBI_LN_ROWS = LnRows<MAXV>::N;
   const int lane = threadIdx.x & 63;
+  const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
   const long long total = (long long)a.images * a.rows;
-  const long long row0 = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * MOBI_LN_ROWS;
-  if (row0 >= total) return;
+  if (row >= total) return;
+  const int img = (int)(row / a.rows);
+  const int r = (int)(row - (long long)img * a.rows);
+  const T* __restrict__ src = reinterpret_cast<const T*>(a.src) + img * a.src_img + (long long)r * a.C;
+  T* __restrict__ out = reinterpret_cast<T*>(a.out) + img * a.out_img + (long long)r * a.C;
   const int V = a.C >> 3;
-  const T* src[MOBI_LN_ROWS];
-  T* out[MOBI_LN_ROWS];
-  bool ok[MOBI_LN_ROWS];
-#pragma unroll
-  for (int r = 0; r < MOBI_LN_ROWS; ++r) {
-    const long long row = row0 + r;
-    ok[r] = row < total;
-    const long long rr = ok[r] ? row : row0;
-    const int img = (int)(rr / a.rows);
-    const int t = (int)(rr - (long long)img * a.rows);
-    src[r] = reinterpret_cast<const T*>(a.src) + img * a.src_img + (long long)t * a.C;
-    out[r] = reinterpret_cast<T*>(a.out) + img * a.out_img + (long long)t * a.C;
-  }
-  u32x4 raw[MOBI_LN_ROWS][MAXV];
-#pragma unroll
-  for (int r = 0; r < MOBI_LN_ROWS; ++r)
-#pragma unroll
-    for (int i = 0; i < MAXV; ++i) {
-      const int v = lane + 64 * i;
-      raw[r][i] = u32x4{0u, 0u, 0u, 0u};
-      if (v < V) raw[r][i] = ld16(src[r] + v * 8);
-    }
-  float gam[MAXV][8], bet[MAXV][8];
+  float f[MAXV][8];
+  float s = 0.f;
 #pragma unroll
   for (int i = 0; i < MAXV; ++i) {
     const int v = lane + 64 * i;
+    if (v < V) {
+      unpack8<T>(ld16(src + v * 8), f[i]);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) { gam[i][j] = v < V ? a.gamma[v * 8 + j] : 0.f; bet[i][j] = v < V ? a.beta[v * 8 + j] : 0.f; }
+      for (int j = 0; j < 8; ++j) s += f[i][j];
+    }
   }
+  const float mean = wave_sum(s) / (float)a.C;
+  float q = 0.f;
 #pragma unroll
-  for (int r = 0; r < MOBI_LN_ROWS; ++r) {
-    __builtin_amdgcn_sched_barrier(0);                       // one row at a time (registers), the loads are all out
-    float f[1][MAXV][8];
-    float s = 0.f;
+  for (int i = 0; i < MAXV; ++i) {
+    const int v = lane + 64 * i;
+    if (v < V) {
 #pragma unroll
-    for (int i = 0; i < MAXV; ++i) {
-      unpack8<T>(raw[r][i], f[0][i]);
-      if (lane + 64 * i < V) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) s += f[0][i][j];
-      }
+      for (int j = 0; j < 8; ++j) { const float d = f[i][j] - mean; q += d * d; }
     }
-    const float mean = wave_sum(s) / (float)a.C;
-    float q = 0.f;
+  }
+  const float rstd = rsqrtf(wave_sum(q) / (float)a.C + a.eps);
 #pragma unroll
-    for (int i = 0; i < MAXV; ++i) {
-      if (lane + 64 * i < V) {
+  for (int i = 0; i < MAXV; ++i) {
+    const int v = lane + 64 * i;
+    if (v < V) {
+      float o[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { const float d = f[0][i][j] - mean; q += d * d; }
-      }
-    }
-    const float rstd = rsqrtf(wave_sum(q) / (float)a.C + a.eps);
-    if (ok[r]) {
-#pragma unroll
-      for (int i = 0; i < MAXV; ++i) {
-        const int v = lane + 64 * i;
-        if (v < V) {
-          float o[8];
-#pragma unroll
-          for (int j = 0; j < 8; ++j) o[j] = (f[0][i][j] - mean) * rstd * gam[i][j] + bet[i][j];
-          st16(out[r] + v * 8, pack8<T>(o));
-        }
-      }
+      for (int j = 0; j < 8; ++j) o[j] = (f[i][j] - mean) * rstd * a.gamma[v * 8 + j] + a.beta[v * 8 + j];
+      st16(out + v * 8, pack8<T>(o));
     }
   }
 }
@@ -269,12 +237,12 @@ static int launch_gn(const GnArgs& a, int batch, hipStream_t st) {
 template <typename T>
 static int launch_ln(const LnArgs& a, hipStream_t st) {
   const long long total = (long long)a.images * a.rows;
+  const unsigned blocks = (unsigned)((total + 3) / 4);
   const int V = a.C >> 3;
-  auto blocks = [&](int rows_per_wave) { return dim3((unsigned)((total + 4 * rows_per_wave - 1) / (4 * rows_per_wave))); };
-  if (V <= 64) hipLaunchKernelGGL((layernorm_kernel<T, 1>), blocks(LnRows<1>::N), dim3(256), 0, st, a);
-  else if (V <= 128) hipLaunchKernelGGL((layernorm_kernel<T, 2>), blocks(LnRows<2>::N), dim3(256), 0, st, a);
-  else if (V <= 192) hipLaunchKernelGGL((layernorm_kernel<T, 3>), blocks(LnRows<3>::N), dim3(256), 0, st, a);
-  else if (V <= 320) hipLaunchKernelGGL((layernorm_kernel<T, 5>), blocks(LnRows<5>::N), dim3(256), 0, st, a);
+  if (V <= 64) hipLaunchKernelGGL((layernorm_kernel<T, 1>), dim3(blocks), dim3(256), 0, st, a);
+  else if (V <= 128) hipLaunchKernelGGL((layernorm_kernel<T, 2>), dim3(blocks), dim3(256), 0, st, a);
+  else if (V <= 192) hipLaunchKernelGGL((layernorm_kernel<T, 3>), dim3(blocks), dim3(256), 0, st, a);
+  else if (V <= 320) hipLaunchKernelGGL((layernorm_kernel<T, 5>), dim3(blocks), dim3(256), 0, st, a);
   else return MOBI_ERR_UNSUPPORTED;
   MOBI_CHECK_LAUNCH();
   return MOBI_OK;

@@ -451,3 +451,71 @@ def test_igemm_persistent_register_epilogue(ops, dtype, blocks, monkeypatch):
         outs[direct] = (y1, y2, y3, yg)
     for ya, yb in zip(outs["1"], outs["0"]):                      # same fp32 arithmetic, one rounding: near-identical
         assert rel(ya.float(), yb.float()) < 2e-3
+
+
+# (images, h, w, cin, cin2, cout, k, residual, rowvec, geglu, persistent blocks)
+PP_CASES = [
+    (3, 16, 16, 64, 0, 160, 3, False, False, False, 0),       # one k-tile per tap, padding on every side, one tile / block
+    (3, 16, 16, 192, 0, 160, 1, False, False, False, 0),      # three k-tiles: the shortest loop the kernel accepts
+    (4, 32, 32, 320, 0, 320, 3, True, False, False, 3),       # few blocks walk many tiles (deferred epilogue, ragged)
+    (4, 32, 32, 128, 0, 128, 3, False, True, False, 5),       # 64-wide wave tiles, per-image vector, no residual
+    (8, 8, 8, 128, 0, 320, 3, True, True, False, 2),          # 8x8 images: four images per 256-pixel tile
+    (2, 64, 64, 320, 0, 640, 1, True, True, False, 7),        # 1x1, residual + per-image vector
+    (2, 32, 32, 128, 64, 160, 3, True, False, False, 3),      # two sources (the un-materialised concat)
+    (1, 128, 128, 128, 0, 128, 3, True, False, False, 0),     # rows wider than a wave's 64 pixels
+    (2, 16, 512, 64, 0, 128, 3, False, False, False, 0),      # half a row per tile
+    (2, 64, 64, 320, 0, 640, 1, False, False, True, 6),       # GEGLU register epilogue
+]
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("case", PP_CASES, ids=[f"pp{i}" for i in range(len(PP_CASES))])
+def test_igemm_pingpong(ops, dtype, case, monkeypatch):
+    """The ping-pong direct-to-LDS kernel (and, with MOBI_IGEMM_HALO=1, the halo-patch 3x3 kernel) against a torch
+    fp32 convolution: the 256-pixel geometry is forced on small problems, a handful of persistent blocks walk many
+    output tiles, and the library must report that it runs the ping-pong variant."""
+    import ctypes as C
+    from mobi_amd import _lib
+    n, h, w, cin, cin2, cout, k, res, rowvec, geglu, blocks = case
+    monkeypatch.setenv("MOBI_IGEMM_WM", "4")
+    if blocks:
+        monkeypatch.setenv("MOBI_IGEMM_PERSIST_BLOCKS", str(blocks))
+    name = "pp." + ".".join(str(int(v)) for v in case)
+    xf, xd = rnd(name + ".x", (n, h, w, cin), dtype)
+    x2f, x2d = rnd(name + ".x2", (n, h, w, cin2), dtype) if cin2 else (None, None)
+    ctot = cin + cin2
+    wf = torch.from_numpy(W.synth_param(name + ".weight", ((2 if geglu else 1) * cout, ctot, k, k))).to(dtype).float()
+    bias = torch.from_numpy(W.synth_param(name + ".bias", ((2 if geglu else 1) * cout,)))
+    rf, rd = rnd(name + ".res", (n, h, w, cout), dtype) if res else (None, None)
+    rv = W.synth_input(name + ".rv", (n, cout)) if rowvec else None
+    xin = xf if x2f is None else torch.cat([xf, x2f], 3)
+    ref = _conv_ref(xin, wf, None if rowvec else bias, 1, (k // 2, k // 2))
+    if geglu:
+        a_, g_ = ref.chunk(2, dim=-1)
+        ref = a_ * F.gelu(g_)
+    if rv is not None:
+        ref = ref + rv[:, None, None, :]
+    if rf is not None:
+        ref = ref + rf
+    for halo in ("0", "1"):
+        monkeypatch.setenv("MOBI_IGEMM_HALO", halo)
+        if geglu:
+            pw = ops.pack_geglu(wf[:, :, 0, 0], bias, dtype, "cuda")
+            y = ops.linear(xd.view(n, h * w, cin), pw).view(n, h, w, cout)
+        else:
+            pw = ops.pack_conv(wf, None if rowvec else bias, dtype, "cuda")
+            y = ops.igemm(xd, pw, x2=x2d, residual=rd, rowvec=None if rv is None else rv.cuda(), rowvec_has_bias=rowvec)
+        assert torch.isfinite(y.float()).all(), (case, halo)
+        assert rel(y.float(), ref) < TOL[dtype] * (1.0 if geglu else 0.5), (case, halo)
+    # the launch really is the ping-pong variant
+    p = _lib.IgemmParams()
+    p.src0, p.weight, p.out = 256, 256, 256                   # non-null, 16-byte aligned placeholders (no launch)
+    p.c0, p.c1, p.batch, p.hin, p.win, p.hout, p.wout = cin, cin2, n, h, w, h, w
+    if cin2:
+        p.src1 = 256
+    p.kh = p.kw = k
+    p.stride, p.pad_h, p.pad_w, p.groups = 1, k // 2, k // 2, 1
+    p.cout, p.n_packed = cout, (2 if geglu else 1) * cout
+    p.epilogue = _lib.EPI_GEGLU if geglu else _lib.EPI_NONE
+    p.scale, p.dtype = 1.0, _lib.MOBI_F16 if dtype == torch.float16 else _lib.MOBI_BF16
+    assert _lib.load().mobi_igemm_kernel_variant(C.byref(p)) == 3
