@@ -184,6 +184,29 @@ typedef struct mobi_ctx_attention_params {
 } mobi_ctx_attention_params;
 int mobi_ctx_attention(const mobi_ctx_attention_params* p, void* stream);
 
+/* The bbox adapter of a transformer block as ONE pass over the tokens (attention.py:237-243 of the reference:
+ *   x = x + connector(to_out(softmax(to_q(norm(x)) k^T * scale) v)),  k, v = to_k / to_v of TWO context tokens).
+ * With two keys the softmax is a sigmoid of the score difference, and every matrix that touches the tokens can be
+ * folded into per-image vectors (exact algebra, done once per context by the caller):
+ *   score difference of head h:  scale * to_q(LN(x))_h . (k1 - k2)_h = rstd * (x . a_h - mean * sum(a_h)) + c_h
+ *       a_h = gamma (.) (Wq_h^T (k1 - k2)_h) * scale,   c_h = beta . (Wq_h^T (k1 - k2)_h) * scale
+ *   update:  x + b + sum_h sigmoid(.)_h * u_h,   u_h = W_h (v1 - v2)_h,   b = W v2 + bias   (W = connector o to_out)
+ * mean / rstd are the LayerNorm statistics of the token (eps).  heads <= 8, channels % 8 == 0, <= 1536.
+ * out may alias x (each token is read before it is written). */
+typedef struct mobi_two_key_adapter_params {
+  const void* x; void* out;                /* T [image][token][channels]                                       */
+  int64_t x_img_stride, out_img_stride;    /* elements between images; 0 = dense                               */
+  const float* a;                          /* f32 [image][heads][channels]                                     */
+  const float* a_sum;                      /* f32 [image][heads]                                               */
+  const float* c;                          /* f32 [image][heads]                                               */
+  const float* u;                          /* f32 [image][heads][channels]                                     */
+  const float* b;                          /* f32 [image][channels]                                            */
+  int32_t images, rows_per_image, channels, heads;
+  float eps;
+  int32_t dtype;
+} mobi_two_key_adapter_params;
+int mobi_two_key_adapter(const mobi_two_key_adapter_params* p, void* stream);
+
 /* Row softmax fp32 -> T (AttnBlock, model.py:189-190). */
 int mobi_softmax_rows(const float* src, void* out, int64_t rows, int32_t cols, int32_t dtype, void* stream);
 

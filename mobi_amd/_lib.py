@@ -60,6 +60,12 @@ class CtxAttentionParams(C.Structure):
                 ("tq", i32), ("tk", i32), ("scale", f32), ("dtype", i32)]
 
 
+class TwoKeyAdapterParams(C.Structure):
+    _fields_ = [("x", vp), ("out", vp), ("x_img_stride", i64), ("out_img_stride", i64), ("a", vp), ("a_sum", vp),
+                ("c", vp), ("u", vp), ("b", vp), ("images", i32), ("rows_per_image", i32), ("channels", i32),
+                ("heads", i32), ("eps", f32), ("dtype", i32)]
+
+
 class SkinnyLinearParams(C.Structure):
     _fields_ = [("x", vp), ("m", i32), ("k", i32), ("x_row_stride", i32), ("weight", vp), ("bias", vp),
                 ("out", vp), ("n", i32), ("out_row_stride", i32), ("pre_act", i32), ("post_act", i32),
@@ -85,7 +91,7 @@ class DdimStepParams(C.Structure):
 
 
 STRUCT_IDS = {0: IgemmParams, 1: GroupNormParams, 2: LayerNormParams, 3: AttentionParams, 4: CtxAttentionParams,
-              5: SkinnyLinearParams, 6: ConvSmallCinParams, 7: ConvSmallCoutParams, 8: DdimStepParams}
+              5: SkinnyLinearParams, 6: ConvSmallCinParams, 7: ConvSmallCoutParams, 8: DdimStepParams, 9: TwoKeyAdapterParams}
 
 # every symbol include/mobi_engine.h declares: name -> (restype, argtypes)
 SYMBOLS = {
@@ -101,6 +107,7 @@ SYMBOLS = {
     "mobi_layernorm": (C.c_int, [C.POINTER(LayerNormParams), vp]),
     "mobi_attention": (C.c_int, [C.POINTER(AttentionParams), vp]),
     "mobi_ctx_attention": (C.c_int, [C.POINTER(CtxAttentionParams), vp]),
+    "mobi_two_key_adapter": (C.c_int, [C.POINTER(TwoKeyAdapterParams), vp]),
     "mobi_softmax_rows": (C.c_int, [vp, vp, i64, i32, i32, vp]),
     "mobi_skinny_linear": (C.c_int, [C.POINTER(SkinnyLinearParams), vp]),
     "mobi_timestep_embedding": (C.c_int, [vp, vp, vp, i32, i32, vp]),

@@ -151,6 +151,7 @@ extern "C" size_t mobi_struct_size(int id) {
     case 6: return sizeof(mobi_conv_small_cin_params);
     case 7: return sizeof(mobi_conv_small_cout_params);
     case 8: return sizeof(mobi_ddim_step_params);
+    case 9: return sizeof(mobi_two_key_adapter_params);
     default: return 0;
   }
 }

@@ -328,6 +328,145 @@ static inline unsigned grid_for(long long total, int block, long long cap = 6553
   return (unsigned)g;
 }
 
+
+// ---------------------------------------------------------------------------------------
+// two-key adapter (include/mobi_engine.h): LayerNorm statistics + `heads` gate logits + gated per-image vectors
+// in one pass over the tokens.  One wave per token row (8 channels per lane and chunk), the per-image tables a / u / b
+// in LDS, the 2 + heads row sums reduced together by a halving butterfly (17 shuffles instead of 6 per sum).
+// ---------------------------------------------------------------------------------------
+template <typename T, int MAXV>
+__global__ __launch_bounds__(256) void two_key_adapter_kernel(const mobi_two_key_adapter_params p, int rows_per_block) {
+  __shared__ __attribute__((aligned(16))) float tk_lds[17 * 512 * MAXV];      // C <= 512 * MAXV
+  const int C = p.channels, H = p.heads, V = C >> 3;
+  float* s_a = tk_lds;                     // [H][C]
+  float* s_u = tk_lds + 8 * C;             // [H][C]
+  float* s_b = tk_lds + 16 * C;            // [C]
+  const int img = blockIdx.y;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  {
+    const float* ga = p.a + (long long)img * H * C;
+    const float* gu = p.u + (long long)img * H * C;
+    const float* gb = p.b + (long long)img * C;
+    for (int i = tid * 4; i < H * C; i += 1024) {
+      *reinterpret_cast<f32x4*>(s_a + i) = *reinterpret_cast<const f32x4*>(ga + i);
+      *reinterpret_cast<f32x4*>(s_u + i) = *reinterpret_cast<const f32x4*>(gu + i);
+    }
+    for (int i = tid * 4; i < C; i += 1024) *reinterpret_cast<f32x4*>(s_b + i) = *reinterpret_cast<const f32x4*>(gb + i);
+  }
+  float a_sum[8], cc[8];
+#pragma unroll
+  for (int h = 0; h < 8; ++h) {
+    a_sum[h] = h < H ? p.a_sum[img * H + h] : 0.f;
+    cc[h] = h < H ? p.c[img * H + h] : 0.f;
+  }
+  __syncthreads();
+  const long long ximg = p.x_img_stride ? p.x_img_stride : (long long)p.rows_per_image * C;
+  const long long oimg = p.out_img_stride ? p.out_img_stride : (long long)p.rows_per_image * C;
+  const T* __restrict__ xb = reinterpret_cast<const T*>(p.x) + img * ximg;
+  T* __restrict__ ob = reinterpret_cast<T*>(p.out) + img * oimg;
+  const int r_begin = blockIdx.x * rows_per_block;
+  const int r_end = min(p.rows_per_image, r_begin + rows_per_block);
+  const float inv_c = 1.0f / (float)C;
+  for (int r = r_begin + wave; r < r_end; r += 4) {
+    float x[MAXV][8];
+    float acc[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+      const int v = lane + 64 * i;
+      if (v < V) {
+        unpack8<T>(ld16(xb + (long long)r * C + v * 8), x[i]);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { acc[0] += x[i][j]; acc[1] += x[i][j] * x[i][j]; }
+#pragma unroll
+        for (int h = 0; h < 8; ++h) {
+          if (h < H) {
+            const f32x4 a0 = *reinterpret_cast<const f32x4*>(s_a + h * C + v * 8);
+            const f32x4 a1 = *reinterpret_cast<const f32x4*>(s_a + h * C + v * 8 + 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[2 + h] += x[i][j] * a0[j] + x[i][4 + j] * a1[j];
+          }
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) x[i][j] = 0.f;
+      }
+    }
+    // halving butterfly: after the step with distance d a lane keeps the half of its sums selected by its bit d
+    float v8[8], v4[4], v2[2], v1;
+    {
+      const bool hi = lane & 32;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const float keep = hi ? acc[i + 8] : acc[i], send = hi ? acc[i] : acc[i + 8];
+        v8[i] = keep + __shfl_xor(send, 32, 64);
+      }
+    }
+    {
+      const bool hi = lane & 16;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float keep = hi ? v8[i + 4] : v8[i], send = hi ? v8[i] : v8[i + 4];
+        v4[i] = keep + __shfl_xor(send, 16, 64);
+      }
+    }
+    {
+      const bool hi = lane & 8;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const float keep = hi ? v4[i + 2] : v4[i], send = hi ? v4[i] : v4[i + 2];
+        v2[i] = keep + __shfl_xor(send, 8, 64);
+      }
+    }
+    {
+      const bool hi = lane & 4;
+      const float keep = hi ? v2[1] : v2[0], send = hi ? v2[0] : v2[1];
+      v1 = keep + __shfl_xor(send, 4, 64);
+    }
+    v1 += __shfl_xor(v1, 2, 64);
+    v1 += __shfl_xor(v1, 1, 64);
+    // sum k = 8 b5 + 4 b4 + 2 b3 + b2 sits in the lanes whose bits 5..2 are (b5, b4, b3, b2)
+    auto total = [&](int k) {
+      const int src = ((k >> 3) & 1) * 32 + ((k >> 2) & 1) * 16 + ((k >> 1) & 1) * 8 + (k & 1) * 4;
+      return __builtin_amdgcn_readlane(__builtin_bit_cast(int, v1), src);
+    };
+    const float mean = __builtin_bit_cast(float, total(0)) * inv_c;
+    float var = __builtin_bit_cast(float, total(1)) * inv_c - mean * mean;
+    var = var < 0.f ? 0.f : var;
+    const float rstd = rsqrtf(var + p.eps);
+    float g[8];
+#pragma unroll
+    for (int h = 0; h < 8; ++h) {
+      g[h] = 0.f;
+      if (h < H) {
+        const float z = rstd * (__builtin_bit_cast(float, total(2 + h)) - mean * a_sum[h]) + cc[h];
+        g[h] = 1.0f / (1.0f + __expf(-z));
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+      const int v = lane + 64 * i;
+      if (v < V) {
+        float o[8];
+        const f32x4 b0 = *reinterpret_cast<const f32x4*>(s_b + v * 8), b1 = *reinterpret_cast<const f32x4*>(s_b + v * 8 + 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { o[j] = x[i][j] + b0[j]; o[4 + j] = x[i][4 + j] + b1[j]; }
+#pragma unroll
+        for (int h = 0; h < 8; ++h) {
+          if (h < H) {
+            const f32x4 u0 = *reinterpret_cast<const f32x4*>(s_u + h * C + v * 8);
+            const f32x4 u1 = *reinterpret_cast<const f32x4*>(s_u + h * C + v * 8 + 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { o[j] += g[h] * u0[j]; o[4 + j] += g[h] * u1[j]; }
+          }
+        }
+        st16(ob + (long long)r * C + v * 8, pack8<T>(o));
+      }
+    }
+  }
+}
+
 }  // namespace mobi
 
 using namespace mobi;
@@ -364,6 +503,29 @@ extern "C" int mobi_ctx_attention(const mobi_ctx_attention_params* p, void* stre
   const unsigned blocks = (unsigned)((total + 255) / 256);
   if (p->dtype == MOBI_F16) hipLaunchKernelGGL((ctx_attention_kernel<f16_t>), dim3(blocks), dim3(256), 0, ST(stream), *p);
   else hipLaunchKernelGGL((ctx_attention_kernel<bf16_t>), dim3(blocks), dim3(256), 0, ST(stream), *p);
+  MOBI_CHECK_LAUNCH();
+  return MOBI_OK;
+}
+
+extern "C" int mobi_two_key_adapter(const mobi_two_key_adapter_params* p, void* stream) {
+  using namespace mobi;
+  if (!p || !p->x || !p->out || !p->a || !p->a_sum || !p->c || !p->u || !p->b) return MOBI_ERR_ARG;
+  if (!DT_OK(p->dtype) || p->images <= 0 || p->images > 65535 || p->rows_per_image <= 0) return MOBI_ERR_ARG;
+  if (p->heads <= 0 || p->heads > 8 || p->channels <= 0 || (p->channels & 7) || p->channels > 1536) return MOBI_ERR_UNSUPPORTED;
+  if ((p->x_img_stride & 7) || (p->out_img_stride & 7)) return MOBI_ERR_ALIGN;
+  if ((reinterpret_cast<uintptr_t>(p->x) | reinterpret_cast<uintptr_t>(p->out) | reinterpret_cast<uintptr_t>(p->a) |
+       reinterpret_cast<uintptr_t>(p->u) | reinterpret_cast<uintptr_t>(p->b)) & 15) return MOBI_ERR_ALIGN;
+  // rows per block: about 512 blocks over the whole launch, at least 16 rows (the tables are re-staged per block)
+  long long rpb = ((long long)p->rows_per_image * p->images + 511) / 512;
+  rpb = (rpb + 3) / 4 * 4;
+  if (rpb < 16) rpb = 16;
+  if (rpb > p->rows_per_image) rpb = (p->rows_per_image + 3) / 4 * 4;
+  const dim3 grid((unsigned)((p->rows_per_image + rpb - 1) / rpb), (unsigned)p->images);
+  const int V = p->channels >> 3;
+#define MOBI_TKA(T_, MV_) hipLaunchKernelGGL((two_key_adapter_kernel<T_, MV_>), grid, dim3(256), 0, ST(stream), *p, (int)rpb)
+  if (p->dtype == MOBI_F16) { if (V <= 64) MOBI_TKA(f16_t, 1); else if (V <= 128) MOBI_TKA(f16_t, 2); else MOBI_TKA(f16_t, 3); }
+  else { if (V <= 64) MOBI_TKA(bf16_t, 1); else if (V <= 128) MOBI_TKA(bf16_t, 2); else MOBI_TKA(bf16_t, 3); }
+#undef MOBI_TKA
   MOBI_CHECK_LAUNCH();
   return MOBI_OK;
 }

@@ -210,7 +210,10 @@ class BasicTransformerBlock(nn.Module):
         checks the tensor's version counter and the weights' versions) instead of once per UNet call."""
         ws = [self.attn2.to_v.weight, self.attn2.to_out[0].weight, self.attn2.to_out[0].bias, self.attn1.to_out[0].bias]
         if self.bbox_cond:
-            ws += [self.cond_adapter_attn.to_k.weight, self.cond_adapter_attn.to_v.weight]
+            ca = self.cond_adapter_attn
+            ws += [ca.to_k.weight, ca.to_v.weight, ca.to_q.weight, ca.to_out[0].weight, ca.to_out[0].bias,
+                   self.cond_adapter_connector.weight, self.cond_adapter_connector.bias,
+                   self.cond_adapter_norm.weight, self.cond_adapter_norm.bias]
         key = (id(ctx), ctx._version, ctx.data_ptr(), tuple(ctx.shape), tuple(w._version for w in ws),
                ws[0].data_ptr(), self.attn2.to_v.skinny()[0].dtype)
         c = self.__dict__.setdefault("_ctx_cache", {})
@@ -219,17 +222,48 @@ class BasicTransformerBlock(nn.Module):
             # (+ attn1.to_out's bias: the launch that adds this vector then passes no separate bias)
             c["ref_vec"] = self.attn2.single_token_vector(ctx[:, 0], extra_bias=self.attn1.to_out[0].bias)
             c["kv"] = self.cond_adapter_attn.context_kv(ctx) if self.bbox_cond else None
-        return c["ref_vec"], c["kv"]
+            c["adapter"] = self._two_key_terms(c["kv"]) if self.bbox_cond and ctx.shape[1] == 2 else None
+        return c["ref_vec"], c["kv"], c["adapter"]
+
+    def _two_key_terms(self, kv):
+        """The bbox adapter (attention.py:237-243 of the reference: `x + connector(attn(norm(x), context))`) against
+        exactly TWO context tokens, folded into per-image vectors -- exact algebra, fp64 on the parameters:
+          softmax over two keys = sigmoid of the score difference:  p0 = sigmoid(scale * q_h . (k0 - k1)_h)
+          q = to_q(LN(x)) has no bias, so  q_h . dk_h = LN(x) . (Wq_h^T dk_h) = rstd * (x . a_h - mean * sum a_h) + c_h
+          attention output = v1 + p0 * (v0 - v1), pushed through W = connector o to_out:  b + sum_h p0_h * u_h
+        so no [T, C] x [C, C] product is left: `ops.two_key_adapter` makes one pass over the tokens.
+        Returns (a [N,H,C], a_sum [N,H], c [N,H], u [N,H,C], b [N,C]) fp32."""
+        ca, ln, con = self.cond_adapter_attn, self.cond_adapter_norm, self.cond_adapter_connector
+        k, v = kv[0].double(), kv[1].double()                                  # [N, 2, C]
+        n, _, ci = k.shape
+        h, dh = ca.heads, ci // ca.heads
+        wq = ca.to_q.weight.detach().double()                                  # [inner, query]
+        wo, bo = ca.to_out[0].weight.detach().double(), ca.to_out[0].bias.detach().double()
+        wc, bc = con.weight.detach().double(), con.bias.detach().double()
+        w = wc @ wo                                                            # [query, inner]
+        b0 = wc @ bo + bc
+        dk = (k[:, 0] - k[:, 1]).view(n, h, dh)
+        dv = (v[:, 0] - v[:, 1]).view(n, h, dh)
+        wt = torch.einsum("hdc,nhd->nhc", wq.view(h, dh, -1), dk)              # Wq_h^T dk_h: [N, H, query]
+        gamma, beta = ln.weight.detach().double(), ln.bias.detach().double()
+        a = wt * gamma * ca.scale
+        c = (wt * beta).sum(-1) * ca.scale
+        u = torch.einsum("chd,nhd->nhc", w.view(-1, h, dh), dv)                # W_h dv_h: [N, H, query]
+        b = v[:, 1] @ w.t() + b0
+        f = lambda t: t.float().contiguous()
+        return f(a), f(a.sum(-1)), f(c), f(u), f(b)
 
     def _forward(self, x, context=None):
         """x: engine tokens [N,T,C]; context: fp32 [N, n_ctx, context_dim]."""
         ctx = context.float().contiguous()
-        ref_vec, ctx_kv = self._context_terms(ctx)
+        ref_vec, ctx_kv, adapter = self._context_terms(ctx)
         # attn1 (self) + attn2 (reference token; norm2 / to_q cancel out of a one-key softmax)
         a = self.attn1.self_attention(self._ln(self.norm1, x))
         x = ops.linear(a, self.attn1.to_out[0].packed(), residual=x, rowvec=ref_vec, rowvec_has_bias=True)
 
-        if self.bbox_cond:
+        if self.bbox_cond and adapter is not None:
+            x = ops.two_key_adapter(x, *adapter, eps=self.cond_adapter_norm.eps, out=x)
+        elif self.bbox_cond:
             ca = self.cond_adapter_attn
             q = ops.linear(self._ln(self.cond_adapter_norm, x), ca.to_q.packed())
             a = ops.ctx_attention(q, ctx_kv[0], ctx_kv[1], ca.heads, ca.scale)

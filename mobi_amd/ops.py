@@ -333,6 +333,29 @@ def ctx_attention(q, k, v, heads, scale):
     return out
 
 
+def two_key_adapter(x, a, a_sum, c, u, b, eps, out=None):
+    """x: [N, T, C] tokens (T storage type, possibly a batch-strided view); a, u: fp32 [N, H, C]; a_sum, c: fp32 [N, H];
+    b: fp32 [N, C].  Returns x + b + sum_h sigmoid(rstd * (x . a_h - mean * a_sum_h) + c_h) * u_h with the token's
+    LayerNorm statistics (include/mobi_engine.h, mobi_two_key_adapter); out=x updates in place."""
+    lib = _lib.load()
+    n, t, ch = x.shape
+    if out is None:
+        out = torch.empty((n, t, ch), device=x.device, dtype=x.dtype)
+    for tns in (a, a_sum, c, u, b):
+        assert tns.dtype == torch.float32 and tns.is_contiguous()
+    assert a.shape == u.shape == (n, a.shape[1], ch) and a_sum.shape == c.shape == (n, a.shape[1]) and b.shape == (n, ch)
+    p = _lib.TwoKeyAdapterParams()
+    p.x, p.out = _ptr(x), _ptr(out)
+    sx, so = _img_stride(x), _img_stride(out)
+    p.x_img_stride = 0 if sx == t * ch else sx
+    p.out_img_stride = 0 if so == t * ch else so
+    p.a, p.a_sum, p.c, p.u, p.b = _ptr(a), _ptr(a_sum), _ptr(c), _ptr(u), _ptr(b)
+    p.images, p.rows_per_image, p.channels, p.heads, p.eps, p.dtype = n, t, ch, a.shape[1], eps, _dt(x.dtype)
+    with _Timed("two_key_adapter", 0.0, 2.0 * x.numel() * 2):
+        _lib.check(lib.mobi_two_key_adapter(C.byref(p), _stream()), "mobi_two_key_adapter")
+    return out
+
+
 def softmax_rows(s, dtype):
     lib = _lib.load()
     assert s.dtype == torch.float32 and s.is_contiguous()

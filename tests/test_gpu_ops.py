@@ -519,3 +519,31 @@ def test_igemm_pingpong(ops, dtype, case, monkeypatch):
     p.epilogue = _lib.EPI_GEGLU if geglu else _lib.EPI_NONE
     p.scale, p.dtype = 1.0, _lib.MOBI_F16 if dtype == torch.float16 else _lib.MOBI_BF16
     assert _lib.load().mobi_igemm_kernel_variant(C.byref(p)) == 3
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("n,t,c,heads,strided", [(3, 100, 320, 8, False), (2, 64, 640, 8, True), (2, 37, 1280, 8, False),
+                                                 (1, 256, 64, 4, False)])
+def test_two_key_adapter(ops, dtype, n, t, c, heads, strided):
+    """One-pass bbox adapter kernel (LayerNorm statistics, per-head gate logits, gated per-image vectors) against the
+    same formula in torch fp32; ragged token counts, three channel widths (1 / 2 / 3 chunks per lane), a
+    batch-strided view updated in place."""
+    name = f"tka.{n}.{t}.{c}.{heads}"
+    full = 2 * n if strided else n
+    xf, xd = rnd(name + ".x", (full, t, c), dtype, scale=2.0)
+    a = W.synth_input(name + ".a", (n, heads, c)) * 0.05
+    u = W.synth_input(name + ".u", (n, heads, c))
+    b = W.synth_input(name + ".b", (n, c))
+    cc = W.synth_input(name + ".c", (n, heads))
+    xs = xf[::2] if strided else xf
+    mean = xs.mean(-1, keepdim=True)
+    rstd = (xs.var(-1, unbiased=False, keepdim=True) + 1e-5).rsqrt()
+    z = rstd * (torch.einsum("ntc,nhc->nth", xs, a) - mean * a.sum(-1)[:, None, :]) + cc[:, None, :]
+    ref = xs + b[:, None, :] + torch.einsum("nth,nhc->ntc", torch.sigmoid(z), u)
+    view = xd[::2] if strided else xd
+    y = ops.two_key_adapter(view, a.cuda(), a.sum(-1).contiguous().cuda(), cc.cuda(), u.cuda(), b.cuda(), 1e-5)
+    assert rel(y.float(), ref) < TOL[dtype] * 0.5
+    y2 = ops.two_key_adapter(view, a.cuda(), a.sum(-1).contiguous().cuda(), cc.cuda(), u.cuda(), b.cuda(), 1e-5, out=view)
+    assert y2.data_ptr() == view.data_ptr() and torch.equal(y2, y)
+    if strided:                                                        # the partner images are untouched
+        assert torch.equal(xd[1::2].float().cpu(), xf[1::2])
