@@ -1258,8 +1258,9 @@ __global__ __launch_bounds__(512, 2) void igemm_pp_kernel(const IgemmArgs a) {
         const int d = (64 * j) & (a.hw_out - 1);
         const int hi = (x_hw0 >> 16) + (d >> a.w_shift) * a.stride + u_ky;
         const int wi = (int)(short)x_hw0 + (d & (a.wout - 1)) * a.stride + u_kx;
-        const bool ok = (unsigned)hi < (unsigned)a.hin && (unsigned)wi < (unsigned)a.win;
-        f_row[j] = ok ? (unsigned)(x_img[j] + hi * a.win + wi) * cs2 + sg16 : OOB;
+        // (nearest x2 upsampling on the load side: window coordinates live on the upsampled grid, a.up = 1)
+        const bool ok = (unsigned)hi < (unsigned)(a.hin << a.up) && (unsigned)wi < (unsigned)(a.win << a.up);
+        f_row[j] = ok ? (unsigned)(x_img[j] + (hi >> a.up) * a.win + (wi >> a.up)) * cs2 + sg16 : OOB;
       }
     }
     const int soff = (src ? u_c - a.c0 : u_c) * 2;
@@ -2105,13 +2106,13 @@ static int igemm_prepare(const mobi_igemm_params* p, mobi::IgemmArgs& a) {
   // ping-pong kernel: window pixels linear in the tap (no upsampling, <= 16 taps), one k range
   auto log2_exact = [](int v) { int s = 0; while ((1 << s) < v) ++s; return (1 << s) == v ? s : -1; };
   a.hw_shift = log2_exact(a.hw_out); a.w_shift = log2_exact(a.wout);
-  a.pp = a.epi_direct && a.splits == 1 && p->upsample == 0 && p->scale == 1.0f && a.hw_shift >= 6 && a.w_shift >= 0 &&
-         a.hin < 32768 && a.win < 32768;
+  a.pp = a.epi_direct && a.splits == 1 && p->scale == 1.0f && a.hw_shift >= 6 && a.w_shift >= 0 &&
+         a.hout < 32768 && a.wout < 32768;
   if (const char* e = getenv("MOBI_IGEMM_PP")) a.pp = a.pp && e[0] != '0';
   // halo-patch kernel: 3x3, stride 1, pad 1, same-size output, tap-major weights, a 256-pixel tile = whole rows of one
   // image (<= 64 wide) or four 8x8 images; the patch must fit 400 pixels
   a.halo = 0;
-  if (a.pp && p->kh == 3 && p->kw == 3 && p->stride == 1 && p->pad_h == 1 && p->pad_w == 1 && p->k_order == 0 &&
+  if (a.pp && p->upsample == 0 && p->kh == 3 && p->kw == 3 && p->stride == 1 && p->pad_h == 1 && p->pad_w == 1 && p->k_order == 0 &&
       p->hout == p->hin && p->wout == p->win && a.wout <= 64) {
     a.hw_tile = a.hw_out < 256 ? a.hw_out : 256;
     a.hw_shift_t = log2_exact(a.hw_tile);

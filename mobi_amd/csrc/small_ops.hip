@@ -343,15 +343,23 @@ __global__ __launch_bounds__(256) void two_key_adapter_kernel(const mobi_two_key
   float* s_b = tk_lds + 16 * C;            // [C]
   const int img = blockIdx.y;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // LDS image of a table row: the FIRST four floats of every 8-channel group, then the SECOND four (a lane reads
+  // 16 bytes at lane * 16 of each half: conflict-free; the natural [channel] order puts lanes 32 bytes apart).
+  // ALWAYS eight head rows (rows >= heads are zero: gate 0.5 x vector 0), so the row loop has no head-count branch
+  // and the compiler batches the 34 LDS reads of a row instead of waiting per head.
   {
-    const float* ga = p.a + (long long)img * H * C;
-    const float* gu = p.u + (long long)img * H * C;
-    const float* gb = p.b + (long long)img * C;
-    for (int i = tid * 4; i < H * C; i += 1024) {
-      *reinterpret_cast<f32x4*>(s_a + i) = *reinterpret_cast<const f32x4*>(ga + i);
-      *reinterpret_cast<f32x4*>(s_u + i) = *reinterpret_cast<const f32x4*>(gu + i);
+    const f32x4* ga = reinterpret_cast<const f32x4*>(p.a + (long long)img * H * C);
+    const f32x4* gu = reinterpret_cast<const f32x4*>(p.u + (long long)img * H * C);
+    const f32x4* gb = reinterpret_cast<const f32x4*>(p.b + (long long)img * C);
+    const int Q = C >> 2;                                    // float4 per table row
+    for (int i = tid; i < 8 * Q; i += 256) {
+      const int h = i / Q, q = i - h * Q;
+      const int d = h * Q + (q & 1) * (Q >> 1) + (q >> 1);
+      const f32x4 z = f32x4{0.f, 0.f, 0.f, 0.f};
+      reinterpret_cast<f32x4*>(s_a)[d] = h < H ? ga[i] : z;
+      reinterpret_cast<f32x4*>(s_u)[d] = h < H ? gu[i] : z;
     }
-    for (int i = tid * 4; i < C; i += 1024) *reinterpret_cast<f32x4*>(s_b + i) = *reinterpret_cast<const f32x4*>(gb + i);
+    for (int q = tid; q < Q; q += 256) reinterpret_cast<f32x4*>(s_b)[(q & 1) * (Q >> 1) + (q >> 1)] = gb[q];
   }
   float a_sum[8], cc[8];
 #pragma unroll
@@ -367,7 +375,21 @@ __global__ __launch_bounds__(256) void two_key_adapter_kernel(const mobi_two_key
   const int r_begin = blockIdx.x * rows_per_block;
   const int r_end = min(p.rows_per_image, r_begin + rows_per_block);
   const float inv_c = 1.0f / (float)C;
+  // the next row's 16-byte loads are in flight while this row is reduced, gated and stored (the per-row chain --
+  // load, six shuffle levels, sigmoid, LDS-fed update -- is otherwise exposed once per row at 8-16 waves per CU)
+  u32x4 cur[MAXV];
+  auto load_row = [&](int r, u32x4 (&raw)[MAXV]) {
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+      const int v = lane + 64 * i;
+      raw[i] = u32x4{0u, 0u, 0u, 0u};
+      if (v < V && r < r_end) raw[i] = ld16(xb + (long long)r * C + v * 8);
+    }
+  };
+  load_row(r_begin + wave, cur);
   for (int r = r_begin + wave; r < r_end; r += 4) {
+    u32x4 nxt[MAXV];
+    load_row(r + 4, nxt);
     float x[MAXV][8];
     float acc[16];
 #pragma unroll
@@ -376,17 +398,15 @@ __global__ __launch_bounds__(256) void two_key_adapter_kernel(const mobi_two_key
     for (int i = 0; i < MAXV; ++i) {
       const int v = lane + 64 * i;
       if (v < V) {
-        unpack8<T>(ld16(xb + (long long)r * C + v * 8), x[i]);
+        unpack8<T>(cur[i], x[i]);
 #pragma unroll
         for (int j = 0; j < 8; ++j) { acc[0] += x[i][j]; acc[1] += x[i][j] * x[i][j]; }
 #pragma unroll
         for (int h = 0; h < 8; ++h) {
-          if (h < H) {
-            const f32x4 a0 = *reinterpret_cast<const f32x4*>(s_a + h * C + v * 8);
-            const f32x4 a1 = *reinterpret_cast<const f32x4*>(s_a + h * C + v * 8 + 4);
+          const f32x4 a0 = reinterpret_cast<const f32x4*>(s_a)[h * (C >> 2) + v];
+          const f32x4 a1 = reinterpret_cast<const f32x4*>(s_a)[h * (C >> 2) + (C >> 3) + v];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[2 + h] += x[i][j] * a0[j] + x[i][4 + j] * a1[j];
-          }
+          for (int j = 0; j < 4; ++j) acc[2 + h] += x[i][j] * a0[j] + x[i][4 + j] * a1[j];
         }
       } else {
 #pragma unroll
@@ -394,22 +414,21 @@ __global__ __launch_bounds__(256) void two_key_adapter_kernel(const mobi_two_key
       }
     }
     // halving butterfly: after the step with distance d a lane keeps the half of its sums selected by its bit d
+    // (distance 32 and 16 by gfx950's lane-row swaps: v_permlane32_swap exchanges the upper half of its first operand
+    //  with the lower half of the second, so first + second afterwards holds sum i in the lower and sum i + 8 in the
+    //  upper half -- no LDS crossbar trip, no select; same for 16-lane rows)
     float v8[8], v4[4], v2[2], v1;
-    {
-      const bool hi = lane & 32;
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const float keep = hi ? acc[i + 8] : acc[i], send = hi ? acc[i] : acc[i + 8];
-        v8[i] = keep + __shfl_xor(send, 32, 64);
-      }
+    for (int i = 0; i < 8; ++i) {
+      float lo = acc[i], hi = acc[i + 8];
+      asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(lo), "+v"(hi));
+      v8[i] = lo + hi;
     }
-    {
-      const bool hi = lane & 16;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const float keep = hi ? v8[i + 4] : v8[i], send = hi ? v8[i] : v8[i + 4];
-        v4[i] = keep + __shfl_xor(send, 16, 64);
-      }
+    for (int i = 0; i < 4; ++i) {
+      float lo = v8[i], hi = v8[i + 4];
+      asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(lo), "+v"(hi));
+      v4[i] = lo + hi;
     }
     {
       const bool hi = lane & 8;
@@ -438,32 +457,29 @@ __global__ __launch_bounds__(256) void two_key_adapter_kernel(const mobi_two_key
     float g[8];
 #pragma unroll
     for (int h = 0; h < 8; ++h) {
-      g[h] = 0.f;
-      if (h < H) {
-        const float z = rstd * (__builtin_bit_cast(float, total(2 + h)) - mean * a_sum[h]) + cc[h];
-        g[h] = 1.0f / (1.0f + __expf(-z));
-      }
+      const float z = rstd * (__builtin_bit_cast(float, total(2 + h)) - mean * a_sum[h]) + cc[h];
+      g[h] = 1.0f / (1.0f + __expf(-z));
     }
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) {
       const int v = lane + 64 * i;
       if (v < V) {
         float o[8];
-        const f32x4 b0 = *reinterpret_cast<const f32x4*>(s_b + v * 8), b1 = *reinterpret_cast<const f32x4*>(s_b + v * 8 + 4);
+        const f32x4 b0 = reinterpret_cast<const f32x4*>(s_b)[v], b1 = reinterpret_cast<const f32x4*>(s_b)[(C >> 3) + v];
 #pragma unroll
         for (int j = 0; j < 4; ++j) { o[j] = x[i][j] + b0[j]; o[4 + j] = x[i][4 + j] + b1[j]; }
 #pragma unroll
         for (int h = 0; h < 8; ++h) {
-          if (h < H) {
-            const f32x4 u0 = *reinterpret_cast<const f32x4*>(s_u + h * C + v * 8);
-            const f32x4 u1 = *reinterpret_cast<const f32x4*>(s_u + h * C + v * 8 + 4);
+          const f32x4 u0 = reinterpret_cast<const f32x4*>(s_u)[h * (C >> 2) + v];
+          const f32x4 u1 = reinterpret_cast<const f32x4*>(s_u)[h * (C >> 2) + (C >> 3) + v];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { o[j] += g[h] * u0[j]; o[4 + j] += g[h] * u1[j]; }
-          }
+          for (int j = 0; j < 4; ++j) { o[j] += g[h] * u0[j]; o[4 + j] += g[h] * u1[j]; }
         }
         st16(ob + (long long)r * C + v * 8, pack8<T>(o));
       }
     }
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) cur[i] = nxt[i];
   }
 }
 
@@ -515,10 +531,11 @@ extern "C" int mobi_two_key_adapter(const mobi_two_key_adapter_params* p, void* 
   if ((p->x_img_stride & 7) || (p->out_img_stride & 7)) return MOBI_ERR_ALIGN;
   if ((reinterpret_cast<uintptr_t>(p->x) | reinterpret_cast<uintptr_t>(p->out) | reinterpret_cast<uintptr_t>(p->a) |
        reinterpret_cast<uintptr_t>(p->u) | reinterpret_cast<uintptr_t>(p->b)) & 15) return MOBI_ERR_ALIGN;
-  // rows per block: about 512 blocks over the whole launch, at least 16 rows (the tables are re-staged per block)
-  long long rpb = ((long long)p->rows_per_image * p->images + 511) / 512;
+  // rows per block: about 1024 blocks over the whole launch (four 35-KB-LDS blocks per CU), at least 8 rows (the
+  // tables are re-staged per block)
+  long long rpb = ((long long)p->rows_per_image * p->images + 1023) / 1024;
   rpb = (rpb + 3) / 4 * 4;
-  if (rpb < 16) rpb = 16;
+  if (rpb < 8) rpb = 8;
   if (rpb > p->rows_per_image) rpb = (p->rows_per_image + 3) / 4 * 4;
   const dim3 grid((unsigned)((p->rows_per_image + rpb - 1) / rpb), (unsigned)p->images);
   const int V = p->channels >> 3;

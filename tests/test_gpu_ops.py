@@ -547,3 +547,16 @@ def test_two_key_adapter(ops, dtype, n, t, c, heads, strided):
     assert y2.data_ptr() == view.data_ptr() and torch.equal(y2, y)
     if strided:                                                        # the partner images are untouched
         assert torch.equal(xd[1::2].float().cpu(), xf[1::2])
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_igemm_pingpong_upsample_and_stride(ops, dtype, monkeypatch):
+    """Nearest-x2 upsampling on the load side and a stride-2 convolution through the ping-pong kernel."""
+    monkeypatch.setenv("MOBI_IGEMM_WM", "4")
+    monkeypatch.setenv("MOBI_IGEMM_PERSIST_BLOCKS", "3")
+    for name, h, cin, cout, stride, up in (("ppup", 8, 128, 160, 1, True), ("pps2", 32, 64, 128, 2, False)):
+        xf, xd = rnd(name + ".x", (4, h, h, cin), dtype)
+        wf = torch.from_numpy(W.synth_param(name + ".weight", (cout, cin, 3, 3))).to(dtype).float()
+        bias = torch.from_numpy(W.synth_param(name + ".bias", (cout,)))
+        y = ops.igemm(xd, ops.pack_conv(wf, bias, dtype, "cuda"), stride=stride, upsample=up)
+        assert rel(y.float(), _conv_ref(xf, wf, bias, stride, (1, 1), up)) < TOL[dtype] * 0.5, name
