@@ -102,10 +102,22 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const GnArgs a) {
   __shared__ __attribute__((aligned(16))) float s_sh[2560];
   const int tid = threadIdx.x;
   const int img = blockIdx.y;
+  // chunk partials -> (mean, rstd) of the 32 groups.  All 256 threads take part: thread (sub = tid >> 5, g = tid & 31)
+  // sums chunks sub, sub + 8, ... of group g in fp64 (independent loads, one round trip), LDS folds the eight
+  // partial sums in a fixed order.  (32 threads walking all chunks serially cost ~8 us of exposed latency per block.)
+  __shared__ double s_ps[8][32], s_pq[8][32];
+  {
+    const int g = tid & 31, sub = tid >> 5;
+    double s = 0.0, q = 0.0;
+    const float* w = a.ws + ((long long)img * a.chunks * 32 + g) * 2;
+    for (int c = sub; c < a.chunks; c += 8) { s += (double)w[c * 64]; q += (double)w[c * 64 + 1]; }
+    s_ps[sub][g] = s; s_pq[sub][g] = q;
+  }
+  __syncthreads();
   if (tid < 32) {
     double s = 0.0, q = 0.0;
-    const float* w = a.ws + ((long long)img * a.chunks * 32 + tid) * 2;
-    for (int c = 0; c < a.chunks; ++c) { s += (double)w[c * 64]; q += (double)w[c * 64 + 1]; }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { s += s_ps[k][tid]; q += s_pq[k][tid]; }
     const double n = (double)a.hw * (double)(a.C / 32);
     const double mean = s / n;
     double var = q / n - mean * mean;
