@@ -20,6 +20,9 @@
 // LDS row strides are odd multiples of the access width (bank-conflict free reads).
 #include "common.h"
 
+#ifndef MOBI_ATTN_DBG
+#define MOBI_ATTN_DBG 0    // diagnosis only (wrong results): bit 0 = no exp, bit 1 = K / V tiles loaded once, bit 2 = no P.V,
+#endif                     // bit 3 = no S = K.Q^T
 #ifndef MOBI_ATTN_DBUF
 #define MOBI_ATTN_DBUF 1   // two LDS images of the K / V tile: one barrier per key tile, the next tile is written while
 #endif                     // this one is still being multiplied (A/B: -DMOBI_ATTN_DBUF=0)
@@ -232,7 +235,11 @@ __global__ __launch_bounds__(256, WPS) void attention_kernel(const AttnArgs a) {
     const int key0 = t * 64;
     const bool more = t + 1 < ntiles;
     const int boff = MOBI_ATTN_DBUF ? (t & 1) * IMG_BYTES : 0;       // image of this tile
+#if MOBI_ATTN_DBG & 2
+    if (more && t == 0) load_tile(key0 + 64);
+#else
     if (more) load_tile(key0 + 64);
+#endif
 
     // ---- S^T = K . Q^T for two 32-key sub-tiles --------------------------------
     f32x16 s[2];
@@ -244,7 +251,12 @@ __global__ __launch_bounds__(256, WPS) void attention_kernel(const AttnArgs a) {
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
         frag_t kf = __builtin_bit_cast(frag_t, ld16(kb + ks * 32));
+#if MOBI_ATTN_DBG & 8
+        asm volatile("" :: "v"(kf));
+        s[kt][ks] += (float)kf[0];
+#else
         s[kt] = mfma32(kf, qf[ks], s[kt]);
+#endif
       }
     }
     // ---- online softmax (one query column per lane) -----------------------------
@@ -283,7 +295,11 @@ __global__ __launch_bounds__(256, WPS) void attention_kernel(const AttnArgs a) {
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
+#if MOBI_ATTN_DBG & 1
+      for (int r = 0; r < 16; ++r) s[kt][r] = __builtin_fmaf(s[kt][r], cexp, -mc);
+#else
       for (int r = 0; r < 16; ++r) s[kt][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kt][r], cexp, -mc));
+#endif
     if (!ONES) {
       float psum = 0.f;
 #pragma unroll
@@ -319,7 +335,11 @@ __global__ __launch_bounds__(256, WPS) void attention_kernel(const AttnArgs a) {
             const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4_t)(vb + d * 64));
             const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4_t)(vb + d * 64 + 8 * VSTR));
             const s16x8 both = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+#if MOBI_ATTN_DBG & 4
+            asm volatile("" :: "v"(both), "v"(pf));
+#else
             o[d] = mfma32(__builtin_bit_cast(frag_t, both), pf, o[d]);
+#endif
           }
         } else {
           const unsigned char* vb = ldsV + boff + ql * VSTR + (kt * 32 + st * 16 + half * 8) * 2;

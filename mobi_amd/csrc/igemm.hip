@@ -1191,8 +1191,9 @@ __global__ __launch_bounds__(512, 2) void igemm_pp_kernel(const IgemmArgs a) {
   typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave & 3, wn = wave >> 2;
-  const bool late = wave >= 4;                               // the half that runs one phase behind
+  const int wave_s = __builtin_amdgcn_readfirstlane(wave);   // provably wave-uniform copy: LDS-DMA bases and the
+  const int wm = wave & 3, wn = wave >> 2;                   // early / late branches stay scalar
+  const bool late = wave_s >= 4;                             // the half that runs one phase behind
   const int group = blockIdx.z;
   const int nblk = a.tiles_m * a.tiles_n;
   const int nk = a.nk;
@@ -1234,7 +1235,7 @@ __global__ __launch_bounds__(512, 2) void igemm_pp_kernel(const IgemmArgs a) {
     }
     w_off = (unsigned)(n0 + 8 * wave + rloc) * (unsigned)a.ktot * 2u + sg16;
     w_rowstep = a.ktot * 128;
-    w_half = __builtin_amdgcn_readfirstlane((wave >> 2) * (a.ktot * 64));
+    w_half = (wave_s >> 2) * (a.ktot * 64);
     u_tap = 0; u_ky = 0; u_kx = 0; u_c = 0; f_tap = -1; f_src = -1;
   };
 
@@ -1268,11 +1269,11 @@ __global__ __launch_bounds__(512, 2) void igemm_pp_kernel(const IgemmArgs a) {
     if (src) {
 #pragma unroll
       for (int j = 0; j < 4; ++j)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rx1, (lds_ptr_t)(st + (8 * wave + 64 * j) * 128), 16, f_row[j], soff, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rx1, (lds_ptr_t)(st + (8 * wave_s + 64 * j) * 128), 16, f_row[j], soff, 0, 0);
     } else {
 #pragma unroll
       for (int j = 0; j < 4; ++j)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rx0, (lds_ptr_t)(st + (8 * wave + 64 * j) * 128), 16, f_row[j], soff, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rx0, (lds_ptr_t)(st + (8 * wave_s + 64 * j) * 128), 16, f_row[j], soff, 0, 0);
     }
     vm_issued += 4;
 #endif
@@ -1287,7 +1288,7 @@ __global__ __launch_bounds__(512, 2) void igemm_pp_kernel(const IgemmArgs a) {
       // rows 8 * wave + rloc + 64 j; the last partial group of 32 rows is fetched by waves 0-3 and (identically,
       // benign duplicate) by waves 4-7 so that every wave issues PIECES requests
       const bool partial = (BN % 64 != 0) && (j == WJ - 1);
-      const int wl = (partial ? 64 * j + 8 * (wave & 3) : 64 * j + 8 * wave) * 128;
+      const int wl = (partial ? 64 * j + 8 * (wave_s & 3) : 64 * j + 8 * wave_s) * 128;
       const int so = kb + j * w_rowstep - (partial ? w_half : 0);
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr_t)(st + X_TILE + wl), 16, w_off, so, 0, 0);
     }
