@@ -164,6 +164,9 @@ def main():
         nz = {k: torch.randn(B, 4, side, side, generator=gi).to(device)
               for k in ("cam_gt", "cam_inpaint", "lidar_gt", "lidar_inpaint")}
         x_T = mk(N, 4, side, side)
+        # per-object depth range of the range-view de-normalisation (ddpm.py:1527-1543, on the device)
+        pp_batch = {"lidar": {"min_depth_obj": torch.linspace(-0.8, -0.2, B).to(device),
+                              "max_depth_obj": torch.linspace(0.1, 0.7, B).to(device)}}
 
         def e2e():
             z_img, z_lid = model.encode_all_stages(img_gt, img_gt * hole, hole, rng_gt, rng_gt * hole, hole, noises=nz)
@@ -174,7 +177,7 @@ def main():
                                     test_model_kwargs={"inpaint_image": z[:, 4:8].contiguous(),
                                                        "inpaint_mask": z[:, 8:9].contiguous()})
             h_cam, h_lid = model.decode_sample(smp, z_lid[:, :4])
-            log, _ = model.log_data(None, None, h_cam.contiguous(), h_lid.contiguous())
+            log, _ = model.log_data(pp_batch, None, h_cam.contiguous(), h_lid.contiguous())
             if backend != "nccl":
                 log = {k: v.cpu() for k, v in log.items()}
             return mdist.gather_decoded(log, B * world)                 # the one collective of the path
@@ -303,7 +306,7 @@ def main():
         if objects_per_s is not None:
             out["objects_per_s"] = round(objects_per_s, 4)
             out["e2e"] = (f"{B} objects/GPU: 4 VAE encodes + DDIM-{args.ddim_steps} + 2 VAE decodes (+clamp) per object, "
-                          f"all-gather of decoded images; conditioning tokens supplied (SURVEY 8(f) row 1)")
+                          f"range-view de-normalisation on the device, all-gather of decoded images; conditioning tokens supplied")
         if roofline:
             out["roofline"] = roofline
         if cpu_baseline:

@@ -291,6 +291,20 @@ int mobi_ddim_step(const mobi_ddim_step_params* p, void* stream);
 int mobi_lincomb4(float* out, const float* e0, const float* e1, const float* e2, const float* e3,
                   float c0, float c1, float c2, float c3, int64_t n, void* stream);
 
+/* Harness post-processing of the decoded range view (first slice): what
+ * LatentDiffusion.log_data does to the clamped lidar sample on the host (ddpm.py:1527-1543 of the reference):
+ *   depth:     inverse_depth_normalization (ldm/data/utils.py:560-580) per sample with that sample's
+ *              (min_d, max_d):  [-alpha, alpha] -> [min_d, max_d],  [-1, -alpha) -> [-1, min_d),  (alpha, 1] -> (max_d, 1]
+ *   intensity: clamp(-0.5 * log(1 - (x + 1) / 2) - 1, -1, 1)
+ * sample: f32 [batch][2][hw] (channel 0 depth, 1 intensity, already clamped to [-1, 1]); depth_out / int_out: f32
+ * [batch][hw] (either may be NULL).  The scalar combinations are passed as the fp32 values the reference's
+ * Python-scalar arithmetic produces (2*alpha, alpha-1, 1-alpha computed in double, then cast), so the depth branch
+ * is bit-identical to the reference's torch-CPU result; the logarithm is not (tolerance 1e-6 absolute).
+ * object_norm = 0 copies the depth channel, int_norm = 0 the intensity channel. */
+int mobi_range_denorm(const float* sample, const float* min_d, const float* max_d, float alpha, float two_alpha,
+                      float alpha_m1, float one_m_alpha, int32_t object_norm, int32_t int_norm, float* depth_out,
+                      float* int_out, int32_t batch, int32_t hw, void* stream);
+
 /* ddim.py:145-148 with q_sample (ddpm.py:284-287):
  *   img = (sa[t]*x0 + s1ma[t]*noise) * mask + (1 - mask) * img
  * mask is [batch][1][hw] broadcast over `channels`. */

@@ -117,6 +117,7 @@ SYMBOLS = {
     "mobi_lincomb4": (C.c_int, [vp, vp, vp, vp, vp, f32, f32, f32, f32, i64, vp]),
     "mobi_mask_blend": (C.c_int, [vp, vp, vp, vp, f32, f32, i32, i32, i32, vp]),
     "mobi_posterior_sample": (C.c_int, [vp, vp, vp, i32, i32, i32, i32, i32, f32, vp]),
+    "mobi_range_denorm": (C.c_int, [vp, vp, vp, f32, f32, f32, f32, i32, i32, vp, vp, i32, i32, vp]),
     "mobi_nearest_resize": (C.c_int, [vp, vp, i32, i32, i32, i32, i32, i32, vp]),
     "mobi_pack_nchw_sources": (C.c_int, [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, i32, vp]),
     "mobi_nchw_f32_to_nhwc": (C.c_int, [vp, vp, i32, i32, i32, i32, vp]),

@@ -51,6 +51,9 @@
 #define MOBI_PP_PHASES 2   // ping-pong kernel: phases per k-tile (4: LOAD / MATRIX per 32-deep k-step; 2: per k-tile --
                            // measured 8 % faster on the 3x3 shapes: half the barriers, 640-cycle MATRIX phases)
 #endif
+#ifndef MOBI_STAGED_PRIO
+#define MOBI_STAGED_PRIO 0 // register-staged kernel: s_setprio 1 around a k-step's MFMAs (A/B)
+#endif
 #ifndef MOBI_PP_PRIO
 #define MOBI_PP_PRIO 1     // ping-pong kernel: s_setprio of the MATRIX phase
 #endif
@@ -806,11 +809,17 @@ __global__ __launch_bounds__(128 * WM, 2) void igemm_kernel(const IgemmArgs a) {
       for (int mi = 0; mi < 4; ++mi) xf[mi] = __builtin_bit_cast(frag_t, ld16(xb + mi * 16 * 128 + sw));
 #pragma unroll
       for (int ni = 0; ni < NT; ++ni) wf[ni] = __builtin_bit_cast(frag_t, ld16(wb + ni * 16 * 128 + sw));
+#if MOBI_STAGED_PRIO
+      __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
       for (int ni = 0; ni < NT; ++ni)
 #pragma unroll
         for (int mi = 0; mi < 4; ++mi)
           acc[ni][mi] = TR ? mfma16(xf[mi], wf[ni], acc[ni][mi]) : mfma16(wf[ni], xf[mi], acc[ni][mi]);
+#if MOBI_STAGED_PRIO
+      __builtin_amdgcn_s_setprio(0);
+#endif
     }
   };
 

@@ -50,6 +50,39 @@ __global__ void mask_blend_kernel(float* img, const float* x0, const float* nois
   }
 }
 
+// range-view post-processing (include/mobi_engine.h, mobi_range_denorm).  Same operation order as the reference's
+// torch expressions; this file is compiled with -ffp-contract=off, so no FMA is formed.
+__global__ void range_denorm_kernel(const float* sample, const float* min_d, const float* max_d, float alpha,
+                                    float two_alpha, float alpha_m1, float one_m_alpha, int object_norm, int int_norm,
+                                    float* depth_out, float* int_out, int batch, int hw) {
+  const long long total = (long long)batch * hw;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int b = (int)(i / hw);
+    const int p = (int)(i - (long long)b * hw);
+    if (depth_out) {
+      const float x = sample[((long long)b * 2) * hw + p];
+      float d = x;
+      if (object_norm) {
+        const float lo = min_d[b], hi = max_d[b];
+        if (x >= -alpha && x <= alpha) d = lo + (x + alpha) * (hi - lo) / two_alpha;
+        else if (x >= -1.0f && x < -alpha) d = -1.0f + -(x + 1.0f) * (lo + 1.0f) / alpha_m1;
+        else if (x > alpha && x <= 1.0f) d = hi + (x - alpha) * (1.0f - hi) / one_m_alpha;
+      }
+      depth_out[i] = d;
+    }
+    if (int_out) {
+      const float x = sample[((long long)b * 2 + 1) * hw + p];
+      float v = x;
+      if (int_norm) {
+        v = -0.5f * logf(1.0f - (x + 1.0f) / 2.0f) - 1.0f;
+        v = fminf(fmaxf(v, -1.0f), 1.0f);
+      }
+      int_out[i] = v;
+    }
+  }
+}
+
 __global__ void posterior_sample_kernel(const float* moments, const float* noise, float* out, int batch, int c, int hw,
                                         int out_c_total, int out_c_off, float scale) {
   const long long total = (long long)batch * c * hw;
@@ -125,6 +158,17 @@ extern "C" int mobi_posterior_sample(const float* moments, const float* noise, f
     return MOBI_ERR_ARG;
   hipLaunchKernelGGL(posterior_sample_kernel, dim3(egrid((long long)batch * c * hw)), dim3(256), 0, ST(stream),
                      moments, noise, out, batch, c, hw, out_c_total, out_c_off, scale);
+  MOBI_CHECK_LAUNCH();
+  return MOBI_OK;
+}
+
+extern "C" int mobi_range_denorm(const float* sample, const float* min_d, const float* max_d, float alpha, float two_alpha,
+                                 float alpha_m1, float one_m_alpha, int32_t object_norm, int32_t int_norm,
+                                 float* depth_out, float* int_out, int32_t batch, int32_t hw, void* stream) {
+  if (!sample || (!depth_out && !int_out) || batch <= 0 || hw <= 0) return MOBI_ERR_ARG;
+  if (object_norm && depth_out && (!min_d || !max_d || !(alpha > 0.0f) || alpha > 1.0f)) return MOBI_ERR_ARG;
+  hipLaunchKernelGGL(range_denorm_kernel, dim3(egrid((long long)batch * hw)), dim3(256), 0, ST(stream), sample, min_d,
+                     max_d, alpha, two_alpha, alpha_m1, one_m_alpha, object_norm, int_norm, depth_out, int_out, batch, hw);
   MOBI_CHECK_LAUNCH();
   return MOBI_OK;
 }

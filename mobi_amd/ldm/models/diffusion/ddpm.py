@@ -311,11 +311,31 @@ class LatentDiffusion(DDPM):
 
     @torch.no_grad()
     def log_data(self, batch, data, h_camera, h_lidar, log_metrics=False, return_sample=True, split="val"):
-        """Decode + clamp of ddpm.py:1475-1476,1503-1504.  The cv2 / matplotlib visualisation and the
-        per-sample lidar error metrics (ddpm.py:1478-1612) stay with the harness."""
+        """Decode + clamp of ddpm.py:1475-1476,1503-1504 and -- when `batch` carries the per-sample depth range -- the
+        range-view de-normalisation of ddpm.py:1527-1543 on the device (`mobi_range_denorm`).  As in the reference,
+        `range_sample_depth` is the DE-NORMALISED depth (the reference overwrites the logged tensor in place, :1533-1537)
+        while `range_sample_int` stays the clamped raw intensity (its inverse is a new tensor used by the metrics only,
+        :1541); the de-normalised intensity is returned as `range_sample_int_denorm`.  The cv2 / matplotlib
+        visualisation and the per-sample error metrics (ddpm.py:1478-1526, :1545-1612) stay with the harness
+        (SURVEY.md 8(f) row 2)."""
         log = {}
         if self.use_camera:
             log["image_sample"] = self.decode_first_stage(h_camera, clamp=(-1., 1.))
         if self.use_lidar:
             log["lidar_sample"] = self.decode_first_stage(h_lidar, module_name="lidar_stage_model", clamp=(-1., 1.))
+            lid = batch.get("lidar") if isinstance(batch, dict) else None
+            if return_sample and lid is not None:
+                smp = log["lidar_sample"].float().contiguous()
+                has_range = self.range_object_norm and "min_depth_obj" in lid and "max_depth_obj" in lid
+                lo = hi = None
+                if has_range:
+                    lo = torch.as_tensor(lid["min_depth_obj"], dtype=torch.float32, device=smp.device).reshape(-1).contiguous()
+                    hi = torch.as_tensor(lid["max_depth_obj"], dtype=torch.float32, device=smp.device).reshape(-1).contiguous()
+                depth, inten = ops.range_denorm(smp, lo, hi, alpha=self.range_object_norm_scale,
+                                                object_norm=bool(has_range), int_norm=bool(self.range_int_norm))
+                log["range_sample_depth"] = depth
+                log["range_sample_int"] = smp[:, [1]]
+                log["range_sample_int_denorm"] = inten
+                if "range_mask" in lid:
+                    log["range_bbox_mask"] = 1 - lid["range_mask"][:, [0]]
         return log, {}

@@ -505,6 +505,23 @@ def mask_blend_(img, x0, noise, mask, sqrt_ac_t, sqrt_1m_ac_t):
     return img
 
 
+def range_denorm(sample, min_d=None, max_d=None, alpha=0.75, object_norm=True, int_norm=True):
+    """sample: fp32 [B, 2, H, W] clamped lidar range sample -> (depth [B,1,H,W], intensity [B,1,H,W]) de-normalised as
+    log_data does on the host (include/mobi_engine.h, mobi_range_denorm).  min_d / max_d: fp32 [B] on the device."""
+    lib = _lib.load()
+    assert sample.dtype == torch.float32 and sample.is_contiguous() and sample.shape[1] == 2
+    b, _, h, w = sample.shape
+    depth = torch.empty((b, 1, h, w), device=sample.device, dtype=torch.float32)
+    inten = torch.empty((b, 1, h, w), device=sample.device, dtype=torch.float32)
+    if object_norm:
+        assert min_d.dtype == max_d.dtype == torch.float32 and min_d.numel() == max_d.numel() == b
+    f32 = lambda v: float(torch.tensor(v, dtype=torch.float64).to(torch.float32))      # as torch wraps a Python scalar
+    _lib.check(lib.mobi_range_denorm(_ptr(sample), _ptr(min_d), _ptr(max_d), f32(alpha), f32(2 * alpha), f32(alpha - 1),
+                                     f32(1 - alpha), int(object_norm), int(int_norm), _ptr(depth), _ptr(inten), b, h * w,
+                                     _stream()), "mobi_range_denorm")
+    return depth, inten
+
+
 def posterior_sample(moments, noise, out, c_off, scale):
     lib = _lib.load()
     b, c2, h, w = moments.shape

@@ -560,3 +560,23 @@ def test_igemm_pingpong_upsample_and_stride(ops, dtype, monkeypatch):
         bias = torch.from_numpy(W.synth_param(name + ".bias", (cout,)))
         y = ops.igemm(xd, ops.pack_conv(wf, bias, dtype, "cuda"), stride=stride, upsample=up)
         assert rel(y.float(), _conv_ref(xf, wf, bias, stride, (1, 1), up)) < TOL[dtype] * 0.5, name
+
+
+def test_range_denorm_vs_reference_golden(ops):
+    """mobi_range_denorm against the golden the REFERENCE's inverse_depth_normalization produced: the depth branch
+    bit-exact (same operation order, no FMA contraction), the logarithm within 1e-6 absolute; plus the oracle on a
+    512 x 512 batch and the pass-through modes."""
+    from oracle import postprocess as opost
+    from tests.golden_cases import load
+    g = load("postprocess")
+    depth, inten = ops.range_denorm(g["sample"].cuda(), g["min_d"].cuda(), g["max_d"].cuda(), alpha=float(g["alpha"]))
+    assert torch.equal(depth.cpu(), g["depth"])
+    assert (inten.cpu() - g["intensity"]).abs().max() < 1e-6
+    x = torch.clamp(W.synth_input("post.big", (8, 2, 512, 512)) * 0.9, -1, 1)
+    lo = torch.linspace(-0.9, 0.2, 8)
+    hi = lo + torch.linspace(0.1, 0.7, 8)
+    d, i = ops.range_denorm(x.cuda(), lo.cuda(), hi.cuda(), alpha=0.6)
+    dr, ir = opost.range_denorm(x, lo, hi, alpha=0.6)
+    assert torch.equal(d.cpu(), dr) and (i.cpu() - ir).abs().max() < 1e-6
+    d, i = ops.range_denorm(x.cuda(), None, None, object_norm=False, int_norm=False)
+    assert torch.equal(d.cpu(), x[:, [0]]) and torch.equal(i.cpu(), x[:, [1]])

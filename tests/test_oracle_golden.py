@@ -203,3 +203,15 @@ def test_plumbing():
     za, ba = pipeline.align_lidar(z, bbox, 8)
     assert za.shape == (2, 9, 8, 8) and torch.equal(za[:, :, 2:6], z[..., 4:12]) and float(za[:, :, :2].abs().sum()) == 0
     assert torch.allclose(ba[..., 0], (bbox[..., 0] * 16 - 4) / 8) and torch.allclose(ba[..., 1], bbox[..., 1] + 0.25)
+
+
+def test_postprocess_oracle_matches_reference_function():
+    """oracle.postprocess against the reference's own inverse_depth_normalization / intensity expression
+    (tests/golden/postprocess.npz): same torch expressions -> bit-exact, branch boundaries included."""
+    from oracle import postprocess as opost
+    g = load("postprocess")
+    depth, inten = opost.range_denorm(g["sample"], g["min_d"], g["max_d"], alpha=float(g["alpha"]))
+    assert torch.equal(depth, g["depth"])
+    assert torch.equal(inten, g["intensity"])
+    d0, i0 = opost.range_denorm(g["sample"], None, None, object_norm=False, int_norm=False)
+    assert torch.equal(d0, g["sample"][:, [0]]) and torch.equal(i0, g["sample"][:, [1]])
