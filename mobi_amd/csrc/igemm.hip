@@ -2,19 +2,19 @@
 //
 //   out[m][n] = epi( scale * sum_k A[m][k] * W[n][k] ),  m = (image, y, x), k = (tap, channel)
 //
-// Block = 256 threads = 4 waves (2 pixel halves x 2 channel halves).
-// Block tile: 128 pixels x (2 * WAVE_N) channels x 64 k; WAVE_N = 80 (all UNet
-// widths are multiples of 160) or 64.  MFMA 16x16x32, fp32 accumulators.
-// Both operand tiles are staged global -> registers -> LDS (double buffered, one
-// barrier per k-tile) as [row][64 k] with 128-byte rows and a 16-byte-slot XOR
-// swizzle (slot ^= row & 7) that makes the ds_read_b128 fragment reads and the
-// ds_write_b128 staging writes bank-conflict free.
-// The activation tile is a GATHER: each row is an output pixel, each 32-channel
-// chunk of k belongs to one filter tap, so 3x3 / 1x5 / strided / asymmetric-pad
-// convolutions, nearest-x2 upsampling on the load side and the channel concat of
-// two sources never materialise an im2col, an upsampled or a concatenated tensor.
-// Epilogue: accumulators go through a per-wave fp32 LDS tile so that bias,
-// per-image vector, residual and GEGLU are applied on coalesced 16-byte rows.
+// The activation operand is a GATHER: each row is an output pixel, each 64-channel k-tile belongs to one filter
+// tap of one source, so 3x3 / 1x5 / strided / asymmetric-pad convolutions, nearest-x2 upsampling on the load side
+// and the channel concat of two sources never materialise an im2col, an upsampled or a concatenated tensor.
+// MFMA 16x16x32, fp32 accumulators, wave tile 64 pixels x 80 (64) channels, [row][64 k] LDS images with 128-byte
+// rows and a 16-byte-slot XOR swizzle (slot ^= row & 7: conflict-free ds_read_b128 fragment reads).
+//
+// Three main loops (igemm_prepare picks one per launch, mobi_igemm_kernel_variant reports it):
+//   igemm_pp_kernel    persistent 256-pixel tiles, operands by LDS-DMA into three stages, PING-PONG schedule (the
+//                      two waves of a SIMD one phase apart: LOAD | MATRIX), deferred register epilogue.  Every
+//                      launch whose tiles are full, whose output is row-major T and that has at most one of
+//                      bias / per-image vector.  (igemm_halo_kernel: its 3x3 halo-patch variant, opt-in.)
+//   igemm_glds_kernel  same geometry in lockstep, LDS-staged epilogues (transposed / fp32 / ragged / bias AND vector)
+//   igemm_kernel       128- / 256-pixel tiles staged through registers, split-K slabs: small m, odd channel counts
 #include <stdlib.h>
 
 #include "common.h"
