@@ -327,3 +327,37 @@ def test_harness_flow_with_conditioning_producer():
     for k, ch in (("image_sample", 3), ("lidar_sample", 2)):
         assert log[k].shape == (B, ch, 64, 64) and bool(torch.isfinite(log[k]).all())
         assert float(log[k].abs().max()) <= 1.0
+
+
+def test_full_size_step_properties():
+    """BASELINE.json's full size (mobi_nusc_512 UNet, 1.04 B parameters, UNet batch 16 = 8 camera/lidar pairs, latent
+    64x64, bf16) has no CPU oracle run (minutes per forward), so it is checked through size-independent properties:
+      * determinism: two forwards of the same inputs are bit-identical (fixed-order reductions everywhere);
+      * pair-permutation equivariance: objects are independent and every 256-pixel tile, GroupNorm / attention
+        reduction lies inside one image, so permuting the (camera, lidar) PAIRS permutes the output bit for bit;
+      * pair coupling is real: swapping only the lidar halves of two objects changes both camera outputs
+        (the cross-modal attention is exercised);
+      * the un-materialised-concat entry point ([x, inpaint, mask] list) equals the concatenated input."""
+    _set(torch.bfloat16)
+    cfg = ounet.UNetConfig()
+    net = _unet(cfg, 64)
+    net.load_state_dict(W.synth_state_dict(ounet.unet_param_shapes(cfg), 11))
+    net = net.cuda()
+    n, side = 16, 64
+    x = W.synth_input("fs.x", (n, 9, side, side)).cuda()
+    ctx = W.synth_input("fs.c", (n, 2, 768)).cuda()
+    t = torch.full((n,), 481, dtype=torch.long, device="cuda")
+    y = net(x, t, context=ctx)
+    assert y.shape == (n, 4, side, side) and torch.isfinite(y).all()
+    assert torch.equal(y, net(x, t, context=ctx))
+    pairs = torch.tensor([3, 0, 7, 1, 6, 2, 5, 4])
+    perm = torch.stack([2 * pairs, 2 * pairs + 1], dim=1).reshape(-1).cuda()
+    yp = net(x[perm].contiguous(), t, context=ctx[perm].contiguous())
+    assert torch.equal(yp, y[perm])
+    swap = torch.arange(n)
+    swap[1], swap[3] = 3, 1                                   # lidar halves of objects 0 and 1 trade places
+    ys = net(x[swap.cuda()].contiguous(), t, context=ctx[swap.cuda()].contiguous())
+    assert not torch.equal(ys[0], y[0]) and not torch.equal(ys[2], y[2])
+    assert torch.equal(ys[4:], y[4:])                         # the other objects do not notice
+    y2 = net([x[:, :4].contiguous(), x[:, 4:8].contiguous(), x[:, 8:].contiguous()], t, context=ctx)
+    assert torch.equal(y2, y)
