@@ -29,6 +29,9 @@
 #ifndef MOBI_ATTN_LOAD_LATE
 #define MOBI_ATTN_LOAD_LATE 1 // next tile requested behind the S MFMAs instead of at the top of the loop (-3.7 %: 653 vs 678 us)
 #endif
+#ifndef MOBI_ATTN_STORE_LATE
+#define MOBI_ATTN_STORE_LATE 0
+#endif
 #ifndef MOBI_ATTN_DBUF
 #define MOBI_ATTN_DBUF 1   // two LDS images of the K / V tile: one barrier per key tile, the next tile is written while
 #endif                     // this one is still being multiplied (A/B: -DMOBI_ATTN_DBUF=0)
@@ -326,7 +329,7 @@ __global__ __launch_bounds__(256, WPS) void attention_kernel(const AttnArgs a) {
       l_run += psum;
     }
 
-#if MOBI_ATTN_DBUF
+#if MOBI_ATTN_DBUF && !MOBI_ATTN_STORE_LATE
     // the next tile goes into the OTHER image: every wave left it at the barrier that ended the previous step, and
     // its loads were issued a whole S / softmax phase ago
     if (more) store_tile(IMG_BYTES - boff);
@@ -372,6 +375,9 @@ __global__ __launch_bounds__(256, WPS) void attention_kernel(const AttnArgs a) {
       }
 #if MOBI_ATTN_PRIO
     __builtin_amdgcn_s_setprio(0);
+#endif
+#if MOBI_ATTN_DBUF && MOBI_ATTN_STORE_LATE
+    if (more) store_tile(IMG_BYTES - boff);   // behind the P.V MFMAs: the loads had the whole softmax to land
 #endif
     __syncthreads();                  // every wave is done with this tile's LDS image (and wrote the next one)
 #if !MOBI_ATTN_DBUF
