@@ -12,7 +12,7 @@
 //   igemm_pp_kernel    persistent 256-pixel tiles, operands by LDS-DMA into three stages, PING-PONG schedule (the
 //                      two waves of a SIMD one phase apart: LOAD | MATRIX), deferred register epilogue.  Every
 //                      launch whose tiles are full, whose output is row-major T and that has at most one of
-//                      bias / per-image vector.  (igemm_halo_kernel: its 3x3 halo-patch variant, opt-in.)
+//                      bias / per-image vector; also the split-K launches with long k ranges (fp32 slabs).
 //   igemm_glds_kernel  same geometry in lockstep, LDS-staged epilogues (transposed / fp32 / ragged / bias AND vector)
 //   igemm_kernel       128- / 256-pixel tiles staged through registers, split-K slabs: small m, odd channel counts
 #include <stdlib.h>
@@ -40,9 +40,6 @@
 #endif
 #ifndef MOBI_PP_DMA_SPLIT
 #define MOBI_PP_DMA_SPLIT 1 // ping-pong kernel: activation pieces requested in LOAD(ks 0), weight pieces in LOAD(ks 1)
-#endif
-#ifndef MOBI_HALO_WPF
-#define MOBI_HALO_WPF 5    // halo kernel: weight k-tiles warmed into L2 this many steps ahead (0 = off)
 #endif
 #ifndef MOBI_PP_DMA_AT
 #define MOBI_PP_DMA_AT 0   // two-phase schedule: requests in the LOAD phase (0), between the MATRIX phase's k-steps (1),
@@ -120,11 +117,6 @@ struct IgemmArgs {
   int epi_direct;          // direct-to-LDS kernel: register epilogue (full tiles, row-major T output)
   int pp;                  // register-epilogue launch on the ping-pong kernel
   int hw_shift, w_shift;   // log2(hw_out), log2(wout) when both are powers of two (ping-pong kernel), else -1
-  int halo;                // 3x3 / stride 1 / pad 1 launch on the halo-patch kernel
-  int hw_tile, hw_shift_t; // pixels of one image inside a 256-pixel tile (min(hw_out, 256)) and its log2
-  int halo_ppix;           // patch pixels per tile ((rows + 2) * (wout + 2) per image)
-  int halo_d1, halo_m1;    // patch pixels per image and ceil(2^20 / d1): p / d1 == (p * m1) >> 20 for p < 512
-  int halo_m2;             // ceil(2^20 / (wout + 2))
 };
 
 // 8 consecutive floats through two 16-byte accesses (LDS stage rows, bias, per-image vectors)
@@ -483,7 +475,7 @@ __device__ __forceinline__ int direct_epilogue(const IgemmArgs& a, f32x4 (&acc)[
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// Register epilogue of the ping-pong / halo kernels.  Differences to the one above: bias / per-image vector are
+// Register epilogue of the ping-pong kernel.  Differences to the one above: bias / per-image vector are
 // already in the sums (they started them); only the residual rows of tile pair p = 0 stay in registers over the
 // k loop (NT x 4 VGPRs), those of pair p = 1 are requested at the START of the epilogue and land while pair 0 is
 // converted and stored (their registers are the k loop's fragment registers, free at a tile boundary).
@@ -1185,7 +1177,8 @@ __global__ __launch_bounds__(512, 2) void igemm_glds_kernel(const IgemmArgs a) {
 // Operands arrive by buffer_load ... lds (SGPR descriptor + 32-bit lane offset): padded pieces use an offset
 // beyond the descriptor's range and the hardware writes zeros.
 // =========================================================================================================
-template <typename T, int NT, bool GEGLU>
+// SLAB: split-K launch -- blockIdx.y owns a k range and leaves fp32 partial sums (no bias / vector / residual)
+template <typename T, int NT, bool GEGLU, bool SLAB = false>
 __global__ __launch_bounds__(512, 2) void igemm_pp_kernel(const IgemmArgs a) {
   typedef typename Vec8<T>::type frag_t;
   constexpr int BM = 256;
@@ -1205,7 +1198,10 @@ __global__ __launch_bounds__(512, 2) void igemm_pp_kernel(const IgemmArgs a) {
   const bool late = wave_s >= 4;                             // the half that runs one phase behind
   const int group = blockIdx.z;
   const int nblk = a.tiles_m * a.tiles_n;
-  const int nk = a.nk;
+  // split-K: blockIdx.y owns k-tiles [kt_begin, kt_begin + nk) and leaves fp32 partial sums for the reduce launch
+  const int kt_begin = SLAB ? blockIdx.y * a.nk_per : 0;
+  const int nk = SLAB ? min(a.nk, kt_begin + a.nk_per) - kt_begin : a.nk;
+  constexpr bool slab = SLAB;
   const T* wgt = reinterpret_cast<const T*>(a.weight) + (long long)group * a.w_group_stride;
   const __amdgpu_buffer_rsrc_t rx0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.src0), 0, a.src0_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rx1 =
@@ -1216,7 +1212,7 @@ __global__ __launch_bounds__(512, 2) void igemm_pp_kernel(const IgemmArgs a) {
   const unsigned sg16 = (unsigned)((lane & 7) ^ rloc) * 16u; // source piece that lands in this lane's slot (swizzle)
 
   // ---- fetch side ----------------------------------------------------------------------------------------------
-  int f_bid = blockIdx.x, f_kt = 0, f_slot = 0;
+  int f_bid = blockIdx.x, f_kt = kt_begin, f_slot = 0;
   int x_hw0 = 0;                                             // window origin of this lane's first row (8 * wave + rloc):
                                                              // (row << 16) | (column & 0xffff), both may be < 0
                                                              // rows 64 j further on: a wave-uniform (row, column) step,
@@ -1245,7 +1241,20 @@ __global__ __launch_bounds__(512, 2) void igemm_pp_kernel(const IgemmArgs a) {
     w_off = (unsigned)(n0 + 8 * wave + rloc) * (unsigned)a.ktot * 2u + sg16;
     w_rowstep = a.ktot * 128;
     w_half = (wave_s >> 2) * (a.ktot * 64);
-    u_tap = 0; u_ky = 0; u_kx = 0; u_c = 0; f_tap = -1; f_src = -1;
+    if constexpr (SLAB) {
+      if (a.k_order) {                     // channel-chunk-major k: taps innermost
+        const int taps_ = a.kh * a.kw;
+        const int cc = kt_begin / taps_;
+        u_tap = kt_begin - cc * taps_; u_c = cc * 64;
+      } else {                             // tap-major k
+        const int c_first = kt_begin * 64;
+        u_tap = c_first / a.C; u_c = c_first - u_tap * a.C;
+      }
+      u_ky = u_tap / a.kw; u_kx = u_tap - u_ky * a.kw;
+    } else {
+      u_tap = 0; u_ky = 0; u_kx = 0; u_c = 0;
+    }
+    f_tap = -1; f_src = -1;
   };
 
   // every vector-memory instruction this wave issues is counted (wave-uniform); mk1 / mk2 = the count right after
@@ -1303,8 +1312,8 @@ __global__ __launch_bounds__(512, 2) void igemm_pp_kernel(const IgemmArgs a) {
     }
     vm_issued += WJ;
 #endif
-    if (++f_kt == nk) {                                      // the sequence moves on to this block's next output tile
-      f_kt = 0;
+    if (++f_kt == kt_begin + nk) {                           // the sequence moves on to this block's next output tile
+      f_kt = kt_begin;
       f_bid += gridDim.x;
       if (f_bid < nblk) set_fetch_tile();
     } else if (a.k_order) {                                  // channel-chunk-major k: taps innermost
@@ -1331,7 +1340,7 @@ __global__ __launch_bounds__(512, 2) void igemm_pp_kernel(const IgemmArgs a) {
   // bias OR per-image vector (never both) of the wave tile at (mw0, nw0): f32 x 4 per 16-column MFMA tile, the
   // accumulator layout.  Requested BEFORE anything else of the phase so that the latency hides behind the
   // epilogue stores; lands in registers that are free at that point (no fragment is live at a tile boundary).
-  const bool has_vec = a.bias || a.rowvec;
+  const bool has_vec = !slab && (a.bias || a.rowvec);      // (split-K: the reduce launch adds them)
   auto request_vec = [&](u32x4 (&bv)[NT], int nw0, int mw0) {
     const float* vec = a.bias;
     if (a.rowvec) {                                          // the wave's 64 pixels lie in one image: hw_out % 64 == 0
@@ -1351,6 +1360,26 @@ __global__ __launch_bounds__(512, 2) void igemm_pp_kernel(const IgemmArgs a) {
     }
   };
 
+  // split-K partial sums straight from the accumulators: a lane holds 4 consecutive channels of pixel r16 per tile
+  auto slab_epilogue = [&](int nw0, int mw0) {
+    float* wsp = a.split_ws + (long long)blockIdx.y * a.M * a.n_packed;
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+      float* rowp = wsp + (long long)(mw0 + mi * 16 + r16) * a.n_packed + nw0 + g4 * 4;
+#pragma unroll
+      for (int ni = 0; ni < NT; ++ni) vm_store16(rowp + ni * 16, __builtin_bit_cast(u32x4, acc[ni][mi]));
+    }
+    return 4 * NT;
+  };
+  auto finish_tile = [&](int nw0, int mw0) {
+    if constexpr (SLAB) return slab_epilogue(nw0, mw0);
+    else return pp_epilogue<T, NT, GEGLU>(a, acc, dq, lane, group, nw0, mw0);
+  };
+  auto request_tile = [&](int nw0, int mw0) {
+    if constexpr (SLAB) return 0;
+    else return pp_epilogue_request<T, NT, GEGLU>(a, dq, lane, group, nw0, mw0);
+  };
+
   int ahead = 0;                                             // requested k-tiles not yet multiplied
   {
     const int L0 = xcd_remap(blockIdx.x, nblk);
@@ -1363,7 +1392,7 @@ __global__ __launch_bounds__(512, 2) void igemm_pp_kernel(const IgemmArgs a) {
     if (f_bid < nblk) { issue_next(); ++ahead; mk1 = vm_issued; }
     wait_vmcnt_le(vm_issued - mk_first);                     // this wave's pieces of the first k-tile (and, older,
     start_sums(bv);                                          // the vector) have landed
-    vm_issued += pp_epilogue_request<T, NT, GEGLU>(a, dq, lane, group, nw0, mw0);
+    vm_issued += request_tile(nw0, mw0);
   }
   int mk_req = vm_issued;
   int c_slot = 0;                                            // LDS stage of the k-tile to multiply next
@@ -1397,10 +1426,10 @@ __global__ __launch_bounds__(512, 2) void igemm_pp_kernel(const IgemmArgs a) {
           if (has_vec) { request_vec(bv, nw0, mw0); vm_issued += NT; }
           const int mk_vec = vm_issued;
           wait_vmcnt_le(vm_issued - mk_req);                 // residual rows of the previous tile
-          vm_issued += pp_epilogue<T, NT, GEGLU>(a, acc, dq, lane, group, p_nw0, p_mw0);
+          vm_issued += finish_tile(p_nw0, p_mw0);
           wait_vmcnt_le(vm_issued - mk_vec);
           start_sums(bv);
-          vm_issued += pp_epilogue_request<T, NT, GEGLU>(a, dq, lane, group, nw0, mw0);
+          vm_issued += request_tile(nw0, mw0);
           mk_req = vm_issued;
         }
         frag_t xf[2][4], wf[2][NT];
@@ -1479,10 +1508,10 @@ __global__ __launch_bounds__(512, 2) void igemm_pp_kernel(const IgemmArgs a) {
           if (has_vec) { request_vec(bv, nw0, mw0); vm_issued += NT; }
           const int mk_vec = vm_issued;
           wait_vmcnt_le(vm_issued - mk_req);                 // residual rows of the previous tile
-          vm_issued += pp_epilogue<T, NT, GEGLU>(a, acc, dq, lane, group, p_nw0, p_mw0);
+          vm_issued += finish_tile(p_nw0, p_mw0);
           wait_vmcnt_le(vm_issued - mk_vec);
           start_sums(bv);
-          vm_issued += pp_epilogue_request<T, NT, GEGLU>(a, dq, lane, group, nw0, mw0);
+          vm_issued += request_tile(nw0, mw0);
           mk_req = vm_issued;
         }
         const int sw = ((ks * 4 + g4) ^ (r16 & 7)) << 4;
@@ -1541,326 +1570,7 @@ __global__ __launch_bounds__(512, 2) void igemm_pp_kernel(const IgemmArgs a) {
   }
   if (!late) MOBI_PP_BARRIER();                              // every wave has passed the same number of barriers
   wait_vmcnt_le(vm_issued - mk_req);
-  pp_epilogue<T, NT, GEGLU>(a, acc, dq, lane, group, p_nw0, p_mw0);
-#if MOBI_STAMP == 3
-  if (g_phase && lane == 0) {
-    unsigned long long* d = g_phase + ((size_t)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) * 8 + wave) * 16;
-    for (int i = 0; i < 8; ++i) d[i] = pp_acc[i >> 2][i & 3];
-    d[8] = pp_n;
-  }
-#endif
-#undef MOBI_PP_T
-#undef MOBI_PP_BARRIER
-}
-
-// =========================================================================================================
-// HALO kernel: 3x3 / stride 1 / pad 1 convolutions on the ping-pong schedule, activation tile held ONCE per
-// 64-channel chunk.
-//
-// Why: the direct-to-LDS loops are bound by operand delivery into the CU (one 1-KiB LDS-DMA request per ~48 cycles
-// beside the matrix work, tools/stamp_pp.py: 56 requests = 2,700 of a k-tile's 3,400 cycles), and the nine taps of
-// a 3x3 window fetch the same pixels nine times (4 of the 7 requests per wave and k-tile; the activation pieces are
-// also the slow ones, they come from beyond L2: without them a 173 us launch takes 141 us, without the weight
-// pieces 168 us -- tools/diag_ingest.sh).
-//
-// Here k runs chunk-major (64 channels, then the nine taps; the ordinary k = tap * C + c weight layout is indexed
-// accordingly) and an output tile = 256 consecutive pixels = whole image rows (or four 8x8 images).  Per chunk the
-// block loads the tile's HALO PATCH -- (rows + 2) x (wout + 2) pixels x 64 channels, <= 400 pixels = 50 KB, zero
-// filled outside the image by out-of-range buffer offsets -- and the nine taps read their B fragments from it at
-// shifted pixel positions.  Per k-tile a wave then issues WJ weight requests + at most one patch request (the next
-// chunk's patch, a 1-KiB slice per k-tile over taps 0-6) instead of 4 + WJ.
-// LDS: patch x 2 (chunk parity) + weight stage x 3 = 2 * 51,200 + 3 * BN * 128 B (160 KB at BN = 160).
-// Swizzle: slot ^= patch pixel & 7 (the 16 pixels of a fragment are consecutive patch pixels: conflict-free as
-// before); the fill side fetches piece slot ^ (pixel & 7), pixel & 7 = the lane's row inside the 8-pixel request.
-// Hazards as in the ping-pong kernel; in addition
-//   RAW  the patch of chunk g+1 is requested during taps 0-6 of chunk g, i.e. BEFORE the weight requests of chunk
-//        g+1's first k-tile (issued at tap 7), whose counted wait therefore covers it (in-order retirement).
-//   WAR  patch (g+1) & 1 was last read in chunk g-1; its first request comes after the first barrier of chunk g.
-// =========================================================================================================
-template <typename T, int NT, bool GEGLU>
-__global__ __launch_bounds__(512, 2) void igemm_halo_kernel(const IgemmArgs a) {
-  typedef typename Vec8<T>::type frag_t;
-  constexpr int BM = 256;
-  constexpr int WAVE_N = NT * 16;
-  constexpr int BN = 2 * WAVE_N;
-  constexpr int W_TILE = BN * 128;
-  constexpr int PATCH_PIX = 400, PATCH = PATCH_PIX * 128;
-  constexpr int WJ = (BN + 63) / 64;                         // weight DMA instructions per thread and k-tile
-  constexpr unsigned OOB = 0x80000000u;                      // beyond every descriptor (extents < 2^31, host check)
-  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * PATCH + 3 * W_TILE];
-  typedef __attribute__((address_space(3))) void* lds_ptr_t;
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave & 3, wn = wave >> 2;
-  const bool late = wave >= 4;                               // the half that runs one phase behind
-  const int group = blockIdx.z;
-  const int nblk = a.tiles_m * a.tiles_n;
-  const int nk = a.nk;                                       // 9 * chunks
-  const int nchunk = a.C >> 6;
-  const T* wgt = reinterpret_cast<const T*>(a.weight) + (long long)group * a.w_group_stride;
-  const __amdgpu_buffer_rsrc_t rx0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.src0), 0, a.src0_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rx1 =
-      __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.src1 ? a.src1 : a.src0), 0, a.src1 ? a.src1_bytes : 0, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(wgt), 0, a.w_bytes, 0x00020000);
-
-  const int rloc = lane >> 3;                                // pixel inside the wave's 8-pixel DMA request
-  const unsigned sg16 = (unsigned)((lane & 7) ^ rloc) * 16u; // source piece that lands in this lane's slot (swizzle)
-  const int r16 = lane & 15, g4 = lane >> 4;
-  const int pw2 = a.wout + 2;                                // patch row length in pixels
-
-  // patch pixel (tap 0, 0) of this lane's pixel in the wave's first 16-pixel MFMA tile (tile independent); tile mi
-  // lies 16 mi pixels further on: a wave-uniform patch step (no carry into the lane's column: wout >= 8, r16 < 16)
-  int pp0;
-  {
-    const int o = wm * 64 + r16;                             // pixel inside the 256-pixel output tile
-    const int oi = o >> a.hw_shift_t, rem = o & (a.hw_tile - 1);      // image inside the tile (8x8 images: 4 per tile)
-    pp0 = oi * a.halo_d1 + (rem >> a.w_shift) * pw2 + (rem & (a.wout - 1));
-  }
-
-  // ---- weight fetch: k-tile sequence (output tile, chunk, tap), runs ahead across output tiles ------------------
-  int f_bid = blockIdx.x, f_kt = 0, f_slot = 0;
-  unsigned w_off = 0;
-  int w_rowstep = 0, w_half = 0;
-  int u_tap = 0, u_c = 0;                                    // tap and channel offset of the next weight k-tile
-  auto set_fetch_tile = [&]() {
-    const int L = xcd_remap(f_bid, nblk);
-    const int n0 = (L % a.tiles_n) * BN;
-    w_off = (unsigned)(n0 + 8 * wave + rloc) * (unsigned)a.ktot * 2u + sg16;
-    w_rowstep = a.ktot * 128;
-    w_half = __builtin_amdgcn_readfirstlane((wave >> 2) * (a.ktot * 64));
-    u_tap = 0; u_c = 0;
-  };
-  int vm_issued = 0, mk1 = 0, mk2 = 0;
-  auto issue_w = [&]() {
-    unsigned char* st = lds + 2 * PATCH + f_slot * W_TILE;
-    f_slot = f_slot == 2 ? 0 : f_slot + 1;
-#if !(MOBI_DBG_SKIP & 2)
-    const int kb = (u_tap * a.C + u_c) * 2;                  // k = tap * C + c in the packed weights
-#pragma unroll
-    for (int j = 0; j < WJ; ++j) {
-      const bool partial = (BN % 64 != 0) && (j == WJ - 1);
-      const int wl = (partial ? 64 * j + 8 * (wave & 3) : 64 * j + 8 * wave) * 128;
-      const int so = kb + j * w_rowstep - (partial ? w_half : 0);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr_t)(st + wl), 16, w_off, so, 0, 0);
-    }
-    vm_issued += WJ;
-#endif
-    if (++f_kt == nk) {
-      f_kt = 0;
-      f_bid += gridDim.x;
-      if (f_bid < nblk) set_fetch_tile();
-    } else if (++u_tap == 9) { u_tap = 0; u_c += 64; }
-  };
-
-  // ---- weight warm-up: the weight k-tile MOBI_HALO_WPF steps ahead (inside this output tile) is pulled into the
-  // XCD's L2 by one 4-byte load per 128-byte line (waves 0-2: 160 lines).  Every block of an XCD multiplies the
-  // same weight k-tile at about the same time, so without this the first touch of each k-tile is a miss beyond L2
-  // that ALL of them wait for, and the three-stage ring is only two k-tiles deep.
-  unsigned wpf_sink = 0;                                     // the loads' (never read) destination register
-  unsigned long long wpf_row = 0;                            // this lane's line: weight row n0 + 64 * wave + lane
-  auto set_wpf_tile = [&](int bid) {
-    const int L = xcd_remap(bid, nblk);
-    const int n0 = (L % a.tiles_n) * BN;
-    int r = 64 * wave + lane;
-    if (r >= BN) r = BN - 1;
-    wpf_row = (unsigned long long)(n0 + r) * (unsigned long long)a.ktot * 2ull;
-  };
-  auto issue_wpf = [&](int tap, int cc) {                    // (tap, chunk) of the k-tile being multiplied
-#if MOBI_HALO_WPF
-    if (wave * 64 >= BN) return;
-    int t2 = tap + MOBI_HALO_WPF, c2 = cc;
-    while (t2 >= 9) { t2 -= 9; ++c2; }
-    if (c2 >= nchunk) return;
-    const unsigned char* g = reinterpret_cast<const unsigned char*>(wgt) + wpf_row + (unsigned long long)((t2 * a.C + c2 * 64) * 2);
-    asm volatile("global_load_dword %0, %1, off sc1" : "+v"(wpf_sink) : "v"(g) : "memory");
-    vm_issued += 1;
-#endif
-  };
-
-  // ---- patch fetch: one 8-pixel request per wave and slice -------------------------------------------------------
-  // slice t (0..6) of wave w covers patch pixels 8 (w + 8 t) .. + 7; requests beyond the patch are not issued
-  int pf_img = 0, pf_h0 = 0, pf_c = 0;                       // image base pixel, first output row, channel offset
-  bool pf_valid = false;
-  int pf_par = 0;                                            // patch buffer the requests fill
-  auto set_patch_tile = [&](int bid) {                       // geometry of output tile `bid`
-    const int L = xcd_remap(bid, nblk);
-    const int m0 = (L / a.tiles_n) * BM;
-    pf_img = (group * a.imgs_per_group + (m0 >> a.hw_shift)) * a.img_pix_stride;
-    pf_h0 = (m0 & (a.hw_out - 1)) >> a.w_shift;
-  };
-  auto issue_patch = [&](int t) {
-    const int q = wave + 8 * t;
-    if (8 * q >= a.halo_ppix) return;                        // wave-uniform
-    const int p = 8 * q + rloc;
-    const int pi = (p * a.halo_m1) >> 20, p1 = p - pi * a.halo_d1;          // image inside the tile, pixel inside its patch
-    const int pr = (p1 * a.halo_m2) >> 20, pc = p1 - pr * pw2;
-    const int hi = pf_h0 + pr - 1, wi = pc - 1;
-    const bool ok = p < a.halo_ppix && (unsigned)hi < (unsigned)a.hin && (unsigned)wi < (unsigned)a.win;
-    const int src = pf_c >= a.c0 ? 1 : 0;
-    const unsigned cs2 = (unsigned)(src ? a.c1 : a.c0) * 2u;
-    const unsigned off = ok ? (unsigned)(pf_img + pi * a.img_pix_stride + hi * a.win + wi) * cs2 + sg16 : OOB;
-    const int soff = (src ? pf_c - a.c0 : pf_c) * 2;
-    unsigned char* dst = lds + pf_par * PATCH + q * 1024;
-#if !(MOBI_DBG_SKIP & 1)
-    if (src) __builtin_amdgcn_raw_ptr_buffer_load_lds(rx1, (lds_ptr_t)dst, 16, off, soff, 0, 0);
-    else     __builtin_amdgcn_raw_ptr_buffer_load_lds(rx0, (lds_ptr_t)dst, 16, off, soff, 0, 0);
-    vm_issued += 1;
-#endif
-  };
-
-#define MOBI_PP_BARRIER()                     \
-  do {                                        \
-    __builtin_amdgcn_sched_barrier(0);        \
-    __builtin_amdgcn_s_barrier();             \
-    __builtin_amdgcn_sched_barrier(0);        \
-  } while (0)
-
-  f32x4 acc[NT][4];
-  PpEpiRegs<NT> dq;                                      // residual rows only: bias / per-image vector start the sums
-  const bool has_vec = a.bias || a.rowvec;
-  auto request_vec = [&](u32x4 (&bv)[NT], int nw0, int mw0) {
-    const float* vec = a.bias;
-    if (a.rowvec) {
-      const int img = __builtin_amdgcn_readfirstlane(mw0 / a.hw_out);
-      vec = a.rowvec + (long long)(group * a.imgs_per_group + img) * a.rowvec_stride;
-    }
-#pragma unroll
-    for (int ni = 0; ni < NT; ++ni) bv[ni] = vm_load16(vec + nw0 + ni * 16 + g4 * 4);
-  };
-  auto start_sums = [&](u32x4 (&bv)[NT]) {
-#pragma unroll
-    for (int ni = 0; ni < NT; ++ni) {
-      f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (has_vec) { asm volatile("" : "+v"(bv[ni])); v = __builtin_bit_cast(f32x4, bv[ni]); }
-#pragma unroll
-      for (int mi = 0; mi < 4; ++mi) acc[ni][mi] = v;
-    }
-  };
-
-  int ahead = 0;                                             // requested weight k-tiles not yet multiplied
-  {
-    const int L0 = xcd_remap(blockIdx.x, nblk);
-    const int nw0 = (L0 % a.tiles_n) * BN + wn * WAVE_N, mw0 = (L0 / a.tiles_n) * BM + wm * 64;
-    u32x4 bv[NT];
-    if (has_vec) { request_vec(bv, nw0, mw0); vm_issued += NT; }
-    set_patch_tile(blockIdx.x);                              // the first chunk's whole patch, then two weight k-tiles
-    pf_c = 0; pf_par = 0;
-#pragma unroll
-    for (int t = 0; t < 7; ++t) issue_patch(t);
-    set_fetch_tile();
-    issue_w(); ++ahead;
-    const int mk_first = vm_issued;
-    if (f_bid < nblk) { issue_w(); ++ahead; mk1 = vm_issued; }
-    wait_vmcnt_le(vm_issued - mk_first);                     // first weight k-tile, and (older) patch + vector
-    start_sums(bv);
-    vm_issued += pp_epilogue_request<T, NT, GEGLU>(a, dq, lane, group, nw0, mw0);
-  }
-  int mk_req = vm_issued;
-  int c_slot = 0;                                            // weight stage of the k-tile to multiply next
-  int c_par = 0;                                             // patch buffer of the chunk being multiplied
-  if (late) MOBI_PP_BARRIER();
-
-  int p_nw0 = 0, p_mw0 = 0;
-  bool f_more = false;
-#if MOBI_STAMP == 3
-  unsigned pp_acc[2][4] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}}, pp_n = 0;
-  unsigned long long pp_t[5];
-#define MOBI_PP_T(i) pp_t[i] = __builtin_amdgcn_s_memtime()
-#else
-#define MOBI_PP_T(i) ((void)0)
-#endif
-  for (int bid = blockIdx.x; bid < nblk; bid += gridDim.x) {
-    const int L = xcd_remap(bid, nblk);
-    const int nw0 = (L % a.tiles_n) * BN + wn * WAVE_N, mw0 = (L / a.tiles_n) * BM + wm * 64;
-    set_wpf_tile(bid);
-#pragma unroll 1
-    for (int cc = 0; cc < nchunk; ++cc) {
-      // the chunk after this one (possibly the next output tile's first): its patch is requested during taps 0-6
-      if (cc + 1 < nchunk) { pf_valid = true; pf_c = (cc + 1) * 64; }
-      else {
-        pf_valid = bid + (int)gridDim.x < nblk; pf_c = 0;
-        if (pf_valid) set_patch_tile(bid + gridDim.x);
-      }
-      pf_par = c_par ^ 1;
-      const unsigned char* pb = lds + c_par * PATCH;
-      int t_ky = 0, t_kx = 0;
-#pragma unroll 1
-      for (int tap = 0; tap < 9; ++tap) {
-        const int toff = t_ky * pw2 + t_kx;
-        if (++t_kx == 3) { t_kx = 0; ++t_ky; }
-        const unsigned char* wb = lds + 2 * PATCH + c_slot * W_TILE + (wn * WAVE_N + r16) * 128;
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-          // ---- LOAD phase --------------------------------------------------------------------------------------
-          MOBI_PP_T(0);
-          MOBI_PP_BARRIER();
-          MOBI_PP_T(1);
-          if (ks == 0 && tap == 0 && cc == 0 && bid != (int)blockIdx.x) {   // tile boundary
-            u32x4 bv[NT];
-            if (has_vec) { request_vec(bv, nw0, mw0); vm_issued += NT; }
-            const int mk_vec = vm_issued;
-            wait_vmcnt_le(vm_issued - mk_req);               // residual rows of the previous tile
-            vm_issued += pp_epilogue<T, NT, GEGLU>(a, acc, dq, lane, group, p_nw0, p_mw0);
-            wait_vmcnt_le(vm_issued - mk_vec);
-            start_sums(bv);
-            vm_issued += pp_epilogue_request<T, NT, GEGLU>(a, dq, lane, group, nw0, mw0);
-            mk_req = vm_issued;
-          }
-          frag_t xf[4], wf[NT];
-#pragma unroll
-          for (int mi = 0; mi < 4; ++mi) {
-            const int pp = pp0 + toff + ((16 * mi) >> a.w_shift) * pw2 + ((16 * mi) & (a.wout - 1));
-            xf[mi] = __builtin_bit_cast(frag_t, ld16(pb + pp * 128 + ((((ks * 4 + g4) ^ pp) & 7) << 4)));
-          }
-          const int sw = ((ks * 4 + g4) ^ (r16 & 7)) << 4;
-#pragma unroll
-          for (int ni = 0; ni < NT; ++ni) wf[ni] = __builtin_bit_cast(frag_t, ld16(wb + ni * 16 * 128 + sw));
-          // requests, behind the reads' latency: ks 0 -- the next chunk's patch slice; ks 1 -- weights two k-tiles on
-          if (ks == 0) { if (pf_valid && tap < 7) issue_patch(tap); issue_wpf(tap, cc); f_more = f_bid < nblk; }
-          if (ks == 1 && f_more) {
-            issue_w(); ++ahead;
-            if (ahead == 2) mk1 = vm_issued; else mk2 = vm_issued;
-          }
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-          if (ks == 1 && late && ahead >= 2) wait_vmcnt_le(vm_issued - mk1);
-          // ---- MATRIX phase ------------------------------------------------------------------------------------
-          MOBI_PP_T(2);
-          MOBI_PP_BARRIER();
-          MOBI_PP_T(3);
-          __builtin_amdgcn_s_setprio(MOBI_PP_PRIO);
-#if MOBI_DBG_SKIP & 4
-#pragma unroll
-          for (int mi = 0; mi < 4; ++mi) asm volatile("" :: "v"(xf[mi]));
-#pragma unroll
-          for (int ni = 0; ni < NT; ++ni) asm volatile("" :: "v"(wf[ni]));
-#else
-#pragma unroll
-          for (int ni = 0; ni < NT; ++ni)
-#pragma unroll
-            for (int mi = 0; mi < 4; ++mi) acc[ni][mi] = mfma16(wf[ni], xf[mi], acc[ni][mi]);
-#endif
-          __builtin_amdgcn_s_setprio(0);
-          MOBI_PP_T(4);
-#if MOBI_STAMP == 3
-          if (tap != 0 || cc != 0) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) pp_acc[ks][i] += (unsigned)(pp_t[i + 1] - pp_t[i]);
-            if (ks) ++pp_n;
-          }
-#endif
-          if (ks == 1 && !late && ahead >= 2) wait_vmcnt_le(vm_issued - mk1);
-        }
-        --ahead; mk1 = mk2;
-        c_slot = c_slot == 2 ? 0 : c_slot + 1;
-      }
-      c_par ^= 1;
-    }
-    p_nw0 = nw0; p_mw0 = mw0;
-  }
-  if (!late) MOBI_PP_BARRIER();
-  asm volatile("" :: "v"(wpf_sink));
-  wait_vmcnt_le(vm_issued - mk_req);
-  pp_epilogue<T, NT, GEGLU>(a, acc, dq, lane, group, p_nw0, p_mw0);
+  finish_tile(p_nw0, p_mw0);
 #if MOBI_STAMP == 3
   if (g_phase && lane == 0) {
     unsigned long long* d = g_phase + ((size_t)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) * 8 + wave) * 16;
@@ -1956,9 +1666,9 @@ static int launch_igemm(const mobi_igemm_params* p, const IgemmArgs& a, int grou
 #define MOBI_GLDS_BY_MODE(NT_)                                                                     \
   do { switch (mode) { case 0: MOBI_GLDS_LAUNCH(NT_, 0); break; case 1: MOBI_GLDS_LAUNCH(NT_, 1); break; \
                        case 2: MOBI_GLDS_LAUNCH(NT_, 2); break; default: MOBI_GLDS_LAUNCH(NT_, 3); break; } } while (0)
-    if (a.pp && a.halo) {
-      if (nt5) hipLaunchKernelGGL((igemm_halo_kernel<T, 5, false>), pgrid, block, 0, st, a);
-      else     hipLaunchKernelGGL((igemm_halo_kernel<T, 4, false>), pgrid, block, 0, st, a);
+    if (a.pp && a.split_ws) {
+      if (nt5) hipLaunchKernelGGL((igemm_pp_kernel<T, 5, false, true>), pgrid, block, 0, st, a);
+      else     hipLaunchKernelGGL((igemm_pp_kernel<T, 4, false, true>), pgrid, block, 0, st, a);
     }
     else if (a.pp) {
 #define MOBI_PP_LAUNCH(NT_, G_) hipLaunchKernelGGL((igemm_pp_kernel<T, NT_, G_>), pgrid, block, 0, st, a)
@@ -2073,6 +1783,9 @@ static int igemm_prepare(const mobi_igemm_params* p, mobi::IgemmArgs& a) {
   {
     const long long tiles256 = ((a.M + 255) / 256) * (long long)((p->n_packed + bn - 1) / bn);
     a.wm = tiles256 >= 256 ? 4 : 2;
+    // split-K launches with long k ranges: 256-pixel tiles (ping-pong kernel) once tiles x splits fill the chip
+    if (p->split_k > 1 && a.M % 256 == 0 && tiles256 * p->split_k >= 256 && a.nk / p->split_k >= 16) a.wm = 4;
+    if (const char* e = getenv("MOBI_IGEMM_PP_SPLIT")) { if (e[0] == '0' && p->split_k > 1 && tiles256 < 256) a.wm = 2; }
     if (const char* e = getenv("MOBI_IGEMM_WM")) { if (e[0] == '2') a.wm = 2; else if (e[0] == '4') a.wm = 4; }
   }
   a.tiles_m = (a.M + 64 * a.wm - 1) / (64 * a.wm);
@@ -2118,25 +1831,12 @@ static int igemm_prepare(const mobi_igemm_params* p, mobi::IgemmArgs& a) {
   a.hw_shift = log2_exact(a.hw_out); a.w_shift = log2_exact(a.wout);
   a.pp = a.epi_direct && a.splits == 1 && p->scale == 1.0f && a.hw_shift >= 6 && a.w_shift >= 0 &&
          a.hout < 32768 && a.wout < 32768;
+  // split-K on the ping-pong kernel (fp32 slabs from the registers, finished by the reduce launch): long k, full tiles
+  if (a.split_ws && a.wm == 4 && a.fast && a.glds && p->out_mode != MOBI_OUT_TRANSPOSED && a.M % 256 == 0 &&
+      p->n_packed % bn == 0 && a.nk_per >= 3 && p->scale == 1.0f && a.hw_shift >= 6 && a.w_shift >= 0 &&
+      a.hout < 32768 && a.wout < 32768)
+    a.pp = 1;
   if (const char* e = getenv("MOBI_IGEMM_PP")) a.pp = a.pp && e[0] != '0';
-  // halo-patch kernel: 3x3, stride 1, pad 1, same-size output, tap-major weights, a 256-pixel tile = whole rows of one
-  // image (<= 64 wide) or four 8x8 images; the patch must fit 400 pixels
-  a.halo = 0;
-  if (a.pp && p->upsample == 0 && p->kh == 3 && p->kw == 3 && p->stride == 1 && p->pad_h == 1 && p->pad_w == 1 && p->k_order == 0 &&
-      p->hout == p->hin && p->wout == p->win && a.wout <= 64) {
-    a.hw_tile = a.hw_out < 256 ? a.hw_out : 256;
-    a.hw_shift_t = log2_exact(a.hw_tile);
-    const int rows = a.hw_tile >> a.w_shift;
-    a.halo_d1 = (rows + 2) * (a.wout + 2);
-    a.halo_ppix = a.halo_d1 * (256 / a.hw_tile);
-    a.halo_m1 = ((1 << 20) + a.halo_d1 - 1) / a.halo_d1;
-    a.halo_m2 = ((1 << 20) + a.wout + 1) / (a.wout + 2);
-    a.halo = a.halo_ppix <= 400 && rows >= 1 && a.hw_tile * (256 / a.hw_tile) == 256;
-    // measured SLOWER than the plain ping-pong kernel (185 vs 158 us on 640 -> 640 at 32x32 x 16: the k loop is bound
-    // by request issue + landing latency, not by bytes -- DESIGN.md section 6), so it only runs on request
-    const char* e = getenv("MOBI_IGEMM_HALO");
-    a.halo = a.halo && e && e[0] == '1';
-  }
   return MOBI_OK;
 }
 

@@ -471,8 +471,7 @@ PP_CASES = [
 @pytest.mark.parametrize("dtype", DT)
 @pytest.mark.parametrize("case", PP_CASES, ids=[f"pp{i}" for i in range(len(PP_CASES))])
 def test_igemm_pingpong(ops, dtype, case, monkeypatch):
-    """The ping-pong direct-to-LDS kernel (and, with MOBI_IGEMM_HALO=1, the halo-patch 3x3 kernel) against a torch
-    fp32 convolution: the 256-pixel geometry is forced on small problems, a handful of persistent blocks walk many
+    """The ping-pong direct-to-LDS kernel against a torch fp32 convolution: the 256-pixel geometry is forced on small problems, a handful of persistent blocks walk many
     output tiles, and the library must report that it runs the ping-pong variant."""
     import ctypes as C
     from mobi_amd import _lib
@@ -497,8 +496,7 @@ def test_igemm_pingpong(ops, dtype, case, monkeypatch):
         ref = ref + rv[:, None, None, :]
     if rf is not None:
         ref = ref + rf
-    for halo in ("0", "1"):
-        monkeypatch.setenv("MOBI_IGEMM_HALO", halo)
+    for halo in ("0",):
         if geglu:
             pw = ops.pack_geglu(wf[:, :, 0, 0], bias, dtype, "cuda")
             y = ops.linear(xd.view(n, h * w, cin), pw).view(n, h, w, cout)
@@ -580,3 +578,34 @@ def test_range_denorm_vs_reference_golden(ops):
     assert torch.equal(d.cpu(), dr) and (i.cpu() - ir).abs().max() < 1e-6
     d, i = ops.range_denorm(x.cuda(), None, None, object_norm=False, int_norm=False)
     assert torch.equal(d.cpu(), x[:, [0]]) and torch.equal(i.cpu(), x[:, [1]])
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("blocks", [0, 5])
+def test_igemm_pingpong_split_k(ops, dtype, blocks, monkeypatch):
+    """Split-K on the ping-pong kernel: every (tile, k range) block leaves fp32 partial sums from its accumulators, the
+    reduce launch adds bias + per-image vector + residual.  Long k (3x3 over 1280 channels), 16 x 16 images, explicit
+    split counts, a few persistent blocks walking several tiles."""
+    import ctypes as C
+    from mobi_amd import _lib
+    if blocks:
+        monkeypatch.setenv("MOBI_IGEMM_PERSIST_BLOCKS", str(blocks))
+    n, h, cin, cout = 16, 16, 1280, 320
+    xf, xd = rnd("pps.x", (n, h, h, cin), dtype)
+    rf, rd = rnd("pps.res", (n, h, h, cout), dtype)
+    wf = torch.from_numpy(W.synth_param("pps.weight", (cout, cin, 3, 3))).to(dtype).float()
+    bias = torch.from_numpy(W.synth_param("pps.bias", (cout,)))
+    rv = W.synth_input("pps.rowvec", (n, cout))
+    ref = _conv_ref(xf, wf, bias) + rv[:, None, None, :] + rf
+    pw = ops.pack_conv(wf, bias, dtype, "cuda")
+    for split in (8, 11):
+        y = ops.igemm(xd, pw, rowvec=rv.cuda(), residual=rd, split_k=split)
+        assert rel(y.float(), ref) < TOL[dtype] * 0.5, split
+    p = _lib.IgemmParams()
+    p.src0, p.weight, p.out, p.ws = 256, 256, 256, 256
+    p.c0, p.batch, p.hin, p.win, p.hout, p.wout = cin, n, h, h, h, h
+    p.kh = p.kw = 3
+    p.stride, p.pad_h, p.pad_w, p.groups, p.split_k = 1, 1, 1, 1, 8
+    p.cout, p.n_packed, p.scale = cout, cout, 1.0
+    p.dtype = _lib.MOBI_F16 if dtype == torch.float16 else _lib.MOBI_BF16
+    assert _lib.load().mobi_igemm_kernel_variant(C.byref(p)) == 3

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Race screen of the ping-pong / halo igemm kernels: many repeats of a few shapes (different persistent block counts,
+"""Race screen of the ping-pong igemm kernel: many repeats of a few shapes (different persistent block counts,
 an HBM-thrashing copy between some repeats to vary landing latencies), every output compared BIT FOR BIT with the first
 and once with a torch fp32 reference.  A LDS read that beats its DMA, or a stage overwritten too early, shows up as a
 rare mismatch.   python tools/race_screen.py [--repeats 150]"""
@@ -26,7 +26,7 @@ def main():
     bad = 0
     for (n, h, cin, cout, k, res, blocks, halo) in [(16, 32, 640, 640, 3, True, 0, "0"), (16, 32, 640, 640, 3, True, 37, "0"),
                                                     (16, 64, 320, 320, 1, True, 0, "0"), (16, 64, 320, 320, 1, True, 61, "0"),
-                                                    (16, 16, 1280, 1280, 1, False, 0, "0"), (8, 32, 640, 640, 3, True, 23, "1"),
+                                                    (16, 16, 1280, 1280, 1, False, 0, "0"), (8, 32, 640, 640, 3, True, 23, "0"),
                                                     (16, 64, 320, 1280, 1, False, 101, "0")]:
         if blocks:
             os.environ["MOBI_IGEMM_PERSIST_BLOCKS"] = str(blocks)
