@@ -18,6 +18,8 @@
 //   v_layout 0: V already transposed [channel][token] (written by a projection's transposed epilogue); the LDS
 //     image is key-permuted so that a fragment is one 16-byte read.
 // LDS row strides are odd multiples of the access width (bank-conflict free reads).
+#include <stdlib.h>
+
 #include "common.h"
 
 #ifndef MOBI_ATTN_DBG
@@ -50,8 +52,11 @@ struct AttnArgs {
 // VVEC: every V^T row start is 16-byte aligned (tk % 8 == 0 rows), the production case; the generic
 // variant loads ragged V^T rows element-wise.  WPS = waves per SIMD the register budget is held to.
 // VMODE 0: V^T, generic (ragged rows, element loads)   1: V^T, 16-byte aligned rows   2: V row-major (tr reads)
-template <typename T, int KS, int VMODE, int WPS>
-__global__ __launch_bounds__(256, WPS) void attention_kernel(const AttnArgs a) {
+// NW = waves per block (4 or 8): 32 NW queries share every staged K / V tile, so with 8 a thread requests and stores half
+// as many 16-byte pieces per key tile (two 8-wave blocks per CU instead of four 4-wave blocks: same occupancy).
+template <typename T, int KS, int VMODE, int WPS, int NW = 4>
+__global__ __launch_bounds__(64 * NW, (WPS * 4) / NW) void attention_kernel(const AttnArgs a) {
+  constexpr int NTHR = 64 * NW;
   typedef typename Vec8<T>::type frag_t;
   constexpr bool VVEC = VMODE == 1;
   constexpr bool VROWS = VMODE == 2;
@@ -63,8 +68,8 @@ __global__ __launch_bounds__(256, WPS) void attention_kernel(const AttnArgs a) {
   constexpr int VSTR = VROWS ? ((DT & 1) ? DT * 64 : DT * 64 + 64) : 144;
   constexpr int K_BYTES = 64 * KSTR;
   constexpr int V_BYTES = VROWS ? 64 * VSTR : DT * 32 * VSTR;
-  constexpr int KP = (64 * KS * 2 + 255) / 256;    // 16-byte K pieces per thread
-  constexpr int VP = VROWS ? KP : (DT * 32 * 8 + 255) / 256;    // 16-byte V pieces per thread
+  constexpr int KP = (64 * KS * 2 + NTHR - 1) / NTHR;    // 16-byte K pieces per thread
+  constexpr int VP = VROWS ? KP : (DT * 32 * 8 + NTHR - 1) / NTHR;    // 16-byte V pieces per thread
   constexpr int NBUF = MOBI_ATTN_DBUF ? 2 : 1;
   constexpr int IMG_BYTES = K_BYTES + V_BYTES;
   __shared__ __attribute__((aligned(16))) unsigned char lds[NBUF * IMG_BYTES];
@@ -74,7 +79,7 @@ __global__ __launch_bounds__(256, WPS) void attention_kernel(const AttnArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int ql = lane & 31, half = lane >> 5;
   const int head = blockIdx.y, img = blockIdx.z;
-  const int q0 = blockIdx.x * 128 + wave * 32;
+  const int q0 = blockIdx.x * (32 * NW) + wave * 32;
   const int dh = a.dh;
   // When the head dim leaves a padded row in the P.V tile (dh < 32*DT: dh = 40, 80, ...; not 64, 160) that
   // row of V^T is filled with ones, so the matrix core accumulates the softmax denominator
@@ -113,13 +118,13 @@ __global__ __launch_bounds__(256, WPS) void attention_kernel(const AttnArgs a) {
   constexpr unsigned OOB = 0x80000000u;
 #pragma unroll
   for (int i = 0; i < KP; ++i) {
-    const int p = tid + 256 * i;
+    const int p = tid + NTHR * i;
     const int row = p / (KS * 2), pc = p - row * (KS * 2);
     koff[i] = (row < 64 && pc * 8 < dh) ? (unsigned)(row * a.k_row + pc * 8) * 2u : OOB;
   }
 #pragma unroll
   for (int i = 0; i < VP; ++i) {
-    const int p = tid + 256 * i;
+    const int p = tid + NTHR * i;
     if (VROWS) {                                        // same piece map as K: (key row, 8 channels)
       const int row = p / (KS * 2), pc = p - row * (KS * 2);
       voff[i] = (row < 64 && pc * 8 < dh) ? (unsigned)(row * a.vt_row + pc * 8) * 2u : OOB;
@@ -134,7 +139,7 @@ __global__ __launch_bounds__(256, WPS) void attention_kernel(const AttnArgs a) {
   if (VROWS) {
     // channels [dh, DT*32) of every key row are written ONCE: zero, except channel dh = 1.0 (the denominator
     // column); the tile stores below only touch channels < dh
-    for (int p = tid; p < 64 * DT * 4; p += 256) {
+    for (int p = tid; p < 64 * DT * 4; p += NTHR) {
       const int row = p / (DT * 4), pc = p - row * (DT * 4);
       if (pc * 8 >= dh) {
         typename Vec8<T>::type e;
@@ -166,14 +171,14 @@ __global__ __launch_bounds__(256, WPS) void attention_kernel(const AttnArgs a) {
       if (key0 + 64 > a.tk) {             // ragged last tile: keys >= tk of a V^T row alias the next row -> zero them
 #pragma unroll
         for (int i = 0; i < VP; ++i) {
-          const int pc = (tid + 256 * i) & 7;
+          const int pc = (tid + NTHR * i) & 7;
           if (key0 + pc * 8 >= a.tk) vr[i] = u32x4{0u, 0u, 0u, 0u};
         }
       }
     } else {
 #pragma unroll
       for (int i = 0; i < KP; ++i) {
-        const int p = tid + 256 * i;
+        const int p = tid + NTHR * i;
         const int row = p / (KS * 2), pc = p - row * (KS * 2);
         const bool ok = row < 64 && key0 + row < a.tk && pc * 8 < dh;
         u32x4 v = {0u, 0u, 0u, 0u};
@@ -182,7 +187,7 @@ __global__ __launch_bounds__(256, WPS) void attention_kernel(const AttnArgs a) {
       }
 #pragma unroll
       for (int i = 0; i < VP; ++i) {
-        const int p = tid + 256 * i;
+        const int p = tid + NTHR * i;
         const int row = p >> 3, pc = p & 7;
         typename Vec8<T>::type e;
 #pragma unroll
@@ -201,14 +206,14 @@ __global__ __launch_bounds__(256, WPS) void attention_kernel(const AttnArgs a) {
     const u32x4 ones = __builtin_bit_cast(u32x4, one8);
 #pragma unroll
     for (int i = 0; i < KP; ++i) {
-      const int p = tid + 256 * i;
+      const int p = tid + NTHR * i;
       const int row = p / (KS * 2), pc = p - row * (KS * 2);
       if (row < 64) st16(ldsK + boff + row * KSTR + pc * 16, kr[i]);
     }
     if (VROWS) {
 #pragma unroll
       for (int i = 0; i < VP; ++i) {
-        const int p = tid + 256 * i;
+        const int p = tid + NTHR * i;
         const int row = p / (KS * 2), pc = p - row * (KS * 2);
         if (row < 64 && pc * 8 < dh) st16(ldsV + boff + row * VSTR + pc * 16, vr[i]);
       }
@@ -216,7 +221,7 @@ __global__ __launch_bounds__(256, WPS) void attention_kernel(const AttnArgs a) {
     }
 #pragma unroll
     for (int i = 0; i < VP; ++i) {
-      const int p = tid + 256 * i;
+      const int p = tid + NTHR * i;
       const int row = p >> 3, pc = p & 7;
       if (row < DT * 32) {
         // the ones row may also cover keys >= tk: their P is exactly 0, so the denominator is unaffected
@@ -422,6 +427,24 @@ template <typename T, int VVEC>
 static int launch_attention_v(const mobi_attention_params* p, const AttnArgs& a, hipStream_t st) {
   dim3 grid((p->tq + 127) / 128, p->heads, p->images), block(256);
   const int ks = (p->dh + 15) / 16;
+  if constexpr (VVEC == 2) {
+    // 8-wave blocks (256 queries per staged K / V tile) for the big launches
+    const long long blocks8 = (long long)((p->tq + 255) / 256) * p->heads * p->images;
+    int nw8 = blocks8 >= 1024 && ks <= 5;             // measured -5.5 % on [16 | 8 images, 4096 x 4096, 8 x 40]
+    if (const char* e = getenv("MOBI_ATTN_NW")) nw8 = ks <= 5 && e[0] == '8';       // tests / A-B: 8 forces, 4 forbids
+    if (nw8) {
+      dim3 grid8((p->tq + 255) / 256, p->heads, p->images), block8(512);
+#define MOBI_ATTN_CASE8(KS_) hipLaunchKernelGGL((attention_kernel<T, KS_, 2, 2, 8>), grid8, block8, 0, st, a)
+      if (ks <= 1) MOBI_ATTN_CASE8(1);
+      else if (ks == 2) MOBI_ATTN_CASE8(2);
+      else if (ks == 3) MOBI_ATTN_CASE8(3);
+      else if (ks == 4) MOBI_ATTN_CASE8(4);
+      else MOBI_ATTN_CASE8(5);
+#undef MOBI_ATTN_CASE8
+      MOBI_CHECK_LAUNCH();
+      return MOBI_OK;
+    }
+  }
 #define MOBI_ATTN_CASE(KS_, WPS_) hipLaunchKernelGGL((attention_kernel<T, KS_, VVEC, WPS_>), grid, block, 0, st, a)
   if (ks <= 1) MOBI_ATTN_CASE(1, 2);
   else if (ks == 2) MOBI_ATTN_CASE(2, 2);

@@ -199,8 +199,9 @@ ATTN_CASES = [(8, 8, 64, 64), (8, 16, 100, 100), (8, 40, 256, 256), (8, 80, 64, 
 @pytest.mark.parametrize("dtype", DT)
 @pytest.mark.parametrize("v_rows", [True, False], ids=["v_rows", "v_transposed"])
 @pytest.mark.parametrize("heads,dh,tq,tk", ATTN_CASES)
-def test_attention(ops, dtype, heads, dh, tq, tk, v_rows):
-    """both V layouts of the C ABI: row-major V (transposing LDS reads) and pre-transposed V^T."""
+def test_attention(ops, dtype, heads, dh, tq, tk, v_rows, monkeypatch):
+    """both V layouts of the C ABI: row-major V (transposing LDS reads) and pre-transposed V^T; the row-major path also
+    with 8-wave blocks (256 queries per staged K / V tile), which the library otherwise picks for big launches only."""
     n, c = 2, heads * dh
     qf, qd = rnd(f"a.q{dh}.{tq}", (n, tq, c), dtype, 1.5)
     kf, kd = rnd(f"a.k{dh}.{tk}", (n, tk, c), dtype, 1.5)
@@ -211,6 +212,10 @@ def test_attention(ops, dtype, heads, dh, tq, tk, v_rows):
     sim = torch.einsum("bhid,bhjd->bhij", sp(qf), sp(kf)) * dh ** -0.5
     ref = torch.einsum("bhij,bhjd->bhid", sim.softmax(-1), sp(vf)).permute(0, 2, 1, 3).reshape(n, tq, c)
     assert rel(y.float(), ref) < TOL[dtype]
+    if v_rows and dh <= 80:
+        monkeypatch.setenv("MOBI_ATTN_NW", "8")
+        y8 = ops.attention(qd, kd, vt, heads, dh ** -0.5, v_rows=v_rows)
+        assert rel(y8.float(), ref) < TOL[dtype]
 
 
 @pytest.mark.parametrize("dtype", DT)
@@ -235,6 +240,13 @@ def test_attention_strided_partner_and_spike(ops, dtype):
     kvd = torch.cat([xd[:, :, c:], vd], dim=2)
     y2 = ops.attention(xd[::2, :, :c], kvd[1::2, :, :c], kvd[1::2, :, c:], heads, dh ** -0.5, v_rows=True)
     assert rel(y2.float(), ref) < TOL[dtype]
+    import os
+    os.environ["MOBI_ATTN_NW"] = "8"                         # the same through 8-wave blocks
+    try:
+        y3 = ops.attention(xd[::2, :, :c], kvd[1::2, :, :c], kvd[1::2, :, c:], heads, dh ** -0.5, v_rows=True)
+    finally:
+        del os.environ["MOBI_ATTN_NW"]
+    assert rel(y3.float(), ref) < TOL[dtype]
 
 
 @pytest.mark.parametrize("dtype", DT)
