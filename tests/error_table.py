@@ -3,7 +3,7 @@
 per storage type, for the quantities BASELINE.json's north star names: one UNet forward, VAE encode / decode and
 whole DDIM trajectories (10 and 50 steps, with and without classifier-free guidance).
 
-    python tools/error_table.py [--out profiles/r01_error_table.txt]      (GPU box; about two minutes)
+    python tests/error_table.py [--out profiles/r01_error_table.txt]      (GPU box; about two minutes)
 """
 import argparse
 import os
@@ -12,7 +12,7 @@ import time
 
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))       # (lives under tests/: it imports the oracle)
 sys.path.insert(0, ROOT)
 
 

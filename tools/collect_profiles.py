@@ -68,7 +68,7 @@ def main():
               "  vmcnt wait (late / early half)",
               f"* `{tag}_pp_ablation.txt` the k loop with parts removed (tools/diag_ingest.sh on the lockstep kernel, tools/diag_halo.sh and",
               "  tools/ab_flags.sh on the ping-pong / halo kernels): no activation DMA / no weight DMA / no DMA / no MFMA",
-              f"* `{tag}_error_table.txt` measured rel-L2 vs the fp32 oracle per storage type (tools/error_table.py)",
+              f"* `{tag}_error_table.txt` measured rel-L2 vs the fp32 oracle per storage type (tests/error_table.py)",
               f"* `{tag}_igemm_phase_stamps.txt`, `{tag}_splitk_sweep.txt` earlier sessions' stamps of the lockstep kernel and the split-K plan sweep"]
     with open(os.path.join(dst, f"{tag}_README.md"), "w") as f:
         f.write("\n".join(lines) + "\n")
