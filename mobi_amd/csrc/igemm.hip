@@ -1198,6 +1198,7 @@ __global__ __launch_bounds__(512, 2) void igemm_pp_kernel(const IgemmArgs a) {
   const bool late = wave_s >= 4;                             // the half that runs one phase behind
   const int group = blockIdx.z;
   const int nblk = a.tiles_m * a.tiles_n;
+  MOBI_STAMP_AT(0);
   // split-K: blockIdx.y owns k-tiles [kt_begin, kt_begin + nk) and leaves fp32 partial sums for the reduce launch
   const int kt_begin = SLAB ? blockIdx.y * a.nk_per : 0;
   const int nk = SLAB ? min(a.nk, kt_begin + a.nk_per) - kt_begin : a.nk;
@@ -1391,6 +1392,7 @@ __global__ __launch_bounds__(512, 2) void igemm_pp_kernel(const IgemmArgs a) {
     const int mk_first = vm_issued;
     if (f_bid < nblk) { issue_next(); ++ahead; mk1 = vm_issued; }
     wait_vmcnt_le(vm_issued - mk_first);                     // this wave's pieces of the first k-tile (and, older,
+    MOBI_STAMP_AT(1);
     start_sums(bv);                                          // the vector) have landed
     vm_issued += request_tile(nw0, mw0);
   }
@@ -1569,8 +1571,18 @@ __global__ __launch_bounds__(512, 2) void igemm_pp_kernel(const IgemmArgs a) {
     p_nw0 = nw0; p_mw0 = mw0;
   }
   if (!late) MOBI_PP_BARRIER();                              // every wave has passed the same number of barriers
+  MOBI_STAMP_AT(2);
   wait_vmcnt_le(vm_issued - mk_req);
   finish_tile(p_nw0, p_mw0);
+#if MOBI_STAMP
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // the stamp then covers this wave's stores too
+  MOBI_STAMP_AT(3);
+  if (g_stamps && threadIdx.x == 0) {
+    unsigned long long* d = g_stamps + (size_t)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) * 8;
+    d[5] = (unsigned long long)nk;
+    d[6] = (unsigned long long)((nblk - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x);
+  }
+#endif
 #if MOBI_STAMP == 3
   if (g_phase && lane == 0) {
     unsigned long long* d = g_phase + ((size_t)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) * 8 + wave) * 16;
