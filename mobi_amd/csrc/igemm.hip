@@ -371,6 +371,21 @@ __device__ __forceinline__ void wait_vmcnt_le(int n) {
 #undef MOBI_VMW
 }
 
+// the same with the steady-state count of a k loop tried first (the cascade above is ~11 scalar compare / branch pairs
+// before it reaches a small count; the ping-pong kernel waits twice per k-tile with n = the requests of one k-tile)
+#ifndef MOBI_PP_WDUP
+#define MOBI_PP_WDUP 0
+#endif
+#ifndef MOBI_PP_FASTWAIT
+#define MOBI_PP_FASTWAIT 1
+#endif
+__device__ __forceinline__ void wait_vmcnt_le_fast(int n) {
+  if (!MOBI_PP_FASTWAIT) { wait_vmcnt_le(n); return; }
+  if (n == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+  else if (n == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  else wait_vmcnt_le(n);
+}
+
 template <int NT>
 struct DirectEpiRegs {
   u32x4 bias[NT];          // f32 x 4: channels 16 ni + 4 g4 + (0..3) of the wave's columns (bias OR per-image vector)
@@ -1304,14 +1319,16 @@ __global__ __launch_bounds__(512, 2) void igemm_pp_kernel(const IgemmArgs a) {
     const int kb = f_kt * 128;
 #pragma unroll
     for (int j = 0; j < WJ; ++j) {
-      // rows 8 * wave + rloc + 64 j; the last partial group of 32 rows is fetched by waves 0-3 and (identically,
-      // benign duplicate) by waves 4-7 so that every wave issues PIECES requests
+      // rows 8 * wave + rloc + 64 j; the last partial group of 32 rows is fetched by waves 0-3 on even k-tiles and by
+      // waves 4-7 on odd ones (MOBI_PP_WDUP = 1: by both, a benign duplicate, so that every wave issues PIECES requests)
       const bool partial = (BN % 64 != 0) && (j == WJ - 1);
       const int wl = (partial ? 64 * j + 8 * (wave_s & 3) : 64 * j + 8 * wave_s) * 128;
       const int so = kb + j * w_rowstep - (partial ? w_half : 0);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr_t)(st + X_TILE + wl), 16, w_off, so, 0, 0);
+      if (MOBI_PP_WDUP || !partial || (((f_kt ^ (wave_s >> 2)) & 1) == 0)) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr_t)(st + X_TILE + wl), 16, w_off, so, 0, 0);
+        ++vm_issued;
+      }
     }
-    vm_issued += WJ;
 #endif
     if (++f_kt == kt_begin + nk) {                           // the sequence moves on to this block's next output tile
       f_kt = kt_begin;
@@ -1456,7 +1473,7 @@ __global__ __launch_bounds__(512, 2) void igemm_pp_kernel(const IgemmArgs a) {
 #if MOBI_STAMP == 3
         pp_t[5] = __builtin_amdgcn_s_memtime();
 #endif
-        if (late && ahead >= 2) wait_vmcnt_le(vm_issued - mk1);
+        if (late && ahead >= 2) wait_vmcnt_le_fast(vm_issued - mk1);
         MOBI_PP_T(2);
         MOBI_PP_BARRIER();
         MOBI_PP_T(3);
@@ -1493,7 +1510,7 @@ __global__ __launch_bounds__(512, 2) void igemm_pp_kernel(const IgemmArgs a) {
         }
         pp_t[5] = __builtin_amdgcn_s_memtime();
 #endif
-        if (!late && ahead >= 2) wait_vmcnt_le(vm_issued - mk1);
+        if (!late && ahead >= 2) wait_vmcnt_le_fast(vm_issued - mk1);
 #if MOBI_STAMP == 3
         if (kt != 0) pp_acc[1][1] += (unsigned)(__builtin_amdgcn_s_memtime() - pp_t[5]);   // the same wait, early waves
 #endif
@@ -1536,7 +1553,7 @@ __global__ __launch_bounds__(512, 2) void igemm_pp_kernel(const IgemmArgs a) {
         }
 #endif
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the stage may be overwritten after two more barriers
-        if (ks == 1 && late && ahead >= 2) wait_vmcnt_le(vm_issued - mk1);      // RAW rule above, late waves
+        if (ks == 1 && late && ahead >= 2) wait_vmcnt_le_fast(vm_issued - mk1);      // RAW rule above, late waves
         // ---- MATRIX phase --------------------------------------------------------------------------------------
         MOBI_PP_T(2);
         MOBI_PP_BARRIER();
@@ -1562,7 +1579,7 @@ __global__ __launch_bounds__(512, 2) void igemm_pp_kernel(const IgemmArgs a) {
           if (ks) ++pp_n;
         }
 #endif
-        if (ks == 1 && !late && ahead >= 2) wait_vmcnt_le(vm_issued - mk1);     // RAW rule above, early waves
+        if (ks == 1 && !late && ahead >= 2) wait_vmcnt_le_fast(vm_issued - mk1);     // RAW rule above, early waves
       }
 #endif
       --ahead; mk1 = mk2;
