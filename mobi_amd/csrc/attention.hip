@@ -20,6 +20,8 @@
 // LDS row strides are odd multiples of the access width (bank-conflict free reads).
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "common.h"
 
 #ifndef MOBI_ATTN_DBG
@@ -423,6 +425,300 @@ __global__ __launch_bounds__(64 * NW, (WPS * 4) / NW) void attention_kernel(cons
   }
 }
 
+// =========================================================================================================
+// SOFTWARE-PIPELINED variant of the 8-wave kernel (V row-major, one 16-byte K and V piece per thread and key tile,
+// odd KS so that the padded head-dim row carries the softmax denominator: dh 33..48 with KS = 3).
+// An A/B ALTERNATIVE (MOBI_ATTN_SP=1), measured slower than the kernel above -- kept because the next step for this
+// kernel starts from it (profiles/r01_attention_ablation.txt):
+//
+// In the kernel above a wave runs  S(t) MFMAs -> softmax(t) -> P.V(t) MFMAs  one after the other, and SQ counters on
+// [16, 4096 x 4096, 8 x 40] show the matrix pipe busy 41 % and the vector pipe 62 % of the time with 18 % in both: the
+// kernel time is the SUM of the two (tools/pmc_attn.sh).  A ping-pong split (one wave of a SIMD in an MFMA-only phase,
+// its partner in the softmax phase, barrier-separated) was worse still (744-789 us): the partner's MFMAs stretched the
+// softmax phase from ~750 to ~1250 cycles.  tools/probes/mfma_valu_overlap.hip says why: v_exp_f32 hides behind a
+// wave's own MFMAs (14 MFMA + 42 v_exp: 480 cycles vs 468 for the MFMAs alone), plain vector instructions mostly do
+// not (14 MFMA + 84 v_fma: 648 vs 468 + 284).
+//
+// Here the three parts of DIFFERENT key tiles share one instruction stream: step t of a wave issues
+//     O^T += V^T(t-1) . P^T(t-1)    (8 MFMAs)      S^T(t+1) = K(t+1) . Q^T    (6 MFMAs)      softmax(t) -> P^T(t)
+// with the softmax's vector instructions dealt into the MFMA gaps by hand, all operand reads of the step requested
+// up front, ONE barrier per key tile.  The rescale of O by the moving maximum is applied one step late, before the
+// P.V of the tile it belongs to (a wave-uniform, rare branch outside the interleaved region).
+// LDS: four images (K tile + V tile), tile t in image t % 4: K(t) is read in step t-1, V(t) in step t+1, tile t+2 is
+// written in step t into the image of tile t-2 (last read in step t-1).
+// =========================================================================================================
+template <typename T, int KS>
+__global__ __launch_bounds__(512, 2) void attention_sp_kernel(const AttnArgs a) {
+  static_assert(KS & 1, "odd KS: a padded head-dim row exists and carries the denominator");
+  constexpr int NTHR = 512;
+  typedef typename Vec8<T>::type frag_t;
+  constexpr int DT = (KS + 1) / 2;
+  constexpr int KSTR = KS * 32 + 16;
+  constexpr int VSTR = (DT & 1) ? DT * 64 : DT * 64 + 64;
+  constexpr int K_BYTES = 64 * KSTR, V_BYTES = 64 * VSTR, IMG_BYTES = K_BYTES + V_BYTES;
+  constexpr int NSLOT = 4;
+  static_assert(64 * KS * 2 <= NTHR, "one 16-byte piece per thread and key tile");
+  __shared__ __attribute__((aligned(16))) unsigned char lds[NSLOT * IMG_BYTES];
+  unsigned char* ldsK = lds;
+  unsigned char* ldsV = lds + K_BYTES;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int ql = lane & 31, half = lane >> 5;
+  const int head = blockIdx.y, img = blockIdx.z;
+  const int q0 = blockIdx.x * 256 + wave * 32;
+  const int dh = a.dh;
+
+  const T* __restrict__ qp = reinterpret_cast<const T*>(a.q) + img * a.q_img + head * dh;
+  const T* __restrict__ kp = reinterpret_cast<const T*>(a.k) + img * a.k_img + head * dh;
+  const T* __restrict__ vp = reinterpret_cast<const T*>(a.vt) + img * a.vt_img + (long long)head * dh;
+  T* __restrict__ op = reinterpret_cast<T*>(a.out) + img * a.out_img + head * dh;
+
+  frag_t qf[KS];
+  {
+    const int qrow = q0 + ql;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const int c = ks * 16 + half * 8;
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (qrow < a.tq && c < dh) v = ld16(qp + (long long)qrow * a.q_row + c);
+      qf[ks] = __builtin_bit_cast(frag_t, v);
+    }
+  }
+
+  // staging: thread -> (key row, 8 channels), the same piece of the K tile and of the V tile
+  constexpr unsigned OOB = 0x80000000u;
+  const int s_row = tid / (KS * 2), s_pc = tid - s_row * (KS * 2);
+  const bool s_on = s_row < 64, s_von = s_on && s_pc * 8 < dh;
+  const unsigned koff = s_von ? (unsigned)(s_row * a.k_row + s_pc * 8) * 2u : OOB;
+  const unsigned voff = s_von ? (unsigned)(s_row * a.vt_row + s_pc * 8) * 2u : OOB;
+  const int k_bytes = ((a.tk - 1) * a.k_row + dh) * 2;
+  const int v_bytes = ((a.tk - 1) * a.vt_row + dh) * 2;
+  const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(kp), 0, k_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(vp), 0, v_bytes, 0x00020000);
+  u32x4 kr, vr;
+  auto load_tile = [&](int key0) {
+    kr = __builtin_amdgcn_raw_buffer_load_b128(rk, koff + (unsigned)key0 * (unsigned)a.k_row * 2u, 0, 0);
+    vr = __builtin_amdgcn_raw_buffer_load_b128(rv, voff + (unsigned)key0 * (unsigned)a.vt_row * 2u, 0, 0);
+  };
+  auto store_tile = [&](int slot) {
+    if (s_on) st16(ldsK + slot * IMG_BYTES + s_row * KSTR + s_pc * 16, kr);
+    if (s_von) st16(ldsV + slot * IMG_BYTES + s_row * VSTR + s_pc * 16, vr);
+  };
+  // channels [dh, DT*32) of every V row are written ONCE: zero, except channel dh = 1.0 (the denominator column)
+  for (int p = tid; p < 64 * DT * 4; p += NTHR) {
+    const int row = p / (DT * 4), pc = p - row * (DT * 4);
+    if (pc * 8 >= dh) {
+      typename Vec8<T>::type e;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) e[j] = (T)0.0f;
+      if (pc * 8 == dh) e[0] = (T)1.0f;
+#pragma unroll
+      for (int b = 0; b < NSLOT; ++b) st16(ldsV + b * IMG_BYTES + row * VSTR + pc * 16, __builtin_bit_cast(u32x4, e));
+    }
+  }
+
+#define MOBI_ASP_BARRIER()                               \
+  do {                                                   \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   \
+    __builtin_amdgcn_sched_barrier(0);                   \
+    __builtin_amdgcn_s_barrier();                        \
+    __builtin_amdgcn_sched_barrier(0);                   \
+  } while (0)
+
+  f32x16 o[DT];
+#pragma unroll
+  for (int d = 0; d < DT; ++d)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
+  f32x16 sa[2], sb[2];
+  frag_t pa[2][2], pb[2][2];
+  float m_run = -INFINITY, alpha = 1.f;
+  const float cexp = a.scale * 1.4426950408889634f;
+  const int ntiles = (a.tk + 63) / 64;
+
+  load_tile(0);
+  store_tile(0);
+  if (ntiles > 1) { load_tile(64); store_tile(1); }
+  if (ntiles > 2) load_tile(128);                      // stays in registers until step 0
+  __syncthreads();
+
+  typedef __attribute__((address_space(3))) s16x4* lds4_t;
+  const int l16 = lane & 15, grp = lane >> 4;
+  frag_t kfr[2][KS];
+  s16x8 vfr[2][2][DT];
+  auto read_k = [&](int t) {
+    const int boff = (t & 3) * IMG_BYTES;
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+      const unsigned char* kb = ldsK + boff + (kt * 32 + ql) * KSTR + half * 16;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) kfr[kt][ks] = __builtin_bit_cast(frag_t, ld16(kb + ks * 32));
+    }
+  };
+  auto read_v = [&](int t) {
+    const int boff = (t & 3) * IMG_BYTES;
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int st = 0; st < 2; ++st) {
+        const unsigned char* vb = ldsV + boff + (kt * 32 + st * 16 + 4 * half + (l16 >> 2)) * VSTR +
+                                  (16 * (grp & 1) + 4 * (l16 & 3)) * 2;
+#pragma unroll
+        for (int d = 0; d < DT; ++d) {
+          const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4_t)(vb + d * 64));
+          const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4_t)(vb + d * 64 + 8 * VSTR));
+          vfr[kt][st][d] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        }
+      }
+  };
+  auto do_pv = [&](frag_t (&pp)[2][2]) {                 // O^T += V^T . P^T of the previous tile
+#pragma unroll
+    for (int d = 0; d < DT; ++d)
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int st = 0; st < 2; ++st)
+          o[d] = mfma32(__builtin_bit_cast(frag_t, vfr[kt][st][d]), pp[kt][st], o[d]);
+  };
+  auto do_s = [&](f32x16 (&sn)[2]) {                     // S^T of the next tile = K . Q^T
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sn[kt][r] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) sn[kt] = mfma32(kfr[kt][ks], qf[ks], sn[kt]);
+    }
+  };
+  auto rescale = [&]() {                                 // O (and the denominator row in it) follows the moving maximum
+    if (!__all(alpha == 1.f)) {
+#pragma unroll
+      for (int d = 0; d < DT; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
+    }
+  };
+  // one step: sc = S(t) (in), sn = S(t+1) (out), pp = P(t-1) (in), pn = P(t) (out)
+  auto step = [&](auto first_tag, int t, f32x16 (&sc)[2], f32x16 (&sn)[2], frag_t (&pp)[2][2], frag_t (&pn)[2][2]) {
+    constexpr bool FIRST = decltype(first_tag)::value;
+    const int key0 = t * 64;
+    if (!FIRST) rescale();                               // by the factor softmax(t-1) found, before P.V(t-1)
+    if (key0 + 64 > a.tk) {                              // ragged last tile
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = key0 + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+          if (key >= a.tk) sc[kt][r] = -INFINITY;
+        }
+    }
+    if (t + 2 < ntiles) store_tile((t + 2) & 3);         // requested one step ago (or in the prologue)
+    if (t + 3 < ntiles) load_tile((t + 3) * 64);
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- interleaved region: 14 MFMA gaps, the vector work of softmax(t) dealt into them by hand (the gaps are
+    // pinned with sched_barrier: left to the scheduler, sched_group_barrier or not, most gaps stayed empty and the
+    // exponentials came in two bursts) ------------------------------------------------------------------------------
+    if (!FIRST) read_v(t - 1);
+    read_k(t + 1);                                       // (past the last tile: a stale image, the result is not used)
+    __builtin_amdgcn_sched_barrier(0);
+    auto mf_pv = [&](int i) {                            // MFMA i of O^T += V^T . P^T: one accumulator's four in a row
+      if (FIRST) return;
+      const int d = i >> 2, kt = (i >> 1) & 1, st = i & 1;
+      o[d] = mfma32(__builtin_bit_cast(frag_t, vfr[kt][st][d]), pp[kt][st], o[d]);
+    };
+    auto mf_s = [&](int i) {                             // MFMA i of S^T(t+1)
+      const int kt = i / KS, ks = i - kt * KS;
+      if (ks == 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sn[kt][r] = 0.f;
+      }
+      sn[kt] = mfma32(kfr[kt][ks], qf[ks], sn[kt]);
+    };
+    float mx = -INFINITY;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {                        // gaps 0-3: the maximum of 8 scores each
+      mf_pv(g);
+#pragma unroll
+      for (int r = 0; r < 8; ++r) mx = fmaxf(mx, sc[g >> 1][(g & 1) * 8 + r]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    mf_pv(4);                                            // gap 4: the column's maximum, the rescale factor
+    {
+      // both halves of a query column by gfx950's lane-row swap (no LDS crossbar trip): v_permlane32_swap exchanges the
+      // upper half of its first operand with the lower half of its second, so max(first, second) afterwards is the
+      // column's maximum in both halves.  Inline asm: with the builtin hipcc folds max(result[0], result[1]) of two
+      // equal inputs into result[0].
+      float lo = mx, hi = mx;
+      asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(lo), "+v"(hi));
+      mx = fmaxf(lo, hi);
+    }
+    const float m_new = fmaxf(m_run, mx);
+    alpha = __builtin_amdgcn_exp2f((m_run - m_new) * cexp);                       // first tile: exp2(-inf) = 0, O = 0
+    m_run = m_new;
+    const float mc = m_new * cexp;
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int g = 0; g < 8; ++g) {                        // gaps 5-12: four exponentials each
+      if (g < 3) mf_pv(5 + g); else mf_s(g - 3);
+      const int kt = g >> 2, st = (g >> 1) & 1, j0 = (g & 1) * 4;
+#pragma unroll
+      for (int j = j0; j < j0 + 4; ++j)
+        pn[kt][st][j] = (T)__builtin_amdgcn_exp2f(__builtin_fmaf(sc[kt][st * 8 + j], cexp, -mc));
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    mf_s(5);
+    // (the step's results are pinned here: without it the compiler sinks the exponentials of this step past the
+    //  barrier, next to their use in the next step's P.V)
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int st = 0; st < 2; ++st) asm volatile("" : "+v"(pn[kt][st]));
+    MOBI_ASP_BARRIER();
+  };
+
+  // S(0)
+  read_k(0);
+  do_s(sa);
+  step(std::true_type{}, 0, sa, sb, pb, pa);
+  int t = 1;
+  for (; t + 1 < ntiles; t += 2) {
+    step(std::false_type{}, t, sb, sa, pa, pb);
+    step(std::false_type{}, t + 1, sa, sb, pb, pa);
+  }
+  const bool odd_left = t < ntiles;                      // one more step, on the (sb, pa) -> pb roles
+  if (odd_left) step(std::false_type{}, t, sb, sa, pa, pb);
+  // the last tile's P.V
+  rescale();
+  read_v(ntiles - 1);
+  if (odd_left) do_pv(pb); else do_pv(pa);
+#undef MOBI_ASP_BARRIER
+
+  float lsum = 0.f;                // row dh of O^T sits in lane-half 0, register (dh % 32) / 2 of tile dh / 32
+#pragma unroll
+  for (int d = 0; d < DT; ++d)
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+      if (d * 32 + g * 8 == dh) lsum = o[d][g * 4];
+  const float l_run = half == 0 ? lsum : 0.f;
+  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  const float inv = 1.0f / l_tot;
+  const int qrow = q0 + ql;
+  if (qrow < a.tq) {
+    T* orow = op + (long long)qrow * a.out_row;
+#pragma unroll
+    for (int d = 0; d < DT; ++d)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int d0 = d * 32 + g * 8 + half * 4;
+        if (d0 < dh) {
+          float f[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) f[j] = o[d][g * 4 + j] * inv;
+          *reinterpret_cast<u32x2*>(orow + d0) = pack4<T>(f);
+        }
+      }
+  }
+}
+
 template <typename T, int VVEC>
 static int launch_attention_v(const mobi_attention_params* p, const AttnArgs& a, hipStream_t st) {
   dim3 grid((p->tq + 127) / 128, p->heads, p->images), block(256);
@@ -434,6 +730,15 @@ static int launch_attention_v(const mobi_attention_params* p, const AttnArgs& a,
     if (const char* e = getenv("MOBI_ATTN_NW")) nw8 = ks <= 5 && e[0] == '8';       // tests / A-B: 8 forces, 4 forbids
     if (nw8) {
       dim3 grid8((p->tq + 255) / 256, p->heads, p->images), block8(512);
+      // software-pipelined kernel (head dims 33..48): measured SLOWER than the kernel above (693 vs 620 us on
+      // [16, 4096 x 4096, 8 x 40], tools/ab_attn.sh), kept selectable for A/B runs and covered by the parity tests
+      int sp = 0;
+      if (const char* e = getenv("MOBI_ATTN_SP")) sp = ks == 3 && e[0] == '1';
+      if (sp) {
+        hipLaunchKernelGGL((attention_sp_kernel<T, 3>), grid8, block8, 0, st, a);
+        MOBI_CHECK_LAUNCH();
+        return MOBI_OK;
+      }
 #define MOBI_ATTN_CASE8(KS_) hipLaunchKernelGGL((attention_kernel<T, KS_, 2, 2, 8>), grid8, block8, 0, st, a)
       if (ks <= 1) MOBI_ATTN_CASE8(1);
       else if (ks == 2) MOBI_ATTN_CASE8(2);

@@ -219,6 +219,30 @@ def test_attention(ops, dtype, heads, dh, tq, tk, v_rows, monkeypatch):
 
 
 @pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("dh,tq,tk", [(40, 300, 40), (40, 1, 64), (48, 257, 100), (40, 256, 128), (40, 70, 190),
+                                      (40, 512, 300), (40, 33, 1)])
+def test_attention_software_pipelined(ops, dtype, dh, tq, tk, monkeypatch):
+    """the software-pipelined 8-wave kernel (head dims 33..48) on 1..5 key tiles, ragged last tiles and ragged query blocks;
+    it is an A/B alternative (MOBI_ATTN_SP=1, slower than the default kernel) and must agree with the default kernel."""
+    n, heads = 2, 4
+    c = heads * dh
+    qf, qd = rnd(f"ap.q{dh}.{tq}", (n, tq, c), dtype, 1.5)
+    kf, kd = rnd(f"ap.k{dh}.{tk}", (n, tk, c), dtype, 1.5)
+    vf, vd = rnd(f"ap.v{dh}.{tk}", (n, tk, c), dtype)
+    sp = lambda t: t.reshape(n, -1, heads, dh).permute(0, 2, 1, 3)
+    sim = torch.einsum("bhid,bhjd->bhij", sp(qf), sp(kf)) * dh ** -0.5
+    ref = torch.einsum("bhij,bhjd->bhid", sim.softmax(-1), sp(vf)).permute(0, 2, 1, 3).reshape(n, tq, c)
+    monkeypatch.setenv("MOBI_ATTN_NW", "8")
+    monkeypatch.setenv("MOBI_ATTN_SP", "1")
+    y = ops.attention(qd, kd, vd, heads, dh ** -0.5, v_rows=True)
+    assert torch.isfinite(y.float()).all()
+    assert rel(y.float(), ref) < TOL[dtype]
+    monkeypatch.setenv("MOBI_ATTN_SP", "0")
+    y0 = ops.attention(qd, kd, vd, heads, dh ** -0.5, v_rows=True)
+    assert rel(y.float(), y0.float()) < 1e-6 + (0 if dtype == torch.float32 else 4e-3)
+
+
+@pytest.mark.parametrize("dtype", DT)
 def test_attention_strided_partner_and_spike(ops, dtype):
     """q from the camera half, k/v from the lidar half of an interleaved batch (image strides), with
     q/k packed in one [.., 2C] tensor (row stride > C) and one huge score (online-softmax rescale)."""
@@ -241,12 +265,16 @@ def test_attention_strided_partner_and_spike(ops, dtype):
     y2 = ops.attention(xd[::2, :, :c], kvd[1::2, :, :c], kvd[1::2, :, c:], heads, dh ** -0.5, v_rows=True)
     assert rel(y2.float(), ref) < TOL[dtype]
     import os
-    os.environ["MOBI_ATTN_NW"] = "8"                         # the same through 8-wave blocks
+    os.environ["MOBI_ATTN_NW"] = "8"                         # the same through 8-wave blocks, both schedules
     try:
         y3 = ops.attention(xd[::2, :, :c], kvd[1::2, :, :c], kvd[1::2, :, c:], heads, dh ** -0.5, v_rows=True)
+        os.environ["MOBI_ATTN_SP"] = "1"
+        y4 = ops.attention(xd[::2, :, :c], kvd[1::2, :, :c], kvd[1::2, :, c:], heads, dh ** -0.5, v_rows=True)
     finally:
         del os.environ["MOBI_ATTN_NW"]
+        os.environ.pop("MOBI_ATTN_SP", None)
     assert rel(y3.float(), ref) < TOL[dtype]
+    assert rel(y4.float(), ref) < TOL[dtype]
 
 
 @pytest.mark.parametrize("dtype", DT)
