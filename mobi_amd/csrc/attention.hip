@@ -617,7 +617,9 @@ __global__ __launch_bounds__(512, 2) void attention_sp_kernel(const AttnArgs a) 
     // ---- interleaved region: 14 MFMA gaps, the vector work of softmax(t) dealt into them by hand (the gaps are
     // pinned with sched_barrier: left to the scheduler, sched_group_barrier or not, most gaps stayed empty and the
     // exponentials came in two bursts) ------------------------------------------------------------------------------
-    if (!FIRST) read_v(t - 1);
+    // K(t+1) fragments now (first used in gap 8); the V(t) fragments of the NEXT step's P.V are requested behind this
+    // step's last P.V MFMA into the registers it frees, so no MFMA waits at the head of a step for the read burst of
+    // all eight waves
     read_k(t + 1);                                       // (past the last tile: a stale image, the result is not used)
     __builtin_amdgcn_sched_barrier(0);
     auto mf_pv = [&](int i) {                            // MFMA i of O^T += V^T . P^T: one accumulator's four in a row
@@ -659,6 +661,7 @@ __global__ __launch_bounds__(512, 2) void attention_sp_kernel(const AttnArgs a) 
 #pragma unroll
     for (int g = 0; g < 8; ++g) {                        // gaps 5-12: four exponentials each
       if (g < 3) mf_pv(5 + g); else mf_s(g - 3);
+      if (g == 3) read_v(t);
       const int kt = g >> 2, st = (g >> 1) & 1, j0 = (g & 1) * 4;
 #pragma unroll
       for (int j = j0; j < j0 + 4; ++j)
@@ -688,7 +691,6 @@ __global__ __launch_bounds__(512, 2) void attention_sp_kernel(const AttnArgs a) 
   if (odd_left) step(std::false_type{}, t, sb, sa, pa, pb);
   // the last tile's P.V
   rescale();
-  read_v(ntiles - 1);
   if (odd_left) do_pv(pb); else do_pv(pa);
 #undef MOBI_ASP_BARRIER
 
