@@ -66,7 +66,7 @@ def main():
               f"* `{tag}_pp_phase_stamps.txt` per-phase `s_memtime` stamps of the ping-pong kernel (tools/stamp_pp.py, -DMOBI_STAMP=3):",
               "  cycles per k-tile at the LOAD barrier, in the LOAD phase, at the MATRIX barrier, in the MATRIX phase, in the counted",
               "  vmcnt wait (late / early half)",
-              f"* `{tag}_pp_ablation.txt` the k loop with parts removed (tools/diag_ingest.sh on the lockstep kernel, tools/diag_halo.sh and",
+              f"* `{tag}_pp_ablation.txt` the k loop with parts removed (tools/diag_ingest.sh on the lockstep kernel, the same ablations of the ping-pong / halo kernels (the halo kernel and its script were removed later) and",
               "  tools/ab_flags.sh on the ping-pong / halo kernels): no activation DMA / no weight DMA / no DMA / no MFMA",
               f"* `{tag}_error_table.txt` measured rel-L2 vs the fp32 oracle per storage type (tests/error_table.py)",
               f"* `{tag}_igemm_phase_stamps.txt`, `{tag}_splitk_sweep.txt` earlier sessions' stamps of the lockstep kernel and the split-K plan sweep"]
