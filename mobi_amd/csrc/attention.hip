@@ -36,6 +36,10 @@
 #ifndef MOBI_ATTN_STORE_LATE
 #define MOBI_ATTN_STORE_LATE 0
 #endif
+#ifndef MOBI_ATTN_FUSE_EXP
+#define MOBI_ATTN_FUSE_EXP 0  // 1: exponentials of a 16-key group issued right before the P.V MFMAs that consume them
+                              // (measured SLOWER at 4 waves per SIMD: 676-681 vs 632-639 us on [16, 4096 x 4096, 8 x 40])
+#endif
 #ifndef MOBI_ATTN_DBUF
 #define MOBI_ATTN_DBUF 1   // two LDS images of the K / V tile: one barrier per key tile, the next tile is written while
 #endif                     // this one is still being multiplied (A/B: -DMOBI_ATTN_DBUF=0)
@@ -319,6 +323,7 @@ __global__ __launch_bounds__(64 * NW, (WPS * 4) / NW) void attention_kernel(cons
       m_run = m_new;
     }
     const float mc = m_run * cexp;
+#if !MOBI_ATTN_FUSE_EXP
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
@@ -335,6 +340,7 @@ __global__ __launch_bounds__(64 * NW, (WPS * 4) / NW) void attention_kernel(cons
         for (int r = 0; r < 16; ++r) psum += s[kt][r];
       l_run += psum;
     }
+#endif
 
 #if MOBI_ATTN_DBUF && !MOBI_ATTN_STORE_LATE
     // the next tile goes into the OTHER image: every wave left it at the barrier that ended the previous step, and
@@ -350,8 +356,23 @@ __global__ __launch_bounds__(64 * NW, (WPS * 4) / NW) void attention_kernel(cons
 #pragma unroll
       for (int st = 0; st < 2; ++st) {
         frag_t pf;
+#if MOBI_ATTN_FUSE_EXP
+        // A/B: the exponentials of a 16-key group right before the MFMAs that consume them, so that groups 1..3 issue
+        // behind the P.V MFMAs of the group before (tools/probes/mfma_valu_overlap.hip); slower in this kernel
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+#if MOBI_ATTN_DBG & 1
+          const float pv = __builtin_fmaf(s[kt][st * 8 + j], cexp, -mc);
+#else
+          const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kt][st * 8 + j], cexp, -mc));
+#endif
+          if (!ONES) l_run += pv;
+          pf[j] = (T)pv;
+        }
+#else
 #pragma unroll
         for (int j = 0; j < 8; ++j) pf[j] = (T)s[kt][st * 8 + j];
+#endif
         if constexpr (VROWS) {
           // lane 4q+p of each 16-lane group addresses key row q, channels 4p..4p+3 of the group's 16-channel block
           // (block = channels 32 d + 16 (group & 1)); it receives channel (lane & 15) of the 4 keys.  Two reads:
