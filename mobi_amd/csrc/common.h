@@ -73,7 +73,11 @@ __device__ __forceinline__ float erf_as_f(float x) {
   const float r = 1.0f - p * t * e;
   return x < 0.f ? -r : r;
 }
+#ifdef MOBI_DBG_NOGELU   // timing only (wrong results): what the GELU arithmetic of a GEGLU epilogue costs
+__device__ __forceinline__ float gelu_erf_f(float x) { return x; }
+#else
 __device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erf_as_f(x * 0.70710678118654752440f)); }
+#endif
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

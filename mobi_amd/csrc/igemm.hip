@@ -373,6 +373,9 @@ __device__ __forceinline__ void wait_vmcnt_le(int n) {
 
 // the same with the steady-state count of a k loop tried first (the cascade above is ~11 scalar compare / branch pairs
 // before it reaches a small count; the ping-pong kernel waits twice per k-tile with n = the requests of one k-tile)
+#ifndef MOBI_PP_GEGLU_STORE16
+#define MOBI_PP_GEGLU_STORE16 1   // GEGLU register epilogue: pairs of 16-channel tiles stored as 16 bytes per lane
+#endif
 #ifndef MOBI_PP_WDUP
 #define MOBI_PP_WDUP 0
 #endif
@@ -385,6 +388,12 @@ __device__ __forceinline__ void wait_vmcnt_le_fast(int n) {
   else if (n == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
   else wait_vmcnt_le(n);
 }
+
+// the four lane-row swaps of one accumulator tile pair as ONE statement: the hazard slots (VALU write -> swap read before,
+// swap write -> VALU read after) are paid once per four independent swaps instead of once per swap
+#define MOBI_SWAP4(INSN, X, Y)                                                                                       \
+  asm volatile("s_nop 1\n\t" INSN " %0, %4\n\t" INSN " %1, %5\n\t" INSN " %2, %6\n\t" INSN " %3, %7\n\ts_nop 1" \
+               : "+v"(X[0]), "+v"(X[1]), "+v"(X[2]), "+v"(X[3]), "+v"(Y[0]), "+v"(Y[1]), "+v"(Y[2]), "+v"(Y[3]))
 
 template <int NT>
 struct DirectEpiRegs {
@@ -461,14 +470,9 @@ __device__ __forceinline__ int direct_epilogue(const IgemmArgs& a, f32x4 (&acc)[
       // (inline asm: hipcc 7.2 merges the four __builtin_amdgcn_permlane*_swap calls of a tile into one and
       //  broadcasts its result; the s_nops cover the VALU-write -> permlane-swap -> VALU-read hazard slots the
       //  compiler would otherwise insert itself)
-      float xs[4], ys[4];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        float xv = x[r], yv = y[r];
-        if constexpr (geglu) asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(xv), "+v"(yv));
-        else asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(xv), "+v"(yv));
-        xs[r] = xv; ys[r] = yv;
-      }
+      float xs[4] = {x[0], x[1], x[2], x[3]}, ys[4] = {y[0], y[1], y[2], y[3]};
+      if constexpr (geglu) MOBI_SWAP4("v_permlane32_swap_b32", xs, ys);
+      else MOBI_SWAP4("v_permlane16_swap_b32", xs, ys);
       if constexpr (geglu) {
         float o[4];
 #pragma unroll
@@ -548,22 +552,30 @@ __device__ __forceinline__ int pp_epilogue(const IgemmArgs& a, f32x4 (&acc)[NT][
 #pragma unroll
       for (int ni = 0; ni < NT; ++ni) asm volatile("" : "+v"(res1[ni]));
     }
+    u32x2 gk[NT];                                            // GEGLU: the lane's 4 packed outputs per 16-channel tile
 #pragma unroll
     for (int ni = 0; ni < NT; ++ni) {
       const f32x4 x = acc[ni][2 * p], y = acc[ni][2 * p + 1];
-      float xs[4], ys[4];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        float xv = x[r], yv = y[r];
-        if constexpr (GEGLU) asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(xv), "+v"(yv));
-        else asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(xv), "+v"(yv));
-        xs[r] = xv; ys[r] = yv;
-      }
+      float xs[4] = {x[0], x[1], x[2], x[3]}, ys[4] = {y[0], y[1], y[2], y[3]};
+      if constexpr (GEGLU) MOBI_SWAP4("v_permlane32_swap_b32", xs, ys);
+      else MOBI_SWAP4("v_permlane16_swap_b32", xs, ys);
       if constexpr (GEGLU) {
         float o[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) o[r] = xs[r] * gelu_erf_f(ys[r]);
-        vm_store8(rowp + (nw0 >> 1) + ni * 8 + 4 * (g4 & 1), pack4<T>(o));
+        gk[ni] = pack4<T>(o);
+        // 16-byte stores (the epilogue is store-ISSUE bound): tiles ni, ni + 1 trade halves across the 16-lane rows, so
+        // that even rows hold outputs 8 ni + 0..7 and odd rows 8 (ni + 1) + 0..7 of their pixel
+        if ((ni & 1) && MOBI_PP_GEGLU_STORE16) {
+          unsigned a0 = gk[ni - 1][0], a1 = gk[ni - 1][1], b0 = gk[ni][0], b1 = gk[ni][1];
+          asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %2\n\tv_permlane16_swap_b32 %1, %3\n\ts_nop 1"
+                       : "+v"(a0), "+v"(a1), "+v"(b0), "+v"(b1));
+          vm_store16(rowp + (nw0 >> 1) + (ni - 1 + (g4 & 1)) * 8, u32x4{a0, a1, b0, b1});
+          ++n_issued;
+        } else if (ni == NT - 1 || !MOBI_PP_GEGLU_STORE16) {
+          vm_store8(rowp + (nw0 >> 1) + ni * 8 + 4 * (g4 & 1), gk[ni]);
+          ++n_issued;
+        }
       } else {
         float o[8] = {xs[0], xs[1], xs[2], xs[3], ys[0], ys[1], ys[2], ys[3]};
         if (resid) {
@@ -573,10 +585,11 @@ __device__ __forceinline__ int pp_epilogue(const IgemmArgs& a, f32x4 (&acc)[NT][
           for (int j = 0; j < 8; ++j) o[j] += rf[j];
         }
         vm_store16(rowp + nw0 + ni * 16 + 8 * (g4 >> 1), pack8<T>(o));
+        ++n_issued;
       }
     }
   }
-  return n_issued + 2 * NT;
+  return n_issued;
 }
 
 // WM = waves along the pixel axis: 2 -> 128-pixel tile, 4 waves, two blocks per CU;
