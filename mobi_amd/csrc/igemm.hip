@@ -1371,7 +1371,11 @@ __global__ __launch_bounds__(512, 2) void igemm_pp_kernel(const IgemmArgs a) {
   // bias OR per-image vector (never both) of the wave tile at (mw0, nw0): f32 x 4 per 16-column MFMA tile, the
   // accumulator layout.  Requested BEFORE anything else of the phase so that the latency hides behind the
   // epilogue stores; lands in registers that are free at that point (no fragment is live at a tile boundary).
+#ifdef MOBI_DBG_NOVEC                                      // timing only (wrong results): no bias / vector request and wait
+  const bool has_vec = false;
+#else
   const bool has_vec = !slab && (a.bias || a.rowvec);      // (split-K: the reduce launch adds them)
+#endif
   auto request_vec = [&](u32x4 (&bv)[NT], int nw0, int mw0) {
     const float* vec = a.bias;
     if (a.rowvec) {                                          // the wave's 64 pixels lie in one image: hw_out % 64 == 0
