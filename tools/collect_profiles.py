@@ -69,7 +69,9 @@ def main():
               f"* `{tag}_pp_ablation.txt` the k loop with parts removed (tools/diag_ingest.sh on the lockstep kernel, the same ablations of the ping-pong / halo kernels (the halo kernel and its script were removed later) and",
               "  tools/ab_flags.sh on the ping-pong / halo kernels): no activation DMA / no weight DMA / no DMA / no MFMA",
               f"* `{tag}_error_table.txt` measured rel-L2 vs the fp32 oracle per storage type (tests/error_table.py)",
-              f"* `{tag}_igemm_phase_stamps.txt`, `{tag}_splitk_sweep.txt` earlier sessions' stamps of the lockstep kernel and the split-K plan sweep"]
+              f"* `{tag}_igemm_phase_stamps.txt`, `{tag}_splitk_sweep.txt` earlier sessions' stamps of the lockstep kernel and the split-K plan sweep",
+              f"* `{tag}_pp_sq_counters.txt` SQ counters of the ping-pong igemm on one 3x3 launch (tools/pmc_kernel.sh); `{tag}_attention_ablation.txt` holds the attention kernel's",
+              f"* `{tag}_other_configs.txt` fp16 / CFG / mobi_nusc_256 / 2-rank-gloo bench lines of the final build"]
     with open(os.path.join(dst, f"{tag}_README.md"), "w") as f:
         f.write("\n".join(lines) + "\n")
     print("\n".join(lines[:14]))
