@@ -14,13 +14,20 @@ Prints ONE JSON line (rank 0): metric = UNet element-forwards per second over al
 kernel = the implicit-GEMM conv/linear kernel, algorithmic FLOPs / measured launch time
 against the 2.5 PFLOP/s dense bf16 MFMA peak) and `cpu_baseline` (the CPU oracle --
 the reference graph in PyTorch CPU fp32 -- timed on this host on a bounded sample).
-Multi-GPU: one process per GPU (torchrun), objects sharded, no collective inside the
-denoising loop; `--e2e` adds VAE encode/decode and the all-gather of decoded images.
+Multi-GPU: `--gpus N` with no WORLD_SIZE in the environment spawns N ranks itself
+(`python -m torch.distributed.run`, one process per GPU, RCCL) BEFORE this process touches the
+GPU, and exits with the child's code; under an external torchrun the ranks run directly.  Objects
+are sharded, no collective inside the denoising loop; the end-to-end pass adds VAE encode/decode
+and the all-gather of decoded images.  The step is issued as ONE HIP graph launch
+(mobi_amd/graph.py); `host_ms_per_step` is the time the host needs to issue a step,
+`gpu_ms_per_step` the HIP-event time of the same region.
 """
 import argparse
 import json
 import math
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -36,6 +43,7 @@ WORKLOADS = {  # BASELINE.json configs[2] / configs[1]
     "mobi_nusc_512": dict(latent=64, objects=8, gflop_per_element=1021.9, gflop_skippable=78.0),
     "mobi_nusc_256": dict(latent=32, objects=4, gflop_per_element=209.7, gflop_skippable=19.5),
 }
+PMC_TRAFFIC = "r02_pmc_traffic.json"   # written by tools/pmc_summary.py from the --pmc passes of this round's build
 PEAK_TFLOPS = 2500.0          # dense bf16/fp16 MFMA, /opt/skills/guides/MI355X_MICROARCH.md
 
 
@@ -59,6 +67,57 @@ def build_model(workload, seed=0):
     return model.eval()
 
 
+def spawn_ranks(n, argv):
+    """`bench.py --gpus N` started as ONE process: launch N fresh ranks (one per GPU) as children of this
+    process, which has not initialised the GPU (no exec of a GPU-holding process, ever), and pass their exit code on."""
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
+    return subprocess.run(cmd, env=env).returncode
+
+
+def stub_main(args, world, rank):
+    """MOBI_BENCH_STUB=1: the launcher / timing / reduction / JSON contract with a CPU stand-in for the step
+    (tests/test_bench_launcher_cpu.py drives `bench.py --gpus 2` through it on gloo, no GPU needed)."""
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend=os.environ.get("MOBI_BENCH_BACKEND", "gloo"))
+    a = torch.randn(64, 64)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        a = torch.tanh(a @ a)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        a = torch.tanh(a @ a)
+        time.sleep(0.002 * (1 + rank))           # rank-dependent: the MAX over ranks must win
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt])
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    if rank == 0:
+        elems = 16
+        print(json.dumps({"metric": "stub", "value": round(args.steps / dt * elems * world, 3), "unit": "stub element-forwards/s",
+                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+                          "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                          "config": {"workload": "stub (launcher test)", "parallelism": f"dp{world}"},
+                          "steps_per_s": round(args.steps / dt, 4)}))
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -74,10 +133,20 @@ def main():
     ap.add_argument("--dump-launches", default=None, help="write per-launch (kind, GFLOP, us) records of one step")
     ap.add_argument("--cpu-threads", type=int, default=32, help="threads for the CPU-oracle baseline leg")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end objects/s pass")
+    ap.add_argument("--no-graph", action="store_true", help="issue every launch from the host (no HIP graph)")
+    ap.add_argument("--no-plms-line", action="store_true", help="skip the PLMS + CFG 5 (shipped invocation) leg")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ:
+        if args.gpus > 1:
+            sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))      # nothing above has touched the GPU
+    elif int(os.environ["WORLD_SIZE"]) != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} disagrees with WORLD_SIZE={os.environ['WORLD_SIZE']}", file=sys.stderr)
+        sys.exit(2)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
+    if os.environ.get("MOBI_BENCH_STUB") == "1":
+        return stub_main(args, world, rank)
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     # MOBI_BENCH_BACKEND=gloo + MOBI_BENCH_ONE_DEVICE=1 let the multi-rank logic be exercised on a 1-GPU box
     backend = os.environ.get("MOBI_BENCH_BACKEND", "nccl")
@@ -107,7 +176,7 @@ def main():
 
     model = build_model(args.workload).to(device)
     net = model.model.diffusion_model
-    sampler = DDIMSampler(model)
+    sampler = DDIMSampler(model, graph=not args.no_graph)
     sampler.make_schedule(args.ddim_steps, ddim_eta=0.0, verbose=False)
     g = torch.Generator(device="cpu").manual_seed(1234 + rank)
     mk = lambda *s: torch.randn(*s, generator=g).to(device)
@@ -122,10 +191,13 @@ def main():
     steps_desc = list(reversed(sampler.ddim_timesteps.tolist()))
 
     def one_step(x, i):
+        # what ddim_sampling does per iteration (ddim.py:141-161 of the reference): the int64 timestep vector, the
+        # UNet evaluation(s), the fp32 update
         index = total - 1 - (i % total)
-        ts = torch.full((N,), int(steps_desc[i % total]), device=device, dtype=torch.long)
+        step = int(steps_desc[i % total])
+        ts = torch.full((N,), step, device=device, dtype=torch.long)
         x, _ = sampler.p_sample_ddim(x, cond, ts, index=index, unconditional_guidance_scale=args.cfg_scale,
-                                     unconditional_conditioning=uc if cfg else None, **kw)
+                                     unconditional_conditioning=uc if cfg else None, step_value=step, **kw)
         return x
 
     def barrier():
@@ -138,16 +210,52 @@ def main():
         for i in range(args.warmup):
             x = one_step(x, i)
         barrier()
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         t0 = time.perf_counter()
+        ev0.record()
         for i in range(args.steps):
             x = one_step(x, args.warmup + i)
+        ev1.record()
+        t_issued = time.perf_counter() - t0            # host time to issue K steps (the GPU may still be running)
         barrier()
         dt = time.perf_counter() - t0
+        gpu_ms_per_step = ev0.elapsed_time(ev1) / args.steps
+        host_ms_per_step = t_issued / args.steps * 1e3
     if world > 1:
         tmax = torch.tensor([dt], device=red_dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
     finite = bool(torch.isfinite(x).all())
+
+    # ---- the shipped invocation (scripts/realism_test_bench.sh:95-102): PLMS, classifier-free guidance 5 -------
+    plms_line = None
+    if not args.no_plms_line:
+        from mobi_amd.ldm.models.diffusion.plms import PLMSSampler
+        psampler = PLMSSampler(model, graph=not args.no_graph)
+        psteps = 5 if args.steps >= 5 else 4             # S with 1000 % S == 0: exactly S sampler steps
+
+        def plms_run(S):
+            return psampler.sample(S=S, batch_size=N, shape=[4, side, side], conditioning=cond, verbose=False, x_T=img,
+                                   unconditional_guidance_scale=5.0, unconditional_conditioning=uc,
+                                   inpaint_image=inpaint, inpaint_mask=mask)[0]
+
+        with torch.no_grad():
+            plms_run(2)                                    # 2 steps, 3 UNet evaluations: warm-up + graph capture
+            barrier()
+            t0 = time.perf_counter()
+            xs = plms_run(psteps)
+            barrier()
+            pdt = time.perf_counter() - t0
+        nsteps = psampler.ddim_timesteps.shape[0]
+        if world > 1:
+            tmax = torch.tensor([pdt], device=red_dev)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            pdt = float(tmax.item())
+        evals = nsteps + 1                                 # the first PLMS step evaluates the UNet twice (plms.py:226-232)
+        plms_line = {"sampler": "plms", "cfg_scale": 5.0, "unet_batch": 2 * N, "sampler_steps": nsteps,
+                     "unet_evaluations": evals, "ms_per_step": round(pdt / nsteps * 1e3, 3),
+                     "value": round(evals * 2 * N * world / pdt, 3), "unit": "UNet element-forwards/s",
+                     "finite": bool(torch.isfinite(xs).all())}
 
     # ---- end-to-end: VAE encodes -> DDIM -> decode_sample -> VAE decodes (+clamp) -> all-gather -------------
     objects_per_s = None
@@ -251,13 +359,19 @@ def main():
                             "region; algorithmic 2*M*N*K of every conv / linear the kernel ran"}
         roofline["algorithmic_mb_per_launch"] = round(dk["bytes"] / dk["launches"] / 1e6, 2)
         roofline["igemm_ms_by_variant"] = {v: round(d["ms"], 3) for v, d in by_variant.items()}
-        pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-        if os.path.exists(pmc):            # HBM bytes per launch from the committed rocprofv3 --pmc passes
+        # HBM bytes per launch come from separate rocprofv3 --pmc passes of THIS command (tools/profile_round.sh);
+        # the committed figure is attached only when it was collected on the same workload / batch / dtype / guidance
+        pmc = os.path.join(ROOT, "profiles", PMC_TRAFFIC)
+        run_cfg = {"workload": args.workload, "objects": B, "dtype": args.dtype, "cfg_scale": args.cfg_scale}
+        if os.path.exists(pmc):
             with open(pmc) as f:
-                rec = json.load(f).get(kname)
-            if rec:
+                doc = json.load(f)
+            rec = doc.get(kname)
+            if rec and doc.get("config") == run_cfg:
                 roofline["traffic"] = round(rec["hbm_bytes_per_launch_corrected"])
-                roofline["traffic_source"] = "profiles/r01_pmc_traffic.json (FETCH_SIZE x2 + WRITE_SIZE, separate --pmc passes)"
+                roofline["traffic_source"] = f"profiles/{PMC_TRAFFIC} (FETCH_SIZE x2 + WRITE_SIZE, separate --pmc passes)"
+            else:
+                roofline["traffic_source"] = f"none: profiles/{PMC_TRAFFIC} was collected on {doc.get('config')}"
         roofline["igemm_all_tflops"] = round(ig["flops"] / (ig["ms"] * 1e-3) / 1e12, 2)
         roofline["igemm_all_launches"] = ig["launches"]
         if "attention" in kinds:
@@ -275,13 +389,15 @@ def main():
         sd = {k: v.detach().float().cpu() for k, v in net.state_dict().items()}
         xc = torch.cat([img[:2], inpaint[:2], mask[:2]], 1).float().cpu()
         tc = torch.full((2,), 500, dtype=torch.long)
+        cc = cond[:2].float().cpu()
         with torch.no_grad():
+            ounet.unet_forward(sd, ounet.UNetConfig(), xc, tc, cc)      # untimed: thread pool, allocator, page-in
             t0 = time.perf_counter()
-            ounet.unet_forward(sd, ounet.UNetConfig(), xc, tc, cond[:2].float().cpu())
+            ounet.unet_forward(sd, ounet.UNetConfig(), xc, tc, cc)
             cdt = time.perf_counter() - t0
         cpu_baseline = {"value": round(2 / cdt, 4), "unit": "UNet element-forwards/s", "cores": ncpu, "kind": "port",
                         "sample": f"1 denoising step of 1 object (UNet batch 2) at latent {side}x{side}, fp32, "
-                                  f"PyTorch CPU oracle of the reference graph, {cdt:.1f} s"}
+                                  f"PyTorch CPU oracle of the reference graph, {cdt:.1f} s (second of two evaluations)"}
         del sd
 
     if rank == 0:
@@ -298,7 +414,9 @@ def main():
                                    f"cfg_scale {args.cfg_scale}",
                        "objects_per_gpu": B, "unet_batch": elems, "latent": side, "sampler": "ddim",
                        "parallelism": f"dp{world} (objects sharded, no collective in the loop)"},
-            "steps_per_s": round(steps_per_s * world, 4),
+            "steps_per_s": round(steps_per_s, 4),          # denoising steps per second of every rank's own batch
+            "host_ms_per_step": round(host_ms_per_step, 3), "gpu_ms_per_step": round(gpu_ms_per_step, 3),
+            "step_graph": bool(not args.no_graph),
             "model_tflops": round(value * useful_gf / 1e3 / world, 2),
             "model_frac_of_peak": round(value * useful_gf / 1e3 / world / PEAK_TFLOPS, 4),
             "finite": finite,
@@ -307,6 +425,8 @@ def main():
             out["objects_per_s"] = round(objects_per_s, 4)
             out["e2e"] = (f"{B} objects/GPU: 4 VAE encodes + DDIM-{args.ddim_steps} + 2 VAE decodes (+clamp) per object, "
                           f"range-view de-normalisation on the device, all-gather of decoded images; conditioning tokens supplied")
+        if plms_line:
+            out["plms_cfg5"] = plms_line
         if roofline:
             out["roofline"] = roofline
         if cpu_baseline:

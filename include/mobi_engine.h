@@ -43,6 +43,9 @@ const char* mobi_error_string(int code);
  * 3 attention, 4 ctx_attention, 5 skinny_linear, 6 conv_small_cin, 7 conv_small_cout,
  * 8 ddim_step.  Returns 0 for an unknown id. */
 size_t mobi_struct_size(int id);
+/* Development hook: the library reads its MOBI_* A/B environment variables once, at the first launch
+ * (mobi_amd/csrc/tuning.h lists them); this re-reads them.  Not needed by a product caller. */
+int mobi_tuning_reload(void);
 
 /* ---------------------------------------------------------------------------
  * Implicit-GEMM convolution / linear layer on the matrix cores.
@@ -277,12 +280,18 @@ int mobi_conv_small_cout(const mobi_conv_small_cout_params* p, void* stream);
  *   e      = e_uncond + cfg_scale * (e_cond - e_uncond)   (e_uncond NULL: e = e_cond)
  *   pred   = (x - sqrt_one_minus_at * e) / sqrt(a_t)
  *   x_prev = sqrt(a_prev) * pred + sqrt(1 - a_prev - sigma^2) * e + sigma * noise * temperature
- * `e_out` (or NULL) receives e (PLMS keeps it in old_eps). */
+ * `e_out` (or NULL) receives e (PLMS keeps it in old_eps).
+ * `coef_dev` (or NULL): DEVICE pointer to four floats {a_t, a_prev, sigma_t, sqrt_one_minus_at} that replace the
+ * by-value fields -- a denoising step captured in a HIP graph reads its per-step coefficients from a buffer the
+ * host refreshes between replays; same fp32 arithmetic, bit-identical results.
+ * sigma_t != 0 with noise == NULL is MOBI_ERR_ARG (the reference always draws the noise, ddim.py:209); with
+ * `coef_dev` the noise pointer is mandatory unless the caller promises eta == 0 by passing sigma_t == 0 by value. */
 typedef struct mobi_ddim_step_params {
   const float* x; const float* e_cond; const float* e_uncond; const float* noise;
   float* x_prev; float* pred_x0; float* e_out;
   int64_t n;
   float cfg_scale, a_t, a_prev, sigma_t, sqrt_one_minus_at, temperature;
+  const float* coef_dev;
 } mobi_ddim_step_params;
 int mobi_ddim_step(const mobi_ddim_step_params* p, void* stream);
 
@@ -304,6 +313,13 @@ int mobi_lincomb4(float* out, const float* e0, const float* e1, const float* e2,
 int mobi_range_denorm(const float* sample, const float* min_d, const float* max_d, float alpha, float two_alpha,
                       float alpha_m1, float one_m_alpha, int32_t object_norm, int32_t int_norm, float* depth_out,
                       float* int_out, int32_t batch, int32_t hw, void* stream);
+
+/* DDPM.q_sample (ddpm.py:284-287) with extract_into_tensor (util.py:96-99): per image b,
+ *   out[b] = sqrt_ac[t[b]] * x0[b] + sqrt_1m_ac[t[b]] * noise[b]
+ * t: int64 [batch] on the device (no host read-back), tables: f32 [table_len]; un-fused mul / add as torch does. */
+int mobi_q_sample(const float* x0, const float* noise, const int64_t* t, const float* sqrt_ac,
+                  const float* sqrt_1m_ac, float* out, int32_t batch, int32_t per_image, int32_t table_len,
+                  void* stream);
 
 /* ddim.py:145-148 with q_sample (ddpm.py:284-287):
  *   img = (sa[t]*x0 + s1ma[t]*noise) * mask + (1 - mask) * img

@@ -87,7 +87,7 @@ class ConvSmallCoutParams(C.Structure):
 class DdimStepParams(C.Structure):
     _fields_ = [("x", vp), ("e_cond", vp), ("e_uncond", vp), ("noise", vp), ("x_prev", vp), ("pred_x0", vp),
                 ("e_out", vp), ("n", i64), ("cfg_scale", f32), ("a_t", f32), ("a_prev", f32), ("sigma_t", f32),
-                ("sqrt_one_minus_at", f32), ("temperature", f32)]
+                ("sqrt_one_minus_at", f32), ("temperature", f32), ("coef_dev", vp)]
 
 
 STRUCT_IDS = {0: IgemmParams, 1: GroupNormParams, 2: LayerNormParams, 3: AttentionParams, 4: CtxAttentionParams,
@@ -98,6 +98,7 @@ SYMBOLS = {
     "mobi_abi_version": (C.c_int, []),
     "mobi_error_string": (C.c_char_p, [C.c_int]),
     "mobi_struct_size": (C.c_size_t, [C.c_int]),
+    "mobi_tuning_reload": (C.c_int, []),
     "mobi_igemm": (C.c_int, [C.POINTER(IgemmParams), vp]),
     "mobi_igemm_plan_splits": (C.c_int, [C.POINTER(IgemmParams)]),
     "mobi_igemm_kernel_variant": (C.c_int, [C.POINTER(IgemmParams)]),
@@ -115,6 +116,7 @@ SYMBOLS = {
     "mobi_conv_small_cout": (C.c_int, [C.POINTER(ConvSmallCoutParams), vp]),
     "mobi_ddim_step": (C.c_int, [C.POINTER(DdimStepParams), vp]),
     "mobi_lincomb4": (C.c_int, [vp, vp, vp, vp, vp, f32, f32, f32, f32, i64, vp]),
+    "mobi_q_sample": (C.c_int, [vp, vp, vp, vp, vp, vp, i32, i32, i32, vp]),
     "mobi_mask_blend": (C.c_int, [vp, vp, vp, vp, f32, f32, i32, i32, i32, vp]),
     "mobi_posterior_sample": (C.c_int, [vp, vp, vp, i32, i32, i32, i32, i32, f32, vp]),
     "mobi_range_denorm": (C.c_int, [vp, vp, vp, f32, f32, f32, f32, i32, i32, vp, vp, i32, i32, vp]),

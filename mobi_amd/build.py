@@ -33,8 +33,21 @@ def _deps_mtime():
     return max(os.path.getmtime(d) for d in deps)
 
 
+STAMP = LIB + ".flags"
+
+
+def _flags_id():
+    """What the library was compiled with besides the sources: a library built with A/B or debug flags
+    (`MOBI_HIPCC_FLAGS=-DMOBI_DBG_...`, timing-only variants with WRONG results) must never pass as current
+    for a plain build, whatever its mtime says."""
+    return repr((ARCH, os.environ.get("MOBI_HIPCC_FLAGS", "").split(), sorted(EXTRA.items())))
+
+
 def up_to_date():
-    return os.path.exists(LIB) and os.path.getmtime(LIB) >= _deps_mtime()
+    if not (os.path.exists(LIB) and os.path.exists(STAMP) and os.path.getmtime(LIB) >= _deps_mtime()):
+        return False
+    with open(STAMP) as f:
+        return f.read() == _flags_id()
 
 
 def hipcc():
@@ -68,6 +81,8 @@ def build(force=False, verbose=True):
     if r.returncode != 0:
         raise RuntimeError(f"link failed:\n{r.stderr}")
     os.replace(tmp, LIB)
+    with open(STAMP, "w") as f:
+        f.write(_flags_id())
     if verbose:
         print(f"built {LIB} ({os.path.getsize(LIB) / 1e6:.1f} MB) from {len(objs)} sources")
     return LIB

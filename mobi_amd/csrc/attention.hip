@@ -23,6 +23,7 @@
 #include <type_traits>
 
 #include "common.h"
+#include "tuning.h"
 
 #ifndef MOBI_ATTN_DBG
 #define MOBI_ATTN_DBG 0    // diagnosis only (wrong results): bit 0 = no exp, bit 1 = K / V tiles loaded once, bit 2 = no P.V,
@@ -750,13 +751,13 @@ static int launch_attention_v(const mobi_attention_params* p, const AttnArgs& a,
     // 8-wave blocks (256 queries per staged K / V tile) for the big launches
     const long long blocks8 = (long long)((p->tq + 255) / 256) * p->heads * p->images;
     int nw8 = blocks8 >= 1024 && ks <= 5;             // measured -5.5 % on [16 | 8 images, 4096 x 4096, 8 x 40]
-    if (const char* e = getenv("MOBI_ATTN_NW")) nw8 = ks <= 5 && e[0] == '8';       // tests / A-B: 8 forces, 4 forbids
+    if (tuning().attn_nw > 0) nw8 = ks <= 5 && tuning().attn_nw == 8;       // tests / A-B: 8 forces, 4 forbids
     if (nw8) {
       dim3 grid8((p->tq + 255) / 256, p->heads, p->images), block8(512);
       // software-pipelined kernel (head dims 33..48): measured SLOWER than the kernel above (693 vs 620 us on
       // [16, 4096 x 4096, 8 x 40], tools/ab_attn.sh), kept selectable for A/B runs and covered by the parity tests
       int sp = 0;
-      if (const char* e = getenv("MOBI_ATTN_SP")) sp = ks == 3 && e[0] == '1';
+      if (tuning().attn_sp == 1) sp = ks == 3;
       if (sp) {
         hipLaunchKernelGGL((attention_sp_kernel<T, 3>), grid8, block8, 0, st, a);
         MOBI_CHECK_LAUNCH();

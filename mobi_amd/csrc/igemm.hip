@@ -18,6 +18,7 @@
 #include <stdlib.h>
 
 #include "common.h"
+#include "tuning.h"
 
 // A/B switch (build with -DMOBI_IGEMM_FENCE=1): pin the load / MFMA / LDS-write phases of a k step
 #ifndef MOBI_FRAG2
@@ -1680,7 +1681,7 @@ __global__ __launch_bounds__(256) void igemm_splitk_reduce_kernel(const IgemmArg
 // CUs of the current device (cached per device ordinal); 256 on MI355X.  MOBI_IGEMM_PERSIST_BLOCKS overrides the
 // persistent grid size (tests: few blocks walk many output tiles).
 static int compute_units() {
-  if (const char* e = getenv("MOBI_IGEMM_PERSIST_BLOCKS")) { const int v = atoi(e); if (v > 0) return v; }
+  if (tuning().persist_blocks > 0) return tuning().persist_blocks;
   static int cached[64] = {0};
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
@@ -1831,8 +1832,8 @@ static int igemm_prepare(const mobi_igemm_params* p, mobi::IgemmArgs& a) {
     a.wm = tiles256 >= 256 ? 4 : 2;
     // split-K launches with long k ranges: 256-pixel tiles (ping-pong kernel) once tiles x splits fill the chip
     if (p->split_k > 1 && a.M % 256 == 0 && tiles256 * p->split_k >= 256 && a.nk / p->split_k >= 16) a.wm = 4;
-    if (const char* e = getenv("MOBI_IGEMM_PP_SPLIT")) { if (e[0] == '0' && p->split_k > 1 && tiles256 < 256) a.wm = 2; }
-    if (const char* e = getenv("MOBI_IGEMM_WM")) { if (e[0] == '2') a.wm = 2; else if (e[0] == '4') a.wm = 4; }
+    if (tuning().pp_split == 0 && p->split_k > 1 && tiles256 < 256) a.wm = 2;
+    if (tuning().wm == 2 || tuning().wm == 4) a.wm = tuning().wm;
   }
   a.tiles_m = (a.M + 64 * a.wm - 1) / (64 * a.wm);
   {
@@ -1842,12 +1843,12 @@ static int igemm_prepare(const mobi_igemm_params* p, mobi::IgemmArgs& a) {
     const long long wext = (long long)p->n_packed * a.ktot * 2;
     a.fast = (a.C % 64 == 0) && (p->c1 == 0 || p->c0 % 64 == 0) && ext0 < 0x7fffffffLL && ext1 < 0x7fffffffLL &&
              wext < 0x7fffffffLL;
-    if (const char* e = getenv("MOBI_IGEMM_FAST")) a.fast = a.fast && e[0] != '0';
+    if (tuning().fast == 0) a.fast = 0;
     a.k_order = p->k_order;
     if (p->k_order != 0 && p->k_order != 1) return MOBI_ERR_ARG;
     if (p->k_order == 1 && !a.fast) return MOBI_ERR_UNSUPPORTED;      // the generic gather walks k tap-major only
     a.glds = 1;
-    if (const char* e = getenv("MOBI_IGEMM_GLDS")) a.glds = e[0] != '0';
+    if (tuning().glds == 0) a.glds = 0;
     a.src0_bytes = (int)(ext0 < 0x7fffffffLL ? ext0 : 0);
     a.src1_bytes = (int)(ext1 < 0x7fffffffLL ? ext1 : 0);
     a.w_bytes = (int)(wext < 0x7fffffffLL ? wext : 0);
@@ -1865,13 +1866,13 @@ static int igemm_prepare(const mobi_igemm_params* p, mobi::IgemmArgs& a) {
   // (taps-innermost k order only: it changes tap every k-tile; measured 1.5-3 % slower than the window re-derivation
   //  on tap-major k, where a tap lasts C/64 k-tiles -- tools/sweep_korder.py)
   a.lin_window = p->k_order == 1 && p->upsample == 0 && p->kh * p->kw <= 16;
-  if (const char* e = getenv("MOBI_IGEMM_LIN")) a.lin_window = a.lin_window && e[0] != '0';
+  if (tuning().lin == 0) a.lin_window = 0;
   // register epilogue of the direct-to-LDS kernel: every tile full, row-major T output, no per-image vector
   // (a per-image vector takes the bias registers: never both, and every wave's 64 pixels inside one image)
   a.epi_direct = a.wm == 4 && a.fast && a.glds && p->out_mode == MOBI_OUT_ROWS && !a.split_ws &&
                  (!p->rowvec || (!p->bias && a.hw_out % 64 == 0)) && a.M % 256 == 0 && p->n_packed % bn == 0 &&
                  a.nk_per >= 3;
-  if (const char* e = getenv("MOBI_IGEMM_EPI_DIRECT")) a.epi_direct = a.epi_direct && e[0] != '0';
+  if (tuning().epi_direct == 0) a.epi_direct = 0;
   // ping-pong kernel: window pixels linear in the tap (no upsampling, <= 16 taps), one k range
   auto log2_exact = [](int v) { int s = 0; while ((1 << s) < v) ++s; return (1 << s) == v ? s : -1; };
   a.hw_shift = log2_exact(a.hw_out); a.w_shift = log2_exact(a.wout);
@@ -1882,7 +1883,7 @@ static int igemm_prepare(const mobi_igemm_params* p, mobi::IgemmArgs& a) {
       p->n_packed % bn == 0 && a.nk_per >= 3 && p->scale == 1.0f && a.hw_shift >= 6 && a.w_shift >= 0 &&
       a.hout < 32768 && a.wout < 32768)
     a.pp = 1;
-  if (const char* e = getenv("MOBI_IGEMM_PP")) a.pp = a.pp && e[0] != '0';
+  if (tuning().pp == 0) a.pp = 0;
   return MOBI_OK;
 }
 

@@ -6,9 +6,13 @@ namespace mobi {
 
 __global__ void ddim_step_kernel(const mobi_ddim_step_params a) {
   // all coefficient math in fp32, in the reference's operation order (ddim.py:200-212)
-  const float sqrt_at = sqrtf(a.a_t);
-  const float sqrt_aprev = sqrtf(a.a_prev);
-  const float dir_c = sqrtf(1.0f - a.a_prev - a.sigma_t * a.sigma_t);
+  float a_t = a.a_t, a_prev = a.a_prev, sigma_t = a.sigma_t, sqrt_one_minus_at = a.sqrt_one_minus_at;
+  if (a.coef_dev) {           // graph-captured step: coefficients of the current step live in device memory
+    a_t = a.coef_dev[0]; a_prev = a.coef_dev[1]; sigma_t = a.coef_dev[2]; sqrt_one_minus_at = a.coef_dev[3];
+  }
+  const float sqrt_at = sqrtf(a_t);
+  const float sqrt_aprev = sqrtf(a_prev);
+  const float dir_c = sqrtf(1.0f - a_prev - sigma_t * sigma_t);
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < a.n;
        i += (long long)gridDim.x * blockDim.x) {
     float e = a.e_cond[i];
@@ -17,9 +21,9 @@ __global__ void ddim_step_kernel(const mobi_ddim_step_params a) {
       e = eu + a.cfg_scale * (e - eu);
     }
     const float x = a.x[i];
-    const float pred = (x - a.sqrt_one_minus_at * e) / sqrt_at;
+    const float pred = (x - sqrt_one_minus_at * e) / sqrt_at;
     const float dir = dir_c * e;
-    const float nz = a.noise ? a.sigma_t * a.noise[i] * a.temperature : 0.0f;
+    const float nz = a.noise ? sigma_t * a.noise[i] * a.temperature : 0.0f;
     if (a.e_out) a.e_out[i] = e;
     if (a.pred_x0) a.pred_x0[i] = pred;
     if (a.x_prev) a.x_prev[i] = sqrt_aprev * pred + dir + nz;
@@ -34,6 +38,19 @@ __global__ void lincomb4_kernel(float* out, const float* e0, const float* e1, co
     if (e2) v += c2 * e2[i];
     if (e3) v += c3 * e3[i];
     out[i] = v;
+  }
+}
+
+// q_sample (ddpm.py:284-287 of the reference): per-image gather of the two schedule tables by the int64 timestep
+__global__ void q_sample_kernel(const float* x0, const float* noise, const long long* t, const float* sqrt_ac,
+                                const float* sqrt_1m_ac, float* out, int batch, int per_image, int table_len) {
+  const long long total = (long long)batch * per_image;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int b = (int)(i / per_image);
+    long long ti = t[b];
+    ti = ti < 0 ? 0 : (ti >= table_len ? table_len - 1 : ti);      // (torch.gather would raise; never read out of range)
+    out[i] = sqrt_ac[ti] * x0[i] + sqrt_1m_ac[ti] * noise[i];
   }
 }
 
@@ -129,6 +146,7 @@ using namespace mobi;
 
 extern "C" int mobi_ddim_step(const mobi_ddim_step_params* p, void* stream) {
   if (!p || !p->x || !p->e_cond || p->n <= 0) return MOBI_ERR_ARG;
+  if (p->sigma_t != 0.0f && !p->noise) return MOBI_ERR_ARG;      // the stochastic term cannot be dropped silently
   hipLaunchKernelGGL(ddim_step_kernel, dim3(egrid(p->n)), dim3(256), 0, ST(stream), *p);
   MOBI_CHECK_LAUNCH();
   return MOBI_OK;
@@ -139,6 +157,17 @@ extern "C" int mobi_lincomb4(float* out, const float* e0, const float* e1, const
   if (!out || !e0 || n <= 0) return MOBI_ERR_ARG;
   hipLaunchKernelGGL(lincomb4_kernel, dim3(egrid(n)), dim3(256), 0, ST(stream), out, e0, e1, e2, e3, c0, c1, c2, c3,
                      (long long)n);
+  MOBI_CHECK_LAUNCH();
+  return MOBI_OK;
+}
+
+extern "C" int mobi_q_sample(const float* x0, const float* noise, const int64_t* t, const float* sqrt_ac,
+                             const float* sqrt_1m_ac, float* out, int32_t batch, int32_t per_image, int32_t table_len,
+                             void* stream) {
+  if (!x0 || !noise || !t || !sqrt_ac || !sqrt_1m_ac || !out || batch <= 0 || per_image <= 0 || table_len <= 0)
+    return MOBI_ERR_ARG;
+  hipLaunchKernelGGL(q_sample_kernel, dim3(egrid((long long)batch * per_image)), dim3(256), 0, ST(stream), x0, noise,
+                     reinterpret_cast<const long long*>(t), sqrt_ac, sqrt_1m_ac, out, batch, per_image, table_len);
   MOBI_CHECK_LAUNCH();
   return MOBI_OK;
 }

@@ -1,0 +1,19 @@
+// Development / A-B knobs of the engine.  The MOBI_* environment variables are read ONCE, at the first launch
+// (never per launch: a denoising step is ~600 launches), into this table; `mobi_tuning_reload()` re-reads them
+// (tests and the tools/ A-B scripts flip a variable and call it).  -1 = unset (the library's own choice).
+#pragma once
+namespace mobi {
+struct Tuning {
+  int persist_blocks;   // MOBI_IGEMM_PERSIST_BLOCKS  persistent grid size (tests: few blocks walk many tiles)
+  int pp_split;         // MOBI_IGEMM_PP_SPLIT        0: split-K launches stay on the register-staged kernel
+  int wm;               // MOBI_IGEMM_WM              2 | 4: force the 128- / 256-pixel block
+  int fast;             // MOBI_IGEMM_FAST            0: generic gather addressing
+  int glds;             // MOBI_IGEMM_GLDS            0: register-staged loads instead of direct-to-LDS
+  int lin;              // MOBI_IGEMM_LIN             0: no linear window stepping (chunk-major k order)
+  int epi_direct;       // MOBI_IGEMM_EPI_DIRECT      0: LDS-staged epilogue
+  int pp;               // MOBI_IGEMM_PP              0: lockstep schedule instead of ping-pong
+  int attn_nw;          // MOBI_ATTN_NW               4 | 8: waves per attention block
+  int attn_sp;          // MOBI_ATTN_SP               1: software-pipelined attention kernel (dh 33..48)
+};
+const Tuning& tuning();
+}  // namespace mobi

@@ -1,0 +1,41 @@
+#include <atomic>
+#include <cstdlib>
+#include <mutex>
+
+#include "common.h"
+#include "tuning.h"
+
+namespace mobi {
+namespace {
+Tuning g_tuning;
+std::once_flag g_once;
+
+int env_int(const char* name) {
+  const char* e = getenv(name);
+  return (e && e[0]) ? atoi(e) : -1;
+}
+void read_env() {
+  g_tuning.persist_blocks = env_int("MOBI_IGEMM_PERSIST_BLOCKS");
+  g_tuning.pp_split = env_int("MOBI_IGEMM_PP_SPLIT");
+  g_tuning.wm = env_int("MOBI_IGEMM_WM");
+  g_tuning.fast = env_int("MOBI_IGEMM_FAST");
+  g_tuning.glds = env_int("MOBI_IGEMM_GLDS");
+  g_tuning.lin = env_int("MOBI_IGEMM_LIN");
+  g_tuning.epi_direct = env_int("MOBI_IGEMM_EPI_DIRECT");
+  g_tuning.pp = env_int("MOBI_IGEMM_PP");
+  g_tuning.attn_nw = env_int("MOBI_ATTN_NW");
+  g_tuning.attn_sp = env_int("MOBI_ATTN_SP");
+}
+}  // namespace
+
+const Tuning& tuning() {
+  std::call_once(g_once, read_env);
+  return g_tuning;
+}
+}  // namespace mobi
+
+extern "C" int mobi_tuning_reload(void) {
+  std::call_once(mobi::g_once, [] {});
+  mobi::read_env();
+  return MOBI_OK;
+}

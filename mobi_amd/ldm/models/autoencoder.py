@@ -25,12 +25,20 @@ class AutoencoderKL(nn.Module):
             self.init_from_ckpt(ckpt_path, ignore_keys=ignore_keys)
 
     def init_from_ckpt(self, path, ignore_keys=list()):
-        sd = torch.load(path, map_location="cpu")["state_dict"]
+        """autoencoder.py:52-60 of the reference, plus the key diagnostics its LatentDiffusion loader prints."""
+        sd = torch.load(path, map_location="cpu")
+        sd = sd.get("state_dict", sd)
         for k in list(sd.keys()):
             if any(k.startswith(ik) for ik in ignore_keys):
+                print("Deleting key {} from state_dict.".format(k))
                 del sd[k]
-        self.load_state_dict(sd, strict=False)
-        print(f"Restored from {path}")
+        missing, unexpected = self.load_state_dict(sd, strict=False)
+        print(f"Restored from {path} with {len(missing)} missing and {len(unexpected)} unexpected keys")
+        if len(missing) > 0:
+            print(f"Missing Keys: {missing}")
+        if len(unexpected) > 0:
+            print(f"Unexpected Keys: {unexpected}")
+        return missing, unexpected
 
     @torch.no_grad()
     def encode(self, x):

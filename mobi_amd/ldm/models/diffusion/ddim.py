@@ -5,7 +5,7 @@ latent state and every coefficient stay fp32; the per-step arithmetic is one HIP
 import numpy as np
 import torch
 
-from .... import ops
+from .... import graph, ops
 from ...modules.diffusionmodules.util import (make_ddim_sampling_parameters, make_ddim_timesteps, noise_like)
 
 
@@ -15,6 +15,7 @@ class DDIMSampler(object):
         self.model = model
         self.ddpm_num_timesteps = model.num_timesteps
         self.schedule = schedule
+        self.use_graph = bool(kwargs.get("graph", True))      # one HIP graph launch per step (mobi_amd/graph.py)
 
     def register_buffer(self, name, attr):
         # the reference pins buffers to "cuda" (ddim.py:19-23); follow the model's device instead
@@ -75,6 +76,9 @@ class DDIMSampler(object):
         intermediates = {"x_inter": [img], "pred_x0": [img]}
         time_range = np.flip(steps)
         total_steps = steps.shape[0]
+        self._weights_fp = graph.weights_fingerprint(self.model)
+        graphed = self.use_graph and graph.usable(img) and isinstance(cond, torch.Tensor)
+        keep = (lambda t_: t_.clone()) if graphed else (lambda t_: t_)     # graph outputs are overwritten next step
         for i, step in enumerate(time_range):
             index = total_steps - i - 1
             ts = torch.full((b,), int(step), device=device, dtype=torch.long)
@@ -88,21 +92,20 @@ class DDIMSampler(object):
             nz = None
             if float(self.ddim_sigmas[index]) != 0.0:
                 nz = step_noise[i] if step_noise is not None else noise_like(img.shape, device)
-            img, pred_x0 = self.p_sample_ddim(img, cond, ts, index=index, temperature=temperature,
-                                              unconditional_guidance_scale=unconditional_guidance_scale,
-                                              unconditional_conditioning=unconditional_conditioning,
-                                              noise=nz, **kwargs)
+            img, pred_x0 = self._step(img, cond, ts, index, temperature, unconditional_guidance_scale,
+                                      unconditional_conditioning, nz, kwargs, step_value=int(step))
             if callback:
                 callback(i)
             if img_callback:
-                img_callback(pred_x0, i)
+                img_callback(keep(pred_x0), i)
             if index % log_every_t == 0 or index == total_steps - 1:
-                intermediates["x_inter"].append(img)
-                intermediates["pred_x0"].append(pred_x0)
-        return img, intermediates
+                intermediates["x_inter"].append(keep(img))
+                intermediates["pred_x0"].append(keep(pred_x0))
+        return keep(img), intermediates
 
-    def _eps(self, x, c, t, unconditional_guidance_scale, unconditional_conditioning, kwargs):
-        """Returns (e_cond, e_uncond|None): the classifier-free mix happens in mobi_ddim_step."""
+    def _eps(self, x, c, t, unconditional_guidance_scale, unconditional_conditioning, kwargs, cfg_ctx=None):
+        """Returns (e_cond, e_uncond|None): the classifier-free mix happens in mobi_ddim_step.
+        cfg_ctx: the caller's own [uncond ; cond] token tensor (a captured step keeps one static buffer)."""
         if "test_model_kwargs" in kwargs:
             kw = kwargs["test_model_kwargs"]
             parts = [x, kw["inpaint_image"], kw["inpaint_mask"]]
@@ -116,21 +119,53 @@ class DDIMSampler(object):
         parts2 = [torch.cat([p] * 2) for p in parts]
         # [uncond ; cond] tokens are the same tensor at every step of a run: build it once so that the UNet's
         # per-context cache (attn2 vector, adapter k/v) hits
-        ck = (id(unconditional_conditioning), id(c), unconditional_conditioning._version, c._version)
-        if getattr(self, "_cfg_ctx_key", None) != ck:
-            self._cfg_ctx_key, self._cfg_ctx_refs = ck, (unconditional_conditioning, c)
-            self._cfg_ctx = torch.cat([unconditional_conditioning, c])
-        out = self.model.apply_model(parts2, torch.cat([t] * 2), self._cfg_ctx)
+        if cfg_ctx is None:
+            ck = (id(unconditional_conditioning), id(c), unconditional_conditioning._version, c._version)
+            if getattr(self, "_cfg_ctx_key", None) != ck:
+                self._cfg_ctx_key, self._cfg_ctx_refs = ck, (unconditional_conditioning, c)
+                self._cfg_ctx = torch.cat([unconditional_conditioning, c])
+            cfg_ctx = self._cfg_ctx
+        out = self.model.apply_model(parts2, torch.cat([t] * 2), cfg_ctx)
         e_uncond, e_cond = out.chunk(2)
         return e_cond.contiguous(), e_uncond.contiguous()
 
+    def _coef_table(self):
+        """fp32 device table [S, 4] = {a_t, a_prev, sigma_t, sqrt(1 - a_t)} of the current schedule: exactly the
+        values `float(...)` of the numpy tables become when passed by value (ctypes c_float rounds the same way)."""
+        key = (id(self.ddim_alphas), id(self.ddim_sigmas), self.model.betas.device)
+        if getattr(self, "_coef_key", None) != key:
+            tab = np.stack([np.asarray(self.ddim_alphas, dtype=np.float64), np.asarray(self.ddim_alphas_prev, np.float64),
+                            np.asarray(self.ddim_sigmas, np.float64),
+                            np.asarray(self.ddim_sqrt_one_minus_alphas, np.float64)], axis=1).astype(np.float32)
+            self._coef_key, self._coef_dev = key, torch.from_numpy(tab).to(self.model.betas.device)
+        return self._coef_dev
+
+    def _step(self, x, c, t, index, temperature, scale, uncond, noise, kwargs, step_value=None):
+        """One denoising step -> (x_prev, pred_x0).  On the GPU the step is ONE graph launch (mobi_amd/graph.py):
+        the returned tensors are then the graph's static outputs, valid until the next step."""
+        sigma = float(self.ddim_sigmas[index])
+        if noise is None and sigma != 0.0:       # the reference draws at every step (ddim.py:209); it matters here only
+            noise = noise_like(x.shape, x.device)
+        if self.use_graph and graph.usable(x) and isinstance(c, torch.Tensor):
+            if step_value is None:
+                step_value = int(t[0])           # (host sync; ddim_sampling passes the value it already has)
+            g = graph.get(self, "ddim", x, c, uncond, scale, kwargs, temperature=temperature, has_noise=sigma != 0.0)
+            return g.run(x, step_value, self._coef_table()[index], noise)
+        e_cond, e_uncond = self._eps(x, c, t, scale, uncond, kwargs)
+        x_prev, pred_x0, _ = ops.ddim_step(
+            x, e_cond, e_uncond=e_uncond, noise=noise, cfg_scale=float(scale),
+            a_t=float(self.ddim_alphas[index]), a_prev=float(self.ddim_alphas_prev[index]), sigma_t=sigma,
+            sqrt_one_minus_at=float(self.ddim_sqrt_one_minus_alphas[index]), temperature=float(temperature))
+        return x_prev, pred_x0
+
     @torch.no_grad()
     def p_sample_ddim(self, x, c, t, index, temperature=1., unconditional_guidance_scale=1.,
-                      unconditional_conditioning=None, noise=None, **kwargs):
-        e_cond, e_uncond = self._eps(x, c, t, unconditional_guidance_scale, unconditional_conditioning, kwargs)
-        x_prev, pred_x0, _ = ops.ddim_step(
-            x, e_cond, e_uncond=e_uncond, noise=noise, cfg_scale=float(unconditional_guidance_scale),
-            a_t=float(self.ddim_alphas[index]), a_prev=float(self.ddim_alphas_prev[index]),
-            sigma_t=float(self.ddim_sigmas[index]),
-            sqrt_one_minus_at=float(self.ddim_sqrt_one_minus_alphas[index]), temperature=float(temperature))
+                      unconditional_conditioning=None, noise=None, step_value=None, **kwargs):
+        """ddim.py:166-213 of the reference.  `step_value`: the (batch-uniform) timestep as a Python int when the
+        caller has it -- saves reading it back from `t`."""
+        x = x.float().contiguous()
+        x_prev, pred_x0 = self._step(x, c, t, index, temperature, unconditional_guidance_scale,
+                                     unconditional_conditioning, noise, kwargs, step_value)
+        if self.use_graph and graph.usable(x) and isinstance(c, torch.Tensor):
+            return x_prev.clone(), pred_x0.clone()       # static graph outputs: hand out copies
         return x_prev, pred_x0

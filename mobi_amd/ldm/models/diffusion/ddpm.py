@@ -63,10 +63,39 @@ class DDPM(nn.Module):
             self.monitor = monitor
         self.register_schedule(given_betas=given_betas, beta_schedule=beta_schedule, timesteps=timesteps,
                                linear_start=linear_start, linear_end=linear_end, cosine_s=cosine_s)
+        if ckpt_path is not None:
+            self.init_from_ckpt(ckpt_path, ignore_keys=ignore_keys, only_model=load_only_unet)
 
     @property
     def device(self):
         return self.betas.device
+
+    def init_from_ckpt(self, path, ignore_keys=list(), only_model=False):
+        """Checkpoint ingestion with the reference's diagnostics (ddpm.py:196-212): keys under an `ignore_keys`
+        prefix are dropped, the missing / unexpected key lists of the non-strict load are printed.  On top of the
+        reference: a checkpoint that leaves part of the UNet or a VAE at its random initialisation samples
+        garbage, so missing keys under those prefixes also raise a RuntimeWarning (not an error: initialising
+        from a checkpoint without the adapter weights is a legitimate use of `strict=False`)."""
+        sd = torch.load(path, map_location="cpu")
+        if "state_dict" in sd:
+            sd = sd["state_dict"]
+        for k in list(sd.keys()):
+            if any(k.startswith(ik) for ik in ignore_keys):
+                print("Deleting key {} from state_dict.".format(k))
+                del sd[k]
+        target = self.model if only_model else self
+        missing, unexpected = target.load_state_dict(sd, strict=False)
+        print(f"Restored from {path} with {len(missing)} missing and {len(unexpected)} unexpected keys")
+        if len(missing) > 0:
+            print(f"Missing Keys: {missing}")
+        if len(unexpected) > 0:
+            print(f"Unexpected Keys: {unexpected}")
+        hot = ("model.diffusion_model.", "first_stage_model.", "lidar_stage_model.", "diffusion_model.")
+        lost = [k for k in missing if k.startswith(hot) and not any(k.startswith(ik) for ik in ignore_keys)]
+        if lost:
+            warnings.warn(f"{path} leaves {len(lost)} UNet / VAE parameters at their initial values "
+                          f"(first: {lost[:4]})", RuntimeWarning)
+        return missing, unexpected
 
     def register_schedule(self, given_betas=None, beta_schedule="linear", timesteps=1000, linear_start=1e-4,
                           linear_end=2e-2, cosine_s=8e-3):
@@ -99,16 +128,12 @@ class DDPM(nn.Module):
         yield None          # use_ema is False in every MObI config (mobi_nusc_512.yaml:47)
 
     def q_sample(self, x_start, t, noise=None):
-        """sqrt(ac[t]) * x0 + sqrt(1 - ac[t]) * noise; a per-batch-uniform t (the samplers' case)
-        runs as one kernel, a ragged t per image."""
+        """sqrt(ac[t]) * x0 + sqrt(1 - ac[t]) * noise (ddpm.py:284-287): one kernel gathers the tables by the
+        device-resident int64 t -- no host read-back."""
         noise = default(noise, lambda: torch.randn_like(x_start))
-        x_start = x_start.float().contiguous()
-        out = torch.empty_like(x_start)
-        sa = extract_into_tensor(self.sqrt_alphas_cumprod, t, (t.shape[0],)).tolist()
-        s1 = extract_into_tensor(self.sqrt_one_minus_alphas_cumprod, t, (t.shape[0],)).tolist()
-        for i in range(x_start.shape[0]):
-            out[i] = ops.lincomb4([x_start[i].contiguous(), noise[i].float().contiguous()], [sa[i], s1[i]])
-        return out
+        return ops.q_sample(x_start.float().contiguous(), noise.float().contiguous(),
+                            t.to(device=x_start.device, dtype=torch.int64).contiguous(),
+                            self.sqrt_alphas_cumprod, self.sqrt_one_minus_alphas_cumprod)
 
     def get_input(self, batch, k):
         return make_contiguous(batch["image"]), make_contiguous(batch["lidar"])
@@ -149,9 +174,10 @@ class LatentDiffusion(DDPM):
         self.lidar_stage_model = self._frozen(lidar_stage_config)
         self.cond_stage_forward = cond_stage_forward
         self.clip_denoised = False
+        self.restarted_from_ckpt = False
         if ckpt_path is not None:
-            sd = torch.load(ckpt_path, map_location="cpu")
-            self.load_state_dict(sd.get("state_dict", sd), strict=False)
+            self.init_from_ckpt(ckpt_path, ignore_keys)
+            self.restarted_from_ckpt = True
 
     @staticmethod
     def _frozen(config):

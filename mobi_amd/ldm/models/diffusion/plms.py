@@ -4,7 +4,7 @@ same fp32 update kernel as DDIM; the first step does two UNet evaluations."""
 import numpy as np
 import torch
 
-from .... import ops
+from .... import graph, ops
 from .ddim import DDIMSampler
 
 
@@ -39,9 +39,16 @@ class PLMSSampler(DDIMSampler):
         intermediates = {"x_inter": [img], "pred_x0": [img]}
         old_eps = []
 
-        def model_eps(x, t):
-            e_c, e_u = self._eps(x, cond, t, unconditional_guidance_scale, unconditional_conditioning, kw)
-            return e_c, e_u
+        self._weights_fp = graph.weights_fingerprint(self.model)
+        graphed = self.use_graph and graph.usable(img) and isinstance(cond, torch.Tensor)
+
+        def model_eps(x, t, step_value):
+            """(e_cond, e_uncond | None); on the GPU one graph launch per UNet evaluation -- its outputs are static
+            buffers, consumed by `update` before the next evaluation overwrites them."""
+            if graphed:
+                g = graph.get(self, "eps", x, cond, unconditional_conditioning, unconditional_guidance_scale, kw)
+                return g.run(x, step_value)
+            return self._eps(x, cond, t, unconditional_guidance_scale, unconditional_conditioning, kw)
 
         def update(x, e, index, e_uncond=None, want_e=False):
             return ops.ddim_step(x, e, e_uncond=e_uncond, cfg_scale=float(unconditional_guidance_scale),
@@ -54,11 +61,12 @@ class PLMSSampler(DDIMSampler):
             ts = torch.full((b,), int(step), device=device, dtype=torch.long)
             ts_next = torch.full((b,), int(time_range[min(i + 1, len(time_range) - 1)]), device=device,
                                  dtype=torch.long)
-            e_c, e_u = model_eps(img, ts)
+            step_next = int(time_range[min(i + 1, len(time_range) - 1)])
+            e_c, e_u = model_eps(img, ts, int(step))
             # one pass of the update kernel also yields e_t (after the CFG mix)
             x_euler, _, e_t = update(img, e_c, index, e_uncond=e_u, want_e=True)
             if len(old_eps) == 0:
-                e_c2, e_u2 = model_eps(x_euler, ts_next)
+                e_c2, e_u2 = model_eps(x_euler, ts_next, step_next)
                 _, _, e_next = update(x_euler, e_c2, index, e_uncond=e_u2, want_e=True)
                 e_prime = ops.lincomb4([e_t, e_next], [0.5, 0.5])
             elif len(old_eps) == 1:

@@ -100,8 +100,21 @@ import os as _os
 _CHUNK_MAJOR = _os.environ.get("MOBI_CHUNK_MAJOR", "0") == "1"
 
 
+# bumped whenever parameters are replaced wholesale (load_state_dict, .to() / .cuda() / .float()): captured step
+# graphs (mobi_amd/graph.py) hold the addresses of the packed copies and are dropped when this moves
+WEIGHTS_EPOCH = [0]
+
+
 class _Holder(nn.Module):
     """Caches device-side packed copies keyed on (dtype, device, parameter versions)."""
+
+    def _apply(self, fn, *args, **kwargs):
+        WEIGHTS_EPOCH[0] += 1
+        return super()._apply(fn, *args, **kwargs)
+
+    def _load_from_state_dict(self, *args, **kwargs):
+        WEIGHTS_EPOCH[0] += 1
+        return super()._load_from_state_dict(*args, **kwargs)
 
     def _cached(self, tag, build):
         ps = list(self.parameters(recurse=False))

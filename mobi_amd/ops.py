@@ -376,7 +376,7 @@ def skinny_linear(x, w, bias=None, pre_act=ACT_NONE, post_act=ACT_NONE, out=None
     assert x.dtype == torch.float32 and x.stride(1) == 1 and w.is_contiguous()
     if out is None:
         out = torch.empty((m, n), device=x.device, dtype=torch.float32)
-    for m0 in range(0, m, 16):                      # the kernel handles up to 16 rows per launch
+    for m0 in range(0, m, 16):                      # one launch per 16 rows (the kernel's LDS row block)
         xs, os_ = x[m0:m0 + 16], out[m0:m0 + 16]
         p = _lib.SkinnyLinearParams()
         p.x, p.m, p.k, p.x_row_stride = _ptr(xs), xs.shape[0], k, x.stride(0)
@@ -471,8 +471,10 @@ def to_nchw_f32(x):
 # --------------------------------------------------------------------------------------
 # sampler / latent arithmetic (fp32 NCHW)
 # --------------------------------------------------------------------------------------
-def ddim_step(x, e_cond, *, e_uncond=None, noise=None, cfg_scale=1.0, a_t, a_prev, sigma_t, sqrt_one_minus_at,
-              temperature=1.0, want_e=False):
+def ddim_step(x, e_cond, *, e_uncond=None, noise=None, cfg_scale=1.0, a_t=1.0, a_prev=1.0, sigma_t=0.0,
+              sqrt_one_minus_at=0.0, temperature=1.0, want_e=False, coef_dev=None):
+    """coef_dev: fp32 device tensor {a_t, a_prev, sigma_t, sqrt_one_minus_at} replacing the by-value coefficients
+    (graph-captured steps, mobi_amd/graph.py)."""
     lib = _lib.load()
     for t in (x, e_cond, e_uncond, noise):
         assert t is None or (t.dtype == torch.float32 and t.is_contiguous())
@@ -483,6 +485,9 @@ def ddim_step(x, e_cond, *, e_uncond=None, noise=None, cfg_scale=1.0, a_t, a_pre
     p.x_prev, p.pred_x0, p.e_out, p.n = _ptr(x_prev), _ptr(pred), _ptr(e_out), x.numel()
     p.cfg_scale, p.a_t, p.a_prev, p.sigma_t = cfg_scale, a_t, a_prev, sigma_t
     p.sqrt_one_minus_at, p.temperature = sqrt_one_minus_at, temperature
+    if coef_dev is not None:
+        assert coef_dev.dtype == torch.float32 and coef_dev.numel() == 4 and coef_dev.is_contiguous()
+        p.coef_dev = _ptr(coef_dev)
     _lib.check(lib.mobi_ddim_step(C.byref(p), _stream()), "mobi_ddim_step")
     return x_prev, pred, e_out
 
@@ -494,6 +499,18 @@ def lincomb4(es, cs):
     out = torch.empty_like(es[0])
     _lib.check(lib.mobi_lincomb4(_ptr(out), _ptr(es[0]), _ptr(es[1]), _ptr(es[2]), _ptr(es[3]),
                                  cs[0], cs[1], cs[2], cs[3], out.numel(), _stream()), "mobi_lincomb4")
+    return out
+
+
+def q_sample(x0, noise, t, sqrt_ac, sqrt_1m_ac):
+    """fp32 [B, ...] x0 / noise, int64 [B] t and the two fp32 schedule tables, all on the device."""
+    lib = _lib.load()
+    for t_ in (x0, noise, sqrt_ac, sqrt_1m_ac):
+        assert t_.dtype == torch.float32 and t_.is_contiguous()
+    assert t.dtype == torch.int64 and t.is_contiguous() and t.numel() == x0.shape[0] and x0.shape == noise.shape
+    out = torch.empty_like(x0)
+    _lib.check(lib.mobi_q_sample(_ptr(x0), _ptr(noise), _ptr(t), _ptr(sqrt_ac), _ptr(sqrt_1m_ac), _ptr(out),
+                                 x0.shape[0], x0[0].numel(), sqrt_ac.numel(), _stream()), "mobi_q_sample")
     return out
 
 

@@ -15,3 +15,23 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return os.path.join(ROOT, "tests", "golden")
+
+
+@pytest.fixture
+def tune(monkeypatch):
+    """A/B environment variables of the library for one test: the library reads them once (mobi_amd/csrc/tuning.h),
+    so every change is followed by `mobi_tuning_reload()`; restored (and re-read) at teardown."""
+    from mobi_amd import _lib
+
+    class Tune:
+        def setenv(self, key, value):
+            monkeypatch.setenv(key, str(value))
+            _lib.load().mobi_tuning_reload()
+
+        def delenv(self, key):
+            monkeypatch.delenv(key, raising=False)
+            _lib.load().mobi_tuning_reload()
+
+    yield Tune()
+    monkeypatch.undo()
+    _lib.load().mobi_tuning_reload()

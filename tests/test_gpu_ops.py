@@ -23,8 +23,11 @@ TOL = {torch.float16: 2e-3, torch.bfloat16: 1.5e-2}
 
 
 def rel(a, b):
+    from tests.golden_cases import record
     a, b = a.detach().double().cpu(), b.detach().double().cpu()
-    return float((a - b).norm() / b.norm().clamp_min(1e-30))
+    err = float((a - b).norm() / b.norm().clamp_min(1e-30))
+    record("rel", err)
+    return err
 
 
 def rnd(name, shape, dtype, scale=1.0):
@@ -199,7 +202,7 @@ ATTN_CASES = [(8, 8, 64, 64), (8, 16, 100, 100), (8, 40, 256, 256), (8, 80, 64, 
 @pytest.mark.parametrize("dtype", DT)
 @pytest.mark.parametrize("v_rows", [True, False], ids=["v_rows", "v_transposed"])
 @pytest.mark.parametrize("heads,dh,tq,tk", ATTN_CASES)
-def test_attention(ops, dtype, heads, dh, tq, tk, v_rows, monkeypatch):
+def test_attention(ops, dtype, heads, dh, tq, tk, v_rows, tune):
     """both V layouts of the C ABI: row-major V (transposing LDS reads) and pre-transposed V^T; the row-major path also
     with 8-wave blocks (256 queries per staged K / V tile), which the library otherwise picks for big launches only."""
     n, c = 2, heads * dh
@@ -213,7 +216,7 @@ def test_attention(ops, dtype, heads, dh, tq, tk, v_rows, monkeypatch):
     ref = torch.einsum("bhij,bhjd->bhid", sim.softmax(-1), sp(vf)).permute(0, 2, 1, 3).reshape(n, tq, c)
     assert rel(y.float(), ref) < TOL[dtype]
     if v_rows and dh <= 80:
-        monkeypatch.setenv("MOBI_ATTN_NW", "8")
+        tune.setenv("MOBI_ATTN_NW", "8")
         y8 = ops.attention(qd, kd, vt, heads, dh ** -0.5, v_rows=v_rows)
         assert rel(y8.float(), ref) < TOL[dtype]
 
@@ -221,7 +224,7 @@ def test_attention(ops, dtype, heads, dh, tq, tk, v_rows, monkeypatch):
 @pytest.mark.parametrize("dtype", DT)
 @pytest.mark.parametrize("dh,tq,tk", [(40, 300, 40), (40, 1, 64), (48, 257, 100), (40, 256, 128), (40, 70, 190),
                                       (40, 512, 300), (40, 33, 1)])
-def test_attention_software_pipelined(ops, dtype, dh, tq, tk, monkeypatch):
+def test_attention_software_pipelined(ops, dtype, dh, tq, tk, tune):
     """the software-pipelined 8-wave kernel (head dims 33..48) on 1..5 key tiles, ragged last tiles and ragged query blocks;
     it is an A/B alternative (MOBI_ATTN_SP=1, slower than the default kernel) and must agree with the default kernel."""
     n, heads = 2, 4
@@ -232,18 +235,18 @@ def test_attention_software_pipelined(ops, dtype, dh, tq, tk, monkeypatch):
     sp = lambda t: t.reshape(n, -1, heads, dh).permute(0, 2, 1, 3)
     sim = torch.einsum("bhid,bhjd->bhij", sp(qf), sp(kf)) * dh ** -0.5
     ref = torch.einsum("bhij,bhjd->bhid", sim.softmax(-1), sp(vf)).permute(0, 2, 1, 3).reshape(n, tq, c)
-    monkeypatch.setenv("MOBI_ATTN_NW", "8")
-    monkeypatch.setenv("MOBI_ATTN_SP", "1")
+    tune.setenv("MOBI_ATTN_NW", "8")
+    tune.setenv("MOBI_ATTN_SP", "1")
     y = ops.attention(qd, kd, vd, heads, dh ** -0.5, v_rows=True)
     assert torch.isfinite(y.float()).all()
     assert rel(y.float(), ref) < TOL[dtype]
-    monkeypatch.setenv("MOBI_ATTN_SP", "0")
+    tune.setenv("MOBI_ATTN_SP", "0")
     y0 = ops.attention(qd, kd, vd, heads, dh ** -0.5, v_rows=True)
     assert rel(y.float(), y0.float()) < 1e-6 + (0 if dtype == torch.float32 else 4e-3)
 
 
 @pytest.mark.parametrize("dtype", DT)
-def test_attention_strided_partner_and_spike(ops, dtype):
+def test_attention_strided_partner_and_spike(ops, dtype, tune):
     """q from the camera half, k/v from the lidar half of an interleaved batch (image strides), with
     q/k packed in one [.., 2C] tensor (row stride > C) and one huge score (online-softmax rescale)."""
     n, t, heads, dh = 4, 130, 8, 40
@@ -264,15 +267,10 @@ def test_attention_strided_partner_and_spike(ops, dtype):
     kvd = torch.cat([xd[:, :, c:], vd], dim=2)
     y2 = ops.attention(xd[::2, :, :c], kvd[1::2, :, :c], kvd[1::2, :, c:], heads, dh ** -0.5, v_rows=True)
     assert rel(y2.float(), ref) < TOL[dtype]
-    import os
-    os.environ["MOBI_ATTN_NW"] = "8"                         # the same through 8-wave blocks, both schedules
-    try:
-        y3 = ops.attention(xd[::2, :, :c], kvd[1::2, :, :c], kvd[1::2, :, c:], heads, dh ** -0.5, v_rows=True)
-        os.environ["MOBI_ATTN_SP"] = "1"
-        y4 = ops.attention(xd[::2, :, :c], kvd[1::2, :, :c], kvd[1::2, :, c:], heads, dh ** -0.5, v_rows=True)
-    finally:
-        del os.environ["MOBI_ATTN_NW"]
-        os.environ.pop("MOBI_ATTN_SP", None)
+    tune.setenv("MOBI_ATTN_NW", "8")                         # the same through 8-wave blocks, both schedules
+    y3 = ops.attention(xd[::2, :, :c], kvd[1::2, :, :c], kvd[1::2, :, c:], heads, dh ** -0.5, v_rows=True)
+    tune.setenv("MOBI_ATTN_SP", "1")
+    y4 = ops.attention(xd[::2, :, :c], kvd[1::2, :, :c], kvd[1::2, :, c:], heads, dh ** -0.5, v_rows=True)
     assert rel(y3.float(), ref) < TOL[dtype]
     assert rel(y4.float(), ref) < TOL[dtype]
 
@@ -420,11 +418,11 @@ def test_igemm_split_k(ops, dtype, split):
 
 @pytest.mark.parametrize("dtype", DT)
 @pytest.mark.parametrize("wm", ["2", "4"])
-def test_igemm_block_heights(ops, dtype, wm, monkeypatch):
+def test_igemm_block_heights(ops, dtype, wm, tune):
     """Both block shapes of the implicit-GEMM kernel (4 waves x 128 pixels, 8 waves x 256 pixels) on the same
     convolutions, incl. ragged pixel counts, two sources, GEGLU and the transposed epilogue."""
     from mobi_amd._lib import OUT_TRANSPOSED
-    monkeypatch.setenv("MOBI_IGEMM_WM", wm)
+    tune.setenv("MOBI_IGEMM_WM", wm)
     for name, cin, cout, kh, kw, h, w, stride, up, asym in IGEMM_CASES[:7]:
         xf, xd = rnd("x." + name, (3, h, w, cin), dtype)
         wf = torch.from_numpy(W.synth_param(name + ".weight", (cout, cin, kh, kw))).to(dtype).float()
@@ -451,14 +449,14 @@ def test_igemm_block_heights(ops, dtype, wm, monkeypatch):
 
 @pytest.mark.parametrize("dtype", DT)
 @pytest.mark.parametrize("blocks", [None, "3"])
-def test_igemm_persistent_register_epilogue(ops, dtype, blocks, monkeypatch):
+def test_igemm_persistent_register_epilogue(ops, dtype, blocks, tune):
     """The persistent direct-to-LDS kernel on full 256-pixel tiles: register epilogue (lane-row exchange, counted
     vector-memory waits) vs the LDS-staged epilogue of the same kernel, both against the fp32 reference.
     1x1 + bias + residual (80- and 64-column wave tiles), 3x3 over two sources, GEGLU.
     blocks="3": three persistent blocks walk all output tiles, so the k-tile sequence rolls across many tiles."""
-    monkeypatch.setenv("MOBI_IGEMM_WM", "4")
+    tune.setenv("MOBI_IGEMM_WM", "4")
     if blocks:
-        monkeypatch.setenv("MOBI_IGEMM_PERSIST_BLOCKS", blocks)
+        tune.setenv("MOBI_IGEMM_PERSIST_BLOCKS", blocks)
     xf, xd = rnd("pd.x", (4, 32, 32, 320), dtype)
     rf, rd = rnd("pd.r", (4, 32, 32, 320), dtype)
     r2f, r2d = rnd("pd.r2", (4, 32, 32, 128), dtype)
@@ -479,7 +477,7 @@ def test_igemm_persistent_register_epilogue(ops, dtype, blocks, monkeypatch):
     p3, pg = ops.pack_conv(w3, b3, dtype, "cuda"), ops.pack_geglu(wg, bg, dtype, "cuda")
     outs = {}
     for direct in ("1", "0"):
-        monkeypatch.setenv("MOBI_IGEMM_EPI_DIRECT", direct)
+        tune.setenv("MOBI_IGEMM_EPI_DIRECT", direct)
         y1 = ops.igemm(xd, p1, residual=rd, scale=0.5)
         y2 = ops.igemm(xd, p2, residual=r2d)
         y3 = ops.igemm(xd, p3, x2=x1d)
@@ -510,15 +508,15 @@ PP_CASES = [
 
 @pytest.mark.parametrize("dtype", DT)
 @pytest.mark.parametrize("case", PP_CASES, ids=[f"pp{i}" for i in range(len(PP_CASES))])
-def test_igemm_pingpong(ops, dtype, case, monkeypatch):
+def test_igemm_pingpong(ops, dtype, case, tune):
     """The ping-pong direct-to-LDS kernel against a torch fp32 convolution: the 256-pixel geometry is forced on small problems, a handful of persistent blocks walk many
     output tiles, and the library must report that it runs the ping-pong variant."""
     import ctypes as C
     from mobi_amd import _lib
     n, h, w, cin, cin2, cout, k, res, rowvec, geglu, blocks = case
-    monkeypatch.setenv("MOBI_IGEMM_WM", "4")
+    tune.setenv("MOBI_IGEMM_WM", "4")
     if blocks:
-        monkeypatch.setenv("MOBI_IGEMM_PERSIST_BLOCKS", str(blocks))
+        tune.setenv("MOBI_IGEMM_PERSIST_BLOCKS", str(blocks))
     name = "pp." + ".".join(str(int(v)) for v in case)
     xf, xd = rnd(name + ".x", (n, h, w, cin), dtype)
     x2f, x2d = rnd(name + ".x2", (n, h, w, cin2), dtype) if cin2 else (None, None)
@@ -588,10 +586,10 @@ def test_two_key_adapter(ops, dtype, n, t, c, heads, strided):
 
 
 @pytest.mark.parametrize("dtype", DT)
-def test_igemm_pingpong_upsample_and_stride(ops, dtype, monkeypatch):
+def test_igemm_pingpong_upsample_and_stride(ops, dtype, tune):
     """Nearest-x2 upsampling on the load side and a stride-2 convolution through the ping-pong kernel."""
-    monkeypatch.setenv("MOBI_IGEMM_WM", "4")
-    monkeypatch.setenv("MOBI_IGEMM_PERSIST_BLOCKS", "3")
+    tune.setenv("MOBI_IGEMM_WM", "4")
+    tune.setenv("MOBI_IGEMM_PERSIST_BLOCKS", "3")
     for name, h, cin, cout, stride, up in (("ppup", 8, 128, 160, 1, True), ("pps2", 32, 64, 128, 2, False)):
         xf, xd = rnd(name + ".x", (4, h, h, cin), dtype)
         wf = torch.from_numpy(W.synth_param(name + ".weight", (cout, cin, 3, 3))).to(dtype).float()
@@ -622,14 +620,14 @@ def test_range_denorm_vs_reference_golden(ops):
 
 @pytest.mark.parametrize("dtype", DT)
 @pytest.mark.parametrize("blocks", [0, 5])
-def test_igemm_pingpong_split_k(ops, dtype, blocks, monkeypatch):
+def test_igemm_pingpong_split_k(ops, dtype, blocks, tune):
     """Split-K on the ping-pong kernel: every (tile, k range) block leaves fp32 partial sums from its accumulators, the
     reduce launch adds bias + per-image vector + residual.  Long k (3x3 over 1280 channels), 16 x 16 images, explicit
     split counts, a few persistent blocks walking several tiles."""
     import ctypes as C
     from mobi_amd import _lib
     if blocks:
-        monkeypatch.setenv("MOBI_IGEMM_PERSIST_BLOCKS", str(blocks))
+        tune.setenv("MOBI_IGEMM_PERSIST_BLOCKS", str(blocks))
     n, h, cin, cout = 16, 16, 1280, 320
     xf, xd = rnd("pps.x", (n, h, h, cin), dtype)
     rf, rd = rnd("pps.res", (n, h, h, cout), dtype)

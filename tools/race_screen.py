@@ -13,13 +13,24 @@ import torch.nn.functional as F
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--repeats", type=int, default=150)
-    a = ap.parse_args()
-    os.environ["MOBI_IGEMM_WM"] = "4"
-    from mobi_amd import build, ops
+def screen(repeats=150):
+    """Returns the number of failures (mismatching repeats + shapes off the fp32 reference)."""
+    from mobi_amd import _lib, build, ops
     build.build(verbose=False)
+    saved = {k: os.environ.get(k) for k in ("MOBI_IGEMM_WM", "MOBI_IGEMM_PERSIST_BLOCKS")}
+    os.environ["MOBI_IGEMM_WM"] = "4"
+    try:
+        return _screen(repeats, _lib, ops)
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+        _lib.load().mobi_tuning_reload()
+
+
+def _screen(repeats, _lib, ops):
     g = torch.Generator().manual_seed(7)
     dt = torch.bfloat16
     trash = torch.empty(256 << 20, dtype=torch.uint8, device="cuda")
@@ -32,7 +43,7 @@ def main():
             os.environ["MOBI_IGEMM_PERSIST_BLOCKS"] = str(blocks)
         else:
             os.environ.pop("MOBI_IGEMM_PERSIST_BLOCKS", None)
-        os.environ["MOBI_IGEMM_HALO"] = halo
+        _lib.load().mobi_tuning_reload()          # the library reads its A/B variables once; re-read them
         x = torch.randn(n, h, h, cin, generator=g).to(dt).cuda()
         w = (torch.randn(cout, cin, k, k, generator=g) / (k * cin ** 0.5)).to(dt)
         b = torch.randn(cout, generator=g)
@@ -44,7 +55,7 @@ def main():
             ref = ref + r.float()
         err = float((y0.float() - ref).norm() / ref.norm())
         mism = 0
-        for i in range(a.repeats):
+        for i in range(repeats):
             if i % 5 == 0:
                 trash.add_(1)                                # evict L2 / MALL, busy HBM
             y = ops.igemm(x, pw, residual=r)
@@ -53,9 +64,16 @@ def main():
         torch.cuda.synchronize()
         bad += mism + (err > 8e-3)
         print(f"n={n} {h}x{h} {cin}->{cout} k{k} res={res} blocks={blocks} halo={halo}: rel={err:.2e} "
-              f"mismatching repeats {mism}/{a.repeats}", flush=True)
+              f"mismatching repeats {mism}/{repeats}", flush=True)
     print("RACE SCREEN", "CLEAN" if bad == 0 else f"FAILED ({bad})")
-    sys.exit(1 if bad else 0)
+    return bad
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--repeats", type=int, default=150)
+    a = ap.parse_args()
+    sys.exit(1 if screen(a.repeats) else 0)
 
 
 if __name__ == "__main__":
