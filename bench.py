@@ -48,12 +48,14 @@ PEAK_TFLOPS = 2500.0          # dense bf16/fp16 MFMA, /opt/skills/guides/MI355X_
 
 
 def build_model(workload, seed=0):
-    """LatentDiffusion (UNet + camera VAE + lidar VAE) from configs/mobi_nusc_512.yaml with random-init
-    weights of the real architecture (also overwrites the zero-initialised layers)."""
+    """LatentDiffusion (UNet + camera VAE + lidar VAE) from configs/<workload>.yaml with random-init weights of
+    the real architecture (also overwrites the zero-initialised layers).  No checkpoint exists offline: the lidar
+    VAE's `ckpt_path` is cleared, and the conditioning tokens are supplied (the CLIP tower is not part of a step)."""
     from mobi_amd.ldm.util import instantiate_from_config, load_config
-    wl = WORKLOADS[workload]
-    cfg = load_config(os.path.join(ROOT, "configs", "mobi_nusc_512.yaml"),
-                      [f"latent_size={wl['latent']}", f"image_height={wl['latent'] * 8}"])
+    cfg = load_config(os.path.join(ROOT, "configs", f"{workload}.yaml"),
+                      ["model.params.lidar_stage_config.params.ckpt_path=null",
+                       "model.params.cond_stage_config=__is_unconditional__"])
+    assert cfg["latent_size"] == WORKLOADS[workload]["latent"]
     model = instantiate_from_config(cfg["model"])
     g = torch.Generator().manual_seed(seed)
     with torch.no_grad():
@@ -285,7 +287,8 @@ def main():
                                     test_model_kwargs={"inpaint_image": z[:, 4:8].contiguous(),
                                                        "inpaint_mask": z[:, 8:9].contiguous()})
             h_cam, h_lid = model.decode_sample(smp, z_lid[:, :4])
-            log, _ = model.log_data(pp_batch, None, h_cam.contiguous(), h_lid.contiguous())
+            log, _ = model.log_data(pp_batch, None, h_cam.contiguous(), h_lid.contiguous(), log_metrics=False,
+                                    return_sample=True, split="test")          # inference_test_bench.py:464
             if backend != "nccl":
                 log = {k: v.cpu() for k, v in log.items()}
             return mdist.gather_decoded(log, B * world)                 # the one collective of the path

@@ -336,7 +336,7 @@ class LatentDiffusion(DDPM):
         return h_camera, h_lidar
 
     @torch.no_grad()
-    def log_data(self, batch, data, h_camera, h_lidar, log_metrics=False, return_sample=True, split="val"):
+    def log_data(self, batch, data, h_camera, h_lidar, log_metrics=True, return_sample=False, split="train"):
         """Decode + clamp of ddpm.py:1475-1476,1503-1504 and -- when `batch` carries the per-sample depth range -- the
         range-view de-normalisation of ddpm.py:1527-1543 on the device (`mobi_range_denorm`).  As in the reference,
         `range_sample_depth` is the DE-NORMALISED depth (the reference overwrites the logged tensor in place, :1533-1537)

@@ -147,19 +147,34 @@ def test_every_product_module_imports():
                 importlib.import_module(rel)
 
 
+CONFIGS = ["mobi_nusc-mini_256", "mobi_nusc-mini_512", "mobi_nusc_256", "mobi_nusc_512", "mobi_nusc_all-classes_256",
+           "mobi_nusc_all-classes_512", "range_autoencoder", "pbe"]
+
+
 @pytest.mark.skipif(not os.path.exists("/root/reference/configs/mobi_nusc_512.yaml"), reason="reference tree not present")
-def test_reference_yaml_drops_in():
-    """The reference's own config file resolves (incl. ${} interpolation) and its `ldm.` targets map onto the
-    engine's classes; the engine's restated YAML describes the same UNet / VAEs."""
+@pytest.mark.parametrize("name", CONFIGS)
+def test_restated_configs_equal_the_reference(name):
+    """configs/*.yaml (the files the GPU box can name) hold exactly the values of the reference's YAML files, before
+    and after `${}` resolution, and the reference's own files load through the engine's loader."""
+    import yaml
+    from mobi_amd.ldm.util import load_config
+    with open(f"/root/reference/configs/{name}.yaml") as f:
+        ref_raw = yaml.safe_load(f)
+    with open(os.path.join(ROOT, "configs", f"{name}.yaml")) as f:
+        mine_raw = yaml.safe_load(f)
+    assert mine_raw == ref_raw
+    assert load_config(os.path.join(ROOT, "configs", f"{name}.yaml")) == load_config(f"/root/reference/configs/{name}.yaml")
+
+
+@pytest.mark.parametrize("name", [c for c in CONFIGS if c.startswith("mobi_")])
+def test_mobi_configs_resolve_onto_engine_classes(name):
     from mobi_amd.ldm.util import get_obj_from_str, load_config
-    ref = load_config("/root/reference/configs/mobi_nusc_512.yaml", ["use_lidar=True"])
-    mine = load_config(os.path.join(ROOT, "configs", "mobi_nusc_512.yaml"))
-    rp, mp_ = ref["model"]["params"], mine["model"]["params"]
-    assert rp["unet_config"]["params"] == mp_["unet_config"]["params"]
+    cfg = load_config(os.path.join(ROOT, "configs", f"{name}.yaml"), ["use_lidar=True"])
+    mp_ = cfg["model"]["params"]
+    assert get_obj_from_str(cfg["model"]["target"]).__module__ == "mobi_amd.ldm.models.diffusion.ddpm"
+    assert get_obj_from_str(mp_["unet_config"]["target"]).__module__ == "mobi_amd.ldm.modules.diffusionmodules.openaimodel"
     for k in ("first_stage_config", "lidar_stage_config"):
-        assert rp[k]["params"]["ddconfig"] == mp_[k]["params"]["ddconfig"]
-        assert get_obj_from_str(rp[k]["target"]).__module__ == "mobi_amd.ldm.models.autoencoder"
-    for k in ("linear_start", "linear_end", "timesteps", "scale_factor", "lidar_scale_factor", "image_size", "channels",
-              "cond_stage_key", "first_stage_key", "conditioning_key", "use_ema"):
-        assert rp[k] == mp_[k], k
-    assert get_obj_from_str(ref["model"]["target"]).__module__ == "mobi_amd.ldm.models.diffusion.ddpm"
+        assert get_obj_from_str(mp_[k]["target"]).__module__ == "mobi_amd.ldm.models.autoencoder"
+    assert get_obj_from_str(mp_["cond_stage_config"]["target"]).__module__ == "mobi_amd.ldm.modules.encoders.modules"
+    assert mp_["image_size"] == cfg["latent_size"] == cfg["image_height"] // 8
+    assert mp_["unet_config"]["params"]["model_channels"] == 320 and mp_["cond_stage_key"] == ["ref_image", "ref_bbox"]

@@ -274,7 +274,8 @@ def test_harness_flow_with_conditioning_producer():
     from mobi_amd.ldm.util import instantiate_from_config, load_config
     import os
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    cfg = load_config(os.path.join(root, "configs", "mobi_nusc_512.yaml"), ["latent_size=8", "image_height=64"])
+    cfg = load_config(os.path.join(root, "configs", "mobi_nusc_512.yaml"),
+                      ["latent_size=8", "image_height=64", "model.params.lidar_stage_config.params.ckpt_path=null"])
     mp = cfg["model"]["params"]
     mp["unet_config"]["params"]["model_channels"] = 64
     for k in ("first_stage_config", "lidar_stage_config"):
@@ -323,7 +324,8 @@ def test_harness_flow_with_conditioning_producer():
                                            test_model_kwargs={"inpaint_image": z[:, 4:8].contiguous(),
                                                               "inpaint_mask": z[:, 8:9].contiguous()})
     h_cam, h_lid = model.decode_sample(samples, data["z_lidar"])
-    log, _ = model.log_data(batch, data, h_cam.contiguous(), h_lid.contiguous())
+    log, _ = model.log_data(batch, data, h_cam.contiguous(), h_lid.contiguous(), log_metrics=False, return_sample=True,
+                            split="test")
     for k, ch in (("image_sample", 3), ("lidar_sample", 2)):
         assert log[k].shape == (B, ch, 64, 64) and bool(torch.isfinite(log[k]).all())
         assert float(log[k].abs().max()) <= 1.0
