@@ -14,7 +14,9 @@
 //                      launch whose tiles are full, whose output is row-major T and that has at most one of
 //                      bias / per-image vector; also the split-K launches with long k ranges (fp32 slabs).
 //   igemm_glds_kernel  same geometry in lockstep, LDS-staged epilogues (transposed / fp32 / ragged / bias AND vector)
-//   igemm_kernel       128- / 256-pixel tiles staged through registers, split-K slabs: small m, odd channel counts
+//   igemm_sm_kernel    128-pixel tiles, four waves, two blocks per CU, operands by LDS-DMA into a ring of four 32-deep
+//                      k-slots: small m, split-K ranges, ragged tiles, every output mode
+//   igemm_kernel       128- / 256-pixel tiles staged through registers: operands beyond 2 GB, chunk-major k
 #include <stdlib.h>
 
 #include "common.h"
@@ -117,6 +119,7 @@ struct IgemmArgs {
   int lin_window;          // direct-to-LDS kernel: window pixels are linear in the tap (no upsampling, <= 16 taps)
   int epi_direct;          // direct-to-LDS kernel: register epilogue (full tiles, row-major T output)
   int pp;                  // register-epilogue launch on the ping-pong kernel
+  int sm;                  // 128-pixel tiles on the LDS-DMA ring kernel (igemm_sm_kernel)
   int hw_shift, w_shift;   // log2(hw_out), log2(wout) when both are powers of two (ping-pong kernel), else -1
 };
 
@@ -1629,6 +1632,174 @@ __global__ __launch_bounds__(512, 2) void igemm_pp_kernel(const IgemmArgs a) {
 #undef MOBI_PP_BARRIER
 }
 
+// =========================================================================================================
+// SMALL-M main loop (every shape the 256-pixel persistent kernels do not take: few rows, split-K ranges, ragged
+// tiles, transposed / fp32 output): 128 pixels x (2 * WAVE_N) channels, FOUR waves (2 x 2, wave tile 64 x WAVE_N),
+// TWO blocks per CU.  Operands arrive by LDS-DMA into a RING of four 32-deep k-slots (18 KB each): the requests of
+// k-step s + 3 are issued while step s is multiplied, so three steps of prefetch cover the landing latency that
+// dominates short launches (the register-staged loop it replaces had one k-tile of cover, measured 2.2 us per
+// 64-deep k-tile at 17 % matrix-pipe use).  One raw s_barrier per k-step:
+//     wait(own pieces of step s landed: counted vmcnt) ; barrier ; read fragments of slot s % 4 ;
+//     request step s + 3 into slot (s + 3) % 4 == (s - 1) % 4 (every wave is past its reads of it) ; multiply
+// The two co-resident blocks are not synchronised with each other: one multiplies while the other requests / waits.
+// LDS image of a slot: [row][4 x 16 B] (64-byte rows); a 1-KiB request is 16 rows; the 16-byte slot of chunk c of
+// row r is c ^ P[(r >> 2) & 3], P = {0, 2, 3, 1}: conflict-free for ds_read_b128's four lane groups (rows r16,
+// chunk g4); applied on the SOURCE side of the request (the lane that fills slot s of row r fetches chunk s ^ P).
+// Padded / out-of-range / past-the-k-range pieces use an offset beyond the descriptor: the hardware writes zeros.
+// Every wave issues the same number of requests per step (R = 2 activation + 2 or 3 weight pieces), also past the
+// end of its k range (all-zero pieces into slots nobody reads), so that every wait is the immediate vmcnt(2 R).
+// Epilogue: the LDS-staged one (all output modes, split-K slabs, ragged tiles) through the drained ring.
+// =========================================================================================================
+template <typename T, int NT, bool TR>
+__global__ __launch_bounds__(256, 2) void igemm_sm_kernel(const IgemmArgs a) {
+  typedef typename Vec8<T>::type frag_t;
+  constexpr int BM = 128;
+  constexpr int WAVE_N = NT * 16;
+  constexpr int BN = 2 * WAVE_N;
+  constexpr int WPIECES = BN / 16;                           // 1-KiB weight requests per k-step (10 | 8)
+  constexpr int SLOT = (BM + BN) * 64;                       // bytes per 32-deep k-slot
+  constexpr int RING = 4 * SLOT;
+  constexpr int STAGE_BYTES = EpiGeom<32, TR, NT>::BYTES;    // per wave
+  constexpr int LDS_BYTES = RING > 4 * STAGE_BYTES ? RING : 4 * STAGE_BYTES;
+  constexpr unsigned OOB = 0x80000000u;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
+  typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wave_s = __builtin_amdgcn_readfirstlane(wave);
+  const int wm = wave & 1, wn = wave >> 1;
+  const int group = blockIdx.z;
+  const int nblk = a.tiles_m * a.tiles_n;
+  const int L = xcd_remap(blockIdx.x, nblk);
+  const int tile_n = L % a.tiles_n, tile_m = L / a.tiles_n;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const T* wgt = reinterpret_cast<const T*>(a.weight) + (long long)group * a.w_group_stride;
+  const __amdgpu_buffer_rsrc_t rx0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.src0), 0, a.src0_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rx1 =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.src1 ? a.src1 : a.src0), 0, a.src1 ? a.src1_bytes : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(wgt), 0, a.w_bytes, 0x00020000);
+
+  // ---- request side: this lane fills slot (lane & 3) of row (lane >> 2) of each 16-row piece -----------------------
+  const int rp = lane >> 2;
+  const unsigned perm = (0x1320u >> (((rp >> 2) & 3) * 4)) & 3u;              // P = {0, 2, 3, 1}
+  const unsigned chunk16 = (((unsigned)lane & 3u) ^ perm) * 16u;
+  int x_base[2], x_h[2], x_w[2];                             // activation rows 32 * wave + 16 j + rp of the tile
+  bool x_ok[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int m = m0 + 32 * wave + 16 * j + rp;
+    x_ok[j] = m < a.M;
+    const int mm = x_ok[j] ? m : 0;
+    const int img = mm / a.hw_out, rem = mm - img * a.hw_out;
+    const int ho = rem / a.wout, wo = rem - ho * a.wout;
+    x_base[j] = (group * a.imgs_per_group + img) * a.img_pix_stride;
+    x_h[j] = ho * a.stride - a.pad_h;
+    x_w[j] = wo * a.stride - a.pad_w;
+  }
+  unsigned w_off[3];                                         // weight rows 16 * (wave + 4 i) + rp of the tile
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int piece = wave + 4 * i;
+    const int n = n0 + 16 * piece + rp;
+    w_off[i] = (piece < WPIECES && n < a.n_packed) ? (unsigned)n * (unsigned)a.ktot * 2u + chunk16 : OOB;
+  }
+  const int hlog = a.hin << a.up, wlog = a.win << a.up;
+  // k range of this block in 32-deep steps (split-K: blockIdx.y owns 64-deep k-tiles [y * nk_per, (y + 1) * nk_per))
+  const int ks_all = a.ktot >> 5;
+  const int ks_begin = blockIdx.y * a.nk_per * 2;
+  const int ks_end = min(ks_all, ks_begin + a.nk_per * 2);
+  int u_c, u_tap, u_ky, u_kx;                                // (tap, channel) of the next step to request (tap-major k)
+  {
+    const long long c_first = (long long)ks_begin * 32;
+    u_tap = (int)(c_first / a.C); u_c = (int)(c_first - (long long)u_tap * a.C);
+    u_ky = u_tap / a.kw; u_kx = u_tap - u_ky * a.kw;
+  }
+  unsigned f_row[2] = {OOB, OOB};
+  int f_tap = -1, f_src = -1, f_ks = ks_begin;
+
+  auto issue_step = [&]() {
+    unsigned char* st = lds + (f_ks & 3) * SLOT;
+    const bool live = f_ks < ks_end;                         // wave-uniform; past the range: all-zero pieces
+    const int src = u_c >= a.c0 ? 1 : 0;
+    if (live && (u_tap != f_tap || src != f_src)) {
+      f_tap = u_tap; f_src = src;
+      const unsigned cs2 = (unsigned)(src ? a.c1 : a.c0) * 2u;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int hi = x_h[j] + u_ky, wi = x_w[j] + u_kx;
+        const bool ok = x_ok[j] && (unsigned)hi < (unsigned)hlog && (unsigned)wi < (unsigned)wlog;
+        f_row[j] = ok ? (unsigned)(x_base[j] + (hi >> a.up) * a.win + (wi >> a.up)) * cs2 + chunk16 : OOB;
+      }
+    }
+    const int soff = (src ? u_c - a.c0 : u_c) * 2;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const unsigned vo = live ? f_row[j] : OOB;
+      if (src) __builtin_amdgcn_raw_ptr_buffer_load_lds(rx1, (lds_ptr_t)(st + (32 * wave_s + 16 * j) * 64), 16, vo, soff, 0, 0);
+      else     __builtin_amdgcn_raw_ptr_buffer_load_lds(rx0, (lds_ptr_t)(st + (32 * wave_s + 16 * j) * 64), 16, vo, soff, 0, 0);
+    }
+    const int kb = f_ks * 64;                                // byte offset of the step inside a weight row
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      if (i == 2 && (NT != 5 || wave_s >= 2)) break;         // pieces 8, 9 exist for NT = 5 only (waves 0, 1)
+      const unsigned vo = live ? w_off[i] : OOB;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr_t)(st + BM * 64 + (wave_s + 4 * i) * 1024), 16, vo, kb, 0, 0);
+    }
+    ++f_ks;
+    if (live) {
+      u_c += 32;
+      if (u_c >= a.C) { u_c = 0; ++u_tap; if (++u_kx == a.kw) { u_kx = 0; ++u_ky; } }
+    }
+  };
+  // own requests of the two youngest steps may stay in flight (R = 5: waves 0, 1 with NT = 5; else 4)
+  auto wait_step = [&]() {
+    if (NT == 5 && wave_s < 2) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  };
+
+  f32x4 acc[NT][4];
+#pragma unroll
+  for (int i = 0; i < NT; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int r16 = lane & 15, g4 = lane >> 4;
+  const unsigned fsw = (((unsigned)g4 ^ ((0x1320u >> (((r16 >> 2) & 3) * 4)) & 3u)) << 4);
+  const unsigned char* xrd = lds + (wm * 64 + r16) * 64 + fsw;
+  const unsigned char* wrd = lds + BM * 64 + (wn * WAVE_N + r16) * 64 + fsw;
+
+  issue_step(); issue_step(); issue_step();
+#pragma clang loop unroll(disable)
+  for (int s = ks_begin; s < ks_end; ++s) {
+    wait_step();
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    const int so = (s & 3) * SLOT;
+    frag_t xf[4], wf[NT];
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) xf[mi] = __builtin_bit_cast(frag_t, ld16(xrd + so + mi * 16 * 64));
+#pragma unroll
+    for (int ni = 0; ni < NT; ++ni) wf[ni] = __builtin_bit_cast(frag_t, ld16(wrd + so + ni * 16 * 64));
+    __builtin_amdgcn_sched_barrier(0);
+    issue_step();                                            // step s + 3, behind the reads' latency
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ni = 0; ni < NT; ++ni)
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi)
+        acc[ni][mi] = TR ? mfma16(xf[mi], wf[ni], acc[ni][mi]) : mfma16(wf[ni], xf[mi], acc[ni][mi]);
+    __builtin_amdgcn_s_setprio(0);
+  }
+  // the ring becomes the epilogue's staging area: every request (also the all-zero ones) must have landed
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  float* stage = reinterpret_cast<float*>(lds) + wave * (STAGE_BYTES / 4);
+  igemm_epilogue<T, NT, TR, 32>(a, stage, acc, lane, group, n0 + wn * WAVE_N, m0 + wm * 64);
+}
+
 // split-K finish: sum the partial slabs, then the ordinary epilogue (bias, per-image vector, residual)
 template <typename T>
 __global__ __launch_bounds__(256) void igemm_splitk_reduce_kernel(const IgemmArgs a) {
@@ -1728,6 +1899,12 @@ static int launch_igemm(const mobi_igemm_params* p, const IgemmArgs& a, int grou
 #undef MOBI_GLDS_LAUNCH
   }
   else if (a.wm == 4) { if (nt5) MOBI_IGEMM_BY_TR(5, 4); else MOBI_IGEMM_BY_TR(4, 4); }
+  else if (a.sm) {
+#define MOBI_SM_LAUNCH(NT_, TR_) hipLaunchKernelGGL((igemm_sm_kernel<T, NT_, TR_>), grid, dim3(256), 0, st, a)
+    if (nt5) { if (tr) MOBI_SM_LAUNCH(5, true); else MOBI_SM_LAUNCH(5, false); }
+    else     { if (tr) MOBI_SM_LAUNCH(4, true); else MOBI_SM_LAUNCH(4, false); }
+#undef MOBI_SM_LAUNCH
+  }
   else                { if (nt5) MOBI_IGEMM_BY_TR(5, 2); else MOBI_IGEMM_BY_TR(4, 2); }
 #undef MOBI_IGEMM_BY_TR
 #undef MOBI_IGEMM_BY_FAST
@@ -1849,6 +2026,10 @@ static int igemm_prepare(const mobi_igemm_params* p, mobi::IgemmArgs& a) {
     if (p->k_order == 1 && !a.fast) return MOBI_ERR_UNSUPPORTED;      // the generic gather walks k tap-major only
     a.glds = 1;
     if (tuning().glds == 0) a.glds = 0;
+    // 128-pixel tiles: the LDS-DMA ring kernel whenever the 32-bit buffer offsets reach every operand byte and k runs
+    // tap-major (k-steps are 32 deep there: channel counts are multiples of 32 by the ABI's own rule)
+    a.sm = a.wm == 2 && p->k_order == 0 && ext0 < 0x7fffffffLL && ext1 < 0x7fffffffLL && wext < 0x7fffffffLL;
+    if (tuning().sm == 0) a.sm = 0;
     a.src0_bytes = (int)(ext0 < 0x7fffffffLL ? ext0 : 0);
     a.src1_bytes = (int)(ext1 < 0x7fffffffLL ? ext1 : 0);
     a.w_bytes = (int)(wext < 0x7fffffffLL ? wext : 0);
@@ -1901,5 +2082,6 @@ extern "C" int mobi_igemm_kernel_variant(const mobi_igemm_params* p) {
   const int rc = igemm_prepare(p, a);
   if (rc != MOBI_OK) return rc;
   if (a.wm == 4 && a.fast && a.glds) return a.pp ? MOBI_IGEMM_PINGPONG : MOBI_IGEMM_DIRECT_LDS;
-  return a.wm == 4 ? MOBI_IGEMM_STAGED_256 : MOBI_IGEMM_STAGED_128;
+  if (a.wm == 4) return MOBI_IGEMM_STAGED_256;
+  return a.sm ? MOBI_IGEMM_RING_128 : MOBI_IGEMM_STAGED_128;
 }

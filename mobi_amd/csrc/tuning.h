@@ -12,6 +12,7 @@ struct Tuning {
   int lin;              // MOBI_IGEMM_LIN             0: no linear window stepping (chunk-major k order)
   int epi_direct;       // MOBI_IGEMM_EPI_DIRECT      0: LDS-staged epilogue
   int pp;               // MOBI_IGEMM_PP              0: lockstep schedule instead of ping-pong
+  int sm;               // MOBI_IGEMM_SM              0: 128-pixel tiles on the register-staged kernel (A/B)
   int attn_nw;          // MOBI_ATTN_NW               4 | 8: waves per attention block
   int attn_sp;          // MOBI_ATTN_SP               1: software-pipelined attention kernel (dh 33..48)
 };

@@ -23,6 +23,7 @@ void read_env() {
   g_tuning.lin = env_int("MOBI_IGEMM_LIN");
   g_tuning.epi_direct = env_int("MOBI_IGEMM_EPI_DIRECT");
   g_tuning.pp = env_int("MOBI_IGEMM_PP");
+  g_tuning.sm = env_int("MOBI_IGEMM_SM");
   g_tuning.attn_nw = env_int("MOBI_ATTN_NW");
   g_tuning.attn_sp = env_int("MOBI_ATTN_SP");
 }

@@ -80,6 +80,13 @@ def install_stubs():
 
 def import_reference():
     install_stubs()
+    # the reference's `ldm` directory has no __init__.py (a namespace package), so ANY regular package called `ldm`
+    # further down sys.path would win over it -- and the repo root holds one (the alias of mobi_amd.ldm).  Take the repo
+    # root off the path for the import (everything this script needs from the repo is imported already).
+    for name in [n for n in sys.modules if n == "ldm" or n.startswith("ldm.")]:
+        del sys.modules[name]
+    sys.meta_path[:] = [f for f in sys.meta_path if type(f).__name__ != "_AliasFinder"]
+    sys.path[:] = [q for q in sys.path if os.path.abspath(q or ".") != REPO]
     sys.path.insert(0, REF)
     import ldm.modules.diffusionmodules.openaimodel as om
     import ldm.modules.diffusionmodules.model as vm
@@ -94,6 +101,7 @@ def import_reference():
     except Exception as e:                                   # pragma: no cover
         print("ddpm import failed:", repr(e))
         ddpm = None
+    assert os.path.abspath(om.__file__).startswith(os.path.abspath(REF)), om.__file__
     return types.SimpleNamespace(om=om, vm=vm, ut=ut, at=at, ddim=ddim, plms=plms, dist=dist, lu=lu, ddpm=ddpm)
 
 
