@@ -41,7 +41,7 @@ const char* mobi_error_string(int code);
 /* sizeof() of a parameter struct as the library was compiled; bindings compare it with
  * their own layout before the first call.  id: 0 igemm, 1 groupnorm, 2 layernorm,
  * 3 attention, 4 ctx_attention, 5 skinny_linear, 6 conv_small_cin, 7 conv_small_cout,
- * 8 ddim_step.  Returns 0 for an unknown id. */
+ * 8 ddim_step, 9 two_key_adapter, 10 range_paste, 11 lidar_metrics.  Returns 0 for an unknown id. */
 size_t mobi_struct_size(int id);
 /* Development hook: the library reads its MOBI_* A/B environment variables once, at the first launch
  * (mobi_amd/csrc/tuning.h lists them); this re-reads them.  Not needed by a product caller. */
@@ -321,6 +321,64 @@ int mobi_range_denorm(const float* sample, const float* min_d, const float* max_
 int mobi_q_sample(const float* x0, const float* noise, const int64_t* t, const float* sqrt_ac,
                   const float* sqrt_1m_ac, float* out, int32_t batch, int32_t per_image, int32_t table_len,
                   void* stream);
+
+/* ---------------------------------------------------------------------------
+ * Harness post-processing on the device.  All buffers are device memory.
+ * ------------------------------------------------------------------------- */
+/* Range view of one batch: postprocess_range_depth_int (ldm/data/utils.py:471-505) =
+ * LidarConverter.undo_default_transforms per sample (ldm/data/lidar_converter.py:436-485: avg-pool resize of the
+ * (hc, wc) sample to (h0, width_crop[b]) -- F.avg_pool2d with kernel (hc / h0, wc / width_crop[b]), sequential fp32
+ * window sums -- pasted over columns [crop_left[b] % w0, +width_crop[b]) of the original sweep, wrapping around),
+ * then, when `planes` is given, the harness's paste of scripts/inference_test_bench.py:567-610:
+ *   points = range2pcd(un-cropped depth, pitch, yaw)      (lidar_converter.py:122-172: (d + 1) / 2 * depth_max,
+ *            valid iff depth_min < depth < depth_max, x = cos(yaw) cos(pitch) d, y = -sin(yaw) cos(pitch) d, z = sin(pitch) d)
+ *   pred_mask = points_in_bbox_corners(points, box)        (ldm/data/box_np_ops.py:453-471, :736-771: a point is inside
+ *            iff x nx + y ny + z nz + d < 0 for all six surfaces; planes = f32 [batch][6][4] = (nx, ny, nz, d), computed
+ *            on the host from the 8 corners as surface_equ_3d does, :712-732)
+ *   final = where(pred_mask | gt_mask, un-cropped sample, original)
+ * sample_int / int_orig / int_unc / int_final may all be NULL (depth only); any output may be NULL. */
+typedef struct mobi_range_paste_params {
+  const float* sample_depth; const float* sample_int;       /* [batch][hc][wc] */
+  const float* depth_orig; const float* int_orig;           /* [batch][h0][w0] */
+  const float* pitch; const float* yaw;                     /* [batch][h0][w0] (needed with planes) */
+  const uint8_t* gt_mask;                                   /* [batch][h0][w0] or NULL */
+  const float* planes;                                      /* [batch][6][4] or NULL: un-crop only */
+  const int32_t* crop_left; const int32_t* width_crop;      /* [batch] */
+  float* depth_unc; float* int_unc; float* depth_final; float* int_final;   /* [batch][h0][w0] */
+  uint8_t* pred_mask;                                       /* [batch][h0][w0] */
+  int32_t batch, hc, wc, h0, w0;
+  float depth_min, depth_max;                               /* LidarConverter.depth_interval = (1.4, 54) */
+} mobi_range_paste_params;
+int mobi_range_paste(const mobi_range_paste_params* p, void* stream);
+
+/* Per-sample lidar error scores of LatentDiffusion.log_data (ddpm.py:1545-1590) for one (pred, gt) pair, without a
+ * host read-back per score: pred / gt are avg-pooled and the two masks max-pooled to (pool_h, width_crop[b])
+ * (pool_resize, lidar_converter.py:8-19); over the cells whose pooled mask == 1,
+ *   out[b][region][0] = sqrt(mean((pred - gt)^2)),  [1] = lower median of |pred - gt| (torch.median),  [2] = cell count
+ * region 0 = instance mask, 1 = box mask; an empty region gives NaN scores (the reference drops / propagates NaN).
+ * pred / gt / inst_mask / box_mask: f32 [batch][h][w]; max_width = max over b of width_crop[b] (sizes the sort space). */
+typedef struct mobi_lidar_metrics_params {
+  const float* pred; const float* gt; const float* inst_mask; const float* box_mask;
+  const int32_t* width_crop;
+  float* out;                                               /* [batch][2][3] */
+  int32_t batch, h, w, pool_h, max_width;
+} mobi_lidar_metrics_params;
+int mobi_lidar_metrics(const mobi_lidar_metrics_params* p, void* stream);
+
+/* Camera paste-back of one sample (scripts/inference_test_bench.py:478-510):
+ *   mobi_paste_patch    F.interpolate(patch, (crop_h, crop_w), bilinear, align_corners=False), (((x + 1) / 2) * 255)
+ *                       -> uint8, RGB planes -> BGR bytes, written into frame[top : top + crop_h, left : left + crop_w]
+ *                       (frame: u8 [H][W][3], zero-filled by the caller = np.zeros_like(image))
+ *   mobi_gaussian_blur  cv2.GaussianBlur(mask, (ksize, ksize), sigma) as a separable pass pair with BORDER_REFLECT_101;
+ *                       kern: f32 [ksize] taps (the host computes cv2.getGaussianKernel's formula); tmp: f32 [H][W]
+ *   mobi_blend_frame    image_recon = m * uint8(image) + (1 - m) * image_pred, f32 [H][W][3] BGR; image: f32 [3][H][W]
+ *                       RGB in [-1, 1] as the batch holds it */
+int mobi_paste_patch(const float* patch, int32_t hs, int32_t ws, uint8_t* frame, int32_t H, int32_t W, int32_t top,
+                     int32_t left, int32_t crop_h, int32_t crop_w, void* stream);
+int mobi_gaussian_blur(const float* src, float* tmp, float* dst, int32_t H, int32_t W, const float* kern, int32_t ksize,
+                       void* stream);
+int mobi_blend_frame(const float* mask_blur, const float* image, const uint8_t* pred, float* out, int32_t H, int32_t W,
+                     void* stream);
 
 /* ddim.py:145-148 with q_sample (ddpm.py:284-287):
  *   img = (sa[t]*x0 + s1ma[t]*noise) * mask + (1 - mask) * img

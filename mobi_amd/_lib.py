@@ -90,8 +90,21 @@ class DdimStepParams(C.Structure):
                 ("sqrt_one_minus_at", f32), ("temperature", f32), ("coef_dev", vp)]
 
 
+class RangePasteParams(C.Structure):
+    _fields_ = [("sample_depth", vp), ("sample_int", vp), ("depth_orig", vp), ("int_orig", vp), ("pitch", vp), ("yaw", vp),
+                ("gt_mask", vp), ("planes", vp), ("crop_left", vp), ("width_crop", vp), ("depth_unc", vp), ("int_unc", vp),
+                ("depth_final", vp), ("int_final", vp), ("pred_mask", vp), ("batch", i32), ("hc", i32), ("wc", i32),
+                ("h0", i32), ("w0", i32), ("depth_min", f32), ("depth_max", f32)]
+
+
+class LidarMetricsParams(C.Structure):
+    _fields_ = [("pred", vp), ("gt", vp), ("inst_mask", vp), ("box_mask", vp), ("width_crop", vp), ("out", vp),
+                ("batch", i32), ("h", i32), ("w", i32), ("pool_h", i32), ("max_width", i32)]
+
+
 STRUCT_IDS = {0: IgemmParams, 1: GroupNormParams, 2: LayerNormParams, 3: AttentionParams, 4: CtxAttentionParams,
-              5: SkinnyLinearParams, 6: ConvSmallCinParams, 7: ConvSmallCoutParams, 8: DdimStepParams, 9: TwoKeyAdapterParams}
+              5: SkinnyLinearParams, 6: ConvSmallCinParams, 7: ConvSmallCoutParams, 8: DdimStepParams, 9: TwoKeyAdapterParams,
+              10: RangePasteParams, 11: LidarMetricsParams}
 
 # every symbol include/mobi_engine.h declares: name -> (restype, argtypes)
 SYMBOLS = {
@@ -120,6 +133,11 @@ SYMBOLS = {
     "mobi_mask_blend": (C.c_int, [vp, vp, vp, vp, f32, f32, i32, i32, i32, vp]),
     "mobi_posterior_sample": (C.c_int, [vp, vp, vp, i32, i32, i32, i32, i32, f32, vp]),
     "mobi_range_denorm": (C.c_int, [vp, vp, vp, f32, f32, f32, f32, i32, i32, vp, vp, i32, i32, vp]),
+    "mobi_range_paste": (C.c_int, [C.POINTER(RangePasteParams), vp]),
+    "mobi_lidar_metrics": (C.c_int, [C.POINTER(LidarMetricsParams), vp]),
+    "mobi_paste_patch": (C.c_int, [vp, i32, i32, vp, i32, i32, i32, i32, i32, i32, vp]),
+    "mobi_gaussian_blur": (C.c_int, [vp, vp, vp, i32, i32, vp, i32, vp]),
+    "mobi_blend_frame": (C.c_int, [vp, vp, vp, vp, i32, i32, vp]),
     "mobi_nearest_resize": (C.c_int, [vp, vp, i32, i32, i32, i32, i32, i32, vp]),
     "mobi_pack_nchw_sources": (C.c_int, [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, i32, vp]),
     "mobi_nchw_f32_to_nhwc": (C.c_int, [vp, vp, i32, i32, i32, i32, vp]),

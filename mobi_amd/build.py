@@ -20,7 +20,7 @@ ARCH = "gfx950"
 
 # per-file extra flags; sampler arithmetic is kept un-contracted (no FMA fusion) so the
 # fp32 latent update is bit-identical to the reference's separate mul / add ops
-EXTRA = {"sampler_ops.hip": ["-ffp-contract=off"]}
+EXTRA = {"sampler_ops.hip": ["-ffp-contract=off"], "postprocess.hip": ["-ffp-contract=off"]}
 
 
 def sources():

@@ -1927,7 +1927,8 @@ static int plan_splits(long long M, int n_packed, int ktot) {
   if (tiles >= 384 || nk < 16) return 1;
   if (tiles >= 256 && nk < 40) return 1;        // measured (tools/sweep_split.py): one full wave of blocks, short k
   long long s = (512 + tiles - 1) / tiles;
-  if (s > 8) s = 8;
+  const long long cap = tiles <= 16 ? 16 : 8;               // a handful of tiles (the 4x4 / 8x8 levels): measured best at 16
+  if (s > cap) s = cap;
   if (s > nk / 8) s = nk / 8;
   return s < 2 ? 1 : (int)s;
 }

@@ -1,0 +1,260 @@
+// Harness post-processing on the device: what scripts/inference_test_bench.py and
+// LatentDiffusion.log_data do with numpy / cv2 / torch-CPU after decoding, one D2H hop per sample today:
+//   range view   un-crop of the 512 x 512 sample back into the 32 x 1096 sweep (avg-pool resize + wrap-around paste),
+//                points-in-box instance mask of the predicted object, np.where paste          -> range_paste_kernel
+//   metrics      avg / max pooled per-sample RMSE and (lower) median error over the object and mask regions,
+//                written to a device table (one read-back per batch instead of ~100 .item() syncs) -> lidar_metrics_kernel
+//   camera       bilinear patch resize + uint8 conversion + paste, 15 x 15 Gaussian blur of the mask
+//                (BORDER_REFLECT_101), blend                                                  -> paste / blur / blend kernels
+// Compiled with -ffp-contract=off: the fp32 expressions are evaluated in the reference's order without FMA fusion.
+#include "common.h"
+
+namespace mobi {
+
+// avg_pool2d with kernel = stride = (kh, kw), as torch-CPU evaluates it: a sequential fp32 sum over the window in
+// (row, column) order, then one division by the window size (lidar_converter.py:8-19 -> F.avg_pool2d)
+__device__ __forceinline__ float avg_window(const float* img, int w, int y0, int x0, int kh, int kw) {
+  float sum = 0.f;
+  for (int dy = 0; dy < kh; ++dy)
+    for (int dx = 0; dx < kw; ++dx) sum += img[(long long)(y0 + dy) * w + x0 + dx];
+  return sum / (float)(kh * kw);
+}
+__device__ __forceinline__ float max_window(const float* img, int w, int y0, int x0, int kh, int kw) {
+  float m = -INFINITY;
+  for (int dy = 0; dy < kh; ++dy)
+    for (int dx = 0; dx < kw; ++dx) m = fmaxf(m, img[(long long)(y0 + dy) * w + x0 + dx]);
+  return m;
+}
+
+__global__ void range_paste_kernel(const mobi_range_paste_params a) {
+  const long long per = (long long)a.h0 * a.w0;
+  const long long total = (long long)a.batch * per;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int b = (int)(i / per);
+    const int p = (int)(i - (long long)b * per);
+    const int y = p / a.w0, x = p - y * a.w0;
+    // LidarConverter.undo_default_transforms (lidar_converter.py:436-485): the crop window [crop_left, crop_left + wc)
+    // wraps around the sweep; inside it the sample is avg-pooled from (hc, wc_in) to (h0, wc)
+    const int wc = a.width_crop[b];
+    int cl = a.crop_left[b] % a.w0;
+    if (cl < 0) cl += a.w0;                                   // Python's % is non-negative
+    int rel = x - cl;
+    if (rel < 0) rel += a.w0;
+    const bool inside = rel < wc;
+    float d = a.depth_orig[i], it = a.int_orig ? a.int_orig[i] : 0.f;
+    if (inside) {
+      const int kh = a.hc / a.h0, kw = a.wc / wc;
+      d = avg_window(a.sample_depth + (long long)b * a.hc * a.wc, a.wc, y * kh, rel * kw, kh, kw);
+      if (a.sample_int) it = avg_window(a.sample_int + (long long)b * a.hc * a.wc, a.wc, y * kh, rel * kw, kh, kw);
+    }
+    if (a.depth_unc) a.depth_unc[i] = d;
+    if (a.int_unc) a.int_unc[i] = it;
+    if (!a.planes) continue;
+    // LidarConverter.range2pcd (:122-172): metric depth, validity window, spherical -> Cartesian
+    float dm = (d + 1.0f) / 2.0f;
+    dm = dm * a.depth_max;
+    const bool valid = dm > a.depth_min && dm < a.depth_max;
+    const float yaw = a.yaw[i], pitch = a.pitch[i];
+    const float cp = cosf(pitch);
+    const float px = cosf(yaw) * cp * dm;
+    const float py = -sinf(yaw) * cp * dm;
+    const float pz = sinf(pitch) * dm;
+    // points_in_convex_polygon_3d_jit (box_np_ops.py:736-771): inside iff every surface's sign is negative
+    bool in_box = valid;
+    const float* pl = a.planes + (long long)b * 24;
+    for (int k = 0; k < 6 && in_box; ++k) {
+      const float sign = px * pl[4 * k] + py * pl[4 * k + 1] + pz * pl[4 * k + 2] + pl[4 * k + 3];
+      if (sign >= 0.f) in_box = false;
+    }
+    if (a.pred_mask) a.pred_mask[i] = in_box ? 1 : 0;
+    const bool paste = in_box || (a.gt_mask && a.gt_mask[i] != 0);       // np.logical_or(pred, gt)
+    if (a.depth_final) a.depth_final[i] = paste ? d : a.depth_orig[i];
+    if (a.int_final) a.int_final[i] = paste ? it : (a.int_orig ? a.int_orig[i] : 0.f);
+  }
+}
+
+// one block per (sample, region): region 0 = object (instance mask), 1 = inpainting mask
+__global__ __launch_bounds__(1024) void lidar_metrics_kernel(const mobi_lidar_metrics_params a) {
+  extern __shared__ float vals[];                            // [cap] absolute errors of the region, then sorted
+  __shared__ unsigned n_vals;
+  __shared__ double red[1024];
+  const int b = blockIdx.x, region = blockIdx.y, tid = threadIdx.x;
+  const int wc = a.width_crop[b];
+  const int kh = a.h / a.pool_h, kw = a.w / wc;
+  const int cells = a.pool_h * wc;
+  const float* pred = a.pred + (long long)b * a.h * a.w;
+  const float* gt = a.gt + (long long)b * a.h * a.w;
+  const float* msk = (region == 0 ? a.inst_mask : a.box_mask) + (long long)b * a.h * a.w;
+  if (tid == 0) n_vals = 0;
+  __syncthreads();
+  double sq = 0.0;
+  for (int c = tid; c < cells; c += blockDim.x) {
+    const int y = c / wc, x = c - y * wc;
+    if (max_window(msk, a.w, y * kh, x * kw, kh, kw) != 1.0f) continue;      // `mask_ == 1` after max pooling
+    const float e = avg_window(pred, a.w, y * kh, x * kw, kh, kw) - avg_window(gt, a.w, y * kh, x * kw, kh, kw);
+    sq += (double)e * (double)e;
+    vals[atomicAdd(&n_vals, 1u)] = fabsf(e);
+  }
+  red[tid] = sq;
+  __syncthreads();
+  for (int s = 512; s > 0; s >>= 1) {                        // fixed-order tree: deterministic
+    if (tid < s) red[tid] += red[tid + s];
+    __syncthreads();
+  }
+  const unsigned n = n_vals;
+  unsigned cap = 1;
+  while (cap < n) cap <<= 1;
+  for (unsigned i = n + tid; i < cap; i += blockDim.x) vals[i] = INFINITY;
+  __syncthreads();
+  for (unsigned k = 2; k <= cap; k <<= 1)                    // bitonic sort (ascending)
+    for (unsigned j = k >> 1; j > 0; j >>= 1) {
+      for (unsigned i = tid; i < cap; i += blockDim.x) {
+        const unsigned l = i ^ j;
+        if (l > i) {
+          const float x = vals[i], y = vals[l];
+          const bool up = (i & k) == 0;
+          if ((x > y) == up) { vals[i] = y; vals[l] = x; }
+        }
+      }
+      __syncthreads();
+    }
+  if (tid == 0) {
+    float* o = a.out + ((long long)b * 2 + region) * 3;
+    o[0] = n ? (float)sqrt(red[0] / (double)n) : NAN;        // (((pred - gt) ** 2).mean() ** 0.5), ddpm.py:1576-1584
+    o[1] = n ? vals[(n - 1) >> 1] : NAN;                     // torch.median: the lower of the two middle values
+    o[2] = (float)n;
+  }
+}
+
+// F.interpolate(patch, (crop_h, crop_w), mode="bilinear") [align_corners=False], then the harness's
+// (((x + 1) / 2) * 255).astype(uint8) in BGR order, written into the frame at (top, left)
+__global__ void paste_patch_kernel(const float* patch, int hs, int ws, unsigned char* frame, int H, int W, int top,
+                                   int left, int crop_h, int crop_w) {
+  const float sy = (float)hs / (float)crop_h, sx = (float)ws / (float)crop_w;
+  const long long total = (long long)crop_h * crop_w;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int y = (int)(i / crop_w), x = (int)(i - (long long)y * crop_w);
+    const int fy = top + y, fx = left + x;
+    if (fy < 0 || fy >= H || fx < 0 || fx >= W) continue;
+    float syf = sy * ((float)y + 0.5f) - 0.5f;
+    if (syf < 0.f) syf = 0.f;
+    float sxf = sx * ((float)x + 0.5f) - 0.5f;
+    if (sxf < 0.f) sxf = 0.f;
+    const int y0 = (int)syf, x0 = (int)sxf;
+    const int y1 = y0 + (y0 < hs - 1 ? 1 : 0), x1 = x0 + (x0 < ws - 1 ? 1 : 0);
+    const float ly = syf - (float)y0, lx = sxf - (float)x0;
+    const float hy = 1.0f - ly, hx = 1.0f - lx;
+    for (int c = 0; c < 3; ++c) {
+      const float* pc = patch + (long long)c * hs * ws;
+      const float v = hy * (hx * pc[(long long)y0 * ws + x0] + lx * pc[(long long)y0 * ws + x1]) +
+                      ly * (hx * pc[(long long)y1 * ws + x0] + lx * pc[(long long)y1 * ws + x1]);
+      float u = ((v + 1.0f) / 2.0f) * 255.0f;
+      u = u < 0.f ? 0.f : (u > 255.f ? 255.f : u);           // (astype wraps out-of-range values; the sample is clamped to [-1, 1])
+      frame[((long long)fy * W + fx) * 3 + (2 - c)] = (unsigned char)(int)u;     // RGB plane c -> BGR byte 2 - c
+    }
+  }
+}
+
+// one pass of the separable blur along x (horizontal = 1) or y; BORDER_REFLECT_101: index -i -> i, n - 1 + i -> n - 1 - i
+__global__ void blur_pass_kernel(const float* src, float* dst, int H, int W, const float* kern, int ksize, int horizontal) {
+  const int r = ksize >> 1;
+  const long long total = (long long)H * W;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int y = (int)(i / W), x = (int)(i - (long long)y * W);
+    const int n = horizontal ? W : H, p = horizontal ? x : y;
+    float acc = 0.f;
+    for (int k = 0; k < ksize; ++k) {
+      int q = p + k - r;
+      if (n == 1) q = 0;
+      else {
+        while (q < 0 || q >= n) q = q < 0 ? -q : 2 * (n - 1) - q;
+      }
+      acc += kern[k] * (horizontal ? src[(long long)y * W + q] : src[(long long)q * W + x]);
+    }
+    dst[i] = acc;
+  }
+}
+
+// image_recon = m * image_u8 + (1 - m) * image_pred  (inference_test_bench.py:508-509); image: f32 [3][H][W] RGB in
+// [-1, 1] (converted to uint8 BGR as the harness does), pred: u8 [H][W][3] BGR, out: f32 [H][W][3] BGR
+__global__ void blend_kernel(const float* mask_blur, const float* image, const unsigned char* pred, float* out, int H,
+                             int W) {
+  const long long total = (long long)H * W;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const float m = mask_blur[i];
+    for (int c = 0; c < 3; ++c) {
+      float u = ((image[(long long)(2 - c) * total + i] + 1.0f) / 2.0f) * 255.0f;
+      u = u < 0.f ? 0.f : (u > 255.f ? 255.f : u);
+      const float iu = (float)(unsigned char)(int)u;
+      out[i * 3 + c] = m * iu + (1.0f - m) * (float)pred[i * 3 + c];
+    }
+  }
+}
+
+static inline int egrid_pp(long long n) {
+  long long b = (n + 255) / 256;
+  return (int)(b < 1 ? 1 : (b > 8192 ? 8192 : b));
+}
+
+}  // namespace mobi
+
+using namespace mobi;
+#define ST(stream) reinterpret_cast<hipStream_t>(stream)
+
+extern "C" int mobi_range_paste(const mobi_range_paste_params* p, void* stream) {
+  if (!p || !p->sample_depth || !p->depth_orig || !p->crop_left || !p->width_crop) return MOBI_ERR_ARG;
+  if (p->batch <= 0 || p->hc <= 0 || p->wc <= 0 || p->h0 <= 0 || p->w0 <= 0 || p->hc % p->h0) return MOBI_ERR_ARG;
+  if (p->planes && (!p->pitch || !p->yaw)) return MOBI_ERR_ARG;
+  if ((p->sample_int != nullptr) != (p->int_orig != nullptr)) return MOBI_ERR_ARG;
+  hipLaunchKernelGGL(range_paste_kernel, dim3(egrid_pp((long long)p->batch * p->h0 * p->w0)), dim3(256), 0, ST(stream), *p);
+  MOBI_CHECK_LAUNCH();
+  return MOBI_OK;
+}
+
+extern "C" int mobi_lidar_metrics(const mobi_lidar_metrics_params* p, void* stream) {
+  if (!p || !p->pred || !p->gt || !p->inst_mask || !p->box_mask || !p->width_crop || !p->out) return MOBI_ERR_ARG;
+  if (p->batch <= 0 || p->h <= 0 || p->w <= 0 || p->pool_h <= 0 || p->h % p->pool_h || p->max_width <= 0) return MOBI_ERR_ARG;
+  unsigned cap = 1;
+  while (cap < (unsigned)(p->pool_h * p->max_width)) cap <<= 1;
+  const size_t shmem = (size_t)cap * sizeof(float);
+  if (shmem > 120 * 1024) return MOBI_ERR_UNSUPPORTED;
+  if (shmem > 48 * 1024 &&
+      hipFuncSetAttribute(reinterpret_cast<const void*>(lidar_metrics_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                          (int)shmem) != hipSuccess)
+    return MOBI_ERR_LAUNCH;
+  hipLaunchKernelGGL(lidar_metrics_kernel, dim3(p->batch, 2), dim3(1024), shmem, ST(stream), *p);
+  MOBI_CHECK_LAUNCH();
+  return MOBI_OK;
+}
+
+extern "C" int mobi_paste_patch(const float* patch, int32_t hs, int32_t ws, uint8_t* frame, int32_t H, int32_t W,
+                                int32_t top, int32_t left, int32_t crop_h, int32_t crop_w, void* stream) {
+  if (!patch || !frame || hs <= 0 || ws <= 0 || H <= 0 || W <= 0 || crop_h <= 0 || crop_w <= 0) return MOBI_ERR_ARG;
+  hipLaunchKernelGGL(paste_patch_kernel, dim3(egrid_pp((long long)crop_h * crop_w)), dim3(256), 0, ST(stream), patch, hs,
+                     ws, frame, H, W, top, left, crop_h, crop_w);
+  MOBI_CHECK_LAUNCH();
+  return MOBI_OK;
+}
+
+extern "C" int mobi_gaussian_blur(const float* src, float* tmp, float* dst, int32_t H, int32_t W, const float* kern,
+                                  int32_t ksize, void* stream) {
+  if (!src || !tmp || !dst || !kern || H <= 0 || W <= 0 || ksize <= 0 || !(ksize & 1)) return MOBI_ERR_ARG;
+  const int g = egrid_pp((long long)H * W);
+  hipLaunchKernelGGL(blur_pass_kernel, dim3(g), dim3(256), 0, ST(stream), src, tmp, H, W, kern, ksize, 1);
+  hipLaunchKernelGGL(blur_pass_kernel, dim3(g), dim3(256), 0, ST(stream), (const float*)tmp, dst, H, W, kern, ksize, 0);
+  MOBI_CHECK_LAUNCH();
+  return MOBI_OK;
+}
+
+extern "C" int mobi_blend_frame(const float* mask_blur, const float* image, const uint8_t* pred, float* out, int32_t H,
+                                int32_t W, void* stream) {
+  if (!mask_blur || !image || !pred || !out || H <= 0 || W <= 0) return MOBI_ERR_ARG;
+  hipLaunchKernelGGL(blend_kernel, dim3(egrid_pp((long long)H * W)), dim3(256), 0, ST(stream), mask_blur, image, pred, out,
+                     H, W);
+  MOBI_CHECK_LAUNCH();
+  return MOBI_OK;
+}

@@ -225,6 +225,8 @@ extern "C" size_t mobi_struct_size(int id) {
     case 7: return sizeof(mobi_conv_small_cout_params);
     case 8: return sizeof(mobi_ddim_step_params);
     case 9: return sizeof(mobi_two_key_adapter_params);
+    case 10: return sizeof(mobi_range_paste_params);
+    case 11: return sizeof(mobi_lidar_metrics_params);
     default: return 0;
   }
 }

@@ -564,3 +564,91 @@ def nearest_resize(src, hout, wout, out=None, c_off=0):
         _lib.check(lib.mobi_nearest_resize(_ptr(src), C.c_void_p(view.data_ptr()), b, h, w, hout, wout,
                                            ct * hout * wout, _stream()), "mobi_nearest_resize")
     return out
+
+
+# --------------------------------------------------------------------------------------
+# harness post-processing
+# --------------------------------------------------------------------------------------
+def _i32(t, device):
+    return torch.as_tensor(t).to(device=device, dtype=torch.int32).reshape(-1).contiguous()
+
+
+def range_paste(sample_depth, depth_orig, crop_left, width_crop, sample_int=None, int_orig=None, pitch=None, yaw=None,
+                planes=None, gt_mask=None, depth_interval=(1.4, 54.0)):
+    """sample_*: fp32 [B, Hc, Wc] (de-normalised range sample), *_orig: fp32 [B, H0, W0]; crop_left / width_crop: [B] ints.
+    Returns dict(depth_unc, int_unc[, depth_final, int_final, pred_mask]) -- include/mobi_engine.h, mobi_range_paste."""
+    lib = _lib.load()
+    dev = sample_depth.device
+    b, hc, wc = sample_depth.shape
+    _, h0, w0 = depth_orig.shape
+    f = lambda t: None if t is None else _dev(t).to(torch.float32).contiguous()
+    sample_depth, sample_int, depth_orig, int_orig, pitch, yaw, planes = map(
+        f, (sample_depth, sample_int, depth_orig, int_orig, pitch, yaw, planes))
+    cl, wcr = _i32(crop_left, dev), _i32(width_crop, dev)
+    assert cl.numel() == wcr.numel() == b and depth_orig.shape[0] == b
+    out = {"depth_unc": torch.empty_like(depth_orig)}
+    if sample_int is not None:
+        out["int_unc"] = torch.empty_like(depth_orig)
+    gm = None
+    if planes is not None:
+        assert planes.shape == (b, 6, 4) and pitch.shape == yaw.shape == depth_orig.shape
+        out["depth_final"] = torch.empty_like(depth_orig)
+        if sample_int is not None:
+            out["int_final"] = torch.empty_like(depth_orig)
+        out["pred_mask"] = torch.empty(depth_orig.shape, device=dev, dtype=torch.uint8)
+        gm = None if gt_mask is None else gt_mask.to(device=dev, dtype=torch.uint8).contiguous()
+    p = _lib.RangePasteParams()
+    p.sample_depth, p.sample_int, p.depth_orig, p.int_orig = _ptr(sample_depth), _ptr(sample_int), _ptr(depth_orig), _ptr(int_orig)
+    p.pitch, p.yaw, p.gt_mask, p.planes = _ptr(pitch), _ptr(yaw), _ptr(gm), _ptr(planes)
+    p.crop_left, p.width_crop = _ptr(cl), _ptr(wcr)
+    p.depth_unc, p.int_unc = _ptr(out["depth_unc"]), _ptr(out.get("int_unc"))
+    p.depth_final, p.int_final, p.pred_mask = _ptr(out.get("depth_final")), _ptr(out.get("int_final")), _ptr(out.get("pred_mask"))
+    p.batch, p.hc, p.wc, p.h0, p.w0 = b, hc, wc, h0, w0
+    p.depth_min, p.depth_max = float(depth_interval[0]), float(depth_interval[1])
+    _lib.check(lib.mobi_range_paste(C.byref(p), _stream()), "mobi_range_paste")
+    return out
+
+
+def lidar_metrics(pred, gt, inst_mask, box_mask, width_crop, pool_h=32):
+    """fp32 [B, H, W] each (0/1 masks) -> fp32 [B, 2 regions (object, mask), 3 (rmse, median, count)] on the device."""
+    lib = _lib.load()
+    dev = pred.device
+    b, h, w = pred.shape
+    f = lambda t: _dev(t).to(torch.float32).reshape(b, h, w).contiguous()
+    pred, gt, inst_mask, box_mask = map(f, (pred, gt, inst_mask, box_mask))
+    wcr = _i32(width_crop, dev)
+    out = torch.empty((b, 2, 3), device=dev, dtype=torch.float32)
+    p = _lib.LidarMetricsParams()
+    p.pred, p.gt, p.inst_mask, p.box_mask, p.width_crop, p.out = _ptr(pred), _ptr(gt), _ptr(inst_mask), _ptr(box_mask), _ptr(wcr), _ptr(out)
+    p.batch, p.h, p.w, p.pool_h, p.max_width = b, h, w, pool_h, w       # width_crop <= w: sort space for the widest case
+    _lib.check(lib.mobi_lidar_metrics(C.byref(p), _stream()), "mobi_lidar_metrics")
+    return out
+
+
+def paste_patch(patch, frame, top, left, crop_h, crop_w):
+    """patch: fp32 [3, hs, ws] RGB in [-1, 1]; frame: uint8 [H, W, 3] BGR (written in place)."""
+    lib = _lib.load()
+    assert patch.dtype == torch.float32 and patch.is_contiguous() and frame.dtype == torch.uint8 and frame.is_contiguous()
+    _lib.check(lib.mobi_paste_patch(_ptr(patch), patch.shape[1], patch.shape[2], _ptr(frame), frame.shape[0], frame.shape[1],
+                                    int(top), int(left), int(crop_h), int(crop_w), _stream()), "mobi_paste_patch")
+    return frame
+
+
+def gaussian_blur(src, kern):
+    """src: fp32 [H, W]; kern: fp32 [ksize] taps; BORDER_REFLECT_101."""
+    lib = _lib.load()
+    assert src.dtype == torch.float32 and src.is_contiguous() and kern.dtype == torch.float32 and kern.is_contiguous()
+    tmp, dst = torch.empty_like(src), torch.empty_like(src)
+    _lib.check(lib.mobi_gaussian_blur(_ptr(src), _ptr(tmp), _ptr(dst), src.shape[0], src.shape[1], _ptr(kern), kern.numel(),
+                                      _stream()), "mobi_gaussian_blur")
+    return dst
+
+
+def blend_frame(mask_blur, image, pred):
+    """mask_blur fp32 [H, W], image fp32 [3, H, W] RGB in [-1, 1], pred uint8 [H, W, 3] BGR -> fp32 [H, W, 3] BGR."""
+    lib = _lib.load()
+    h, w = mask_blur.shape
+    assert image.shape == (3, h, w) and pred.shape == (h, w, 3) and image.is_contiguous() and pred.is_contiguous()
+    out = torch.empty((h, w, 3), device=mask_blur.device, dtype=torch.float32)
+    _lib.check(lib.mobi_blend_frame(_ptr(mask_blur), _ptr(image), _ptr(pred), _ptr(out), h, w, _stream()), "mobi_blend_frame")
+    return out

@@ -21,8 +21,7 @@ import make_golden as MG                             # noqa: E402  (stubs for th
 
 
 def main():
-    MG.install_stubs()
-    sys.path.insert(0, MG.REF)
+    MG.import_reference()                              # stubs + the reference's `ldm` first on the path
     from ldm.data.utils import inverse_depth_normalization
     alpha = 0.75
     b, h, w = 3, 16, 24

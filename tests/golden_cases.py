@@ -25,7 +25,7 @@ UNET_SEED, VAE_SEED, OPS_SEED = 7, 11, 1
 
 def load(name):
     with np.load(os.path.join(GOLDEN, name + ".npz")) as z:
-        return {k: torch.from_numpy(z[k]) if z[k].dtype != object else z[k] for k in z.files}
+        return {k: torch.from_numpy(z[k]) if z[k].dtype.kind in "fiub" else z[k] for k in z.files}
 
 
 def record(name, err, tol=float("nan")):
