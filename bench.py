@@ -350,7 +350,7 @@ def main():
         dom = max(by_variant, key=lambda v: by_variant[v]["ms"]) if by_variant else "igemm"
         dk = by_variant.get(dom, ig)
         kname = {"pingpong": "igemm_pp_kernel", "direct_lds": "igemm_glds_kernel", "staged128": "igemm_kernel",
-                 "staged256": "igemm_kernel", "ring128": "igemm_sm_kernel"}.get(dom, "igemm_kernel")
+                 "staged256": "igemm_kernel", "ring128": "igemm_ring_kernel", "ring256": "igemm_ring_kernel", "ring128w": "igemm_ring_kernel"}.get(dom, "igemm_kernel")
         ach = dk["flops"] / (dk["ms"] * 1e-3) / 1e12
         roofline = {"bound": "mfma", "kernel": kname, "achieved": round(ach, 2), "peak": PEAK_TFLOPS,
                     "unit": "TFLOP/s", "frac": round(ach / PEAK_TFLOPS, 4), "traffic": None,

@@ -68,8 +68,10 @@ def build(force=False, verbose=True):
     def compile_one(src):
         obj = os.path.join(OBJ, src.replace(".hip", ".o"))
         cmd = common + EXTRA.get(src, []) + ["-c", os.path.join(CSRC, src), "-o", obj]
+        if os.path.exists(obj):
+            os.remove(obj)                      # a failed compile must never leave yesterday's object to be linked
         r = subprocess.run(cmd, capture_output=True, text=True)
-        if r.returncode != 0:
+        if r.returncode != 0 or not os.path.exists(obj) or "error:" in r.stderr:
             raise RuntimeError(f"hipcc failed on {src}:\n{r.stderr}")
         return obj
 

@@ -14,7 +14,7 @@
 //                      launch whose tiles are full, whose output is row-major T and that has at most one of
 //                      bias / per-image vector; also the split-K launches with long k ranges (fp32 slabs).
 //   igemm_glds_kernel  same geometry in lockstep, LDS-staged epilogues (transposed / fp32 / ragged / bias AND vector)
-//   igemm_sm_kernel    128-pixel tiles, four waves, two blocks per CU, operands by LDS-DMA into a ring of four 32-deep
+//   igemm_ring_kernel    128-pixel tiles, four waves, two blocks per CU, operands by LDS-DMA into a ring of four 32-deep
 //                      k-slots: small m, split-K ranges, ragged tiles, every output mode
 //   igemm_kernel       128- / 256-pixel tiles staged through registers: operands beyond 2 GB, chunk-major k
 #include <stdlib.h>
@@ -56,6 +56,9 @@
 #endif
 #ifndef MOBI_PP_PRIO
 #define MOBI_PP_PRIO 1     // ping-pong kernel: s_setprio of the MATRIX phase
+#endif
+#ifndef MOBI_RING_STAGGER
+#define MOBI_RING_STAGGER 1 // 256 x 320 ring kernel: waves 4-7 half a step behind waves 0-3 (0: lockstep, A/B)
 #endif
 #ifndef MOBI_STAMP
 #define MOBI_STAMP 0       // 1: in-kernel phase stamps of the direct-to-LDS kernel (tools/stamp_igemm.py), never in a release build
@@ -119,7 +122,8 @@ struct IgemmArgs {
   int lin_window;          // direct-to-LDS kernel: window pixels are linear in the tap (no upsampling, <= 16 taps)
   int epi_direct;          // direct-to-LDS kernel: register epilogue (full tiles, row-major T output)
   int pp;                  // register-epilogue launch on the ping-pong kernel
-  int sm;                  // 128-pixel tiles on the LDS-DMA ring kernel (igemm_sm_kernel)
+  int sm;                  // 128-pixel tiles on the LDS-DMA ring kernel (igemm_ring_kernel<.., false>)
+  int wide;                // ring kernel with eight waves: 2 = 256 x 320 (256) tiles, 1 = 128 x 320 (256) tiles
   int hw_shift, w_shift;   // log2(hw_out), log2(wout) when both are powers of two (ping-pong kernel), else -1
 };
 
@@ -1650,17 +1654,25 @@ __global__ __launch_bounds__(512, 2) void igemm_pp_kernel(const IgemmArgs a) {
 // end of its k range (all-zero pieces into slots nobody reads), so that every wait is the immediate vmcnt(2 R).
 // Epilogue: the LDS-staged one (all output modes, split-K slabs, ragged tiles) through the drained ring.
 // =========================================================================================================
-template <typename T, int NT, bool TR>
-__global__ __launch_bounds__(256, 2) void igemm_sm_kernel(const IgemmArgs a) {
+// Geometries (NW waves as 2 along pixels x NW / 2 along channels; MT 16-pixel MFMA tiles per wave):
+//   NW 4, MT 4  128 x (2 WAVE_N) tile, wave tile  64 x WAVE_N, two blocks per CU          (small m)
+//   NW 8, MT 4  128 x (4 WAVE_N) tile, wave tile  64 x WAVE_N, one block per CU           (medium m: twice the blocks)
+//   NW 8, MT 8  256 x (4 WAVE_N) tile, wave tile 128 x WAVE_N, one block per CU: 29 % fewer operand bytes per FLOP than
+//               the 256 x 160 tile of the ping-pong kernel (the LDS-DMA path accepts ~42 B per clock and CU, which is
+//               exactly what that tile needs at full matrix rate) and 13 instead of 18 fragment reads per 40 MFMAs
+template <typename T, int NT, bool TR, int NW, int MT>
+__global__ __launch_bounds__(NW * 64, 2) void igemm_ring_kernel(const IgemmArgs a) {
   typedef typename Vec8<T>::type frag_t;
-  constexpr int BM = 128;
+  constexpr bool WIDE = NW == 8;                             // eight waves: the two halves run half a step apart
+  constexpr int BM = 2 * MT * 16;
+  constexpr int APW = BM / 16 / NW;                          // 1-KiB activation requests per wave and k-step (1 | 2)
   constexpr int WAVE_N = NT * 16;
-  constexpr int BN = 2 * WAVE_N;
-  constexpr int WPIECES = BN / 16;                           // 1-KiB weight requests per k-step (10 | 8)
+  constexpr int BN = (NW / 2) * WAVE_N;
+  constexpr int WPIECES = BN / 16;                           // 1-KiB weight requests per k-step
   constexpr int SLOT = (BM + BN) * 64;                       // bytes per 32-deep k-slot
   constexpr int RING = 4 * SLOT;
   constexpr int STAGE_BYTES = EpiGeom<32, TR, NT>::BYTES;    // per wave
-  constexpr int LDS_BYTES = RING > 4 * STAGE_BYTES ? RING : 4 * STAGE_BYTES;
+  constexpr int LDS_BYTES = RING > NW * STAGE_BYTES ? RING : NW * STAGE_BYTES;
   constexpr unsigned OOB = 0x80000000u;
   __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
   typedef __attribute__((address_space(3))) void* lds_ptr_t;
@@ -1683,11 +1695,11 @@ __global__ __launch_bounds__(256, 2) void igemm_sm_kernel(const IgemmArgs a) {
   const int rp = lane >> 2;
   const unsigned perm = (0x1320u >> (((rp >> 2) & 3) * 4)) & 3u;              // P = {0, 2, 3, 1}
   const unsigned chunk16 = (((unsigned)lane & 3u) ^ perm) * 16u;
-  int x_base[2], x_h[2], x_w[2];                             // activation rows 32 * wave + 16 j + rp of the tile
-  bool x_ok[2];
+  int x_base[APW], x_h[APW], x_w[APW];                       // activation rows 16 * (APW * wave + j) + rp of the tile
+  bool x_ok[APW];
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int m = m0 + 32 * wave + 16 * j + rp;
+  for (int j = 0; j < APW; ++j) {
+    const int m = m0 + 16 * (APW * wave + j) + rp;
     x_ok[j] = m < a.M;
     const int mm = x_ok[j] ? m : 0;
     const int img = mm / a.hw_out, rem = mm - img * a.hw_out;
@@ -1696,10 +1708,10 @@ __global__ __launch_bounds__(256, 2) void igemm_sm_kernel(const IgemmArgs a) {
     x_h[j] = ho * a.stride - a.pad_h;
     x_w[j] = wo * a.stride - a.pad_w;
   }
-  unsigned w_off[3];                                         // weight rows 16 * (wave + 4 i) + rp of the tile
+  unsigned w_off[3];                                         // weight rows 16 * (wave + NW i) + rp of the tile
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
-    const int piece = wave + 4 * i;
+    const int piece = wave + NW * i;
     const int n = n0 + 16 * piece + rp;
     w_off[i] = (piece < WPIECES && n < a.n_packed) ? (unsigned)n * (unsigned)a.ktot * 2u + chunk16 : OOB;
   }
@@ -1714,7 +1726,9 @@ __global__ __launch_bounds__(256, 2) void igemm_sm_kernel(const IgemmArgs a) {
     u_tap = (int)(c_first / a.C); u_c = (int)(c_first - (long long)u_tap * a.C);
     u_ky = u_tap / a.kw; u_kx = u_tap - u_ky * a.kw;
   }
-  unsigned f_row[2] = {OOB, OOB};
+  unsigned f_row[APW];
+#pragma unroll
+  for (int j = 0; j < APW; ++j) f_row[j] = OOB;
   int f_tap = -1, f_src = -1, f_ks = ks_begin;
 
   auto issue_step = [&]() {
@@ -1725,7 +1739,7 @@ __global__ __launch_bounds__(256, 2) void igemm_sm_kernel(const IgemmArgs a) {
       f_tap = u_tap; f_src = src;
       const unsigned cs2 = (unsigned)(src ? a.c1 : a.c0) * 2u;
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
+      for (int j = 0; j < APW; ++j) {
         const int hi = x_h[j] + u_ky, wi = x_w[j] + u_kx;
         const bool ok = x_ok[j] && (unsigned)hi < (unsigned)hlog && (unsigned)wi < (unsigned)wlog;
         f_row[j] = ok ? (unsigned)(x_base[j] + (hi >> a.up) * a.win + (wi >> a.up)) * cs2 + chunk16 : OOB;
@@ -1733,17 +1747,17 @@ __global__ __launch_bounds__(256, 2) void igemm_sm_kernel(const IgemmArgs a) {
     }
     const int soff = (src ? u_c - a.c0 : u_c) * 2;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
+    for (int j = 0; j < APW; ++j) {
       const unsigned vo = live ? f_row[j] : OOB;
-      if (src) __builtin_amdgcn_raw_ptr_buffer_load_lds(rx1, (lds_ptr_t)(st + (32 * wave_s + 16 * j) * 64), 16, vo, soff, 0, 0);
-      else     __builtin_amdgcn_raw_ptr_buffer_load_lds(rx0, (lds_ptr_t)(st + (32 * wave_s + 16 * j) * 64), 16, vo, soff, 0, 0);
+      if (src) __builtin_amdgcn_raw_ptr_buffer_load_lds(rx1, (lds_ptr_t)(st + 16 * (APW * wave_s + j) * 64), 16, vo, soff, 0, 0);
+      else     __builtin_amdgcn_raw_ptr_buffer_load_lds(rx0, (lds_ptr_t)(st + 16 * (APW * wave_s + j) * 64), 16, vo, soff, 0, 0);
     }
     const int kb = f_ks * 64;                                // byte offset of the step inside a weight row
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
-      if (i == 2 && (NT != 5 || wave_s >= 2)) break;         // pieces 8, 9 exist for NT = 5 only (waves 0, 1)
+      if (i == 2 && (NT != 5 || wave_s >= NW / 2)) break;    // a third piece exists for NT = 5 only (lower half of the waves)
       const unsigned vo = live ? w_off[i] : OOB;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr_t)(st + BM * 64 + (wave_s + 4 * i) * 1024), 16, vo, kb, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr_t)(st + BM * 64 + (wave_s + NW * i) * 1024), 16, vo, kb, 0, 0);
     }
     ++f_ks;
     if (live) {
@@ -1751,53 +1765,104 @@ __global__ __launch_bounds__(256, 2) void igemm_sm_kernel(const IgemmArgs a) {
       if (u_c >= a.C) { u_c = 0; ++u_tap; if (++u_kx == a.kw) { u_kx = 0; ++u_ky; } }
     }
   };
-  // own requests of the two youngest steps may stay in flight (R = 5: waves 0, 1 with NT = 5; else 4)
+  // own requests of the two youngest steps may stay in flight: R = APW + 2, + 1 for the lower half of the waves with NT = 5
   auto wait_step = [&]() {
-    if (NT == 5 && wave_s < 2) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    if (NT == 5 && wave_s < NW / 2) {
+      if (APW == 2) asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    } else {
+      if (APW == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    }
   };
 
-  f32x4 acc[NT][4];
+  f32x4 acc[NT][MT];
 #pragma unroll
   for (int i = 0; i < NT; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < MT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int r16 = lane & 15, g4 = lane >> 4;
   const unsigned fsw = (((unsigned)g4 ^ ((0x1320u >> (((r16 >> 2) & 3) * 4)) & 3u)) << 4);
-  const unsigned char* xrd = lds + (wm * 64 + r16) * 64 + fsw;
+  const unsigned char* xrd = lds + (wm * MT * 16 + r16) * 64 + fsw;
   const unsigned char* wrd = lds + BM * 64 + (wn * WAVE_N + r16) * 64 + fsw;
 
-  issue_step(); issue_step(); issue_step();
-#pragma clang loop unroll(disable)
-  for (int s = ks_begin; s < ks_end; ++s) {
-    wait_step();
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
+  auto read_frags = [&](int s, frag_t (&xf)[MT], frag_t (&wf)[NT]) {
     const int so = (s & 3) * SLOT;
-    frag_t xf[4], wf[NT];
 #pragma unroll
-    for (int mi = 0; mi < 4; ++mi) xf[mi] = __builtin_bit_cast(frag_t, ld16(xrd + so + mi * 16 * 64));
+    for (int mi = 0; mi < MT; ++mi) xf[mi] = __builtin_bit_cast(frag_t, ld16(xrd + so + mi * 16 * 64));
 #pragma unroll
     for (int ni = 0; ni < NT; ++ni) wf[ni] = __builtin_bit_cast(frag_t, ld16(wrd + so + ni * 16 * 64));
-    __builtin_amdgcn_sched_barrier(0);
-    issue_step();                                            // step s + 3, behind the reads' latency
-    __builtin_amdgcn_sched_barrier(0);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  };
+  auto multiply = [&](const frag_t (&xf)[MT], const frag_t (&wf)[NT]) {
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int ni = 0; ni < NT; ++ni)
 #pragma unroll
-      for (int mi = 0; mi < 4; ++mi)
+      for (int mi = 0; mi < MT; ++mi)
         acc[ni][mi] = TR ? mfma16(xf[mi], wf[ni], acc[ni][mi]) : mfma16(wf[ni], xf[mi], acc[ni][mi]);
     __builtin_amdgcn_s_setprio(0);
+  };
+#define MOBI_RING_BARRIER()                   \
+  do {                                        \
+    __builtin_amdgcn_sched_barrier(0);        \
+    __builtin_amdgcn_s_barrier();             \
+    __builtin_amdgcn_sched_barrier(0);        \
+  } while (0)
+
+  issue_step(); issue_step(); issue_step();
+  if constexpr (WIDE && MOBI_RING_STAGGER) {
+    // Two waves share a SIMD (w and w + 4).  In lockstep both read / request, then both queue on the one matrix
+    // pipe; here waves 4-7 run HALF A STEP behind waves 0-3: every step is a LOAD phase (fragment reads, the requests
+    // of step s + 3, the counted wait) and a MATRIX phase (40 MFMAs), a barrier at every phase boundary, so that one
+    // wave of each SIMD multiplies while its partner loads.
+    //   RAW  step s + 1 is first read in the phase after the one in which every wave waits for its own pieces of it
+    //        (early waves: behind MATRIX(s); late waves: at the end of LOAD(s) -- the same phase).
+    //   WAR  the requests of step s + 3 overwrite slot (s - 1) % 4, last read by the late waves two phases earlier.
+    const bool late = wave_s >= NW / 2;
+    wait_step();
+    if (late) MOBI_RING_BARRIER();
+#pragma clang loop unroll(disable)
+    for (int s = ks_begin; s < ks_end; ++s) {
+      MOBI_RING_BARRIER();
+      frag_t xf[MT], wf[NT];
+      read_frags(s, xf, wf);
+      __builtin_amdgcn_sched_barrier(0);
+      issue_step();
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (late) wait_step();
+      MOBI_RING_BARRIER();
+      multiply(xf, wf);
+      if (!late) wait_step();
+    }
+    if (!late) MOBI_RING_BARRIER();
+  } else {
+#pragma clang loop unroll(disable)
+    for (int s = ks_begin; s < ks_end; ++s) {
+      wait_step();
+      MOBI_RING_BARRIER();
+      frag_t xf[MT], wf[NT];
+      read_frags(s, xf, wf);
+      __builtin_amdgcn_sched_barrier(0);
+      issue_step();                                          // step s + 3, behind the reads' latency
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      multiply(xf, wf);
+    }
   }
+#undef MOBI_RING_BARRIER
   // the ring becomes the epilogue's staging area: every request (also the all-zero ones) must have landed
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   float* stage = reinterpret_cast<float*>(lds) + wave * (STAGE_BYTES / 4);
-  igemm_epilogue<T, NT, TR, 32>(a, stage, acc, lane, group, n0 + wn * WAVE_N, m0 + wm * 64);
+#pragma unroll
+  for (int h = 0; h < MT / 4; ++h) {                         // the epilogue takes 64-pixel wave tiles
+    f32x4 part[NT][4];
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) part[i][j] = acc[i][4 * h + j];
+    igemm_epilogue<T, NT, TR, 32>(a, stage, part, lane, group, n0 + wn * WAVE_N, m0 + wm * MT * 16 + 64 * h);
+  }
 }
 
 // split-K finish: sum the partial slabs, then the ordinary epilogue (bias, per-image vector, residual)
@@ -1875,7 +1940,15 @@ static int launch_igemm(const mobi_igemm_params* p, const IgemmArgs& a, int grou
   do { if (a.fast) MOBI_IGEMM_LAUNCH(NT_, TR_, WM_, true); else MOBI_IGEMM_LAUNCH(NT_, TR_, WM_, false); } while (0)
 #define MOBI_IGEMM_BY_TR(NT_, WM_) \
   do { if (tr) MOBI_IGEMM_BY_FAST(NT_, true, WM_); else MOBI_IGEMM_BY_FAST(NT_, false, WM_); } while (0)
-  if (a.wm == 4 && a.fast && a.glds) {
+  if (a.wide == 2) {
+    if (nt5) hipLaunchKernelGGL((igemm_ring_kernel<T, 5, false, 8, 8>), grid, dim3(512), 0, st, a);
+    else     hipLaunchKernelGGL((igemm_ring_kernel<T, 4, false, 8, 8>), grid, dim3(512), 0, st, a);
+  }
+  else if (a.wide == 1) {
+    if (nt5) hipLaunchKernelGGL((igemm_ring_kernel<T, 5, false, 8, 4>), grid, dim3(512), 0, st, a);
+    else     hipLaunchKernelGGL((igemm_ring_kernel<T, 4, false, 8, 4>), grid, dim3(512), 0, st, a);
+  }
+  else if (a.wm == 4 && a.fast && a.glds) {
     // persistent: one 156-KB-LDS block per CU walks the output tiles
     dim3 block(512);
     dim3 pgrid(grid.x < (unsigned)compute_units() ? grid.x : (unsigned)compute_units(), grid.y, grid.z);
@@ -1900,7 +1973,7 @@ static int launch_igemm(const mobi_igemm_params* p, const IgemmArgs& a, int grou
   }
   else if (a.wm == 4) { if (nt5) MOBI_IGEMM_BY_TR(5, 4); else MOBI_IGEMM_BY_TR(4, 4); }
   else if (a.sm) {
-#define MOBI_SM_LAUNCH(NT_, TR_) hipLaunchKernelGGL((igemm_sm_kernel<T, NT_, TR_>), grid, dim3(256), 0, st, a)
+#define MOBI_SM_LAUNCH(NT_, TR_) hipLaunchKernelGGL((igemm_ring_kernel<T, NT_, TR_, 4, 4>), grid, dim3(256), 0, st, a)
     if (nt5) { if (tr) MOBI_SM_LAUNCH(5, true); else MOBI_SM_LAUNCH(5, false); }
     else     { if (tr) MOBI_SM_LAUNCH(4, true); else MOBI_SM_LAUNCH(4, false); }
 #undef MOBI_SM_LAUNCH
@@ -2014,6 +2087,7 @@ static int igemm_prepare(const mobi_igemm_params* p, mobi::IgemmArgs& a) {
     if (tuning().wm == 2 || tuning().wm == 4) a.wm = tuning().wm;
   }
   a.tiles_m = (a.M + 64 * a.wm - 1) / (64 * a.wm);
+  bool ring_ok = false;
   {
     // FAST path: k-tiles never straddle a tap or a source, and every byte offset fits 31 bits
     const long long ext0 = (((long long)p->batch - 1) * ips + hw_in) * p->c0 * 2;
@@ -2029,7 +2103,8 @@ static int igemm_prepare(const mobi_igemm_params* p, mobi::IgemmArgs& a) {
     if (tuning().glds == 0) a.glds = 0;
     // 128-pixel tiles: the LDS-DMA ring kernel whenever the 32-bit buffer offsets reach every operand byte and k runs
     // tap-major (k-steps are 32 deep there: channel counts are multiples of 32 by the ABI's own rule)
-    a.sm = a.wm == 2 && p->k_order == 0 && ext0 < 0x7fffffffLL && ext1 < 0x7fffffffLL && wext < 0x7fffffffLL;
+    ring_ok = p->k_order == 0 && ext0 < 0x7fffffffLL && ext1 < 0x7fffffffLL && wext < 0x7fffffffLL;
+    a.sm = a.wm == 2 && ring_ok;
     if (tuning().sm == 0) a.sm = 0;
     a.src0_bytes = (int)(ext0 < 0x7fffffffLL ? ext0 : 0);
     a.src1_bytes = (int)(ext1 < 0x7fffffffLL ? ext1 : 0);
@@ -2066,6 +2141,28 @@ static int igemm_prepare(const mobi_igemm_params* p, mobi::IgemmArgs& a) {
       a.hout < 32768 && a.wout < 32768)
     a.pp = 1;
   if (tuning().pp == 0) a.pp = 0;
+  // 256 x 320 (256) tiles on the ring kernel
+  // (measured, tools/ab_wide.py: 3x3 convolutions at 64x64 x 16: 1071-1245 vs 813-976 TFLOP/s on the ping-pong kernel;
+  //  it needs about one block per CU: with 128 tiles -- the 32x32 level at N = 640 -- half the chip idles and it loses;
+  //  there the 128 x 320 tile gives twice the blocks at the ping-pong tile's bytes per FLOP)
+  a.wide = 0;
+  if ((a.wm == 4 || tuning().wide > 0) && ring_ok && p->out_mode != MOBI_OUT_TRANSPOSED && tuning().wide != 0) {
+    const int bnw = (p->n_packed % 160) == 0 ? 320 : 256;
+    const long long tn = (p->n_packed + bnw - 1) / bnw;
+    auto fills = [&](long long blocks) {
+      const long long rounds = (blocks + 255) / 256;
+      return blocks >= 200 && blocks * 5 >= rounds * 256 * 4;          // last round at least 80 % full on average
+    };
+    const long long t256 = ((a.M + 255) / 256) * tn * a.splits, t128 = ((a.M + 127) / 128) * tn * a.splits;
+    int pick = tuning().wide > 0 ? tuning().wide : (fills(t256) ? 2 : (fills(t128) && tuning().wide128 != 0 ? 1 : 0));
+    if (pick) {
+      a.wide = pick;
+      a.wm = pick == 2 ? 4 : 2;
+      a.tiles_m = (a.M + 64 * a.wm - 1) / (64 * a.wm);
+      a.tiles_n = (int)tn;
+      a.sm = 0;
+    }
+  }
   return MOBI_OK;
 }
 
@@ -2082,6 +2179,7 @@ extern "C" int mobi_igemm_kernel_variant(const mobi_igemm_params* p) {
   mobi::IgemmArgs a;
   const int rc = igemm_prepare(p, a);
   if (rc != MOBI_OK) return rc;
+  if (a.wide) return a.wide == 2 ? MOBI_IGEMM_RING_256 : MOBI_IGEMM_RING_128W;
   if (a.wm == 4 && a.fast && a.glds) return a.pp ? MOBI_IGEMM_PINGPONG : MOBI_IGEMM_DIRECT_LDS;
   if (a.wm == 4) return MOBI_IGEMM_STAGED_256;
   return a.sm ? MOBI_IGEMM_RING_128 : MOBI_IGEMM_STAGED_128;

@@ -122,7 +122,9 @@ def test_gpu_log_data_scores_and_keys():
                                    split="test")
     assert sorted(metrics) == sorted(ref)
     for k, v in ref.items():
-        tol = 0 if "median" in k else 1e-6                         # medians are selections: exact
+        # depth scores: the de-normalisation is bit-exact, so medians (selections) are exact and RMSEs differ only by the
+        # summation order of torch's fp32 mean; intensity scores go through a logarithm (device logf vs torch-CPU log)
+        tol = 1e-5 if "int" in k else (0 if "median" in k else 1e-6)
         assert abs(metrics[k] - v) <= tol * abs(v), (k, metrics[k], v)
     assert torch.equal(log["range_sample_depth"].cpu(), g["met_range_sample_depth"])
     assert tuple(log["range_depth_pred"].shape) == tuple(int(v) for v in g["met_depth_pred_rows"])
