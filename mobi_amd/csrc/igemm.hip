@@ -2144,7 +2144,8 @@ static int igemm_prepare(const mobi_igemm_params* p, mobi::IgemmArgs& a) {
   // 256 x 320 (256) tiles on the ring kernel
   // (measured, tools/ab_wide.py: 3x3 convolutions at 64x64 x 16: 1071-1245 vs 813-976 TFLOP/s on the ping-pong kernel;
   //  it needs about one block per CU: with 128 tiles -- the 32x32 level at N = 640 -- half the chip idles and it loses;
-  //  there the 128 x 320 tile gives twice the blocks at the ping-pong tile's bytes per FLOP)
+  //  the 128 x 320 tile (twice the blocks at the ping-pong tile's bytes per FLOP) measured 829-965 TFLOP/s there against
+  //  982-1085 on the ping-pong kernel: kept for A/B (MOBI_IGEMM_WIDE128=1), not routed)
   a.wide = 0;
   if ((a.wm == 4 || tuning().wide > 0) && ring_ok && p->out_mode != MOBI_OUT_TRANSPOSED && tuning().wide != 0) {
     const int bnw = (p->n_packed % 160) == 0 ? 320 : 256;
@@ -2154,7 +2155,7 @@ static int igemm_prepare(const mobi_igemm_params* p, mobi::IgemmArgs& a) {
       return blocks >= 200 && blocks * 5 >= rounds * 256 * 4;          // last round at least 80 % full on average
     };
     const long long t256 = ((a.M + 255) / 256) * tn * a.splits, t128 = ((a.M + 127) / 128) * tn * a.splits;
-    int pick = tuning().wide > 0 ? tuning().wide : (fills(t256) ? 2 : (fills(t128) && tuning().wide128 != 0 ? 1 : 0));
+    int pick = tuning().wide > 0 ? tuning().wide : (fills(t256) ? 2 : (fills(t128) && tuning().wide128 == 1 ? 1 : 0));
     if (pick) {
       a.wide = pick;
       a.wm = pick == 2 ? 4 : 2;
