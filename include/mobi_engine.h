@@ -221,7 +221,7 @@ int mobi_softmax_rows(const float* src, void* out, int64_t rows, int32_t cols, i
  * 219-225, 874-875), attn2's to_v/to_out on the reference token
  * (attention.py:235), the bbox adapter's to_k/to_v.
  * ------------------------------------------------------------------------- */
-enum { MOBI_ACT_NONE = 0, MOBI_ACT_SILU = 1 };
+enum { MOBI_ACT_NONE = 0, MOBI_ACT_SILU = 1, MOBI_ACT_GELU = 2 /* erf form, post only: the token mapper's MLP, xf.py:47-57 */ };
 typedef struct mobi_skinny_linear_params {
   const float* x; int32_t m, k; int32_t x_row_stride;   /* elements */
   const void* weight;      /* T [n][k] */
@@ -231,6 +231,15 @@ typedef struct mobi_skinny_linear_params {
   int32_t dtype;
 } mobi_skinny_linear_params;
 int mobi_skinny_linear(const mobi_skinny_linear_params* p, void* stream);
+
+/* LayerNorm over the last axis of fp32 rows (row strides in elements): the single-token mapper and its final_ln
+ * (ldm/modules/encoders/xf.py:78-101, modules.py:153-168 of the reference). */
+int mobi_layernorm_rows_f32(const float* x, const float* gamma, const float* beta, float* out, int32_t rows, int32_t cols,
+                            int32_t x_stride, int32_t out_stride, float eps, void* stream);
+
+/* out = x * sigmoid(1.702 x) elementwise on n T values (n % 8 == 0): the activation of the CLIP vision tower's MLP
+ * (transformers' "quick_gelu"; FrozenCLIPImageEmbedder, ldm/modules/encoders/modules.py:142-180 -- SURVEY.md 8(f) row 1). */
+int mobi_quick_gelu(const void* src, void* out, int64_t n, int32_t dtype, void* stream);
 
 /* Sinusoidal timestep embedding (util.py:151-171); `freqs` is the fp32 table
  * exp(-ln(1e4) * i / half) computed by the host exactly as the reference does. */

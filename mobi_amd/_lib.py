@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(HERE, "libmobi_hip.so")
 MOBI_F16, MOBI_BF16 = 0, 1
 EPI_NONE, EPI_GEGLU = 0, 1
 OUT_ROWS, OUT_TRANSPOSED, OUT_ROWS_F32 = 0, 1, 2
-ACT_NONE, ACT_SILU = 0, 1
+ACT_NONE, ACT_SILU, ACT_GELU = 0, 1, 2
 
 vp, i32, i64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 
@@ -124,6 +124,8 @@ SYMBOLS = {
     "mobi_two_key_adapter": (C.c_int, [C.POINTER(TwoKeyAdapterParams), vp]),
     "mobi_softmax_rows": (C.c_int, [vp, vp, i64, i32, i32, vp]),
     "mobi_skinny_linear": (C.c_int, [C.POINTER(SkinnyLinearParams), vp]),
+    "mobi_layernorm_rows_f32": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, i32, f32, vp]),
+    "mobi_quick_gelu": (C.c_int, [vp, vp, i64, i32, vp]),
     "mobi_timestep_embedding": (C.c_int, [vp, vp, vp, i32, i32, vp]),
     "mobi_conv_small_cin": (C.c_int, [C.POINTER(ConvSmallCinParams), vp]),
     "mobi_conv_small_cout": (C.c_int, [C.POINTER(ConvSmallCoutParams), vp]),

@@ -74,11 +74,42 @@ __global__ __launch_bounds__(256) void skinny_linear_kernel(const mobi_skinny_li
           if (lane == 0 && n < a.n) {
             float o = s + (a.bias ? a.bias[n] : 0.f);
             if (a.post_act == MOBI_ACT_SILU) o = silu_f(o);
+            else if (a.post_act == MOBI_ACT_GELU) o = gelu_erf_f(o);
             a.out[(long long)m * a.out_row_stride + n] = o;
           }
         }
       }
     }
+}
+
+// LayerNorm over the last axis of a few fp32 rows (the token mapper / bbox MLP work on ONE fp32 token per image): one wave
+// per row, two passes in registers (mean, then centred variance), torch's formula (x - mean) * rsqrt(var + eps) * g + b
+__global__ void layernorm_rows_f32_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                          const float* __restrict__ beta, float* __restrict__ out, int rows, int cols,
+                                          int x_stride, int out_stride, float eps) {
+  const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  const float* xr = x + (long long)row * x_stride;
+  float s = 0.f;
+  for (int c = lane; c < cols; c += 64) s += xr[c];
+  const float mean = wave_sum(s) / (float)cols;
+  float v = 0.f;
+  for (int c = lane; c < cols; c += 64) { const float d = xr[c] - mean; v += d * d; }
+  const float rstd = rsqrtf(wave_sum(v) / (float)cols + eps);
+  float* o = out + (long long)row * out_stride;
+  for (int c = lane; c < cols; c += 64) o[c] = (xr[c] - mean) * rstd * gamma[c] + beta[c];
+}
+
+// CLIP's "quick_gelu" (transformers: x * sigmoid(1.702 x)), elementwise on a T tensor, 8 values per thread
+template <typename T>
+__global__ void quick_gelu_kernel(const T* __restrict__ src, T* __restrict__ out, long long vecs) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < vecs; i += (long long)gridDim.x * blockDim.x) {
+    float f[8];
+    unpack8<T>(ld16(src + i * 8), f);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) f[j] = f[j] / (1.0f + __expf(-1.702f * f[j]));
+    st16(out + i * 8, pack8<T>(f));
+  }
 }
 
 __global__ void timestep_embedding_kernel(const int64_t* t, const float* freqs, float* out, int n, int half) {
@@ -543,6 +574,30 @@ extern "C" int mobi_two_key_adapter(const mobi_two_key_adapter_params* p, void* 
   if (p->dtype == MOBI_F16) { if (V <= 64) MOBI_TKA(f16_t, 1); else if (V <= 128) MOBI_TKA(f16_t, 2); else MOBI_TKA(f16_t, 3); }
   else { if (V <= 64) MOBI_TKA(bf16_t, 1); else if (V <= 128) MOBI_TKA(bf16_t, 2); else MOBI_TKA(bf16_t, 3); }
 #undef MOBI_TKA
+  MOBI_CHECK_LAUNCH();
+  return MOBI_OK;
+}
+
+extern "C" int mobi_layernorm_rows_f32(const float* x, const float* gamma, const float* beta, float* out, int32_t rows,
+                                       int32_t cols, int32_t x_stride, int32_t out_stride, float eps, void* stream) {
+  if (!x || !gamma || !beta || !out || rows <= 0 || cols <= 0 || x_stride < cols || out_stride < cols) return MOBI_ERR_ARG;
+  hipLaunchKernelGGL(layernorm_rows_f32_kernel, dim3((rows + 3) / 4), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x,
+                     gamma, beta, out, rows, cols, x_stride, out_stride, eps);
+  MOBI_CHECK_LAUNCH();
+  return MOBI_OK;
+}
+
+extern "C" int mobi_quick_gelu(const void* src, void* out, int64_t n, int32_t dtype, void* stream) {
+  if (!src || !out || n <= 0 || (n & 7) || !DT_OK(dtype)) return MOBI_ERR_ARG;
+  const long long vecs = n >> 3;
+  long long blocks = (vecs + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  if (dtype == MOBI_F16)
+    hipLaunchKernelGGL((quick_gelu_kernel<f16_t>), dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                       reinterpret_cast<const f16_t*>(src), reinterpret_cast<f16_t*>(out), vecs);
+  else
+    hipLaunchKernelGGL((quick_gelu_kernel<bf16_t>), dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                       reinterpret_cast<const bf16_t*>(src), reinterpret_cast<bf16_t*>(out), vecs);
   MOBI_CHECK_LAUNCH();
   return MOBI_OK;
 }

@@ -15,7 +15,7 @@ from typing import Optional
 import torch
 
 from . import _lib
-from ._lib import (ACT_NONE, ACT_SILU, EPI_GEGLU, EPI_NONE, MOBI_BF16, MOBI_F16, OUT_ROWS, OUT_ROWS_F32,
+from ._lib import (ACT_GELU, ACT_NONE, ACT_SILU, EPI_GEGLU, EPI_NONE, MOBI_BF16, MOBI_F16, OUT_ROWS, OUT_ROWS_F32,
                    OUT_TRANSPOSED)
 
 
@@ -383,6 +383,25 @@ def skinny_linear(x, w, bias=None, pre_act=ACT_NONE, post_act=ACT_NONE, out=None
         p.weight, p.bias, p.out, p.n, p.out_row_stride = _ptr(w), _ptr(bias), _ptr(os_), n, out.stride(0)
         p.pre_act, p.post_act, p.dtype = pre_act, post_act, _dt(w.dtype)
         _lib.check(lib.mobi_skinny_linear(C.byref(p), _stream()), "mobi_skinny_linear")
+    return out
+
+
+def layernorm_rows_f32(x, gamma, beta, eps=1e-5):
+    """fp32 [rows, cols] (row stride free) -> fp32 [rows, cols]."""
+    lib = _lib.load()
+    assert x.dtype == torch.float32 and x.dim() == 2 and x.stride(1) == 1
+    out = torch.empty((x.shape[0], x.shape[1]), device=x.device, dtype=torch.float32)
+    _lib.check(lib.mobi_layernorm_rows_f32(_ptr(x), _ptr(gamma), _ptr(beta), _ptr(out), x.shape[0], x.shape[1], x.stride(0),
+                                           out.stride(0), eps, _stream()), "mobi_layernorm_rows_f32")
+    return out
+
+
+def quick_gelu(x):
+    """T tensor -> x * sigmoid(1.702 x), same shape."""
+    lib = _lib.load()
+    assert x.is_contiguous() and x.numel() % 8 == 0
+    out = torch.empty_like(x)
+    _lib.check(lib.mobi_quick_gelu(_ptr(x), _ptr(out), x.numel(), _dt(x.dtype), _stream()), "mobi_quick_gelu")
     return out
 
 

@@ -13,7 +13,7 @@ import json
 import os
 import sys
 
-FAMILIES = ["igemm_pp_kernel", "igemm_halo_kernel", "igemm_glds_kernel", "igemm_kernel", "igemm_splitk_reduce_kernel", "attention_kernel", "gn_stats_kernel",
+FAMILIES = ["igemm_pp_kernel", "igemm_ring_kernel", "igemm_halo_kernel", "igemm_glds_kernel", "igemm_kernel", "igemm_splitk_reduce_kernel", "attention_kernel", "gn_stats_kernel",
             "gn_apply_kernel", "layernorm_kernel", "ctx_attention_kernel"]
 
 
@@ -46,8 +46,10 @@ def main():
     for spec in sys.argv[2:]:
         counter, directory = spec.split("=", 1)
         raw[counter] = fold(directory, counter)
-    res = {"command": "rocprofv3 --pmc <counter> (one pass per counter) -- python bench.py --steps 2 --warmup 1 "
-                      "--no-e2e --no-cpu-baseline --no-roofline",
+    res = {"command": "rocprofv3 --pmc <counter> (one pass per counter) -- python3 bench.py --steps 2 --warmup 1 "
+                      "--no-e2e --no-cpu-baseline --no-roofline --no-graph --no-plms-line",
+           # bench.py attaches `roofline.traffic` only to a run of this very configuration
+           "config": {"workload": "mobi_nusc_512", "objects": 8, "dtype": "bf16", "cfg_scale": 1.0},
            "units": "FETCH_SIZE / WRITE_SIZE in KB per launch as reported; gfx950 correction (MI355X_MICROARCH.md, "
                     "HBM): FETCH_SIZE tallies 64 B per 128-B request of wide coalesced reads -> doubled",
            "raw": raw}
