@@ -19,7 +19,9 @@ The replayed launches are the same kernels with the same arguments as the eager 
 (tests/test_gpu_graph.py).  PyTorch is used for what it is here for: the capture stream, the private memory pool of
 the capture (`torch.cuda.graph`) and `hipGraphLaunch` on the current stream.
 """
+import gc
 import os
+import weakref
 
 import torch
 import torch.nn as nn
@@ -67,7 +69,9 @@ class StepGraph:
     (e_cond, e_uncond | None) (PLMS mixes the eps history eagerly)."""
 
     def __init__(self, sampler, kind, x, cond, uncond, scale, parts_extra, parts_key, temperature, has_noise):
-        self.sampler, self.kind = sampler, kind
+        # (weak: the sampler owns this object through its graph table -- a strong back-reference would make a cycle whose
+        #  collection could destroy a hipGraph in the middle of some later capture)
+        self._sampler, self.kind = weakref.ref(sampler), kind
         dev = x.device
         self.cfg = uncond is not None and scale != 1.
         self.scale, self.temperature = float(scale), float(temperature)
@@ -94,8 +98,23 @@ class StepGraph:
             self._body()
         torch.cuda.current_stream().wait_stream(side)
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
-            self.outputs = self._body()
+        # no cyclic garbage collection while the stream is capturing: a collected tensor / graph / event is released
+        # through HIP calls that are illegal during capture (torch collects once before the capture starts)
+        gc_was_on = gc.isenabled()
+        gc.disable()
+        try:
+            with torch.cuda.graph(self.graph):
+                self.outputs = self._body()
+        finally:
+            if gc_was_on:
+                gc.enable()
+
+    @property
+    def sampler(self):
+        s = self._sampler()
+        if s is None:
+            raise RuntimeError("the sampler that owns this step graph is gone")
+        return s
 
     def _kwargs(self):
         if self.parts_key == "test_model_kwargs":

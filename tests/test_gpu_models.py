@@ -364,3 +364,84 @@ def test_full_size_step_properties():
     assert torch.equal(ys[4:], y[4:])                         # the other objects do not notice
     y2 = net([x[:, :4].contiguous(), x[:, 4:8].contiguous(), x[:, 8:].contiguous()], t, context=ctx)
     assert torch.equal(y2, y)
+
+
+def test_harness_flow_reference_spelling():
+    """scripts/inference_test_bench.py:337-464 with the imports and calls spelled as the reference spells them:
+    `from omegaconf import OmegaConf`, `from ldm.util import instantiate_from_config`, `from ldm.models.diffusion.{ddim,plms}
+    import ...`, config load + dot-list merge, `model.get_input(batch, model.first_stage_key, force_c_encode=True,
+    return_vae_rec=True)`, NON-CONTIGUOUS `data["z"][:, 4:8]` / `data["z"][:, [8]]`, the PLMS keyword form
+    (`inpaint_image=`), `decode_sample`, `log_data(..., log_metrics=False, return_sample=..., split="test")`."""
+    _set(torch.float16)
+    import os
+    omegaconf = pytest.importorskip("omegaconf")
+    OmegaConf = omegaconf.OmegaConf
+    from ldm.util import instantiate_from_config
+    from ldm.models.diffusion.ddim import DDIMSampler
+    from ldm.models.diffusion.plms import PLMSSampler
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    config = OmegaConf.load(os.path.join(root, "configs", "mobi_nusc_256.yaml"))
+    cli_conf = OmegaConf.from_dotlist(["latent_size=8", "image_height=64", "use_lidar=True",
+                                       "model.params.lidar_stage_config.params.ckpt_path=null",
+                                       "model.params.unet_config.params.model_channels=64",
+                                       "model.params.first_stage_config.params.ddconfig.ch=32",
+                                       "model.params.lidar_stage_config.params.ddconfig.ch=32",
+                                       "model.params.cond_stage_config.params.clip_config.hidden_size=1024",
+                                       "model.params.cond_stage_config.params.clip_config.intermediate_size=256",
+                                       "model.params.cond_stage_config.params.clip_config.num_hidden_layers=1",
+                                       "model.params.cond_stage_config.params.clip_config.num_attention_heads=16",
+                                       "model.params.cond_stage_config.params.clip_config.image_size=28",
+                                       "model.params.cond_stage_config.params.clip_config.patch_size=14"])
+    config = OmegaConf.merge(config, cli_conf)
+    model = instantiate_from_config(config.model)
+    W.fill_module_(model, seed=19)
+    device = torch.device("cuda")
+    model = model.to(device)
+    model.eval()
+    B = 2
+    batch = {"image": {"GT": W.synth_input("hs.img", (B, 3, 64, 64), kind="uniform"), "inpaint_mask": torch.ones(B, 1, 64, 64),
+                       "cond": {"ref_image": W.synth_input("hs.ref", (B, 3, 28, 28)),
+                                "ref_bbox": W.synth_input("hs.bbox", (B, 8, 3), kind="uniform") * 0.5 + 0.5}},
+             "lidar": {"range_data": W.synth_input("hs.rng", (B, 2, 64, 64), kind="uniform"), "range_mask": torch.ones(B, 1, 64, 64),
+                       "range_instance_mask": (W.synth_input("hs.inst", (B, 1, 64, 64)) > 1.0).float(),
+                       "min_depth_obj": torch.tensor([-0.6, -0.3]), "max_depth_obj": torch.tensor([0.2, 0.5]),
+                       "width_crop": torch.tensor([32, 64]),
+                       "cond": {"ref_image": W.synth_input("hs.ref", (B, 3, 28, 28)),
+                                "ref_bbox": W.synth_input("hs.bbox2", (B, 8, 3), kind="uniform") * 0.5 + 0.5}}}
+    batch["image"]["inpaint_mask"][:, :, 16:48, 16:48] = 0
+    batch["lidar"]["range_mask"][:, :, 16:48, 16:48] = 0
+    batch["image"]["inpaint_image"] = batch["image"]["GT"] * batch["image"]["inpaint_mask"]
+    batch["lidar"]["range_data_inpaint"] = batch["lidar"]["range_data"] * batch["lidar"]["range_mask"]
+    move = lambda d: {k: move(v) if isinstance(v, dict) else v.to(device) for k, v in d.items()}
+    batch = move(batch)
+    with torch.no_grad(), model.ema_scope():
+        data = model.get_input(batch, model.first_stage_key, force_c_encode=True, return_vae_rec=True)
+        uc = [model.learnable_vector.repeat(data["z"].shape[0], 1, 1)]
+        if "ref_bbox" in model.cond_stage_key:
+            uc.append(model.bbox_uncond_vector.repeat(data["z"].shape[0], 1, 1))
+        uc = torch.cat(uc, dim=1)
+        c = data["cond"]
+        shape = [model.channels, model.image_size, model.image_size]
+        start_code = torch.randn([data["z"].shape[0], *shape], device=device)
+        assert not data["z"][:, 4:8].is_contiguous()
+        out = {}
+        for name, sampler in (("ddim", DDIMSampler(model)), ("plms", PLMSSampler(model))):
+            kw = dict(S=4, conditioning=c, batch_size=data["z"].shape[0], shape=shape, verbose=False,
+                      unconditional_guidance_scale=5.0, unconditional_conditioning=uc, eta=0.0, x_T=start_code)
+            if name == "plms":
+                samples, _ = sampler.sample(**kw, inpaint_image=data["z"][:, 4:8], inpaint_mask=data["z"][:, [8]])
+            else:
+                samples, _ = sampler.sample(**kw, test_model_kwargs={"inpaint_image": data["z"][:, 4:8],
+                                                                      "inpaint_mask": data["z"][:, [8]]})
+            h_camera, h_lidar = model.decode_sample(samples, data.get("z_lidar"))
+            log, lidar_metrics = model.log_data(batch, data, h_camera, h_lidar, log_metrics=False, return_sample=True,
+                                                split="test")
+            out[name] = log
+            for k in ("image_preds", "image_preds_no_box", "image_sample", "range_depth_pred", "range_int_pred",
+                      "range_sample_depth", "range_sample_int"):                 # the keys the harness indexes (:469-470, :529-585)
+                assert k in log, k
+            assert log["image_preds"].dtype == torch.uint8 and log["image_preds"].shape == (B, 3, 4 * 512, 512)
+            assert log["image_sample"].shape == (B, 3, 64, 64) and log["range_sample_depth"].shape == (B, 1, 64, 64)
+            assert set(k.split("/")[1] for k in lidar_metrics) == {"mse", "median_error"} and len(lidar_metrics) == 16
+            assert all(k.startswith("test/") for k in lidar_metrics)
+        assert not torch.equal(out["ddim"]["image_sample"], out["plms"]["image_sample"])
