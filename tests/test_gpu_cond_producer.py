@@ -13,7 +13,7 @@ pytestmark = pytest.mark.gpu
 
 CLIP_CFG = dict(hidden_size=1024, intermediate_size=256, num_hidden_layers=1, num_attention_heads=16,
                 image_size=28, patch_size=14, projection_dim=64, hidden_act="quick_gelu")
-TOL = {torch.float16: 5e-3, torch.bfloat16: 3e-2}
+TOL = {torch.float16: 1.5e-3, torch.bfloat16: 1.2e-2}      # 2x measured (7.6e-4 / 6.0e-3)
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])

@@ -2,11 +2,13 @@
 (1) the committed golden vectors that the REFERENCE's modules produced, and
 (2) the CPU oracle on seeded inputs, including the full-width mobi_nusc_512 UNet.
 
-Tolerances (relative L2 against the fp32 reference / oracle; stated per storage type):
-  whole UNet forward      fp16 5e-3    bf16 3e-2
-  VAE encode / decode     fp16 5e-3    bf16 3e-2
-  DDIM/PLMS-10 trajectory fp16 2e-2    bf16 1e-1
-The north-star 1e-3 figure is reported as measured by bench.py / DESIGN.md, not assumed.
+Tolerances (relative L2 against the fp32 reference / oracle, per storage type) are 2x the largest value measured on the
+MI355X for each group (profiles/r02_error_table.txt):
+  single operators        fp16 1.3e-3  bf16 1.1e-2     (measured 6.5e-4 / 5.2e-3)
+  whole UNet forward      fp16 4e-3    bf16 3e-2       (1.9e-3 / 1.5e-2)
+  VAE encode / decode     fp16 4.6e-3  bf16 3.5e-2     (2.3e-3 / 1.7e-2)
+  DDIM/PLMS-10 trajectory fp16 3.1e-3  bf16 2.6e-2     (1.5e-3 / 1.3e-2)
+The north-star figure (1e-3 after DDIM-50, fp16 storage) is asserted in tests/test_gpu_production.py.
 """
 import numpy as np
 import pytest
@@ -18,8 +20,10 @@ from tests.golden_cases import OPS_SEED, UNET_CFGS, UNET_SEED, VAE_CFGS, VAE_SEE
 pytestmark = pytest.mark.gpu
 
 DT = [torch.float16, torch.bfloat16]
-TOL_NET = {torch.float16: 5e-3, torch.bfloat16: 3e-2}
-TOL_TRAJ = {torch.float16: 2e-2, torch.bfloat16: 1e-1}
+TOL_OP = {torch.float16: 1.3e-3, torch.bfloat16: 1.1e-2}
+TOL_NET = {torch.float16: 4e-3, torch.bfloat16: 3e-2}
+TOL_VAE = {torch.float16: 4.6e-3, torch.bfloat16: 3.5e-2}
+TOL_TRAJ = {torch.float16: 3.1e-3, torch.bfloat16: 2.6e-2}
 
 
 def _set(dtype):
@@ -57,25 +61,25 @@ def test_operator_goldens(dtype):
         m = om.ResBlock(cin, 128, 0.0, out_channels=cout)
         W.fill_module_(m, seed=OPS_SEED, prefix=tag + ".")
         y = m.cuda()(W.synth_input(f"ops.{tag}.x", (4, cin, 8, 8)).cuda(), emb)
-        assert rel_l2(y.cpu(), g[tag + "_y"]) < TOL_NET[dtype], tag
+        assert rel_l2(y.cpu(), g[tag + "_y"]) < TOL_OP[dtype], tag
     m = om.Downsample(64, True, out_channels=64)
     W.fill_module_(m, seed=OPS_SEED, prefix="down64.")
-    assert rel_l2(m.cuda()(W.synth_input("ops.down64.x", (2, 64, 8, 8)).cuda()).cpu(), g["down64_y"]) < TOL_NET[dtype]
+    assert rel_l2(m.cuda()(W.synth_input("ops.down64.x", (2, 64, 8, 8)).cuda()).cpu(), g["down64_y"]) < TOL_OP[dtype]
     m = om.Upsample(64, True, out_channels=64)
     W.fill_module_(m, seed=OPS_SEED, prefix="up64.")
-    assert rel_l2(m.cuda()(W.synth_input("ops.up64.x", (2, 64, 4, 4)).cuda()).cpu(), g["up64_y"]) < TOL_NET[dtype]
+    assert rel_l2(m.cuda()(W.synth_input("ops.up64.x", (2, 64, 4, 4)).cuda()).cpu(), g["up64_y"]) < TOL_OP[dtype]
     m = SpatialTransformer(64, 8, 8, depth=1, context_dim=768, bbox_cond=True, multimodal=True)
     W.fill_module_(m, seed=OPS_SEED, prefix="st64.")
     y = m.cuda()(W.synth_input("ops.st64.x", (4, 64, 8, 8)).cuda(), W.synth_input("ops.st64.ctx", (4, 2, 768)).cuda())
-    assert rel_l2(y.cpu(), g["st64_y"]) < TOL_NET[dtype]
+    assert rel_l2(y.cpu(), g["st64_y"]) < TOL_OP[dtype]
     for tag, ks, pad in (("vres3", 3, 1), ("vres15", (1, 5), (0, 2))):
         m = vm.ResnetBlock(in_channels=32, out_channels=64, temb_channels=0, dropout=0.0, kernel_size=ks, padding=pad)
         W.fill_module_(m, seed=OPS_SEED, prefix=tag + ".")
         y = m.cuda()(W.synth_input(f"ops.{tag}.x", (2, 32, 8, 8)).cuda())
-        assert rel_l2(y.cpu(), g[tag + "_y"]) < TOL_NET[dtype], tag
+        assert rel_l2(y.cpu(), g[tag + "_y"]) < TOL_OP[dtype], tag
     m = vm.AttnBlock(64)
     W.fill_module_(m, seed=OPS_SEED, prefix="vattn.")
-    assert rel_l2(m.cuda()(W.synth_input("ops.vattn.x", (2, 64, 8, 8)).cuda()).cpu(), g["vattn_y"]) < TOL_NET[dtype]
+    assert rel_l2(m.cuda()(W.synth_input("ops.vattn.x", (2, 64, 8, 8)).cuda()).cpu(), g["vattn_y"]) < TOL_OP[dtype]
 
 
 @pytest.mark.parametrize("dtype", DT)
@@ -141,11 +145,11 @@ def test_vae_golden(dtype, name):
     vae.load_state_dict(W.synth_state_dict(ovae.vae_param_shapes(cfg), VAE_SEED))
     vae = vae.cuda()
     post = vae.encode(g["x"].cuda())
-    assert rel_l2(post.parameters.cpu(), g["moments"]) < TOL_NET[dtype]
+    assert rel_l2(post.parameters.cpu(), g["moments"]) < TOL_VAE[dtype]
     z = post.sample(noise=g["noise"].cuda())
-    assert rel_l2(z.cpu(), g["z"]) < TOL_NET[dtype] * 2
+    assert rel_l2(z.cpu(), g["z"]) < TOL_VAE[dtype]
     rec = vae.decode(g["z"].cuda())
-    assert rel_l2(rec.cpu(), g["rec"]) < TOL_NET[dtype]
+    assert rel_l2(rec.cpu(), g["rec"]) < TOL_VAE[dtype]
 
 
 @pytest.mark.parametrize("dtype", DT)
@@ -252,14 +256,14 @@ def test_latent_diffusion_plumbing(dtype):
         noises={"cam_gt": c(g["n_cam_gt"]), "cam_inpaint": c(g["n_cam_inp"]), "lidar_gt": c(g["n_lid_gt"]),
                 "lidar_inpaint": c(g["n_lid_inp"])})
     assert torch.equal(z_image[:, 8].cpu(), g["z_image"][:, 8]) and torch.equal(z_lidar[:, 8].cpu(), g["z_lidar"][:, 8])
-    assert rel_l2(z_image.cpu(), g["z_image"]) < TOL_NET[dtype] * 2
-    assert rel_l2(z_lidar.cpu(), g["z_lidar"]) < TOL_NET[dtype] * 2
+    assert rel_l2(z_image.cpu(), g["z_image"]) < TOL_VAE[dtype]
+    assert rel_l2(z_lidar.cpu(), g["z_lidar"]) < TOL_VAE[dtype]
     h_cam, h_lid = ld.decode_sample(c(g["sample"]), c(g["z_lidar"][:, :4]))
     assert torch.equal(h_cam.cpu(), g["h_cam"]) and torch.equal(h_lid.cpu(), g["h_lid"])
     lid_sd = W.synth_state_dict(ovae.vae_param_shapes(lid_cfg), VAE_SEED)
     ref = pipeline.decode_first_stage(lid_sd, lid_cfg, g["h_lid"], 0.18215)
     got = ld.decode_first_stage(h_lid, module_name="lidar_stage_model", clamp=(-1., 1.))
-    assert rel_l2(got.cpu(), ref) < TOL_NET[dtype]
+    assert rel_l2(got.cpu(), ref) < TOL_VAE[dtype]
     assert float(got.max()) <= 1.0 and float(got.min()) >= -1.0
 
 
@@ -316,7 +320,7 @@ def test_harness_flow_with_conditioning_producer():
             c = model.cond_stage_model.encode({k: dev_batch[mod]["cond"][k].clone() for k in ("ref_image", "ref_bbox")})
             ref.append(torch.cat([F.linear(c["ref_image_token"].cpu(), proj_w, proj_b), c["ref_bbox_token"].cpu()], dim=1))
         ref = torch.stack(ref, dim=1).reshape(2 * B, 2, 768)
-    assert rel_l2(data["cond"].cpu(), ref) < 2e-3
+    assert rel_l2(data["cond"].cpu(), ref) < 5e-4            # measured 2.1e-4 (fp16 weights in the proj_out GEMV)
     uc = torch.cat([model.learnable_vector, model.bbox_uncond_vector], dim=1).repeat(2 * B, 1, 1)
     z = data["z"]
     samples, _ = DDIMSampler(model).sample(S=4, batch_size=2 * B, shape=[4, 8, 8], conditioning=data["cond"],

@@ -19,7 +19,9 @@ from oracle import weights as W
 pytestmark = pytest.mark.gpu
 
 DT = [torch.float16, torch.bfloat16]
-TOL = {torch.float16: 2e-3, torch.bfloat16: 1.5e-2}
+# rel-L2 of one kernel against fp32 torch on inputs pre-rounded to the storage type: 2x the largest value measured on the
+# MI355X over every case of this file (fp16 2.5e-4, bf16 2.0e-3: profiles/r02_error_table.txt)
+TOL = {torch.float16: 5e-4, torch.bfloat16: 4e-3}
 
 
 def rel(a, b):
@@ -123,7 +125,7 @@ def test_igemm_conv(ops, dtype, case):
         y = ops.igemm(xd, pw, stride=stride, pad=pad, upsample=up)
     ref = _conv_ref(xf, wf, bias, stride, pad, up, asym)
     assert y.shape == ref.shape
-    assert rel(y.float(), ref) < TOL[dtype] * 0.5
+    assert rel(y.float(), ref) < TOL[dtype]
 
 
 @pytest.mark.parametrize("dtype", DT)
@@ -139,7 +141,7 @@ def test_igemm_epilogues(ops, dtype):
     pw = ops.pack_conv(wf, bias, dtype, "cuda")
     ref = _conv_ref(torch.cat([x0f, x1f], 3), wf, bias) + rv[:, None, None, :] + rf
     y = ops.igemm(x0d, pw, x2=x1d, rowvec=rvd, residual=rd)
-    assert rel(y.float(), ref) < TOL[dtype] * 0.5
+    assert rel(y.float(), ref) < TOL[dtype]
     from mobi_amd._lib import OUT_ROWS_F32, OUT_TRANSPOSED
     ref2 = _conv_ref(torch.cat([x0f, x1f], 3), wf, bias)
     y32 = ops.igemm(x0d, pw, x2=x1d, out_mode=OUT_ROWS_F32, scale=0.5)
@@ -147,13 +149,13 @@ def test_igemm_epilogues(ops, dtype):
     assert y32.dtype == torch.float32 and rel(y32, ref_s) < 2e-5 * (100 if dtype == torch.bfloat16 else 1) + 1e-6
     yt = ops.igemm(x0d, pw, x2=x1d, out_mode=OUT_TRANSPOSED)
     assert yt.shape == (4, 160, 64)
-    assert rel(yt.float(), ref2.reshape(4, 64, 160).permute(0, 2, 1)) < TOL[dtype] * 0.5
+    assert rel(yt.float(), ref2.reshape(4, 64, 160).permute(0, 2, 1)) < TOL[dtype]
     # transposed with a spatial size that is not a multiple of 8 (scalar store path)
     xs_f, xs_d = rnd("e.xs", (3, 1, 3, 32), dtype)
     ws = torch.from_numpy(W.synth_param("e.ws", (40, 32, 1, 1))).to(dtype).float()
     pws = ops.pack_conv(ws, None, dtype, "cuda")
     yt = ops.igemm(xs_d, pws, out_mode=OUT_TRANSPOSED)
-    assert rel(yt.float(), _conv_ref(xs_f, ws, None, pad=(0, 0)).reshape(3, 3, 40).permute(0, 2, 1)) < TOL[dtype] * 0.5
+    assert rel(yt.float(), _conv_ref(xs_f, ws, None, pad=(0, 0)).reshape(3, 3, 40).permute(0, 2, 1)) < TOL[dtype]
 
 
 @pytest.mark.parametrize("dtype", DT)
@@ -316,7 +318,7 @@ def test_small_convs(ops, dtype):
     bias = torch.from_numpy(W.synth_param("sc.bias", (64,)))
     y = ops.conv_small_cin([a.cuda(), b.cuda(), m.cuda()], w.reshape(64, -1).cuda(), bias.cuda(), 3, 3, (1, 1), dtype)
     ref = F.conv2d(torch.cat([a, b, m], 1), w, bias, padding=1).permute(0, 2, 3, 1)
-    assert rel(y.float(), ref) < TOL[dtype] * 0.5
+    assert rel(y.float(), ref) < TOL[dtype]
     # 1x5 lidar conv_in, fp32 NCHW out
     r = W.synth_input("sc.r", (2, 2, 6, 20))
     w15 = torch.from_numpy(W.synth_param("sc15.weight", (5, 2, 1, 5)))
@@ -407,7 +409,7 @@ def test_igemm_split_k(ops, dtype, split):
     for chunk_major in (False, True):
         pw = ops.pack_conv(wf, bias, dtype, "cuda", chunk_major=chunk_major)
         y = ops.igemm(xd, pw, x2=x1d, rowvec=rv.cuda(), residual=rd, split_k=split)
-        assert rel(y.float(), ref) < TOL[dtype] * 0.5, chunk_major
+        assert rel(y.float(), ref) < TOL[dtype], chunk_major
     if split is None:
         from mobi_amd import _lib
         import ctypes as C
@@ -434,7 +436,7 @@ def test_igemm_block_heights(ops, dtype, wm, tune):
                 y = ops.igemm(xd, pw, stride=2, pad=(0, 0), hout=(h + 1 - 3) // 2 + 1, wout=(w + 1 - 3) // 2 + 1)
             else:
                 y = ops.igemm(xd, pw, stride=stride, pad=pad, upsample=up)
-            assert rel(y.float(), _conv_ref(xf, wf, bias, stride, pad, up, asym)) < TOL[dtype] * 0.5, (name, chunk_major)
+            assert rel(y.float(), _conv_ref(xf, wf, bias, stride, pad, up, asym)) < TOL[dtype], (name, chunk_major)
     xf, xd = rnd("bh.x", (2, 300, 320), dtype)
     wf = torch.from_numpy(W.synth_param("bh.g.weight", (2560, 320))).to(dtype).float()
     bf = torch.from_numpy(W.synth_param("bh.g.bias", (2560,)))
@@ -444,7 +446,7 @@ def test_igemm_block_heights(ops, dtype, wm, tune):
     wv = torch.from_numpy(W.synth_param("bh.v.weight", (320, 320))).to(dtype).float()
     xs_f, xs_d = rnd("bh.xs", (2, 304, 320), dtype)
     yt = ops.linear(xs_d, ops.pack_linear(wv, None, dtype, "cuda"), out_mode=OUT_TRANSPOSED)
-    assert rel(yt.float(), F.linear(xs_f, wv).permute(0, 2, 1)) < TOL[dtype] * 0.5
+    assert rel(yt.float(), F.linear(xs_f, wv).permute(0, 2, 1)) < TOL[dtype]
 
 
 @pytest.mark.parametrize("dtype", DT)
@@ -482,9 +484,9 @@ def test_igemm_persistent_register_epilogue(ops, dtype, blocks, tune):
         y2 = ops.igemm(xd, p2, residual=r2d)
         y3 = ops.igemm(xd, p3, x2=x1d)
         yg = ops.linear(xd.view(4, 1024, 320), pg)
-        assert rel(y1.float(), ref1) < TOL[dtype] * 0.5, direct
-        assert rel(y2.float(), ref2) < TOL[dtype] * 0.5, direct
-        assert rel(y3.float(), ref3) < TOL[dtype] * 0.5, direct
+        assert rel(y1.float(), ref1) < TOL[dtype], direct
+        assert rel(y2.float(), ref2) < TOL[dtype], direct
+        assert rel(y3.float(), ref3) < TOL[dtype], direct
         assert rel(yg.float(), refg) < TOL[dtype], direct
         outs[direct] = (y1, y2, y3, yg)
     for ya, yb in zip(outs["1"], outs["0"]):                      # same fp32 arithmetic, one rounding: near-identical
@@ -542,7 +544,7 @@ def test_igemm_pingpong(ops, dtype, case, tune):
             pw = ops.pack_conv(wf, None if rowvec else bias, dtype, "cuda")
             y = ops.igemm(xd, pw, x2=x2d, residual=rd, rowvec=None if rv is None else rv.cuda(), rowvec_has_bias=rowvec)
         assert torch.isfinite(y.float()).all(), (case, halo)
-        assert rel(y.float(), ref) < TOL[dtype] * (1.0 if geglu else 0.5), (case, halo)
+        assert rel(y.float(), ref) < TOL[dtype], (case, halo)
     # the launch really is the ping-pong variant
     p = _lib.IgemmParams()
     p.src0, p.weight, p.out = 256, 256, 256                   # non-null, 16-byte aligned placeholders (no launch)
@@ -578,7 +580,7 @@ def test_two_key_adapter(ops, dtype, n, t, c, heads, strided):
     ref = xs + b[:, None, :] + torch.einsum("nth,nhc->ntc", torch.sigmoid(z), u)
     view = xd[::2] if strided else xd
     y = ops.two_key_adapter(view, a.cuda(), a.sum(-1).contiguous().cuda(), cc.cuda(), u.cuda(), b.cuda(), 1e-5)
-    assert rel(y.float(), ref) < TOL[dtype] * 0.5
+    assert rel(y.float(), ref) < TOL[dtype]
     y2 = ops.two_key_adapter(view, a.cuda(), a.sum(-1).contiguous().cuda(), cc.cuda(), u.cuda(), b.cuda(), 1e-5, out=view)
     assert y2.data_ptr() == view.data_ptr() and torch.equal(y2, y)
     if strided:                                                        # the partner images are untouched
@@ -595,7 +597,7 @@ def test_igemm_pingpong_upsample_and_stride(ops, dtype, tune):
         wf = torch.from_numpy(W.synth_param(name + ".weight", (cout, cin, 3, 3))).to(dtype).float()
         bias = torch.from_numpy(W.synth_param(name + ".bias", (cout,)))
         y = ops.igemm(xd, ops.pack_conv(wf, bias, dtype, "cuda"), stride=stride, upsample=up)
-        assert rel(y.float(), _conv_ref(xf, wf, bias, stride, (1, 1), up)) < TOL[dtype] * 0.5, name
+        assert rel(y.float(), _conv_ref(xf, wf, bias, stride, (1, 1), up)) < TOL[dtype], name
 
 
 def test_range_denorm_vs_reference_golden(ops):
@@ -638,7 +640,7 @@ def test_igemm_pingpong_split_k(ops, dtype, blocks, tune):
     pw = ops.pack_conv(wf, bias, dtype, "cuda")
     for split in (8, 11):
         y = ops.igemm(xd, pw, rowvec=rv.cuda(), residual=rd, split_k=split)
-        assert rel(y.float(), ref) < TOL[dtype] * 0.5, split
+        assert rel(y.float(), ref) < TOL[dtype], split
     p = _lib.IgemmParams()
     p.src0, p.weight, p.out, p.ws = 256, 256, 256, 256
     p.c0, p.batch, p.hin, p.win, p.hout, p.wout = cin, n, h, h, h, h

@@ -29,12 +29,14 @@ from tests.test_gpu_models import _unet, _vae
 pytestmark = pytest.mark.gpu
 
 DT = [torch.float16, torch.bfloat16]
-# rel-L2 vs the fp32 CPU oracle; measured (MI355X, this round): see profiles/r02_error_table.txt
+# rel-L2 vs the fp32 CPU oracle, <= 2x the values measured on the MI355X this round (profiles/r02_error_table.txt): full
+# width forward fp16 1.36e-3 / bf16 1.07e-2 (worst pair 2.09e-3 / 1.36e-2); VAE 1.76e-3 / 1.43e-2; DDIM-50 3.9e-4 / 2.97e-3
+# without guidance (the 1e-3 of fp16 is the north star's own number), 1.03e-3 / 9.2e-3 with scale 5; DDIM-250 3.5e-4
 TOL_FULL = {torch.float16: 2.6e-3, torch.bfloat16: 1.9e-2}          # one full-width UNet forward
 TOL_VAE = {torch.float16: 3e-3, torch.bfloat16: 2.4e-2}
 TOL_DDIM50 = {(torch.float16, 1.0): 1e-3, (torch.float16, 5.0): 2.1e-3,
               (torch.bfloat16, 1.0): 6e-3, (torch.bfloat16, 5.0): 1.8e-2}
-TOL_DDIM250 = {torch.float16: 1e-3}
+TOL_DDIM250 = {torch.float16: 7e-4}
 
 
 def _set(dtype):
@@ -79,7 +81,7 @@ def test_full_width_forward_vs_oracle(dtype, side, n):
     check(rel_l2(y.cpu(), ref), TOL_FULL[dtype], f"unet_full_width_{side}x{side}_b{n}_{dtype}")
     # every pair on its own is within the same bound (an error concentrated in one image must not hide in the norm)
     worst = max(rel_l2(y[i:i + 2].cpu(), ref[i:i + 2]) for i in range(0, n, 2))
-    check(worst, TOL_FULL[dtype] * 1.5, f"unet_full_width_{side}x{side}_b{n}_{dtype}_worst_pair")
+    check(worst, TOL_FULL[dtype] * 1.4, f"unet_full_width_{side}x{side}_b{n}_{dtype}_worst_pair")
 
 
 def _traj_case(S):
