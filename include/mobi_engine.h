@@ -46,6 +46,9 @@ size_t mobi_struct_size(int id);
 /* Development hook: the library reads its MOBI_* A/B environment variables once, at the first launch
  * (mobi_amd/csrc/tuning.h lists them); this re-reads them.  Not needed by a product caller. */
 int mobi_tuning_reload(void);
+/* Bit 0: the library was built with -DMOBI_DEV, i.e. it also carries the A/B partner kernels (lockstep direct-to-LDS
+ * igemm, fast-addressing register-staged igemm, software-pipelined attention) that the shipped build leaves out. */
+int mobi_build_info(void);
 
 /* ---------------------------------------------------------------------------
  * Implicit-GEMM convolution / linear layer on the matrix cores.

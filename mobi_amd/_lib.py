@@ -112,6 +112,7 @@ SYMBOLS = {
     "mobi_error_string": (C.c_char_p, [C.c_int]),
     "mobi_struct_size": (C.c_size_t, [C.c_int]),
     "mobi_tuning_reload": (C.c_int, []),
+    "mobi_build_info": (C.c_int, []),
     "mobi_igemm": (C.c_int, [C.POINTER(IgemmParams), vp]),
     "mobi_igemm_plan_splits": (C.c_int, [C.POINTER(IgemmParams)]),
     "mobi_igemm_kernel_variant": (C.c_int, [C.POINTER(IgemmParams)]),

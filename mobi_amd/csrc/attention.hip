@@ -447,6 +447,7 @@ __global__ __launch_bounds__(64 * NW, (WPS * 4) / NW) void attention_kernel(cons
   }
 }
 
+#ifdef MOBI_DEV   // development build only: the software-pipelined A/B alternative (measured slower, MOBI_ATTN_SP=1)
 // =========================================================================================================
 // SOFTWARE-PIPELINED variant of the 8-wave kernel (V row-major, one 16-byte K and V piece per thread and key tile,
 // odd KS so that the padded head-dim row carries the softmax denominator: dh 33..48 with KS = 3).
@@ -743,6 +744,8 @@ __global__ __launch_bounds__(512, 2) void attention_sp_kernel(const AttnArgs a) 
   }
 }
 
+#endif  // MOBI_DEV
+
 template <typename T, int VVEC>
 static int launch_attention_v(const mobi_attention_params* p, const AttnArgs& a, hipStream_t st) {
   dim3 grid((p->tq + 127) / 128, p->heads, p->images), block(256);
@@ -756,6 +759,7 @@ static int launch_attention_v(const mobi_attention_params* p, const AttnArgs& a,
       dim3 grid8((p->tq + 255) / 256, p->heads, p->images), block8(512);
       // software-pipelined kernel (head dims 33..48): measured SLOWER than the kernel above (693 vs 620 us on
       // [16, 4096 x 4096, 8 x 40], tools/ab_attn.sh), kept selectable for A/B runs and covered by the parity tests
+#ifdef MOBI_DEV
       int sp = 0;
       if (tuning().attn_sp == 1) sp = ks == 3;
       if (sp) {
@@ -763,6 +767,7 @@ static int launch_attention_v(const mobi_attention_params* p, const AttnArgs& a,
         MOBI_CHECK_LAUNCH();
         return MOBI_OK;
       }
+#endif
 #define MOBI_ATTN_CASE8(KS_) hipLaunchKernelGGL((attention_kernel<T, KS_, 2, 2, 8>), grid8, block8, 0, st, a)
       if (ks <= 1) MOBI_ATTN_CASE8(1);
       else if (ks == 2) MOBI_ATTN_CASE8(2);

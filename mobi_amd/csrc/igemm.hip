@@ -150,7 +150,9 @@ struct EpiGeom {
   static constexpr int BYTES = ROWS * STRIDE * 4;                   // per wave
 };
 
-template <typename T, int NT, bool TR, int RPP>
+// RES_EARLY = false: the residual rows of a pass are requested at the start of THAT pass (the 256 x 320 ring kernel holds
+// 160 accumulator registers through the epilogue: all passes' rows up front would spill)
+template <typename T, int NT, bool TR, int RPP, bool RES_EARLY = true>
 __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& a, float* stage, f32x4 (&acc)[NT][4], int lane,
                                                int group, int nw0, int mw0) {
   constexpr int WAVE_N = NT * 16;
@@ -194,28 +196,31 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& a, float* stage,
   // ---- residual rows of every pass (plain path) --------------------------------------------------------------
   constexpr int TPR_P = WAVE_N / 8;
   constexpr int NIT_P = (RPP * TPR_P + 63) / 64;
-  u32x4 rres[NPASS][NIT_P];
-  if (plain && resid) {
+  u32x4 rres[RES_EARLY ? NPASS : 1][NIT_P];
+  auto request_rows = [&](int pass, u32x4 (&dst)[NIT_P]) {
 #pragma unroll
-    for (int pass = 0; pass < NPASS; ++pass)
-#pragma unroll
-      for (int it = 0; it < NIT_P; ++it) {
-        rres[pass][it] = u32x4{0u, 0u, 0u, 0u};
-        const int task = lane + 64 * it;
-        const int row = task / TPR_P, cg = task - row * TPR_P;
-        const int rt = pass * RPP + row;
-        const int n = nw0 + cg * 8;
-        if (task < RPP * TPR_P && mw0 + rt < a.M && n < a.cout) {
-          int img, rem;
-          locate(rt, img, rem);
-          const long long gi = (long long)(group * a.imgs_per_group + img);
-          rres[pass][it] = ld16(resid + gi * a.res_img_stride + (long long)rem * a.cout + n);
-        }
+    for (int it = 0; it < NIT_P; ++it) {
+      dst[it] = u32x4{0u, 0u, 0u, 0u};
+      const int task = lane + 64 * it;
+      const int row = task / TPR_P, cg = task - row * TPR_P;
+      const int rt = pass * RPP + row;
+      const int n = nw0 + cg * 8;
+      if (task < RPP * TPR_P && mw0 + rt < a.M && n < a.cout) {
+        int img, rem;
+        locate(rt, img, rem);
+        const long long gi = (long long)(group * a.imgs_per_group + img);
+        dst[it] = ld16(resid + gi * a.res_img_stride + (long long)rem * a.cout + n);
       }
+    }
+  };
+  if (RES_EARLY && plain && resid) {
+#pragma unroll
+    for (int pass = 0; pass < NPASS; ++pass) request_rows(pass, rres[pass]);
   }
 
 #pragma unroll
   for (int pass = 0; pass < NPASS; ++pass) {
+    if (!RES_EARLY && plain && resid) request_rows(pass, rres[0]);
     // (the caller's last barrier ordered every wave's fragment reads before these writes; the passes of one
     //  wave are ordered by the waits below)
     if (!TR) {
@@ -299,7 +304,7 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& a, float* stage,
           }
           if (resid) {
             float rf[8];
-            unpack8<T>(rres[pass][it], rf);
+            unpack8<T>(rres[RES_EARLY ? pass : 0][it], rf);
 #pragma unroll
             for (int j = 0; j < 8; ++j) o[j] += rf[j];
           }
@@ -524,10 +529,13 @@ __device__ __forceinline__ void pp_residual_request(const IgemmArgs& a, u32x4 (&
   for (int ni = 0; ni < NT; ++ni) r[ni] = vm_load16(rowp + ni * 16);
 }
 // request of pair 0 at the start of an output tile; returns the number of vector-memory instructions issued
+#ifndef MOBI_PP_RES0_EARLY
+#define MOBI_PP_RES0_EARLY 0   // 1: pair 0's residual rows are requested at the START of the tile's k loop and held in NT x 4
+#endif                         //    VGPRs across it (the NT = 5 instance then needs 264 registers: 8 spilled to scratch)
 template <typename T, int NT, bool GEGLU>
 __device__ __forceinline__ int pp_epilogue_request(const IgemmArgs& a, PpEpiRegs<NT>& q, int lane, int group, int nw0,
                                                    int mw0) {
-  if (GEGLU || !a.residual) return 0;
+  if (!MOBI_PP_RES0_EARLY || GEGLU || !a.residual) return 0;
   pp_residual_request<T, NT>(a, q.res0, 0, lane, group, nw0, mw0);
   return NT;
 }
@@ -542,8 +550,15 @@ __device__ __forceinline__ int pp_epilogue(const IgemmArgs& a, f32x4 (&acc)[NT][
   u32x4 res1[NT];
   int n_issued = 0;
   if (resid) {
+    if (!MOBI_PP_RES0_EARLY) {                               // both pairs now: pair 0's rows land first (issue order)
+      pp_residual_request<T, NT>(a, q.res0, 0, lane, group, nw0, mw0);
+      n_issued += NT;
+    }
     pp_residual_request<T, NT>(a, res1, 1, lane, group, nw0, mw0);
     n_issued += NT;
+    if (!MOBI_PP_RES0_EARLY) {
+      if (NT == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    }
 #pragma unroll
     for (int ni = 0; ni < NT; ++ni) asm volatile("" : "+v"(q.res0[ni]));
   }
@@ -881,6 +896,8 @@ __global__ __launch_bounds__(128 * WM, 2) void igemm_kernel(const IgemmArgs a) {
   igemm_epilogue<T, NT, TR, 32>(a, stage, acc, lane, group, n0 + wn * WAVE_N, m0 + wm * 64);
 }
 
+#ifdef MOBI_DEV   // development build only (A/B partner of the ping-pong kernel, MOBI_IGEMM_PP=0): the shipped library routes
+                  // every launch it used to take (LDS-staged epilogues of the 256-pixel geometry) to igemm_ring_kernel
 // =========================================================================================================
 // Direct-to-LDS main loop (FAST shapes only):  256 pixels x (2 * WAVE_N) channels, 8 waves (4 x 2), THREE LDS
 // stages filled by global_load_lds_dwordx4 (no VGPR staging, no ds_write), one raw s_barrier per k-tile and a
@@ -1186,6 +1203,8 @@ __global__ __launch_bounds__(512, 2) void igemm_glds_kernel(const IgemmArgs a) {
 #endif
 }
 
+#endif  // MOBI_DEV
+
 // =========================================================================================================
 // PING-PONG main loop (register-epilogue launches of the direct-to-LDS geometry: full 256 x (2 * WAVE_N) tiles,
 // row-major output, no split-K, window pixels linear in the tap).
@@ -1466,11 +1485,13 @@ __global__ __launch_bounds__(512, 2) void igemm_pp_kernel(const IgemmArgs a) {
         MOBI_PP_BARRIER();
         MOBI_PP_T(1);
         if (kt == 0 && bid != (int)blockIdx.x) {             // tile boundary: previous tile's registers -> memory
+          // (the next tile's bias / per-image vector is requested AFTER the previous tile's epilogue: requested before it,
+          //  its NT x 4 registers are live across the epilogue and the NT = 5 instance spills 8 VGPRs to scratch)
+          wait_vmcnt_le(vm_issued - mk_req);                 // residual rows of the previous tile
+          vm_issued += finish_tile(p_nw0, p_mw0);
           u32x4 bv[NT];
           if (has_vec) { request_vec(bv, nw0, mw0); vm_issued += NT; }
           const int mk_vec = vm_issued;
-          wait_vmcnt_le(vm_issued - mk_req);                 // residual rows of the previous tile
-          vm_issued += finish_tile(p_nw0, p_mw0);
           wait_vmcnt_le(vm_issued - mk_vec);
           start_sums(bv);
           vm_issued += request_tile(nw0, mw0);
@@ -1548,11 +1569,13 @@ __global__ __launch_bounds__(512, 2) void igemm_pp_kernel(const IgemmArgs a) {
         MOBI_PP_BARRIER();
         MOBI_PP_T(1);
         if (ks == 0 && kt == 0 && bid != (int)blockIdx.x) {  // tile boundary: previous tile's registers -> memory
+          // (the next tile's bias / per-image vector is requested AFTER the previous tile's epilogue: requested before it,
+          //  its NT x 4 registers are live across the epilogue and the NT = 5 instance spills 8 VGPRs to scratch)
+          wait_vmcnt_le(vm_issued - mk_req);                 // residual rows of the previous tile
+          vm_issued += finish_tile(p_nw0, p_mw0);
           u32x4 bv[NT];
           if (has_vec) { request_vec(bv, nw0, mw0); vm_issued += NT; }
           const int mk_vec = vm_issued;
-          wait_vmcnt_le(vm_issued - mk_req);                 // residual rows of the previous tile
-          vm_issued += finish_tile(p_nw0, p_mw0);
           wait_vmcnt_le(vm_issued - mk_vec);
           start_sums(bv);
           vm_issued += request_tile(nw0, mw0);
@@ -1861,7 +1884,7 @@ __global__ __launch_bounds__(NW * 64, 2) void igemm_ring_kernel(const IgemmArgs 
     for (int i = 0; i < NT; ++i)
 #pragma unroll
       for (int j = 0; j < 4; ++j) part[i][j] = acc[i][4 * h + j];
-    igemm_epilogue<T, NT, TR, 32>(a, stage, part, lane, group, n0 + wn * WAVE_N, m0 + wm * MT * 16 + 64 * h);
+    igemm_epilogue<T, NT, TR, 32, MT == 4>(a, stage, part, lane, group, n0 + wn * WAVE_N, m0 + wm * MT * 16 + 64 * h);
   }
 }
 
@@ -1936,20 +1959,40 @@ static int launch_igemm(const mobi_igemm_params* p, const IgemmArgs& a, int grou
   dim3 grid(a.tiles_m * a.tiles_n, a.splits, groups);
 #define MOBI_IGEMM_LAUNCH(NT_, TR_, WM_, FAST_) \
   hipLaunchKernelGGL((igemm_kernel<T, NT_, TR_, WM_, FAST_>), grid, dim3(128 * WM_), 0, st, a)
+#ifdef MOBI_DEV   // the register-staged kernel's fast-addressing instances: A/B partners of the ring kernel only
 #define MOBI_IGEMM_BY_FAST(NT_, TR_, WM_) \
   do { if (a.fast) MOBI_IGEMM_LAUNCH(NT_, TR_, WM_, true); else MOBI_IGEMM_LAUNCH(NT_, TR_, WM_, false); } while (0)
+#else             // shipped: the generic-gather instance is the fallback for operands beyond 2 GB / chunk-major k
+#define MOBI_IGEMM_BY_FAST(NT_, TR_, WM_) MOBI_IGEMM_LAUNCH(NT_, TR_, WM_, false)
+#endif
 #define MOBI_IGEMM_BY_TR(NT_, WM_) \
   do { if (tr) MOBI_IGEMM_BY_FAST(NT_, true, WM_); else MOBI_IGEMM_BY_FAST(NT_, false, WM_); } while (0)
   if (a.wide == 2) {
-    if (nt5) hipLaunchKernelGGL((igemm_ring_kernel<T, 5, false, 8, 8>), grid, dim3(512), 0, st, a);
-    else     hipLaunchKernelGGL((igemm_ring_kernel<T, 4, false, 8, 8>), grid, dim3(512), 0, st, a);
+#define MOBI_W2_LAUNCH(NT_, TR_) hipLaunchKernelGGL((igemm_ring_kernel<T, NT_, TR_, 8, 8>), grid, dim3(512), 0, st, a)
+    if (nt5) { if (tr) MOBI_W2_LAUNCH(5, true); else MOBI_W2_LAUNCH(5, false); }
+    else     { if (tr) MOBI_W2_LAUNCH(4, true); else MOBI_W2_LAUNCH(4, false); }
+#undef MOBI_W2_LAUNCH
   }
   else if (a.wide == 1) {
     if (nt5) hipLaunchKernelGGL((igemm_ring_kernel<T, 5, false, 8, 4>), grid, dim3(512), 0, st, a);
     else     hipLaunchKernelGGL((igemm_ring_kernel<T, 4, false, 8, 4>), grid, dim3(512), 0, st, a);
   }
-  else if (a.wm == 4 && a.fast && a.glds) {
+  else if (a.wm == 4 && a.fast && a.glds && a.pp) {
     // persistent: one 156-KB-LDS block per CU walks the output tiles
+    dim3 block(512);
+    dim3 pgrid(grid.x < (unsigned)compute_units() ? grid.x : (unsigned)compute_units(), grid.y, grid.z);
+    if (a.split_ws) {
+      if (nt5) hipLaunchKernelGGL((igemm_pp_kernel<T, 5, false, true>), pgrid, block, 0, st, a);
+      else     hipLaunchKernelGGL((igemm_pp_kernel<T, 4, false, true>), pgrid, block, 0, st, a);
+    } else {
+#define MOBI_PP_LAUNCH(NT_, G_) hipLaunchKernelGGL((igemm_pp_kernel<T, NT_, G_>), pgrid, block, 0, st, a)
+      if (a.epilogue == MOBI_EPI_GEGLU) { if (nt5) MOBI_PP_LAUNCH(5, true); else MOBI_PP_LAUNCH(4, true); }
+      else                              { if (nt5) MOBI_PP_LAUNCH(5, false); else MOBI_PP_LAUNCH(4, false); }
+#undef MOBI_PP_LAUNCH
+    }
+  }
+#ifdef MOBI_DEV
+  else if (a.wm == 4 && a.fast && a.glds) {
     dim3 block(512);
     dim3 pgrid(grid.x < (unsigned)compute_units() ? grid.x : (unsigned)compute_units(), grid.y, grid.z);
     const int mode = tr ? 1 : (a.epi_direct ? (a.epilogue == MOBI_EPI_GEGLU ? 3 : 2) : 0);
@@ -1957,20 +2000,11 @@ static int launch_igemm(const mobi_igemm_params* p, const IgemmArgs& a, int grou
 #define MOBI_GLDS_BY_MODE(NT_)                                                                     \
   do { switch (mode) { case 0: MOBI_GLDS_LAUNCH(NT_, 0); break; case 1: MOBI_GLDS_LAUNCH(NT_, 1); break; \
                        case 2: MOBI_GLDS_LAUNCH(NT_, 2); break; default: MOBI_GLDS_LAUNCH(NT_, 3); break; } } while (0)
-    if (a.pp && a.split_ws) {
-      if (nt5) hipLaunchKernelGGL((igemm_pp_kernel<T, 5, false, true>), pgrid, block, 0, st, a);
-      else     hipLaunchKernelGGL((igemm_pp_kernel<T, 4, false, true>), pgrid, block, 0, st, a);
-    }
-    else if (a.pp) {
-#define MOBI_PP_LAUNCH(NT_, G_) hipLaunchKernelGGL((igemm_pp_kernel<T, NT_, G_>), pgrid, block, 0, st, a)
-      if (mode == 3) { if (nt5) MOBI_PP_LAUNCH(5, true); else MOBI_PP_LAUNCH(4, true); }
-      else           { if (nt5) MOBI_PP_LAUNCH(5, false); else MOBI_PP_LAUNCH(4, false); }
-#undef MOBI_PP_LAUNCH
-    }
-    else if (nt5) MOBI_GLDS_BY_MODE(5); else MOBI_GLDS_BY_MODE(4);
+    if (nt5) MOBI_GLDS_BY_MODE(5); else MOBI_GLDS_BY_MODE(4);
 #undef MOBI_GLDS_BY_MODE
 #undef MOBI_GLDS_LAUNCH
   }
+#endif
   else if (a.wm == 4) { if (nt5) MOBI_IGEMM_BY_TR(5, 4); else MOBI_IGEMM_BY_TR(4, 4); }
   else if (a.sm) {
 #define MOBI_SM_LAUNCH(NT_, TR_) hipLaunchKernelGGL((igemm_ring_kernel<T, NT_, TR_, 4, 4>), grid, dim3(256), 0, st, a)
@@ -2147,7 +2181,7 @@ static int igemm_prepare(const mobi_igemm_params* p, mobi::IgemmArgs& a) {
   //  the 128 x 320 tile (twice the blocks at the ping-pong tile's bytes per FLOP) measured 829-965 TFLOP/s there against
   //  982-1085 on the ping-pong kernel: kept for A/B (MOBI_IGEMM_WIDE128=1), not routed)
   a.wide = 0;
-  if ((a.wm == 4 || tuning().wide > 0) && ring_ok && p->out_mode != MOBI_OUT_TRANSPOSED && tuning().wide != 0) {
+  if ((a.wm == 4 || tuning().wide > 0) && ring_ok && tuning().wide != 0) {
     const int bnw = (p->n_packed % 160) == 0 ? 320 : 256;
     const long long tn = (p->n_packed + bnw - 1) / bnw;
     auto fills = [&](long long blocks) {
@@ -2156,6 +2190,11 @@ static int igemm_prepare(const mobi_igemm_params* p, mobi::IgemmArgs& a) {
     };
     const long long t256 = ((a.M + 255) / 256) * tn * a.splits, t128 = ((a.M + 127) / 128) * tn * a.splits;
     int pick = tuning().wide > 0 ? tuning().wide : (fills(t256) ? 2 : (fills(t128) && tuning().wide128 == 1 ? 1 : 0));
+#ifndef MOBI_DEV
+    // launches of the 256-pixel geometry that the ping-pong kernel's register epilogue does not take (transposed / fp32
+    // output, ragged tiles, bias AND per-image vector, per-image weights): the ring kernel's LDS-staged epilogue does
+    if (!pick && a.wm == 4 && !a.pp) pick = 2;
+#endif
     if (pick) {
       a.wide = pick;
       a.wm = pick == 2 ? 4 : 2;

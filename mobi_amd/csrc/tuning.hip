@@ -42,3 +42,11 @@ extern "C" int mobi_tuning_reload(void) {
   mobi::read_env();
   return MOBI_OK;
 }
+
+extern "C" int mobi_build_info(void) {
+#ifdef MOBI_DEV
+  return 1;
+#else
+  return 0;
+#endif
+}

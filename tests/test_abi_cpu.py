@@ -178,3 +178,36 @@ def test_mobi_configs_resolve_onto_engine_classes(name):
     assert get_obj_from_str(mp_["cond_stage_config"]["target"]).__module__ == "mobi_amd.ldm.modules.encoders.modules"
     assert mp_["image_size"] == cfg["latent_size"] == cfg["image_height"] // 8
     assert mp_["unet_config"]["params"]["model_channels"] == 320 and mp_["cond_stage_key"] == ["ref_image", "ref_bbox"]
+
+
+def test_shipped_library_has_no_scratch_and_no_dev_kernels():
+    """Every kernel of the shipped library keeps its state in registers (no scratch_load / scratch_store in the gfx950
+    code objects: a spilling main loop was the round-1 library's slowest igemm path) and the A/B partner kernels of the
+    development build (-DMOBI_DEV) are not in it."""
+    import shutil
+    import subprocess
+    import tempfile
+    from mobi_amd import _lib, build
+    bundler = "/opt/rocm/lib/llvm/bin/clang-offload-bundler"
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    if not (os.path.exists(bundler) and os.path.exists(objdump)):
+        pytest.skip("ROCm LLVM tools not present")
+    assert _lib.load().mobi_build_info() == 0
+    objs = [os.path.join(build.OBJ, f) for f in os.listdir(build.OBJ) if f.endswith(".o")]
+    assert len(objs) >= 7
+    objcopy = "/opt/rocm/lib/llvm/bin/llvm-objcopy"
+    with tempfile.TemporaryDirectory() as tmp:
+        for o in objs:
+            fat, co = os.path.join(tmp, "fat.bin"), os.path.join(tmp, os.path.basename(o) + ".co")
+            if subprocess.run([objcopy, f"--dump-section=.hip_fatbin={fat}", o], capture_output=True).returncode != 0:
+                continue                                         # a host-only object (tuning.o has no kernels)
+            r = subprocess.run([bundler, "--unbundle", "--type=o", f"--input={fat}",
+                                "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--output={co}"], capture_output=True, text=True)
+            assert r.returncode == 0 and os.path.getsize(co) > 0, r.stderr
+            asm = subprocess.run([objdump, "-d", co], capture_output=True, text=True).stdout
+            assert "s_endpgm" in asm
+            assert "scratch_load" not in asm and "scratch_store" not in asm, o
+            for dev_only in ("igemm_glds_kernel", "attention_sp_kernel"):
+                assert dev_only not in asm, (o, dev_only)
+            if o.endswith(("igemm.o", "attention.o")):
+                assert "v_mfma_f32_16x16x32" in asm or "v_mfma_f32_32x32x16" in asm
