@@ -2132,6 +2132,9 @@ static int igemm_prepare(const mobi_igemm_params* p, mobi::IgemmArgs& a) {
     if (tuning().fast == 0) a.fast = 0;
     a.k_order = p->k_order;
     if (p->k_order != 0 && p->k_order != 1) return MOBI_ERR_ARG;
+#ifndef MOBI_DEV
+    if (p->k_order == 1) return MOBI_ERR_UNSUPPORTED;      // chunk-major k: development build only (measured slower)
+#endif
     if (p->k_order == 1 && !a.fast) return MOBI_ERR_UNSUPPORTED;      // the generic gather walks k tap-major only
     a.glds = 1;
     if (tuning().glds == 0) a.glds = 0;

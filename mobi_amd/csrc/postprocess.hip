@@ -76,7 +76,7 @@ __global__ void range_paste_kernel(const mobi_range_paste_params a) {
 
 // one block per (sample, region): region 0 = object (instance mask), 1 = inpainting mask
 __global__ __launch_bounds__(1024) void lidar_metrics_kernel(const mobi_lidar_metrics_params a) {
-  extern __shared__ float vals[];                            // [cap] absolute errors of the region, then sorted
+  __shared__ float vals[16384];                              // absolute errors of the region (<= 32 x 512 cells), then sorted
   __shared__ unsigned n_vals;
   __shared__ double red[1024];
   const int b = blockIdx.x, region = blockIdx.y, tid = threadIdx.x;
@@ -218,15 +218,8 @@ extern "C" int mobi_range_paste(const mobi_range_paste_params* p, void* stream) 
 extern "C" int mobi_lidar_metrics(const mobi_lidar_metrics_params* p, void* stream) {
   if (!p || !p->pred || !p->gt || !p->inst_mask || !p->box_mask || !p->width_crop || !p->out) return MOBI_ERR_ARG;
   if (p->batch <= 0 || p->h <= 0 || p->w <= 0 || p->pool_h <= 0 || p->h % p->pool_h || p->max_width <= 0) return MOBI_ERR_ARG;
-  unsigned cap = 1;
-  while (cap < (unsigned)(p->pool_h * p->max_width)) cap <<= 1;
-  const size_t shmem = (size_t)cap * sizeof(float);
-  if (shmem > 120 * 1024) return MOBI_ERR_UNSUPPORTED;
-  if (shmem > 48 * 1024 &&
-      hipFuncSetAttribute(reinterpret_cast<const void*>(lidar_metrics_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                          (int)shmem) != hipSuccess)
-    return MOBI_ERR_LAUNCH;
-  hipLaunchKernelGGL(lidar_metrics_kernel, dim3(p->batch, 2), dim3(1024), shmem, ST(stream), *p);
+  if ((long long)p->pool_h * p->max_width > 16384) return MOBI_ERR_UNSUPPORTED;      // the sort space in LDS
+  hipLaunchKernelGGL(lidar_metrics_kernel, dim3(p->batch, 2), dim3(1024), 0, ST(stream), *p);
   MOBI_CHECK_LAUNCH();
   return MOBI_OK;
 }

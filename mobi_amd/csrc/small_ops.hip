@@ -2,6 +2,7 @@
 // vectors, timestep embedding, few-token context attention, row softmax, direct
 // convolutions for the thin ends of the networks, layout converters.
 #include "common.h"
+#include "tuning.h"
 
 namespace mobi {
 
@@ -514,6 +515,191 @@ __global__ __launch_bounds__(256) void two_key_adapter_kernel(const mobi_two_key
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Two-key adapter on the matrix cores.  The VALU kernel above spends ~280 instructions per token row on two skinny
+// products (8 gate logits = LN(x) . a_h, and the gated sum of 8 per-image vectors) and 34 LDS table reads; here both
+// are MFMA 16x16x32 products on 16-row groups:
+//   logits  D[h][token]  = sum_c  A[h][c] x[token][c]                (first operand: table rows, second: x rows)
+//   update  D[ch][token] = sum_h  U^T[ch][h] g[token][h]             (k = 8 heads, zero-padded to 32)
+// The fp32 tables are split into hi + lo parts of the storage type (two MFMAs each), so the products carry ~16
+// mantissa bits whatever the storage type; a_sum is re-derived from the split table, so the LayerNorm mean term
+// cancels against the SAME numbers the logits were formed with.  x is staged once through LDS (coalesced 16-byte
+// loads), read as MFMA fragments (LN statistics come from the same registers) and as 8-byte pieces in the
+// accumulator layout for the final add; the result goes back through the same LDS tile for coalesced stores.
+// Per 16 rows and wave: 60 MFMAs, ~500 vector instructions (31 per row instead of 280).
+// ---------------------------------------------------------------------------------------------------------
+template <typename T, int CMAX>
+__global__ __launch_bounds__(256) void two_key_adapter_mfma_kernel(const mobi_two_key_adapter_params p, int rows_per_block) {
+  typedef typename Vec8<T>::type frag_t;
+  // static LDS, sized for CMAX channels (320: 64 KB, two blocks per CU; 640: 127 KB)
+  __shared__ __attribute__((aligned(16))) unsigned char tka_lds[2 * 8 * (CMAX * 2 + 16) + 2 * CMAX * 16 + (CMAX + 8) * 4 +
+                                                                4 * 16 * (CMAX * 2 + 16)];
+  const int C = p.channels, H = p.heads;
+  const int AST = C * 2 + 16;                       // bytes per table row (hi or lo), 16-byte aligned, odd multiple of 16 ...
+  const int XST = C * 2 + 16;                       // ... and per x row: conflict-free fragment reads
+  unsigned char* s_ahi = tka_lds;                   // T [8][C] (+pad): rows >= H are zero (MFMA rows 8..15 read zeros)
+  unsigned char* s_alo = s_ahi + 8 * AST;
+  unsigned char* s_uhi = s_alo + 8 * AST;           // T [C][8]: U^T, heads contiguous
+  unsigned char* s_ulo = s_uhi + C * 16;
+  float* s_b = reinterpret_cast<float*>(s_ulo + C * 16);          // [C]
+  float* s_asum = s_b + C;                          // [8] sums of the split table rows
+  unsigned char* s_x = reinterpret_cast<unsigned char*>(s_asum + 8);
+  const int img = blockIdx.y;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r16 = lane & 15, g4 = lane >> 4;
+  unsigned char* xt = s_x + wave * 16 * XST;        // this wave's 16-row tile
+
+  // ---- tables (once per block) --------------------------------------------------------------------------------
+  {
+    const float* ga = p.a + (long long)img * H * C;
+    const float* gu = p.u + (long long)img * H * C;
+    for (int i = tid; i < 8 * C; i += 256) {
+      const int h = i / C, c = i - h * C;
+      const float v = h < H ? ga[i] : 0.f;
+      const T hi = (T)v;
+      const T lo = (T)(v - (float)hi);
+      *reinterpret_cast<T*>(s_ahi + h * AST + c * 2) = hi;
+      *reinterpret_cast<T*>(s_alo + h * AST + c * 2) = lo;
+    }
+    for (int i = tid; i < 8 * C; i += 256) {
+      const int h = i / C, c = i - h * C;
+      const float v = h < H ? gu[i] : 0.f;
+      const T hi = (T)v;
+      const T lo = (T)(v - (float)hi);
+      *reinterpret_cast<T*>(s_uhi + c * 16 + h * 2) = hi;
+      *reinterpret_cast<T*>(s_ulo + c * 16 + h * 2) = lo;
+    }
+    for (int c = tid; c < C; c += 256) s_b[c] = p.b[(long long)img * C + c];
+  }
+  __syncthreads();
+  {                                                 // sums of the numbers the matrix product will use: 32 threads per head
+    const int h = tid >> 5, l = tid & 31;
+    float sum = 0.f;
+    for (int c = l; c < C; c += 32)
+      sum += (float)*reinterpret_cast<const T*>(s_ahi + h * AST + c * 2) + (float)*reinterpret_cast<const T*>(s_alo + h * AST + c * 2);
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+    if (l == 0) s_asum[h] = sum;
+  }
+  __syncthreads();
+  float a_sum[4], cc[4];                            // the lane's four heads: 4 g4 .. 4 g4 + 3 (g4 < 2)
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int h = 4 * g4 + j;
+    a_sum[j] = h < 8 ? s_asum[h] : 0.f;
+    cc[j] = h < H ? p.c[img * H + h] : 0.f;
+  }
+  const long long ximg = p.x_img_stride ? p.x_img_stride : (long long)p.rows_per_image * C;
+  const long long oimg = p.out_img_stride ? p.out_img_stride : (long long)p.rows_per_image * C;
+  const T* __restrict__ xb = reinterpret_cast<const T*>(p.x) + img * ximg;
+  T* __restrict__ ob = reinterpret_cast<T*>(p.out) + img * oimg;
+  const int r_begin = blockIdx.x * rows_per_block;
+  const int r_end = min(p.rows_per_image, r_begin + rows_per_block);
+  const float inv_c = 1.0f / (float)C;
+  const int pieces = 16 * (C >> 3);                 // 16-byte pieces of a 16-row tile (rows are contiguous in memory)
+  const int ppr = C >> 3;                           // pieces per row
+
+  // the next tile's 16-byte pieces are in flight (in registers) while this one is multiplied
+  constexpr int NP = (16 * (CMAX >> 3) + 63) / 64;  // pieces per lane
+  u32x4 nxt[NP];
+  auto fetch = [&](int r0) {
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+      const int i = lane + 64 * j;
+      const int row = i / ppr, pc = i - row * ppr;
+      nxt[j] = u32x4{0u, 0u, 0u, 0u};
+      if (i < pieces && r0 + row < r_end) nxt[j] = ld16(xb + (long long)(r0 + row) * C + pc * 8);
+    }
+  };
+  fetch(r_begin + 16 * wave);
+  for (int r0 = r_begin + 16 * wave; r0 < r_end; r0 += 64) {
+    // ---- x tile: registers -> LDS, next tile requested -----------------------------------------------------------
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+      const int i = lane + 64 * j;
+      const int row = i / ppr, pc = i - row * ppr;
+      if (i < pieces) st16(xt + row * XST + pc * 16, nxt[j]);
+    }
+    fetch(r0 + 64);
+    __builtin_amdgcn_s_waitcnt(0xc07f);             // lgkmcnt(0); the tile is private to the wave
+    __builtin_amdgcn_wave_barrier();
+    // ---- logits + LayerNorm sums --------------------------------------------------------------------------------
+    f32x4 lg = f32x4{0.f, 0.f, 0.f, 0.f};
+    float sx = 0.f, sxx = 0.f;
+    for (int k0 = 0; k0 < C; k0 += 32) {
+      const frag_t xf = __builtin_bit_cast(frag_t, ld16(xt + r16 * XST + (k0 + 8 * g4) * 2));
+      frag_t ah, al;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { ah[j] = (T)0.0f; al[j] = (T)0.0f; }
+      if (r16 < 8) {
+        ah = __builtin_bit_cast(frag_t, ld16(s_ahi + r16 * AST + (k0 + 8 * g4) * 2));
+        al = __builtin_bit_cast(frag_t, ld16(s_alo + r16 * AST + (k0 + 8 * g4) * 2));
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { const float v = (float)xf[j]; sx += v; sxx += v * v; }
+      lg = mfma16(ah, xf, lg);
+      lg = mfma16(al, xf, lg);
+    }
+    sx += __shfl_xor(sx, 16, 64); sx += __shfl_xor(sx, 32, 64);            // the four k-chunk lanes of a token
+    sxx += __shfl_xor(sxx, 16, 64); sxx += __shfl_xor(sxx, 32, 64);
+    const float mean = sx * inv_c;
+    float var = sxx * inv_c - mean * mean;
+    var = var < 0.f ? 0.f : var;
+    const float rstd = rsqrtf(var + p.eps);
+    float g[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float z = rstd * (lg[j] - mean * a_sum[j]) + cc[j];
+      g[j] = 1.0f / (1.0f + __expf(-z));
+    }
+    // gates of heads 4..7 live 16 lanes further on: bring them to the g4 = 0 lanes, which supply k = 0..7
+    float gh[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) gh[j] = __shfl_down(g[j], 16, 64);
+    frag_t gf;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { gf[j] = g4 == 0 ? (T)g[j] : (T)0.0f; gf[4 + j] = g4 == 0 ? (T)gh[j] : (T)0.0f; }
+    // the gates are rounded to the storage type: carry the remainder as a second k-block so the product stays ~16-bit
+    frag_t gl;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      gl[j] = g4 == 0 ? (T)(g[j] - (float)gf[j]) : (T)0.0f;
+      gl[4 + j] = g4 == 0 ? (T)(gh[j] - (float)gf[4 + j]) : (T)0.0f;
+    }
+    // ---- update, final add, back into the tile -------------------------------------------------------------------
+    for (int c0 = 0; c0 < C; c0 += 16) {
+      frag_t uh, ul;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { uh[j] = (T)0.0f; ul[j] = (T)0.0f; }
+      if (g4 == 0) {
+        uh = __builtin_bit_cast(frag_t, ld16(s_uhi + (c0 + r16) * 16));
+        ul = __builtin_bit_cast(frag_t, ld16(s_ulo + (c0 + r16) * 16));
+      }
+      f32x4 d = f32x4{0.f, 0.f, 0.f, 0.f};
+      d = mfma16(uh, gf, d);
+      d = mfma16(ul, gf, d);
+      d = mfma16(uh, gl, d);
+      const int c = c0 + 4 * g4;                    // the lane's four channels of this tile, token r16
+      const u32x2 xr = *reinterpret_cast<const u32x2*>(xt + r16 * XST + c * 2);
+      typename Vec8<T>::half_type x4 = __builtin_bit_cast(typename Vec8<T>::half_type, xr);
+      const f32x4 b4 = *reinterpret_cast<const f32x4*>(s_b + c);
+      float o[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o[j] = (float)x4[j] + b4[j] + d[j];
+      *reinterpret_cast<u32x2*>(xt + r16 * XST + c * 2) = pack4<T>(o);
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+    // ---- LDS -> global ------------------------------------------------------------------------------------------
+    for (int i = lane; i < pieces; i += 64) {
+      const int row = i / ppr, pc = i - row * ppr;
+      if (r0 + row < r_end) st16(ob + (long long)(r0 + row) * C + pc * 8, ld16(xt + row * XST + pc * 16));
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
 }  // namespace mobi
 
 using namespace mobi;
@@ -562,6 +748,22 @@ extern "C" int mobi_two_key_adapter(const mobi_two_key_adapter_params* p, void* 
   if ((p->x_img_stride & 7) || (p->out_img_stride & 7)) return MOBI_ERR_ALIGN;
   if ((reinterpret_cast<uintptr_t>(p->x) | reinterpret_cast<uintptr_t>(p->out) | reinterpret_cast<uintptr_t>(p->a) |
        reinterpret_cast<uintptr_t>(p->u) | reinterpret_cast<uintptr_t>(p->b)) & 15) return MOBI_ERR_ALIGN;
+  // (measured, tools/kbench.py tka: C = 320 at 64 x 64 x 16 37.0 vs 67.3 us; at C = 640 its 127 KB of LDS leave one block
+  //  per CU and it loses, 39.8 vs 36.8 us: the vector-ALU kernel keeps the wider levels; MOBI_TKA_MFMA=1 forces it to 640)
+  if ((p->channels & 31) == 0 && p->channels <= (mobi::tuning().tka_mfma == 1 ? 640 : 320) && mobi::tuning().tka_mfma != 0) {
+    // matrix-core kernel: blocks of 64 rows (16 per wave) x k; about 512 blocks over the launch (tables re-staged per block)
+    const int C = p->channels;
+    long long rows = ((long long)p->rows_per_image * p->images + 511) / 512;
+    rows = (rows + 63) / 64 * 64;
+    if (rows > p->rows_per_image) rows = (p->rows_per_image + 63) / 64 * 64;
+    const dim3 g2((unsigned)((p->rows_per_image + rows - 1) / rows), (unsigned)p->images);
+#define MOBI_TKM(T_, CM_) hipLaunchKernelGGL((two_key_adapter_mfma_kernel<T_, CM_>), g2, dim3(256), 0, ST(stream), *p, (int)rows)
+    if (p->dtype == MOBI_F16) { if (C <= 320) MOBI_TKM(f16_t, 320); else MOBI_TKM(f16_t, 640); }
+    else                      { if (C <= 320) MOBI_TKM(bf16_t, 320); else MOBI_TKM(bf16_t, 640); }
+#undef MOBI_TKM
+    MOBI_CHECK_LAUNCH();
+    return MOBI_OK;
+  }
   // rows per block: about 1024 blocks over the whole launch (four 35-KB-LDS blocks per CU), at least 8 rows (the
   // tables are re-staged per block)
   long long rpb = ((long long)p->rows_per_image * p->images + 1023) / 1024;

@@ -32,7 +32,7 @@ def timeit(fn, iters, warm=3):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("kind", choices=["attn", "conv", "linear", "gn", "ln"])
+    ap.add_argument("kind", choices=["attn", "conv", "linear", "gn", "ln", "tka"])
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--heads", type=int, default=8)
@@ -94,6 +94,27 @@ def main():
         by = 2.0 * a.rows * (a.cin + a.cout * (2 if a.residual else 1))
         print(f"linear {a.cin}->{a.cout} rows={a.rows} geglu={a.geglu} residual={a.residual}: {us:.1f} us  "
               f"{fl / us / 1e6:.1f} TFLOP/s  {by / us / 1e3:.0f} GB/s")
+    elif a.kind == "tka":
+        # two-key adapter: matrix-core kernel vs the vector-ALU kernel (MOBI_TKA_MFMA=0), interleaved best of 3
+        from mobi_amd import _lib
+        x = rn(a.images, a.hw, a.c)
+        f = lambda *s_: torch.randn(*s_, generator=g).to(dev)
+        aa, u, b, cc = f(a.images, 8, a.c) * 0.05, f(a.images, 8, a.c), f(a.images, a.c), f(a.images, 8)
+        fn = lambda: ops.two_key_adapter(x, aa, aa.sum(-1).contiguous(), cc, u, b, 1e-5)
+        best, outs = {}, {}
+        for rep in range(3):
+            for tag, env in (("mfma", {}), ("valu", {"MOBI_TKA_MFMA": "0"})):
+                os.environ.update(env)
+                _lib.load().mobi_tuning_reload()
+                outs[tag] = fn().float()
+                best[tag] = min(best.get(tag, 1e30), timeit(fn, a.iters))
+                for k_ in env:
+                    os.environ.pop(k_, None)
+        _lib.load().mobi_tuning_reload()
+        by = 2.0 * x.numel() * 2
+        d = float((outs["mfma"] - outs["valu"]).norm() / outs["valu"].norm())
+        print(f"two_key_adapter C={a.c} tokens={a.hw} images={a.images}: " +
+              " | ".join(f"{t} {v:.1f} us {by / v / 1e3:.0f} GB/s" for t, v in best.items()) + f" | rel diff {d:.2e}")
     elif a.kind == "ln":
         x = rn(a.images, a.hw, a.c)
         gam, bet = torch.ones(a.c, device=dev), torch.zeros(a.c, device=dev)
