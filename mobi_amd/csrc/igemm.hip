@@ -1708,6 +1708,7 @@ __global__ __launch_bounds__(NW * 64, 2) void igemm_ring_kernel(const IgemmArgs 
   const int L = xcd_remap(blockIdx.x, nblk);
   const int tile_n = L % a.tiles_n, tile_m = L / a.tiles_n;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
+  MOBI_STAMP_AT(0);
   const T* wgt = reinterpret_cast<const T*>(a.weight) + (long long)group * a.w_group_stride;
   const __amdgpu_buffer_rsrc_t rx0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.src0), 0, a.src0_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rx1 =
@@ -1842,6 +1843,7 @@ __global__ __launch_bounds__(NW * 64, 2) void igemm_ring_kernel(const IgemmArgs 
     //   WAR  the requests of step s + 3 overwrite slot (s - 1) % 4, last read by the late waves two phases earlier.
     const bool late = wave_s >= NW / 2;
     wait_step();
+    MOBI_STAMP_AT(1);
     if (late) MOBI_RING_BARRIER();
 #pragma clang loop unroll(disable)
     for (int s = ks_begin; s < ks_end; ++s) {
@@ -1873,6 +1875,7 @@ __global__ __launch_bounds__(NW * 64, 2) void igemm_ring_kernel(const IgemmArgs 
     }
   }
 #undef MOBI_RING_BARRIER
+  MOBI_STAMP_AT(2);
   // the ring becomes the epilogue's staging area: every request (also the all-zero ones) must have landed
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
@@ -1886,6 +1889,19 @@ __global__ __launch_bounds__(NW * 64, 2) void igemm_ring_kernel(const IgemmArgs 
       for (int j = 0; j < 4; ++j) part[i][j] = acc[i][4 * h + j];
     igemm_epilogue<T, NT, TR, 32, MT == 4>(a, stage, part, lane, group, n0 + wn * WAVE_N, m0 + wm * MT * 16 + 64 * h);
   }
+#if MOBI_STAMP                                                // (eight-wave geometry: tools/stamp_ring.py)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  MOBI_STAMP_AT(3);
+  if (g_stamps && threadIdx.x == 0) {
+    unsigned long long* d = g_stamps + (size_t)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) * 8;
+    unsigned hw, xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    d[4] = ((unsigned long long)xcc << 32) | hw;
+    d[5] = (unsigned long long)(ks_end - ks_begin);
+    d[6] = 1;
+  }
+#endif
 }
 
 // split-K finish: sum the partial slabs, then the ordinary epilogue (bias, per-image vector, residual)
@@ -2189,7 +2205,8 @@ static int igemm_prepare(const mobi_igemm_params* p, mobi::IgemmArgs& a) {
     const long long tn = (p->n_packed + bnw - 1) / bnw;
     auto fills = [&](long long blocks) {
       const long long rounds = (blocks + 255) / 256;
-      return blocks >= 200 && blocks * 5 >= rounds * 256 * 4;          // last round at least 80 % full on average
+      return blocks >= 190 && blocks * 5 >= rounds * 256 * 4 - 64 * (rounds == 1);   // rounds about 80 % full on average
+                                                                       // (192 blocks, 1280 -> 3840 at 16 x 16 x 16: 43.4 vs 51.7 us)
     };
     const long long t256 = ((a.M + 255) / 256) * tn * a.splits, t128 = ((a.M + 127) / 128) * tn * a.splits;
     int pick = tuning().wide > 0 ? tuning().wide : (fills(t256) ? 2 : (fills(t128) && tuning().wide128 == 1 ? 1 : 0));

@@ -16,6 +16,8 @@ CONVS = [  # (images, hw, cin, cin2, cout, k, residual)
     (16, 32, 640, 0, 640, 3, True), (16, 32, 1280, 0, 640, 3, True), (16, 32, 320, 0, 640, 3, False),
     (16, 16, 1280, 0, 1280, 3, True), (16, 64, 320, 0, 320, 1, True), (16, 64, 320, 0, 960, 1, False),
     (16, 64, 1280, 0, 320, 1, True), (16, 32, 640, 0, 1920, 1, False), (16, 32, 2560, 0, 640, 1, True),
+    (8, 64, 320, 0, 320, 1, True), (16, 32, 640, 0, 640, 1, True), (8, 32, 640, 0, 640, 1, True),
+    (16, 16, 1280, 0, 1280, 1, True), (8, 16, 1280, 0, 1280, 1, True), (16, 16, 1280, 0, 3840, 1, False),
 ]
 GEGLU = [(65536, 320, 1280), (16384, 640, 2560), (4096, 1280, 5120)]
 
@@ -34,7 +36,7 @@ def main():
         # variants are timed INTERLEAVED, three rounds, best of each: the first kernel timed after a pause runs ~10 %
         # slower (clocks), which an A-then-B order books to A
         variants = (("routed", {}), ("pp", {"MOBI_IGEMM_WIDE": "0"}), ("w256", {"MOBI_IGEMM_WIDE": "2"}),
-                    ("w128", {"MOBI_IGEMM_WIDE": "1"}))
+                    ("w128", {"MOBI_IGEMM_WIDE": "1"}), ("sm", {"MOBI_IGEMM_WM": "2", "MOBI_IGEMM_WIDE": "0"}))
         best, outs = {}, {}
         for rep in range(3):
             for tag, env in variants:
