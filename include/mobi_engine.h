@@ -377,6 +377,32 @@ typedef struct mobi_lidar_metrics_params {
 } mobi_lidar_metrics_params;
 int mobi_lidar_metrics(const mobi_lidar_metrics_params* p, void* stream);
 
+/* Dataset side: the object's range view for a whole batch in one launch (ldm/data/nuscenes.py:418-470 over
+ * lidar_converter.py:387-434 tile / bbox_crop / resize, data/utils.py:537-557 depth_normalization):
+ *   view[b][r][c] = sweep[b][nn(r: height <- h0)][(crop_left[b] + nn(c: width <- width_crop[b])) mod w0]   (nn = cv2's
+ *   INTER_NEAREST index), depth through the object normalisation (alpha, [min_depth, max_depth] per sample) when
+ *   object_norm, intensity ((i / 255) - 0.5) * 2 and, when int_norm, clamp(2 (1 - exp(-2 (x + 1))) - 1, -1, 1);
+ *   range_data = [depth, intensity]; range_data_inpaint = range_data * edit_mask; inst_out = view of inst_orig.
+ * Needs width_crop[b] <= width and h0 <= height (the enlarging case of `resize`; else MOBI_ERR_UNSUPPORTED). */
+typedef struct mobi_range_prepare_params {
+  const float* depth_orig; const float* int_orig; const float* inst_orig;      /* [batch][h0][w0]; inst may be NULL */
+  const int32_t* crop_left; const int32_t* width_crop;                         /* [batch] (columns of the 3-sweep tiling) */
+  const float* min_depth; const float* max_depth;                              /* [batch] (object_norm) */
+  const float* edit_mask;                                                      /* [batch][1][height][width], 1 = keep */
+  float* range_data; float* range_data_inpaint;                                /* [batch][2][height][width] */
+  float* inst_out;                                                             /* [batch][1][height][width] or NULL */
+  int32_t batch, h0, w0, height, width;
+  float alpha;
+  int32_t object_norm, int_norm;
+} mobi_range_prepare_params;
+int mobi_range_prepare(const mobi_range_prepare_params* p, void* stream);
+
+/* Edit masks of a batch of projected boxes (ldm/data/utils.py:146-198): corners_xy f32 [batch][8][2] pixel coordinates
+ * (truncated to integers as before cv2.fillPoly), out f32 [batch][H][W] = 0 inside / on the outline of one of the six
+ * faces, 1 elsewhere.  cv2's rasteriser is restated (centre inside the convex face or within half a pixel of its
+ * outline); single outline pixels can differ from OpenCV's. */
+int mobi_box_mask(const float* corners_xy, float* out, int32_t batch, int32_t H, int32_t W, void* stream);
+
 /* Camera paste-back of one sample (scripts/inference_test_bench.py:478-510):
  *   mobi_paste_patch    F.interpolate(patch, (crop_h, crop_w), bilinear, align_corners=False), (((x + 1) / 2) * 255)
  *                       -> uint8, RGB planes -> BGR bytes, written into frame[top : top + crop_h, left : left + crop_w]

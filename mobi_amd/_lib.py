@@ -102,9 +102,16 @@ class LidarMetricsParams(C.Structure):
                 ("batch", i32), ("h", i32), ("w", i32), ("pool_h", i32), ("max_width", i32)]
 
 
+class RangePrepareParams(C.Structure):
+    _fields_ = [("depth_orig", vp), ("int_orig", vp), ("inst_orig", vp), ("crop_left", vp), ("width_crop", vp),
+                ("min_depth", vp), ("max_depth", vp), ("edit_mask", vp), ("range_data", vp), ("range_data_inpaint", vp),
+                ("inst_out", vp), ("batch", i32), ("h0", i32), ("w0", i32), ("height", i32), ("width", i32),
+                ("alpha", f32), ("object_norm", i32), ("int_norm", i32)]
+
+
 STRUCT_IDS = {0: IgemmParams, 1: GroupNormParams, 2: LayerNormParams, 3: AttentionParams, 4: CtxAttentionParams,
               5: SkinnyLinearParams, 6: ConvSmallCinParams, 7: ConvSmallCoutParams, 8: DdimStepParams, 9: TwoKeyAdapterParams,
-              10: RangePasteParams, 11: LidarMetricsParams}
+              10: RangePasteParams, 11: LidarMetricsParams, 12: RangePrepareParams}
 
 # every symbol include/mobi_engine.h declares: name -> (restype, argtypes)
 SYMBOLS = {
@@ -138,6 +145,8 @@ SYMBOLS = {
     "mobi_range_denorm": (C.c_int, [vp, vp, vp, f32, f32, f32, f32, i32, i32, vp, vp, i32, i32, vp]),
     "mobi_range_paste": (C.c_int, [C.POINTER(RangePasteParams), vp]),
     "mobi_lidar_metrics": (C.c_int, [C.POINTER(LidarMetricsParams), vp]),
+    "mobi_range_prepare": (C.c_int, [C.POINTER(RangePrepareParams), vp]),
+    "mobi_box_mask": (C.c_int, [vp, vp, i32, i32, i32, vp]),
     "mobi_paste_patch": (C.c_int, [vp, i32, i32, vp, i32, i32, i32, i32, i32, i32, vp]),
     "mobi_gaussian_blur": (C.c_int, [vp, vp, vp, i32, i32, vp, i32, vp]),
     "mobi_blend_frame": (C.c_int, [vp, vp, vp, vp, i32, i32, vp]),

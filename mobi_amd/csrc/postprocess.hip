@@ -200,6 +200,92 @@ static inline int egrid_pp(long long n) {
   return (int)(b < 1 ? 1 : (b > 8192 ? 8192 : b));
 }
 
+
+// ---------------------------------------------------------------------------------------------------------
+// Dataset side, one launch per batch (ldm/data/nuscenes.py:418-470 with lidar_converter.py:387-434): the object's view
+// of the sweep -- three sweeps side by side, a window of width_crop columns from column crop_left, nearest-neighbour
+// resize to (height, width) -- then the depth / intensity normalisation and the edit-mask product.  The tiled array
+// is never built: column (crop_left + sx) mod w0 of the sweep is the same pixel.  Nearest index as OpenCV's resizeNN:
+// min(floor(d * (1 / (dst / src))), src - 1) in double.  Float expressions in the reference's operation order
+// (this file is compiled without FMA contraction).
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void range_prepare_kernel(const mobi_range_prepare_params a) {
+  const long long total = (long long)a.batch * a.height * a.width;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int c = (int)(i % a.width);
+    const int r = (int)((i / a.width) % a.height);
+    const int b = (int)(i / ((long long)a.width * a.height));
+    const int wc = a.width_crop[b];
+    int sy = (int)floor((double)r * (1.0 / ((double)a.height / (double)a.h0)));
+    int sx = (int)floor((double)c * (1.0 / ((double)a.width / (double)wc)));
+    sy = sy < a.h0 - 1 ? sy : a.h0 - 1;
+    sx = sx < wc - 1 ? sx : wc - 1;
+    int col = (a.crop_left[b] + sx) % a.w0;
+    if (col < 0) col += a.w0;
+    const long long src = ((long long)b * a.h0 + sy) * a.w0 + col;
+    float d = a.depth_orig[src];
+    if (a.object_norm) {
+      const float lo = a.min_depth[b], hi = a.max_depth[b], al = a.alpha;
+      const float two_al = (float)(2.0 * (double)a.alpha), rest = (float)(-((double)a.alpha - 1.0)), rest_hi = (float)(1.0 - (double)a.alpha);
+      float o = 0.f;
+      if (d >= lo && d <= hi) o = -al + (two_al * (d - lo)) / (hi - lo);
+      else if (d >= -1.f && d < lo) o = -1.f + (rest * (d + 1.f)) / (lo + 1.f);
+      else if (d > hi && d <= 1.f) o = al + (rest_hi * (d - hi)) / (1.f - hi);
+      d = o;
+    }
+    float v = ((a.int_orig[src] / 255.f) - 0.5f) * 2.f;
+    if (a.int_norm) {
+      v = 1.f - expf(-2.f * (v + 1.f));
+      v = 2.f * v - 1.f;
+      v = v < -1.f ? -1.f : (v > 1.f ? 1.f : v);
+    }
+    const long long hw = (long long)a.height * a.width, px = (long long)r * a.width + c;
+    const float m = a.edit_mask[b * hw + px];
+    a.range_data[(b * 2 + 0) * hw + px] = d;
+    a.range_data[(b * 2 + 1) * hw + px] = v;
+    a.range_data_inpaint[(b * 2 + 0) * hw + px] = d * m;
+    a.range_data_inpaint[(b * 2 + 1) * hw + px] = v * m;
+    if (a.inst_out) a.inst_out[b * hw + px] = a.inst_orig[src];
+  }
+}
+
+// Edit mask of a batch of projected boxes (ldm/data/utils.py:146-198; cv2.fillPoly restated, see
+// mobi_amd/ldm/data/utils.py:fill_box_faces): out = 0 where the pixel centre is inside one of the six faces (corner
+// coordinates truncated to integers) or within half a pixel of a face's outline, else 1.  Double arithmetic, the host
+// restatement's own expressions.
+__global__ __launch_bounds__(256) void box_mask_kernel(const float* __restrict__ corners_xy, float* __restrict__ out, int batch,
+                                                        int H, int W) {
+  const int FACES[6][4] = {{0, 1, 2, 3}, {4, 5, 6, 7}, {0, 1, 5, 4}, {2, 3, 7, 6}, {0, 4, 7, 3}, {1, 5, 6, 2}};
+  const long long total = (long long)batch * H * W;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int x = (int)(i % W), y = (int)((i / W) % H), b = (int)(i / ((long long)W * H));
+    const float* q = corners_xy + (long long)b * 16;
+    bool hit = false;
+    for (int f = 0; f < 6 && !hit; ++f) {
+      double px[4], py[4];
+      for (int k = 0; k < 4; ++k) { px[k] = (double)(int)q[FACES[f][k] * 2]; py[k] = (double)(int)q[FACES[f][k] * 2 + 1]; }
+      bool pos = true, neg = true, near = false;
+      double lox = px[0], hix = px[0], loy = py[0], hiy = py[0];
+      for (int k = 1; k < 4; ++k) {
+        lox = px[k] < lox ? px[k] : lox; hix = px[k] > hix ? px[k] : hix;
+        loy = py[k] < loy ? py[k] : loy; hiy = py[k] > hiy ? py[k] : hiy;
+      }
+      const bool box = (double)x >= lox && (double)x <= hix && (double)y >= loy && (double)y <= hiy;
+      for (int k = 0; k < 4; ++k) {
+        const double ax = px[k], ay = py[k], ex = px[(k + 1) & 3] - ax, ey = py[(k + 1) & 3] - ay;
+        const double cross = ex * ((double)y - ay) - ey * ((double)x - ax);
+        pos = pos && cross >= 0; neg = neg && cross <= 0;
+        const double ll = ex * ex + ey * ey;
+        double t = ll > 0 ? (((double)x - ax) * ex + ((double)y - ay) * ey) / ll : 0.0;
+        t = t < 0.0 ? 0.0 : (t > 1.0 ? 1.0 : t);
+        const double dx = (double)x - (ax + t * ex), dy = (double)y - (ay + t * ey);
+        near = near || dx * dx + dy * dy <= 0.25;
+      }
+      hit = ((pos || neg) && box) || near;
+    }
+    out[i] = hit ? 0.f : 1.f;
+  }
+}
 }  // namespace mobi
 
 using namespace mobi;
@@ -248,6 +334,28 @@ extern "C" int mobi_blend_frame(const float* mask_blur, const float* image, cons
   if (!mask_blur || !image || !pred || !out || H <= 0 || W <= 0) return MOBI_ERR_ARG;
   hipLaunchKernelGGL(blend_kernel, dim3(egrid_pp((long long)H * W)), dim3(256), 0, ST(stream), mask_blur, image, pred, out,
                      H, W);
+  MOBI_CHECK_LAUNCH();
+  return MOBI_OK;
+}
+
+extern "C" int mobi_range_prepare(const mobi_range_prepare_params* p, void* stream) {
+  if (!p || !p->depth_orig || !p->int_orig || !p->crop_left || !p->width_crop || !p->edit_mask || !p->range_data ||
+      !p->range_data_inpaint) return MOBI_ERR_ARG;
+  if ((p->inst_orig != nullptr) != (p->inst_out != nullptr)) return MOBI_ERR_ARG;
+  if (p->object_norm && (!p->min_depth || !p->max_depth)) return MOBI_ERR_ARG;
+  if (p->batch <= 0 || p->h0 <= 0 || p->w0 <= 0 || p->height <= 0 || p->width <= 0) return MOBI_ERR_ARG;
+  // (whole-factor REDUCTIONS take the reference's pooling branch, lidar_converter.py:262-267; MObI's views enlarge)
+  if (p->height < p->h0) return MOBI_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(range_prepare_kernel, dim3(egrid_pp((long long)p->batch * p->height * p->width)), dim3(256), 0,
+                     ST(stream), *p);
+  MOBI_CHECK_LAUNCH();
+  return MOBI_OK;
+}
+
+extern "C" int mobi_box_mask(const float* corners_xy, float* out, int32_t batch, int32_t H, int32_t W, void* stream) {
+  if (!corners_xy || !out || batch <= 0 || H <= 0 || W <= 0) return MOBI_ERR_ARG;
+  hipLaunchKernelGGL(box_mask_kernel, dim3(egrid_pp((long long)batch * H * W)), dim3(256), 0, ST(stream), corners_xy, out,
+                     batch, H, W);
   MOBI_CHECK_LAUNCH();
   return MOBI_OK;
 }

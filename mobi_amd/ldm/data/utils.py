@@ -202,3 +202,132 @@ def get_lidar_vis(*, sample, input, rec, bboxes, range_depth_orig, range_shift_l
         for k in range(3):
             vis[k].append(visualize_lidar(clouds[k][0], bboxes=clouds[2][1], bbox_color=(255, 165, 0)))
     return tuple(torch.from_numpy(np.stack(v)).permute(0, 3, 1, 2) for v in vis)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# dataset side (reference: ldm/data/utils.py -- get_image_coords :44-73, rotate_bbox :75-103, translate_bbox :106-122,
+# get_camera_coords :125-144, get_inpaint_mask :146-171, get_range_inpaint_mask :174-198, get_2d_bbox :254-265,
+# expand_bbox_corners :268-278).  Eight corners per call: numpy, the reference's own operation order (float64).
+# ----------------------------------------------------------------------------------------------------------------------
+BOX_FACES = ((0, 1, 2, 3), (4, 5, 6, 7), (0, 1, 5, 4), (2, 3, 7, 6), (0, 4, 7, 3), (1, 5, 6, 2))
+
+
+def _homogeneous(bbox_corners, matrix):
+    pts = np.concatenate([bbox_corners.reshape(-1, 3), np.ones((8, 1))], axis=-1)
+    return (pts @ matrix.copy().reshape(4, 4).T).reshape(8, 4)
+
+
+def get_image_coords(bbox_corners, lidar2image, include_depth=False):
+    """[8, 3] lidar-frame corners -> pixel (x, y[, depth]); depth clipped to [1e-5, 1e5] before the divide."""
+    pr = _homogeneous(bbox_corners, lidar2image)
+    pr[..., 2] = np.clip(pr[..., 2], a_min=1e-5, a_max=1e5)
+    pr[..., :2] /= pr[..., 2, None]
+    return pr[..., :3].reshape(8, 3) if include_depth else pr[..., :2].reshape(8, 2)
+
+
+def get_camera_coords(bbox_corners, lidar2camera):
+    return _homogeneous(bbox_corners, lidar2camera)[..., :3]
+
+
+def _about_centre(bbox_corners, fn):
+    import copy
+    box = copy.deepcopy(bbox_corners)
+    centre = np.mean(box, axis=0)
+    box -= centre
+    return fn(box, centre)
+
+
+def rotate_bbox(bbox_corners, angle=0):
+    """Turn the box about the vertical axis through its centre (degrees)."""
+    if angle == 0:
+        return bbox_corners
+    a = np.deg2rad(angle)
+    rot = np.array([[np.cos(a), -np.sin(a), 0], [np.sin(a), np.cos(a), 0], [0, 0, 1]])
+
+    def turn(box, centre):
+        box = box @ rot.T
+        box += centre
+        return box
+    return _about_centre(bbox_corners, turn)
+
+
+def translate_bbox(bbox_corners, new_center):
+    def move(box, centre):
+        box += new_center
+        return box
+    return _about_centre(bbox_corners, move)
+
+
+def expand_bbox_corners(bbox_corners, expand_ratio=0.1):
+    if expand_ratio == 0:
+        return bbox_corners
+
+    def grow(box, centre):
+        box *= (1 + expand_ratio)
+        box += centre
+        return box
+    return _about_centre(bbox_corners, grow)
+
+
+def get_2d_bbox(bbox_corners, transform, H, W, expand_ratio=0.1):
+    """Axis-aligned pixel box (x1, y1, x2, y2) of the projected (expanded) corners, clipped to the image."""
+    xy = get_image_coords(expand_bbox_corners(bbox_corners, expand_ratio), transform)
+    box = np.concatenate([np.min(xy, axis=-2), np.max(xy, axis=-2)], axis=-1).astype(int)
+    box[0::2] = np.clip(box[0::2], a_min=0, a_max=W - 1)
+    box[1::2] = np.clip(box[1::2], a_min=0, a_max=H - 1)
+    return box
+
+
+def fill_box_faces(coords_xy, H, W):
+    """uint8 [H, W]: 1 where a pixel belongs to one of the six projected faces of a box (corner pixel coordinates
+    truncated to int32 first, as before the reference's `cv2.fillPoly(mask, [points], 1, cv2.LINE_AA)`).
+
+    cv2 is not in this image, so its polygon rasteriser is RESTATED, not pinned: a pixel is taken when its centre lies
+    inside the (convex) face or within half a pixel of the face's outline -- OpenCV fills the scan-line interior and
+    draws the outline on top, whose anti-aliased pixels reach the fill colour 1 at >= 50 % coverage.  The two can
+    differ on single outline pixels only.  The batched device form is `ops.box_mask`."""
+    mask = np.zeros((H, W), dtype=np.uint8)
+    for face in BOX_FACES:
+        q = coords_xy[list(face)].astype(np.int32).astype(np.float64)
+        x0, x1 = int(max(0, np.floor(q[:, 0].min() - 1))), int(min(W - 1, np.ceil(q[:, 0].max() + 1)))
+        y0, y1 = int(max(0, np.floor(q[:, 1].min() - 1))), int(min(H - 1, np.ceil(q[:, 1].max() + 1)))
+        if x1 < x0 or y1 < y0:
+            continue
+        xs, ys = np.meshgrid(np.arange(x0, x1 + 1, dtype=np.float64), np.arange(y0, y1 + 1, dtype=np.float64))
+        pos = np.ones_like(xs, dtype=bool)
+        neg = np.ones_like(xs, dtype=bool)
+        near = np.zeros_like(xs, dtype=bool)
+        for k in range(4):
+            ax, ay = q[k]
+            bx, by = q[(k + 1) % 4]
+            ex, ey = bx - ax, by - ay
+            cross = ex * (ys - ay) - ey * (xs - ax)
+            pos &= cross >= 0
+            neg &= cross <= 0
+            ll = ex * ex + ey * ey
+            t = np.clip(((xs - ax) * ex + (ys - ay) * ey) / ll, 0.0, 1.0) if ll > 0 else np.zeros_like(xs)
+            dx, dy = xs - (ax + t * ex), ys - (ay + t * ey)
+            near |= dx * dx + dy * dy <= 0.25
+        box = (xs >= q[:, 0].min()) & (xs <= q[:, 0].max()) & (ys >= q[:, 1].min()) & (ys <= q[:, 1].max())
+        mask[y0:y1 + 1, x0:x1 + 1] |= (((pos | neg) & box) | near).astype(np.uint8)
+    return mask
+
+
+def get_inpaint_mask(bbox_corners, transform, H, W, expand_ratio=0.1, use_3d_edit_mask=True):
+    """float [H, W]: 0 inside the edit region (the projected faces of the expanded box, or its 2D bounding box), 1 outside."""
+    if use_3d_edit_mask:
+        mask = fill_box_faces(get_image_coords(expand_bbox_corners(bbox_corners, expand_ratio), transform), H, W)
+    else:
+        x1, y1, x2, y2 = get_2d_bbox(bbox_corners, transform, H, W, expand_ratio)
+        mask = np.zeros((H, W), dtype=np.uint8)
+        mask[y1:y2, x1:x2] = 1
+    return 1. - torch.tensor(mask > 0.5).float()
+
+
+def get_range_inpaint_mask(bbox_corners, range_height, range_width, expand_ratio=0.1, crop_left=None, width_crop=None):
+    conv = LidarConverter()
+    coords = conv.get_range_coords(expand_bbox_corners(bbox_corners, expand_ratio))
+    _, _, _, coords, _, _ = conv.apply_default_transforms(coords, height=range_height, width=range_width,
+                                                          crop_left=crop_left, width_crop=width_crop)
+    mask = fill_box_faces(coords[:, :2], range_height, range_width)
+    return 1. - torch.tensor(mask > 0.5).float()

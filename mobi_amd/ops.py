@@ -628,6 +628,44 @@ def range_paste(sample_depth, depth_orig, crop_left, width_crop, sample_int=None
     return out
 
 
+def range_prepare(depth_orig, int_orig, inst_orig, crop_left, width_crop, min_depth, max_depth, edit_mask, *, height, width,
+                  alpha=0.75, object_norm=True, int_norm=False):
+    """Dataset side, a whole batch in one launch (include/mobi_engine.h, mobi_range_prepare): sweeps fp32 [B, H0, W0]
+    (depth code, raw intensity 0..255, instance mask), crop windows [B], object depth ranges [B], edit masks
+    [B, 1, height, width] -> (range_data [B, 2, h, w], range_data_inpaint [B, 2, h, w], range_instance_mask [B, 1, h, w])."""
+    lib = _lib.load()
+    dev = depth_orig.device
+    b, h0, w0 = depth_orig.shape
+    f = lambda t: None if t is None else _dev(t).to(torch.float32).contiguous()
+    depth_orig, int_orig, inst_orig, min_depth, max_depth, edit_mask = map(
+        f, (depth_orig, int_orig, inst_orig, min_depth, max_depth, edit_mask))
+    cl, wcr = _i32(crop_left, dev), _i32(width_crop, dev)
+    assert cl.numel() == wcr.numel() == b and edit_mask.numel() == b * height * width
+    if int(wcr.max()) > width or int(wcr.min()) <= 0:
+        raise ValueError("range_prepare: crop windows must be 1 ... width columns wide")
+    rd = torch.empty((b, 2, height, width), device=dev, dtype=torch.float32)
+    rdi = torch.empty_like(rd)
+    inst = None if inst_orig is None else torch.empty((b, 1, height, width), device=dev, dtype=torch.float32)
+    p = _lib.RangePrepareParams()
+    p.depth_orig, p.int_orig, p.inst_orig = _ptr(depth_orig), _ptr(int_orig), _ptr(inst_orig)
+    p.crop_left, p.width_crop, p.min_depth, p.max_depth = _ptr(cl), _ptr(wcr), _ptr(min_depth), _ptr(max_depth)
+    p.edit_mask, p.range_data, p.range_data_inpaint, p.inst_out = _ptr(edit_mask), _ptr(rd), _ptr(rdi), _ptr(inst)
+    p.batch, p.h0, p.w0, p.height, p.width = b, h0, w0, height, width
+    p.alpha, p.object_norm, p.int_norm = float(alpha), int(object_norm), int(int_norm)
+    _lib.check(lib.mobi_range_prepare(C.byref(p), _stream()), "mobi_range_prepare")
+    return rd, rdi, inst
+
+
+def box_mask(corners_xy, height, width):
+    """fp32 [B, 8, 2] projected box corners (pixels) -> fp32 [B, height, width] edit masks (0 = edit region)."""
+    lib = _lib.load()
+    c = _dev(corners_xy).to(torch.float32).contiguous()
+    assert c.dim() == 3 and c.shape[1:] == (8, 2)
+    out = torch.empty((c.shape[0], height, width), device=c.device, dtype=torch.float32)
+    _lib.check(lib.mobi_box_mask(_ptr(c), _ptr(out), c.shape[0], height, width, _stream()), "mobi_box_mask")
+    return out
+
+
 def lidar_metrics(pred, gt, inst_mask, box_mask, width_crop, pool_h=32):
     """fp32 [B, H, W] each (0/1 masks) -> fp32 [B, 2 regions (object, mask), 3 (rmse, median, count)] on the device."""
     lib = _lib.load()

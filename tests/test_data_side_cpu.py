@@ -1,0 +1,183 @@
+"""Dataset side on the host: the reference's own outputs for everything that runs without
+cv2 / torchvision (tests/golden/data_side.npz, made by tests/golden/make_golden_data_side.py), and the batch schema A0
+from a miniature database in the reference's on-disk formats."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from mobi_amd.ldm.data import utils as du
+from mobi_amd.ldm.data.lidar_converter import LidarConverter
+
+G = np.load(os.path.join(os.path.dirname(__file__), "golden", "data_side.npz"))
+
+
+@pytest.mark.parametrize("log_scale", [False, True])
+def test_pcd2range_matches_reference(log_scale):
+    tag = "log" if log_scale else "lin"
+    d, i, keep, p, y = LidarConverter(log_scale=log_scale).pcd2range(G["p2r_points"], G["p2r_label"])
+    for name, got in (("depth", d), ("int", i), ("keep", keep), ("pitch", p), ("yaw", y)):
+        want = G[f"p2r_{tag}_{name}"]
+        assert got.dtype == want.dtype and np.array_equal(got, want), name       # bit for bit, indices included
+    assert (d > -1).sum() > 10000 and keep.sum() < len(keep)                    # the sweep is populated; the range filter bit
+
+
+def test_range_coords_and_views_match_reference():
+    bx = G["boxes"]
+    assert np.array_equal(np.stack([LidarConverter().get_range_coords(b) for b in bx]), G["range_coords"])
+    assert np.array_equal(np.stack([LidarConverter(log_scale=True).get_range_coords(b) for b in bx]), G["range_coords_log"])
+    for k, b in enumerate(bx):                       # the coordinate pass of apply_default_transforms, both window modes
+        conv = LidarConverter()
+        c = conv.get_range_coords(du.expand_bbox_corners(b, 0.1))
+        _, _, _, c2, cl, wc = conv.apply_default_transforms(c, height=512, width=512)
+        assert np.array_equal(np.concatenate([c2.reshape(-1), [cl, wc]]), G["adt_coords"][k])
+        assert wc in (64, 128, 256, 512)
+        conv = LidarConverter()
+        c = conv.get_range_coords(du.expand_bbox_corners(b, 0.1))
+        _, _, _, c3, cl3, wc3 = conv.apply_default_transforms(c, height=256, width=256, crop_left=1096 + 37 * k, width_crop=128)
+        assert np.array_equal(np.concatenate([c3.reshape(-1), [cl3, wc3]]), G["adt_given"][k])
+    conv = LidarConverter()
+    c = conv.get_range_coords(bx[0])
+    d3, i3, m3, c3 = conv.tile(G["rv_depth"], G["rv_int"], G["rv_mask"], c, n=3)
+    assert d3.shape == (32, 3 * 1096) and conv.current_W == 3 * 1096
+    d4, i4, m4, c4, cl = conv.bbox_crop(c3, d3, i3, m3, width=256)
+    d5, i5, m5, c5 = conv.resize(d4, i4, m4, c4, new_W=64, new_H=16)
+    for got, key in ((cl, "rv_crop_left"), (d4, "rv_crop_depth"), (i4, "rv_crop_int"), (m4, "rv_crop_mask"), (c4, "rv_crop_coords"),
+                     (d5, "rv_pool_depth"), (i5, "rv_pool_int"), (m5, "rv_pool_mask"), (c5, "rv_pool_coords")):
+        assert np.array_equal(np.asarray(got), G[key]), key
+
+
+def test_nearest_resize_is_opencv_rule():
+    """cv2.resize(INTER_NEAREST) restated: whole-factor enlargement repeats pixels; the general case follows
+    floor(d * (1 / (dst / src))) clamped -- checked against the rule written out per index."""
+    a = np.arange(32 * 64, dtype=np.float32).reshape(32, 64)
+    up = LidarConverter._nearest(a, 512, 512)
+    assert np.array_equal(up, np.repeat(np.repeat(a, 16, 0), 8, 1))
+    odd = LidarConverter._nearest(a, 50, 100)
+    for r in (0, 7, 49):
+        for c in (0, 33, 99):
+            assert odd[r, c] == a[min(int(np.floor(r * (1.0 / (50 / 32)))), 31), min(int(np.floor(c * (1.0 / (100 / 64)))), 63)]
+
+
+def test_box_geometry_matches_reference():
+    fwd, l2i, l2c, l2s = G["cam_boxes"], G["lidar2image"], G["lidar2camera"], G["lidar2image_small"]
+    eq = lambda got, key: np.array_equal(got, G[key])
+    assert eq(np.stack([du.get_image_coords(b, l2i, include_depth=True) for b in fwd]), "image_coords")
+    assert eq(np.stack([du.get_image_coords(b, l2i) for b in fwd]), "image_coords_2d")
+    assert eq(np.stack([du.get_camera_coords(b, l2c) for b in fwd]), "camera_coords")
+    assert eq(np.stack([du.rotate_bbox(b.copy(), 30.0 * k) for k, b in enumerate(fwd)]), "rotated")
+    assert eq(np.stack([du.translate_bbox(b.copy(), np.array([3.0, -10.0, -1.5])) for b in fwd]), "translated")
+    assert eq(np.stack([du.expand_bbox_corners(b.copy(), 0.1) for b in fwd]), "expanded")
+    assert eq(np.stack([du.get_2d_bbox(b.copy(), l2i, 900, 1600, 0.1) for b in fwd]), "bbox_2d")
+    assert eq(np.stack([du.get_2d_bbox(b.copy(), l2s, 90, 160, 0.1) for b in fwd[:6]]), "bbox_2d_small")
+    assert eq(np.stack([du.get_inpaint_mask(b.copy(), l2s, 90, 160, 0.1, use_3d_edit_mask=False).numpy() for b in fwd[:6]]),
+              "mask_2d_small")
+    b = fwd[0]
+    assert du.rotate_bbox(b, 0) is b and du.expand_bbox_corners(b, 0) is b            # the reference's short cuts
+
+
+def test_face_fill_properties():
+    """cv2.fillPoly is restated (unpinned): interior pixels in, pixels a pixel or more outside out, outline pixels in."""
+    sq = np.array([[10, 10], [30, 10], [30, 25], [10, 25]] * 2, dtype=np.float64) + 0.7      # truncation to int first
+    m = du.fill_box_faces(sq, 40, 50)
+    assert m.dtype == np.uint8 and m[10:26, 10:31].all() and m.sum() == 16 * 21
+    tri = np.array([[5, 5], [35, 8], [20, 30], [20, 30]] * 2, dtype=np.float64)             # degenerate quad = triangle
+    m = du.fill_box_faces(tri, 40, 50)
+    assert m[15, 20] == 1 and m[6, 6] == 1 and m[2, 2] == 0 and m[30, 20] == 1 and m[32, 20] == 0
+    assert du.fill_box_faces(sq + 1000, 40, 50).sum() == 0                                   # off-image
+
+
+def test_resize_linear_u8_rule():
+    """cv2.resize(INTER_LINEAR) on uint8, restated: identity at the same size, exact on constants and on 2x enlargement
+    of a ramp (weights 0.25 / 0.75 at 11 bits), clamped at the border."""
+    from mobi_amd.ldm.data.nuscenes import resize_linear_u8
+    rng = np.random.default_rng(0)
+    a = rng.integers(0, 256, (37, 53, 3)).astype(np.uint8)
+    assert np.array_equal(resize_linear_u8(a, 37, 53), a)
+    assert (resize_linear_u8(np.full((9, 7, 3), 201, np.uint8), 224, 224) == 201).all()
+    ramp = np.tile((np.arange(8) * 32).astype(np.uint8)[None, :, None], (4, 1, 3))
+    up = resize_linear_u8(ramp, 8, 16)
+    assert up.shape == (8, 16, 3) and list(up[0, :6, 0]) == [0, 8, 24, 40, 56, 72] and up[0, -1, 0] == 224
+    out = resize_linear_u8(a, 224, 224)
+    assert out.shape == (224, 224, 3) and out.dtype == np.uint8
+    assert abs(out.astype(np.float64).mean() - a.astype(np.float64).mean()) < 3.0
+
+
+@pytest.fixture(scope="module")
+def mini(tmp_path_factory):
+    from tests import mini_db
+    root = str(tmp_path_factory.mktemp("mini_db"))
+    csv, pkl = mini_db.build(root)
+    return csv, pkl
+
+
+def _dataset(mini, **kw):
+    from ldm.util import instantiate_from_config                     # the reference's spelling (top-level alias)
+    params = dict(state="test", use_lidar=True, use_camera=True, object_database_path=mini[0], scene_database_path=mini[1],
+                  expand_mask_ratio=0.1, expand_ref_ratio=0, object_area_crop=0.2, num_samples_per_class=2, fixed_sampling=True,
+                  object_random_crop=False, ref_aug=False, ref_mode="id-ref", image_height=128, image_width=128,
+                  range_height=128, range_width=128, object_classes=["car", "pedestrian"], range_object_norm=True,
+                  range_object_norm_scale=0.75, range_int_norm=True, min_lidar_points=8)
+    params.update(kw)
+    return instantiate_from_config({"target": "ldm.data.nuscenes.NuScenesDataset", "params": params})
+
+
+def test_dataset_items_have_the_reference_schema(mini):
+    torch.manual_seed(0)
+    np.random.seed(0)
+    ds = _dataset(mini, return_original_image=True)
+    assert len(ds) == 4
+    loader = torch.utils.data.DataLoader(ds, batch_size=4, num_workers=0, shuffle=False, drop_last=False)
+    batch = next(iter(loader))
+    B, R = 4, 128
+    img, lid = batch["image"], batch["lidar"]
+    assert img["GT"].shape == (B, 3, R, R) and img["inpaint_image"].shape == (B, 3, R, R) and img["inpaint_mask"].shape == (B, 1, R, R)
+    assert img["cond"]["ref_image"].shape == (B, 3, 224, 224) and img["cond"]["ref_bbox"].shape == (B, 8, 3)
+    assert lid["range_data"].shape == (B, 2, R, R) and lid["range_data_inpaint"].shape == (B, 2, R, R)
+    assert lid["range_mask"].shape == (B, 1, R, R) and lid["range_instance_mask"].shape == (B, 1, R, R)
+    assert lid["cond"]["ref_bbox"].shape == (B, 8, 3) and lid["range_depth_orig"].shape == (B, 32, 1096)
+    for k in ("range_int_orig", "range_instance_mask_orig", "range_pitch", "range_yaw"):
+        assert lid[k].shape == (B, 32, 1096), k
+    for k in ("range_shift_left", "width_crop", "min_depth_obj", "max_depth_obj"):
+        assert lid[k].shape == (B,), k
+    assert len(batch["id_name"]) == B and batch["id_name"][0].startswith("sample-scene") and "_id-ref_rot-0" in batch["id_name"][0]
+    assert batch["bbox_3d"].shape == (B, 8, 3) and set(batch["ref_class"]) <= {"car", "pedestrian"}
+    assert img["GT"].dtype == torch.float32 and float(img["GT"].min()) >= -1 and float(img["GT"].max()) <= 1
+    assert torch.equal(img["inpaint_image"], img["GT"] * img["inpaint_mask"])
+    assert torch.equal(lid["range_data_inpaint"], lid["range_data"] * lid["range_mask"])
+    assert float(lid["range_data"].min()) >= -1 and float(lid["range_data"].max()) <= 1
+    hole = 1 - img["inpaint_mask"]
+    assert (hole.flatten(1).sum(1) > 0.05 * R * R).all() and (hole.flatten(1).sum(1) < 0.6 * R * R).all()    # ~ object_area_crop
+    hole = 1 - lid["range_mask"]
+    assert (hole.flatten(1).sum(1) > 0).all()
+    # the camera box token carries the range view's depth code; x / y are fractions of the crop
+    assert torch.equal(img["cond"]["ref_bbox"][..., 2], lid["cond"]["ref_bbox"][..., 2])
+    assert float(lid["cond"]["ref_bbox"][..., 2].abs().max()) <= 0.75 + 1e-6              # inside the object range: |z| <= alpha
+    assert float(img["cond"]["ref_bbox"][..., :2].min()) > -1 and float(img["cond"]["ref_bbox"][..., :2].max()) < 2
+    # returns of the object sit in the edit region, with depth codes inside [-alpha, alpha]
+    inst = lid["range_instance_mask"] > 0
+    assert inst.any() and ((1 - lid["range_mask"])[inst] == 1).float().mean() > 0.6       # (the fixture's objects are spheres)
+    assert float(lid["range_data"][:, :1][inst].abs().max()) <= 0.8                     # (sphere returns just outside the box range)
+    assert img["orig"]["crop"].shape == (B, 4) and img["orig"]["image"].shape[1:] == (3, 450, 800)
+    # windows: a power of two between 64 and the view width, left edge inside the middle copy of the tiled sweep
+    assert all(int(w) in (64, 128) for w in lid["width_crop"]) and all(0 <= int(s) < 3 * 1096 for s in lid["range_shift_left"])
+
+
+def test_dataset_options(mini):
+    np.random.seed(1)
+    ds = _dataset(mini, num_samples_per_class=None, use_camera=False)
+    assert len(ds) == 6 and ds[0]["image"] == {} and ds[0]["lidar"]["range_data"].shape == (2, 128, 128)
+    rot = _dataset(mini, rot_every_angle=90, object_classes=["car"], num_samples_per_class=1)
+    assert len(rot) == 4 and [int(rot.objects_meta.loc[i, "bbox_rot_angle"]) for i in range(4)] == [0, 90, 180, 270]
+    a, b = rot[0], rot[1]
+    assert a["id_name"].endswith("rot-0") and b["id_name"].endswith("rot-90")
+    assert np.allclose(a["bbox_3d"].mean(0), b["bbox_3d"].mean(0)) and not np.allclose(a["bbox_3d"], b["bbox_3d"])
+    erase = _dataset(mini, ref_mode="erase-ref")
+    it = erase[0]
+    assert it["ref_class"] == "empty" and float(it["image"]["cond"]["ref_bbox"].abs().max()) == 0
+    name = ds.get_id_name(ds.objects_meta.loc[0])
+    one = _dataset(mini, specific_object=name)
+    assert len(one) == 1 and one[one.objects_meta.index[0]]["id_name"] == name
+    with pytest.raises(NotImplementedError):
+        _dataset(mini, ref_aug=True)
