@@ -247,8 +247,17 @@ class NuScenesDataset(data.Dataset):
             return tracked.iloc[np.random.choice(len(gaps), p=w / np.sum(w))]
         raise ValueError("Invalid ref_mode")
 
-    def get_reference(self, current_object_meta, index):
+    def _frame(self, path):
+        """RGB uint8 [H, W, 3] of a camera JPEG; the last frame stays decoded (with `id-ref` the reference patch and the
+        edited view come from the same file: one decode instead of two)."""
         from PIL import Image
+        hit = self.__dict__.get("_last_frame")
+        if hit is None or hit[0] != path:
+            hit = (path, np.array(Image.open(path).convert("RGB")))
+            self.__dict__["_last_frame"] = hit
+        return hit[1]
+
+    def get_reference(self, current_object_meta, index):
         meta = self._reference_meta(current_object_meta, index)
         scene = self.scenes_info[meta["scene_token"]]
         cam = meta["cam_idx"]
@@ -257,7 +266,7 @@ class NuScenesDataset(data.Dataset):
         if self.ref_mode == "erase-ref" or current_object_meta["is_erase_box"]:
             patch, ref_class = np.zeros((224, 224, 3), dtype=np.uint8), "empty"
         else:
-            frame = np.array(Image.open(scene["image_paths"][cam]).convert("RGB"))
+            frame = self._frame(scene["image_paths"][cam])
             H, W = frame.shape[:2]
             x1, y1, x2, y2 = get_2d_bbox(box, scene["lidar2image_transforms"][cam], H, W, self.expand_ref_ratio)
             w, h = np.maximum(x2 - x1 + 1, 1), np.maximum(y2 - y1 + 1, 1)
@@ -344,12 +353,11 @@ class NuScenesDataset(data.Dataset):
 
     # ------------------------------------------------------------------------------------------------------------------
     def get_image_data(self, scene_info, cam_idx, bbox_3d):
-        from PIL import Image
         lidar2image = scene_info["lidar2image_transforms"][cam_idx]
         path = scene_info["image_paths"][cam_idx]
-        frame = Image.open(path).convert("RGB")
-        W, H = frame.size
-        image = get_tensor()(np.array(frame))
+        frame = self._frame(path)
+        H, W = frame.shape[:2]
+        image = get_tensor()(frame)
         token = get_image_coords(bbox_3d, lidar2image, include_depth=True)
         mask = get_inpaint_mask(bbox_3d, lidar2image, H, W, self.expand_mask_ratio,
                                 random.random() < self.prob_use_3d_edit_mask)

@@ -639,10 +639,11 @@ def range_prepare(depth_orig, int_orig, inst_orig, crop_left, width_crop, min_de
     f = lambda t: None if t is None else _dev(t).to(torch.float32).contiguous()
     depth_orig, int_orig, inst_orig, min_depth, max_depth, edit_mask = map(
         f, (depth_orig, int_orig, inst_orig, min_depth, max_depth, edit_mask))
+    wc_given = torch.as_tensor(width_crop)
+    if not wc_given.is_cuda and (int(wc_given.max()) > width or int(wc_given.min()) <= 0):   # (device-resident windows: no
+        raise ValueError("range_prepare: crop windows must be 1 ... width columns wide")   #  read-back; the kernel clamps)
     cl, wcr = _i32(crop_left, dev), _i32(width_crop, dev)
     assert cl.numel() == wcr.numel() == b and edit_mask.numel() == b * height * width
-    if int(wcr.max()) > width or int(wcr.min()) <= 0:
-        raise ValueError("range_prepare: crop windows must be 1 ... width columns wide")
     rd = torch.empty((b, 2, height, width), device=dev, dtype=torch.float32)
     rdi = torch.empty_like(rd)
     inst = None if inst_orig is None else torch.empty((b, 1, height, width), device=dev, dtype=torch.float32)

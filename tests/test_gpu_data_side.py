@@ -88,7 +88,7 @@ def test_range_prepare_matches_written_out_transforms(int_norm):
         assert torch.equal(io[b, 0].cpu(), torch.from_numpy(views[2])), b
     from mobi_amd import _lib
     with pytest.raises(ValueError):
-        ops.range_prepare(t(depth), t(inten), t(inst), t(crop_left), t(width_crop * 8), t(lo), t(hi), t(mask), height=R, width=R)
+        ops.range_prepare(t(depth), t(inten), t(inst), t(crop_left), width_crop * 8, t(lo), t(hi), t(mask), height=R, width=R)
     with pytest.raises(_lib.EngineError):                              # a REDUCING view is the reference's pooling branch
         ops.range_prepare(t(depth), t(inten), None, t(crop_left), t(np.minimum(width_crop, 16)), t(lo), t(hi), t(mask[:, :, :16, :16].copy()),
                           height=16, width=16)
@@ -145,3 +145,76 @@ def test_dataset_batch_feeds_get_input(mini):
     assert data["z"].shape == (4, 9, 16, 16) and data["cond"].shape == (4, 2, 768) and data["z_lidar"].shape == (2, 4, 16, 16)
     assert torch.isfinite(data["z"]).all() and torch.isfinite(data["cond"]).all()
     assert data["image_rec"].shape == (2, 3, 128, 128) and data["lidar_rec"].shape == (2, 2, 128, 128)
+
+
+def test_harness_loop_on_mini_db(mini):
+    """scripts/inference_test_bench.py:376-610 end to end on the miniature database, every stage on the engine:
+    dataset (return_original_image, as `--save_samples` sets it) -> DataLoader -> get_input -> DDIM -> decode_sample ->
+    log_data -> camera paste-back into the full frame (orig.crop / orig.mask) and range-view paste into the full sweep
+    (range_shift_left / width_crop / pitch / yaw / bbox_3d / instance mask)."""
+    import os
+    import mobi_amd
+    from ldm.util import instantiate_from_config
+    from ldm.models.diffusion.ddim import DDIMSampler
+    from ldm.data import utils as du
+    from mobi_amd.ldm.util import load_config
+    from oracle import weights as W
+    mobi_amd.set_engine_dtype(torch.float16)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg = load_config(os.path.join(root, "configs", "mobi_nusc_256.yaml"),
+                      ["latent_size=16", "image_height=128", "use_lidar=True",
+                       "model.params.lidar_stage_config.params.ckpt_path=null",
+                       "model.params.unet_config.params.model_channels=64",
+                       "model.params.first_stage_config.params.ddconfig.ch=32",
+                       "model.params.lidar_stage_config.params.ddconfig.ch=32",
+                       "model.params.cond_stage_config.params.clip_config.hidden_size=1024",
+                       "model.params.cond_stage_config.params.clip_config.intermediate_size=256",
+                       "model.params.cond_stage_config.params.clip_config.num_hidden_layers=1",
+                       "model.params.cond_stage_config.params.clip_config.num_attention_heads=16"])
+    model = instantiate_from_config(cfg["model"])
+    W.fill_module_(model, seed=29)
+    model = model.cuda().eval()
+    sampler = DDIMSampler(model)
+    ds = _dataset(mini, return_original_image=True)
+    loader = torch.utils.data.DataLoader(ds, batch_size=2, num_workers=0, pin_memory=True, shuffle=False, drop_last=False)
+    move = lambda d: {k: move(v) if isinstance(v, dict) else (v.cuda() if isinstance(v, torch.Tensor) else v) for k, v in d.items()}
+    seen = 0
+    with torch.no_grad(), model.ema_scope():
+        for batch in loader:
+            ids = batch["id_name"]
+            batch = move(batch)
+            data = model.get_input(batch, model.first_stage_key, force_c_encode=True, return_vae_rec=True)
+            n = data["z"].shape[0]
+            uc = torch.cat([model.learnable_vector.repeat(n, 1, 1), model.bbox_uncond_vector.repeat(n, 1, 1)], dim=1)
+            shape = [model.channels, model.image_size, model.image_size]
+            samples, _ = sampler.sample(S=4, conditioning=data["cond"], batch_size=n, shape=shape, verbose=False,
+                                        unconditional_guidance_scale=5.0, unconditional_conditioning=uc, eta=0.0,
+                                        x_T=torch.randn([n, *shape], device="cuda"),
+                                        test_model_kwargs={"inpaint_image": data["z"][:, 4:8], "inpaint_mask": data["z"][:, [8]]})
+            h_cam, h_lid = model.decode_sample(samples, data.get("z_lidar"))
+            log, metrics = model.log_data(batch, data, h_cam, h_lid, log_metrics=False, return_sample=True, split="test")
+            assert metrics is not None and all(np.isfinite(v) or np.isnan(v) for v in metrics.values())
+            B = len(ids)
+            for i in range(B):                                        # camera: :478-510
+                orig = batch["image"]["orig"]
+                recon, pred = du.paste_camera_patch(patch_pred=log["image_sample"][[i]], image=orig["image"][i],
+                                                    mask=orig["mask"][i], crop=orig["crop"][i])
+                assert recon.shape == (450, 800, 3) and pred.dtype == torch.uint8 and torch.isfinite(recon).all()
+                left, top, cw, ch = (int(v) for v in orig["crop"][i])
+                assert int(pred[top:top + ch, left:left + cw].sum()) > 0 and int(pred.sum()) == int(pred[top:top + ch, left:left + cw].sum())
+                far = (orig["mask"][i] == 1)                           # far from the edit region the frame is untouched
+                far[max(0, top - 30):top + ch + 30, max(0, left - 30):left + cw + 30] = False
+                frame_bgr = ((orig["image"][i].permute(1, 2, 0).flip(-1) + 1) / 2 * 255).to(torch.uint8).float()
+                assert float((recon[far] - frame_bgr[far]).abs().max()) <= 1.0
+            lid = batch["lidar"]                                       # lidar: :567-610, the whole batch in one launch
+            out = du.paste_range_objects(range_depth=log["range_sample_depth"], range_int=log["range_sample_int"],
+                                         range_depth_orig=lid["range_depth_orig"], range_int_orig=lid["range_int_orig"],
+                                         crop_left=lid["range_shift_left"], width_crop=lid["width_crop"],
+                                         range_pitch=lid["range_pitch"], range_yaw=lid["range_yaw"], bbox_3d=batch["bbox_3d"],
+                                         gt_instance_mask=lid["range_instance_mask_orig"])
+            assert out["depth_final"].shape == (B, 32, 1096) and torch.isfinite(out["depth_final"]).all()
+            changed = (out["depth_final"] != lid["range_depth_orig"].float())
+            inside = (out["pred_mask"] != 0) | (lid["range_instance_mask_orig"] != 0)
+            assert not (changed & ~inside).any()                       # the sweep only changes where an object is / was
+            seen += B
+    assert seen == len(ds)
