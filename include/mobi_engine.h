@@ -397,11 +397,24 @@ typedef struct mobi_range_prepare_params {
 } mobi_range_prepare_params;
 int mobi_range_prepare(const mobi_range_prepare_params* p, void* stream);
 
-/* Edit masks of a batch of projected boxes (ldm/data/utils.py:146-198): corners_xy f32 [batch][8][2] pixel coordinates
- * (truncated to integers as before cv2.fillPoly), out f32 [batch][H][W] = 0 inside / on the outline of one of the six
- * faces, 1 elsewhere.  cv2's rasteriser is restated (centre inside the convex face or within half a pixel of its
- * outline); single outline pixels can differ from OpenCV's. */
-int mobi_box_mask(const float* corners_xy, float* out, int32_t batch, int32_t H, int32_t W, void* stream);
+/* Edit masks of a batch of projected boxes (ldm/data/utils.py:146-198): corners_xy int32 [batch][8][2] pixel coordinates
+ * (already truncated, as before cv2.fillPoly); out f32 [batch][H][W] = 0 inside / on the outline of one of the six faces,
+ * 1 elsewhere (may be NULL); stats int32 [batch][5] = {edit pixels, min x, max x, min y, max y}, pre-set by the caller to
+ * {0, W, -1, H, -1} (may be NULL).  cv2's rasteriser is restated (centre inside the convex face or within half a pixel
+ * of its outline); single outline pixels can differ from OpenCV's. */
+int mobi_box_mask(const int32_t* corners_xy, float* out, int32_t* stats, int32_t batch, int32_t H, int32_t W, void* stream);
+
+/* Dataset side, the camera view of a whole batch in one launch (ldm/data/nuscenes.py:495-594): frames u8 [batch][H][W][3]
+ * RGB -> ((u8 / 255) - 0.5) / 0.5, edit mask from corners_xy (as mobi_box_mask; flipped where invert[b]), crop
+ * (left, top, crop_w, crop_h) per sample, bilinear resize to (height, width) with align_corners = False and no
+ * antialias (torchvision 0.11 tensor Resize): gt f32 [batch][3][height][width], mask f32 [batch][1][height][width],
+ * inpaint = gt * mask. */
+typedef struct mobi_image_prepare_params {
+  const uint8_t* frames; const int32_t* corners_xy; const int32_t* invert; const int32_t* crop;
+  float* gt; float* inpaint; float* mask;
+  int32_t batch, H, W, height, width;
+} mobi_image_prepare_params;
+int mobi_image_prepare(const mobi_image_prepare_params* p, void* stream);
 
 /* Camera paste-back of one sample (scripts/inference_test_bench.py:478-510):
  *   mobi_paste_patch    F.interpolate(patch, (crop_h, crop_w), bilinear, align_corners=False), (((x + 1) / 2) * 255)

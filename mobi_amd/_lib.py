@@ -109,9 +109,14 @@ class RangePrepareParams(C.Structure):
                 ("alpha", f32), ("object_norm", i32), ("int_norm", i32)]
 
 
+class ImagePrepareParams(C.Structure):
+    _fields_ = [("frames", vp), ("corners_xy", vp), ("invert", vp), ("crop", vp), ("gt", vp), ("inpaint", vp), ("mask", vp),
+                ("batch", i32), ("H", i32), ("W", i32), ("height", i32), ("width", i32)]
+
+
 STRUCT_IDS = {0: IgemmParams, 1: GroupNormParams, 2: LayerNormParams, 3: AttentionParams, 4: CtxAttentionParams,
               5: SkinnyLinearParams, 6: ConvSmallCinParams, 7: ConvSmallCoutParams, 8: DdimStepParams, 9: TwoKeyAdapterParams,
-              10: RangePasteParams, 11: LidarMetricsParams, 12: RangePrepareParams}
+              10: RangePasteParams, 11: LidarMetricsParams, 12: RangePrepareParams, 13: ImagePrepareParams}
 
 # every symbol include/mobi_engine.h declares: name -> (restype, argtypes)
 SYMBOLS = {
@@ -146,7 +151,8 @@ SYMBOLS = {
     "mobi_range_paste": (C.c_int, [C.POINTER(RangePasteParams), vp]),
     "mobi_lidar_metrics": (C.c_int, [C.POINTER(LidarMetricsParams), vp]),
     "mobi_range_prepare": (C.c_int, [C.POINTER(RangePrepareParams), vp]),
-    "mobi_box_mask": (C.c_int, [vp, vp, i32, i32, i32, vp]),
+    "mobi_box_mask": (C.c_int, [vp, vp, vp, i32, i32, i32, vp]),
+    "mobi_image_prepare": (C.c_int, [C.POINTER(ImagePrepareParams), vp]),
     "mobi_paste_patch": (C.c_int, [vp, i32, i32, vp, i32, i32, i32, i32, i32, i32, vp]),
     "mobi_gaussian_blur": (C.c_int, [vp, vp, vp, i32, i32, vp, i32, vp]),
     "mobi_blend_frame": (C.c_int, [vp, vp, vp, vp, i32, i32, vp]),

@@ -249,43 +249,108 @@ __global__ __launch_bounds__(256) void range_prepare_kernel(const mobi_range_pre
   }
 }
 
-// Edit mask of a batch of projected boxes (ldm/data/utils.py:146-198; cv2.fillPoly restated, see
-// mobi_amd/ldm/data/utils.py:fill_box_faces): out = 0 where the pixel centre is inside one of the six faces (corner
-// coordinates truncated to integers) or within half a pixel of a face's outline, else 1.  Double arithmetic, the host
-// restatement's own expressions.
-__global__ __launch_bounds__(256) void box_mask_kernel(const float* __restrict__ corners_xy, float* __restrict__ out, int batch,
-                                                        int H, int W) {
+// Edit region of a projected box (ldm/data/utils.py:146-198; cv2.fillPoly restated, see
+// mobi_amd/ldm/data/utils.py:fill_box_faces): a pixel belongs to it when its centre is inside one of the six faces
+// (integer corner coordinates) or within half a pixel of a face's outline.  Double arithmetic, the host restatement's
+// own expressions.
+__device__ __forceinline__ bool in_box_faces(const int* __restrict__ q, int x, int y) {
   const int FACES[6][4] = {{0, 1, 2, 3}, {4, 5, 6, 7}, {0, 1, 5, 4}, {2, 3, 7, 6}, {0, 4, 7, 3}, {1, 5, 6, 2}};
-  const long long total = (long long)batch * H * W;
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-    const int x = (int)(i % W), y = (int)((i / W) % H), b = (int)(i / ((long long)W * H));
-    const float* q = corners_xy + (long long)b * 16;
-    bool hit = false;
-    for (int f = 0; f < 6 && !hit; ++f) {
-      double px[4], py[4];
-      for (int k = 0; k < 4; ++k) { px[k] = (double)(int)q[FACES[f][k] * 2]; py[k] = (double)(int)q[FACES[f][k] * 2 + 1]; }
-      bool pos = true, neg = true, near = false;
-      double lox = px[0], hix = px[0], loy = py[0], hiy = py[0];
-      for (int k = 1; k < 4; ++k) {
-        lox = px[k] < lox ? px[k] : lox; hix = px[k] > hix ? px[k] : hix;
-        loy = py[k] < loy ? py[k] : loy; hiy = py[k] > hiy ? py[k] : hiy;
-      }
-      const bool box = (double)x >= lox && (double)x <= hix && (double)y >= loy && (double)y <= hiy;
-      for (int k = 0; k < 4; ++k) {
-        const double ax = px[k], ay = py[k], ex = px[(k + 1) & 3] - ax, ey = py[(k + 1) & 3] - ay;
-        const double cross = ex * ((double)y - ay) - ey * ((double)x - ax);
-        pos = pos && cross >= 0; neg = neg && cross <= 0;
-        const double ll = ex * ex + ey * ey;
-        double t = ll > 0 ? (((double)x - ax) * ex + ((double)y - ay) * ey) / ll : 0.0;
-        t = t < 0.0 ? 0.0 : (t > 1.0 ? 1.0 : t);
-        const double dx = (double)x - (ax + t * ex), dy = (double)y - (ay + t * ey);
-        near = near || dx * dx + dy * dy <= 0.25;
-      }
-      hit = ((pos || neg) && box) || near;
+  for (int f = 0; f < 6; ++f) {
+    double px[4], py[4];
+    for (int k = 0; k < 4; ++k) { px[k] = (double)q[FACES[f][k] * 2]; py[k] = (double)q[FACES[f][k] * 2 + 1]; }
+    bool pos = true, neg = true, near = false;
+    double lox = px[0], hix = px[0], loy = py[0], hiy = py[0];
+    for (int k = 1; k < 4; ++k) {
+      lox = px[k] < lox ? px[k] : lox; hix = px[k] > hix ? px[k] : hix;
+      loy = py[k] < loy ? py[k] : loy; hiy = py[k] > hiy ? py[k] : hiy;
     }
-    out[i] = hit ? 0.f : 1.f;
+    if ((double)x < lox - 1 || (double)x > hix + 1 || (double)y < loy - 1 || (double)y > hiy + 1) continue;
+    const bool box = (double)x >= lox && (double)x <= hix && (double)y >= loy && (double)y <= hiy;
+    for (int k = 0; k < 4; ++k) {
+      const double ax = px[k], ay = py[k], ex = px[(k + 1) & 3] - ax, ey = py[(k + 1) & 3] - ay;
+      const double cross = ex * ((double)y - ay) - ey * ((double)x - ax);
+      pos = pos && cross >= 0; neg = neg && cross <= 0;
+      const double ll = ex * ex + ey * ey;
+      double t = ll > 0 ? (((double)x - ax) * ex + ((double)y - ay) * ey) / ll : 0.0;
+      t = t < 0.0 ? 0.0 : (t > 1.0 ? 1.0 : t);
+      const double dx = (double)x - (ax + t * ex), dy = (double)y - (ay + t * ey);
+      near = near || dx * dx + dy * dy <= 0.25;
+    }
+    if (((pos || neg) && box) || near) return true;
+  }
+  return false;
+}
+
+// out = 0 inside the edit region, 1 elsewhere; stats (optional): per box {pixels inside, min x, max x, min y, max y},
+// pre-set by the caller to {0, W, -1, H, -1}
+__global__ __launch_bounds__(256) void box_mask_kernel(const int* __restrict__ corners_xy, float* __restrict__ out,
+                                                        int* __restrict__ stats, int batch, int H, int W) {
+  const long long per = (long long)H * W;
+  const int b = blockIdx.y;
+  const int* q = corners_xy + (long long)b * 16;
+  int cnt = 0, lox = W, hix = -1, loy = H, hiy = -1;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < per; i += (long long)gridDim.x * 256) {
+    const int x = (int)(i % W), y = (int)(i / W);
+    const bool hit = in_box_faces(q, x, y);
+    if (out) out[b * per + i] = hit ? 0.f : 1.f;
+    if (hit) { ++cnt; lox = x < lox ? x : lox; hix = x > hix ? x : hix; loy = y < loy ? y : loy; hiy = y > hiy ? y : hiy; }
+  }
+  if (stats) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      cnt += __shfl_xor(cnt, o, 64);
+      const int a = __shfl_xor(lox, o, 64), c = __shfl_xor(hix, o, 64), d = __shfl_xor(loy, o, 64), e = __shfl_xor(hiy, o, 64);
+      lox = a < lox ? a : lox; hix = c > hix ? c : hix; loy = d < loy ? d : loy; hiy = e > hiy ? e : hiy;
+    }
+    if ((threadIdx.x & 63) == 0 && cnt) {
+      atomicAdd(stats + b * 5, cnt);
+      atomicMin(stats + b * 5 + 1, lox); atomicMax(stats + b * 5 + 2, hix);
+      atomicMin(stats + b * 5 + 3, loy); atomicMax(stats + b * 5 + 4, hiy);
+    }
   }
 }
+
+// Camera side of a batch in one launch (ldm/data/nuscenes.py:495-594): frame pixels ((u8 / 255) - 0.5) / 0.5, the edit
+// mask evaluated at the source pixels, both cropped to (left, top, crop_w, crop_h) and resized to (height, width) as
+// torchvision 0.11's tensor Resize does (F.interpolate bilinear, align_corners=False, no antialias);
+// GT = image, inpaint_image = image * mask.  invert[b]: the mask had no edit pixel and was flipped (:513-515).
+__global__ __launch_bounds__(256) void image_prepare_kernel(const mobi_image_prepare_params a) {
+  const long long hw = (long long)a.height * a.width, total = (long long)a.batch * hw;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int x = (int)(i % a.width), y = (int)((i / a.width) % a.height), b = (int)(i / hw);
+    const int left = a.crop[b * 4], top = a.crop[b * 4 + 1], cw = a.crop[b * 4 + 2], ch = a.crop[b * 4 + 3];
+    const float sy = (float)ch / (float)a.height, sx = (float)cw / (float)a.width;
+    float fy = sy * ((float)y + 0.5f) - 0.5f, fx = sx * ((float)x + 0.5f) - 0.5f;
+    fy = fy < 0.f ? 0.f : fy; fx = fx < 0.f ? 0.f : fx;
+    const int y0 = (int)fy, x0 = (int)fx;
+    const int y1 = y0 + (y0 < ch - 1 ? 1 : 0), x1 = x0 + (x0 < cw - 1 ? 1 : 0);
+    const float ly1 = fy - (float)y0, lx1 = fx - (float)x0, ly0 = 1.f - ly1, lx0 = 1.f - lx1;
+    const unsigned char* fr = a.frames + (long long)b * a.H * a.W * 3;
+    const int* q = a.corners_xy + (long long)b * 16;
+    const int Y[2] = {top + y0, top + y1}, X[2] = {left + x0, left + x1};
+    float m[2][2];
+    for (int r = 0; r < 2; ++r)
+      for (int c = 0; c < 2; ++c) {
+        const bool hit = in_box_faces(q, X[c], Y[r]);
+        m[r][c] = (hit != (a.invert[b] != 0)) ? 0.f : 1.f;
+      }
+    const float mk = ly0 * (lx0 * m[0][0] + lx1 * m[0][1]) + ly1 * (lx0 * m[1][0] + lx1 * m[1][1]);
+    a.mask[b * hw + (long long)y * a.width + x] = mk;
+    for (int ch3 = 0; ch3 < 3; ++ch3) {
+      float v[2][2];
+      for (int r = 0; r < 2; ++r)
+        for (int c = 0; c < 2; ++c) {
+          const float u = (float)fr[((long long)Y[r] * a.W + X[c]) * 3 + ch3] / 255.f;
+          v[r][c] = (u - 0.5f) / 0.5f;
+        }
+      const float g = ly0 * (lx0 * v[0][0] + lx1 * v[0][1]) + ly1 * (lx0 * v[1][0] + lx1 * v[1][1]);
+      const long long o = ((long long)b * 3 + ch3) * hw + (long long)y * a.width + x;
+      a.gt[o] = g;
+      a.inpaint[o] = g * mk;
+    }
+  }
+}
+
 }  // namespace mobi
 
 using namespace mobi;
@@ -352,10 +417,21 @@ extern "C" int mobi_range_prepare(const mobi_range_prepare_params* p, void* stre
   return MOBI_OK;
 }
 
-extern "C" int mobi_box_mask(const float* corners_xy, float* out, int32_t batch, int32_t H, int32_t W, void* stream) {
-  if (!corners_xy || !out || batch <= 0 || H <= 0 || W <= 0) return MOBI_ERR_ARG;
-  hipLaunchKernelGGL(box_mask_kernel, dim3(egrid_pp((long long)batch * H * W)), dim3(256), 0, ST(stream), corners_xy, out,
-                     batch, H, W);
+extern "C" int mobi_box_mask(const int32_t* corners_xy, float* out, int32_t* stats, int32_t batch, int32_t H, int32_t W,
+                             void* stream) {
+  if (!corners_xy || (!out && !stats) || batch <= 0 || H <= 0 || W <= 0) return MOBI_ERR_ARG;
+  int gx = egrid_pp((long long)H * W);
+  gx = gx > 256 ? 256 : gx;
+  hipLaunchKernelGGL(box_mask_kernel, dim3(gx, batch), dim3(256), 0, ST(stream), corners_xy, out, stats, batch, H, W);
+  MOBI_CHECK_LAUNCH();
+  return MOBI_OK;
+}
+
+extern "C" int mobi_image_prepare(const mobi_image_prepare_params* p, void* stream) {
+  if (!p || !p->frames || !p->corners_xy || !p->invert || !p->crop || !p->gt || !p->inpaint || !p->mask) return MOBI_ERR_ARG;
+  if (p->batch <= 0 || p->H <= 0 || p->W <= 0 || p->height <= 0 || p->width <= 0) return MOBI_ERR_ARG;
+  hipLaunchKernelGGL(image_prepare_kernel, dim3(egrid_pp((long long)p->batch * p->height * p->width)), dim3(256), 0,
+                     ST(stream), *p);
   MOBI_CHECK_LAUNCH();
   return MOBI_OK;
 }

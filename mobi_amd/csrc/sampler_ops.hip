@@ -228,6 +228,7 @@ extern "C" size_t mobi_struct_size(int id) {
     case 10: return sizeof(mobi_range_paste_params);
     case 11: return sizeof(mobi_lidar_metrics_params);
     case 12: return sizeof(mobi_range_prepare_params);
+    case 13: return sizeof(mobi_image_prepare_params);
     default: return 0;
   }
 }

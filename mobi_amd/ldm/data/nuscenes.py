@@ -211,15 +211,18 @@ class NuScenesDataset(data.Dataset):
         box = rotate_bbox(box, meta.get("bbox_rot_angle", 0))
         item = {"id_name": self.get_id_name(meta), "bbox_3d": box, "ref_class": ref_class, "image": {}, "lidar": {}}
         if self.use_camera:
-            item["image"] = self.get_image_data(scene, cam_idx, box)
+            item["image"] = self.get_image_data(scene, cam_idx, box, raw=raw)
             item["image"]["cond"]["ref_image"] = ref_image
         if self.use_lidar:
             item["lidar"] = self.get_range_data(scene, box, meta["scene_obj_idx"], raw=raw)
             item["lidar"]["cond"]["ref_image"] = ref_image
-            if self.use_camera:                              # the camera box token carries the RANGE-view depth code
+            if self.use_camera and not raw:                  # the camera box token carries the RANGE-view depth code
                 item["image"]["cond"]["ref_bbox"][..., 2] = item["lidar"]["cond"]["ref_bbox"][..., 2]
-        if meta["is_erase_box"] or self.ref_mode == "erase-ref":
-            if self.use_lidar:
+        erase = bool(meta["is_erase_box"] or self.ref_mode == "erase-ref")
+        if raw:
+            item["erase"] = erase                            # (the camera token is finished by `collate_device`)
+        if erase:
+            if self.use_lidar and not raw:
                 item["image"]["cond"]["ref_bbox"] *= 0
             if self.use_camera:
                 item["lidar"]["cond"]["ref_bbox"] *= 0
@@ -332,9 +335,9 @@ class NuScenesDataset(data.Dataset):
                "range_yaw": yaw, "min_depth_obj": lo, "max_depth_obj": hi, "cond": {"ref_bbox": tok},
                "file_name": scene_info["lidar_path"].split("/")[-1]}
         if raw:
-            out["range_mask_corners"] = torch.tensor(mcoords[:, :2]).float()
+            out["range_mask_corners"] = torch.from_numpy(mcoords[:, :2].astype(np.int32))
             return out
-        mask = (1. - torch.tensor(fill_box_faces(mcoords[:, :2], self.range_height, self.range_width) > 0.5).float()).unsqueeze(0)
+        mask = (1. - torch.tensor(fill_box_faces(mcoords[:, :2].astype(np.int32), self.range_height, self.range_width) > 0.5).float()).unsqueeze(0)
         out["range_mask"] = mask
         depth = _to_tensor(depth)
         if self.range_object_norm:
@@ -352,25 +355,10 @@ class NuScenesDataset(data.Dataset):
         return out
 
     # ------------------------------------------------------------------------------------------------------------------
-    def get_image_data(self, scene_info, cam_idx, bbox_3d):
-        lidar2image = scene_info["lidar2image_transforms"][cam_idx]
-        path = scene_info["image_paths"][cam_idx]
-        frame = self._frame(path)
-        H, W = frame.shape[:2]
-        image = get_tensor()(frame)
-        token = get_image_coords(bbox_3d, lidar2image, include_depth=True)
-        mask = get_inpaint_mask(bbox_3d, lidar2image, H, W, self.expand_mask_ratio,
-                                random.random() < self.prob_use_3d_edit_mask)
-        if self.return_original_image:
-            image_orig, mask_orig = image.clone(), mask.clone()
-        if (mask == 1).all():
-            mask = 1 - mask                                   # an erase box that projects nowhere: edit the whole frame
-        hole = torch.nonzero(1 - mask)
-        y1, x1 = hole.min(dim=0)[0]
-        y2, x2 = hole.max(dim=0)[0]
-
-        # a square window in which the edit region takes `object_area_crop` of the area, grown where the region is longer
-        side = int(np.sqrt((1 - mask).sum().item() / self.object_area_crop))
+    def _crop_window(self, count, x1, x2, y1, y2, H, W):
+        """(left, top, crop_W, crop_H): a square in which the edit region (count pixels, extent x1..x2 / y1..y2) takes
+        `object_area_crop` of the area, stretched where the region is longer, centred on it (or placed at random)."""
+        side = int(np.sqrt(count / self.object_area_crop))
         crop_H = crop_W = side
         if y2 - y1 > crop_H:
             crop_W += crop_H - (y2 - y1)
@@ -379,16 +367,49 @@ class NuScenesDataset(data.Dataset):
             crop_H += crop_W - (x2 - x1)
             crop_W = x2 - x1
         crop_H, crop_W = min(crop_H, H), min(crop_W, W)
-        mid = lambda a, b: torch.div(a + b, 2, rounding_mode="floor")
         lo_x, hi_x = max(0, x2 - crop_W), min(x1, W - crop_W)
         lo_y, hi_y = max(0, y2 - crop_H), min(y1, H - crop_H)
+        centred = ((lo_x + hi_x) // 2, (lo_y + hi_y) // 2)
         if self.object_random_crop:
             try:
                 left, top = random.randint(lo_x, hi_x), random.randint(lo_y, hi_y)
             except Exception:
-                left, top = mid(lo_x, hi_x), mid(lo_y, hi_y)
+                left, top = centred
         else:
-            left, top = mid(lo_x, hi_x), mid(lo_y, hi_y)
+            left, top = centred
+        return left, top, crop_W, crop_H
+
+    def _edit_corners(self, bbox_3d, lidar2image, H, W):
+        """int32 [8, 2]: the projected corners whose six faces are the edit region; with the 2D-box mask a flat box
+        covering rows y1 .. y2 - 1, columns x1 .. x2 - 1 (off-image when empty)."""
+        if random.random() < self.prob_use_3d_edit_mask:
+            xy = get_image_coords(expand_bbox_corners(bbox_3d, self.expand_mask_ratio), lidar2image)
+            return xy.astype(np.int32)
+        x1, y1, x2, y2 = get_2d_bbox(bbox_3d, lidar2image, H, W, self.expand_mask_ratio)
+        if x2 <= x1 or y2 <= y1:
+            return np.full((8, 2), -16, dtype=np.int32)
+        return np.array([[x1, y1], [x2 - 1, y1], [x2 - 1, y2 - 1], [x1, y2 - 1]] * 2, dtype=np.int32)
+
+    def get_image_data(self, scene_info, cam_idx, bbox_3d, raw=False):
+        lidar2image = scene_info["lidar2image_transforms"][cam_idx]
+        path = scene_info["image_paths"][cam_idx]
+        frame = self._frame(path)
+        H, W = frame.shape[:2]
+        token = get_image_coords(bbox_3d, lidar2image, include_depth=True)
+        corners = self._edit_corners(bbox_3d, lidar2image, H, W)
+        extra = {"file_name": path.split("/")[-1], "cam_type": scene_info["cam_types"][cam_idx], "lidar2image": lidar2image}
+        if raw:                                               # the pixels are `collate_device`'s
+            return {"frame": torch.from_numpy(frame), "mask_corners": torch.from_numpy(corners),
+                    "token": torch.from_numpy(token), "cond": {}, "orig": extra}
+        image = get_tensor()(frame)
+        mask = 1. - torch.tensor(fill_box_faces(corners, H, W) > 0.5).float()
+        if self.return_original_image:
+            image_orig, mask_orig = image.clone(), mask.clone()
+        if (mask == 1).all():
+            mask = 1 - mask                                   # an erase box that projects nowhere: edit the whole frame
+        hole = torch.nonzero(1 - mask)
+        (y1, x1), (y2, x2) = (int(v) for v in hole.min(dim=0)[0]), (int(v) for v in hole.max(dim=0)[0])
+        left, top, crop_W, crop_H = self._crop_window((1 - mask).sum().item(), x1, x2, y1, y2, H, W)
 
         image = image[:, top:top + crop_H, left:left + crop_W]
         mask = mask[top:top + crop_H, left:left + crop_W]
@@ -405,25 +426,57 @@ class NuScenesDataset(data.Dataset):
             image = image * (1 - mask)
         out = {"GT": image, "inpaint_image": inpaint, "inpaint_mask": mask, "cond": {"ref_bbox": token}}
         if self.return_original_image:
-            out["orig"] = {"crop": torch.tensor([left, top, crop_W, crop_H]), "image": image_orig, "mask": mask_orig,
-                           "file_name": path.split("/")[-1], "cam_type": scene_info["cam_types"][cam_idx],
-                           "lidar2image": lidar2image}
+            out["orig"] = dict(extra, crop=torch.tensor([left, top, crop_W, crop_H]), image=image_orig, mask=mask_orig)
         return out
 
     # ------------------------------------------------------------------------------------------------------------------
+    # ------------------------------------------------------------------------------------------------------------------
     def collate_device(self, items, device="cuda"):
-        """Default-collate a list of `raw_item`s and build `lidar.range_data / range_data_inpaint / range_instance_mask`
-        for the whole batch: `mobi_box_mask` rasterises the edit regions, `mobi_range_prepare` does tile x 3 -> window ->
-        nearest resize, depth / intensity normalisation and the edit-mask product in one launch."""
+        """Default-collate a list of `raw_item`s and finish the batch on the device.  Camera: `mobi_box_mask` gives every
+        edit region's pixel count and extent (one small read-back), the host places the crop windows, `mobi_image_prepare`
+        normalises / masks / crops / resizes all frames in one launch.  Lidar: `mobi_box_mask` rasterises the edit regions,
+        `mobi_range_prepare` does tile x 3 -> window -> nearest resize, depth / intensity normalisation and the edit-mask
+        product in one launch."""
         from torch.utils.data import default_collate
         from ... import ops
         batch = default_collate(items)
         move = lambda d: {k: move(v) if isinstance(v, dict) else (v.to(device) if isinstance(v, torch.Tensor) else v)
                           for k, v in d.items()}
         batch = move(batch)
-        lid = batch["lidar"]
         if self.prob_drop_context:
             raise NotImplementedError("context dropping is a training-side option")
+        erase = batch.pop("erase")
+        if self.use_camera:
+            img = batch["image"]
+            frames, corners, token = img.pop("frame"), img.pop("mask_corners"), img.pop("token").cpu().numpy()
+            B, H, W, _ = frames.shape
+            stats = ops.box_mask(corners, H, W, want_mask=False, want_stats=True).cpu().tolist()   # ONE read-back per batch
+            crops, invert = [], []
+            for count, x1, x2, y1, y2 in stats:
+                invert.append(int(count == 0))                # (:513-515: nothing to edit -> the whole frame is the hole)
+                if count == 0:
+                    count, x1, x2, y1, y2 = H * W, 0, W - 1, 0, H - 1
+                crops.append(self._crop_window(float(count), x1, x2, y1, y2, H, W))
+            crop_t = torch.tensor(crops, dtype=torch.int32)
+            img["GT"], img["inpaint_image"], img["inpaint_mask"] = ops.image_prepare(
+                frames, corners, invert, crop_t, height=self.image_height, width=self.image_width)
+            token = token - np.array([[[c[0], c[1], 0]] for c in crops], dtype=np.float64)
+            token[..., 0] /= np.array([c[2] for c in crops], dtype=np.float64)[:, None]
+            token[..., 1] /= np.array([c[3] for c in crops], dtype=np.float64)[:, None]
+            tok = torch.tensor(token).float().to(device)
+            if self.use_lidar:
+                tok[..., 2] = batch["lidar"]["cond"]["ref_bbox"][..., 2]
+                tok = tok * (1 - erase.to(device).float())[:, None, None]
+            img["cond"]["ref_bbox"] = tok
+            if self.return_original_image:
+                full = ops.box_mask(corners, H, W)
+                img["orig"].update(crop=crop_t.to(device).long(), mask=full,
+                                   image=((frames.permute(0, 3, 1, 2).float().div(255) - 0.5) / 0.5))
+            else:
+                img.pop("orig")
+        if not self.use_lidar:
+            return batch
+        lid = batch["lidar"]
         lid["range_mask"] = ops.box_mask(lid.pop("range_mask_corners"), self.range_height, self.range_width)[:, None]
         rd, rdi, inst = ops.range_prepare(
             lid["range_depth_orig"].float(), lid["range_int_orig"].float(), lid["range_instance_mask_orig"].float(),

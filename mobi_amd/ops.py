@@ -657,14 +657,52 @@ def range_prepare(depth_orig, int_orig, inst_orig, crop_left, width_crop, min_de
     return rd, rdi, inst
 
 
-def box_mask(corners_xy, height, width):
-    """fp32 [B, 8, 2] projected box corners (pixels) -> fp32 [B, height, width] edit masks (0 = edit region)."""
+def box_mask(corners_xy, height, width, *, want_mask=True, want_stats=False):
+    """[B, 8, 2] projected box corners (pixels; truncated towards zero like `.astype(np.int32)`) -> fp32 [B, height, width]
+    edit masks (0 = edit region) and / or int32 [B, 5] = (edit pixels, min x, max x, min y, max y)."""
     lib = _lib.load()
-    c = _dev(corners_xy).to(torch.float32).contiguous()
+    c = _dev(corners_xy)
+    c = (c.to(torch.float64).trunc() if c.is_floating_point() else c).to(torch.int32).contiguous()
     assert c.dim() == 3 and c.shape[1:] == (8, 2)
-    out = torch.empty((c.shape[0], height, width), device=c.device, dtype=torch.float32)
-    _lib.check(lib.mobi_box_mask(_ptr(c), _ptr(out), c.shape[0], height, width, _stream()), "mobi_box_mask")
-    return out
+    b = c.shape[0]
+    out = torch.empty((b, height, width), device=c.device, dtype=torch.float32) if want_mask else None
+    stats = None
+    if want_stats:
+        stats = torch.zeros((b, 5), device=c.device, dtype=torch.int32)
+        stats[:, 1], stats[:, 2], stats[:, 3], stats[:, 4] = width, -1, height, -1
+    _lib.check(lib.mobi_box_mask(_ptr(c), _ptr(out), _ptr(stats), b, height, width, _stream()), "mobi_box_mask")
+    if want_mask and want_stats:
+        return out, stats
+    return out if want_mask else stats
+
+
+def image_prepare(frames, corners_xy, invert, crop, *, height, width):
+    """Dataset side, the camera view of a batch (include/mobi_engine.h, mobi_image_prepare): frames uint8 [B, H, W, 3],
+    int corners [B, 8, 2], invert [B], crop [B, 4] = (left, top, crop_w, crop_h) -> (GT [B, 3, h, w], inpaint_image,
+    inpaint_mask [B, 1, h, w])."""
+    lib = _lib.load()
+    frames = _dev(frames).contiguous()
+    assert frames.dtype == torch.uint8 and frames.dim() == 4 and frames.shape[3] == 3
+    b, H, W, _ = frames.shape
+    dev = frames.device
+    c = torch.as_tensor(corners_xy).to(dev)
+    c = (c.to(torch.float64).trunc() if c.is_floating_point() else c).to(torch.int32).contiguous()
+    inv, cr = _i32(invert, dev), _i32(crop, dev)
+    assert c.shape == (b, 8, 2) and inv.numel() == b and cr.numel() == 4 * b
+    crh = torch.as_tensor(crop)
+    if not crh.is_cuda:
+        crh = crh.reshape(b, 4)
+        if bool(((crh[:, 0] < 0) | (crh[:, 1] < 0) | (crh[:, 2] <= 0) | (crh[:, 3] <= 0) | (crh[:, 0] + crh[:, 2] > W) |
+                 (crh[:, 1] + crh[:, 3] > H)).any()):
+            raise ValueError("image_prepare: a crop window leaves its frame")
+    gt = torch.empty((b, 3, height, width), device=dev, dtype=torch.float32)
+    inp, mask = torch.empty_like(gt), torch.empty((b, 1, height, width), device=dev, dtype=torch.float32)
+    p = _lib.ImagePrepareParams()
+    p.frames, p.corners_xy, p.invert, p.crop = _ptr(frames), _ptr(c), _ptr(inv), _ptr(cr)
+    p.gt, p.inpaint, p.mask = _ptr(gt), _ptr(inp), _ptr(mask)
+    p.batch, p.H, p.W, p.height, p.width = b, H, W, height, width
+    _lib.check(lib.mobi_image_prepare(C.byref(p), _stream()), "mobi_image_prepare")
+    return gt, inp, mask
 
 
 def lidar_metrics(pred, gt, inst_mask, box_mask, width_crop, pool_h=32):

@@ -39,11 +39,17 @@ def test_box_mask_matches_host_fill():
     corners.append(np.full((8, 2), 500.0))                       # off-image
     corners.append(np.array([[20.9, 20.2], [60.1, 20.7], [60.5, 50.5], [20.3, 50.9]] * 2))    # fractional corners: truncated
     corners = np.stack(corners)
-    got = ops.box_mask(torch.tensor(corners, dtype=torch.float32).cuda(), H, W).cpu().numpy()
+    got, stats = ops.box_mask(torch.tensor(corners).cuda(), H, W, want_stats=True)
+    got, stats = got.cpu().numpy(), stats.cpu().numpy()
     for k in range(len(corners)):
-        want = 1.0 - (fill_box_faces(corners[k].astype(np.float32).astype(np.float64), H, W) > 0.5)
-        assert np.array_equal(got[k], want.astype(np.float32)), k
+        filled = fill_box_faces(corners[k], H, W) > 0.5
+        assert np.array_equal(got[k], (1.0 - filled).astype(np.float32)), k
+        ys, xs = np.nonzero(filled)
+        want = [filled.sum(), xs.min(), xs.max(), ys.min(), ys.max()] if filled.any() else [0, W, -1, H, -1]
+        assert list(stats[k]) == want, k
     assert got[-2].min() == 1 and got[-1][20:51, 20:61].max() == 0 and got[-1].sum() == H * W - 31 * 41
+    only = ops.box_mask(torch.tensor(corners).cuda(), H, W, want_mask=False, want_stats=True)
+    assert torch.equal(only.cpu(), torch.from_numpy(stats))
 
 
 @pytest.mark.parametrize("int_norm", [False, True])
@@ -108,10 +114,25 @@ def test_collate_device_equals_host_items(mini, int_norm):
     assert float((dl["range_data"][:, 1:].cpu() - hl["range_data"][:, 1:]).abs().max()) <= tol
     assert float((dl["range_data_inpaint"].cpu() - hl["range_data_inpaint"]).abs().max()) <= tol
     assert torch.equal(dl["range_instance_mask"].cpu(), hl["range_instance_mask"])
+    # camera: frame normalisation, edit mask, crop and the bilinear resize in one launch; torch's CPU bilinear and the
+    # kernel evaluate the same four-tap expression (rounding may differ in the last bit of a product)
     for k in ("GT", "inpaint_image", "inpaint_mask"):
-        assert torch.equal(dev["image"][k].cpu(), host["image"][k]), k
+        assert float((dev["image"][k].cpu() - host["image"][k]).abs().max()) <= 1e-6, k
+    assert torch.equal(dev["image"]["cond"]["ref_bbox"].cpu(), host["image"]["cond"]["ref_bbox"])
+    assert torch.equal(dev["image"]["cond"]["ref_image"].cpu(), host["image"]["cond"]["ref_image"])
     assert torch.equal(dl["cond"]["ref_bbox"].cpu(), hl["cond"]["ref_bbox"]) and dev["id_name"] == host["id_name"]
-    assert "range_mask_corners" not in dl and dl["range_data"].is_cuda
+    assert "range_mask_corners" not in dl and dl["range_data"].is_cuda and "frame" not in dev["image"] and "erase" not in dev
+    assert set(dev["image"]) == set(host["image"]) and set(dl) == set(hl)
+    if int_norm:
+        dso = _dataset(mini, return_original_image=True, object_classes=["car"])
+        h = default_collate([dso[i] for i in range(len(dso))])["image"]["orig"]
+        d = dso.collate_device([dso.raw_item(i) for i in range(len(dso))])["image"]["orig"]
+        assert torch.equal(d["crop"].cpu(), h["crop"]) and torch.equal(d["mask"].cpu(), h["mask"])
+        assert float((d["image"].cpu() - h["image"]).abs().max()) <= 2.4e-7 and d["file_name"] == h["file_name"]   # x / 255: 1 ulp
+        cam_only = _dataset(mini, use_lidar=False)
+        hc = default_collate([cam_only[i] for i in range(2)])
+        dc = cam_only.collate_device([cam_only.raw_item(i) for i in range(2)])
+        assert torch.equal(dc["image"]["cond"]["ref_bbox"].cpu(), hc["image"]["cond"]["ref_bbox"]) and dc["lidar"] == {}
 
 
 def test_dataset_batch_feeds_get_input(mini):

@@ -48,9 +48,18 @@ def main():
     us = timeit(lambda: ops.range_prepare(*args, height=R, width=R, alpha=0.75, object_norm=True, int_norm=True), 20, warm=2)
     nbytes = B * R * R * 4 * (2 + 2 + 1 + 1)                     # written views + the edit mask read (sweeps: L2-resident)
     print(f"mobi_range_prepare [{B}, {R}, {R}]: {us:.1f} us, {nbytes / us / 1e3:.0f} GB/s of {8000} (algorithmic {nbytes / 1e6:.1f} MB)")
-    corners = torch.rand(B, 8, 2, device="cuda") * R
+    corners = (torch.rand(B, 8, 2, device="cuda") * R).to(torch.int32)
     us = timeit(lambda: ops.box_mask(corners, R, R), 20, warm=2)
     print(f"mobi_box_mask [{B}, {R}, {R}]: {us:.1f} us, {B * R * R * 4 / us / 1e3:.0f} GB/s written (24 edge tests per pixel in fp64: ALU-bound)")
+    frames = torch.randint(0, 256, (B, 900, 1600, 3), dtype=torch.uint8, device="cuda")
+    cw = (torch.rand(B, 8, 2, device="cuda") * 300 + 500).to(torch.int32)
+    crop = torch.tensor([[400, 300, 420, 420]] * B, dtype=torch.int32).cuda()
+    inv = torch.zeros(B, dtype=torch.int32, device="cuda")
+    us = timeit(lambda: ops.image_prepare(frames, cw, inv, crop, height=R, width=R), 20, warm=2)
+    nb = B * R * R * 4 * 7 + B * 420 * 420 * 3
+    print(f"mobi_image_prepare [{B}, 900 x 1600 -> {R} x {R}]: {us:.1f} us, {nb / us / 1e3:.0f} GB/s (algorithmic {nb / 1e6:.1f} MB)")
+    us = timeit(lambda: ops.box_mask(cw, 900, 1600, want_mask=False, want_stats=True), 20, warm=2)
+    print(f"mobi_box_mask stats only [{B}, 900, 1600]: {us:.1f} us")
 
 
 if __name__ == "__main__":
