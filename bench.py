@@ -361,8 +361,15 @@ def main():
         kname = {"pingpong": "igemm_pp_kernel", "direct_lds": "igemm_glds_kernel", "staged128": "igemm_kernel",
                  "staged256": "igemm_kernel", "ring128": "igemm_ring_kernel", "ring256": "igemm_ring_kernel", "ring128w": "igemm_ring_kernel"}.get(dom, "igemm_kernel")
         ach = dk["flops"] / (dk["ms"] * 1e-3) / 1e12
-        roofline = {"bound": "mfma", "kernel": kname, "achieved": round(ach, 2), "peak": PEAK_TFLOPS,
-                    "unit": "TFLOP/s", "frac": round(ach / PEAK_TFLOPS, 4), "traffic": None,
+        # which roof bounds the kernel's launches of this step taken together: their matrix time at the dense peak against
+        # their algorithmic bytes at the HBM peak (both ideal); MFMA for every variant on these workloads
+        t_mfma, t_hbm = dk["flops"] / (PEAK_TFLOPS * 1e12), dk["bytes"] / 8.0e12
+        bound = "mfma" if t_mfma >= t_hbm else "hbm"
+        peak, unit = (PEAK_TFLOPS, "TFLOP/s") if bound == "mfma" else (8000.0, "GB/s")
+        if bound == "hbm":
+            ach = dk["bytes"] / (dk["ms"] * 1e-3) / 1e9
+        roofline = {"bound": bound, "kernel": kname, "achieved": round(ach, 2), "peak": peak,
+                    "unit": unit, "frac": round(ach / peak, 4), "traffic": None,
                     "launches_per_step": dk["launches"],
                     "avg_launch_us": round(dk["ms"] * 1e3 / dk["launches"], 2),
                     "gflop_per_launch": round(dk["flops"] / dk["launches"] / 1e9, 3),
@@ -370,6 +377,7 @@ def main():
                     "note": "HIP-event-bracketed launches (on the launch stream) of one extra step after the timed "
                             "region; algorithmic 2*M*N*K of every conv / linear the kernel ran"}
         roofline["algorithmic_mb_per_launch"] = round(dk["bytes"] / dk["launches"] / 1e6, 2)
+        roofline["ideal_ms_mfma_vs_hbm"] = [round(t_mfma * 1e3, 3), round(t_hbm * 1e3, 3)]
         roofline["igemm_ms_by_variant"] = {v: round(d["ms"], 3) for v, d in by_variant.items()}
         # HBM bytes per launch come from separate rocprofv3 --pmc passes of THIS command (tools/profile_round.sh);
         # the committed figure is attached only when it was collected on the same workload / batch / dtype / guidance
