@@ -186,15 +186,20 @@ struct LnArgs {
   const float* gamma; const float* beta; float eps;
 };
 
-// one wave per token row; C <= 64*8*MAXV
-template <typename T, int MAXV>
+// LPR lanes per token row (64 / LPR rows per wave, four waves per block); a lane holds up to MAXV 8-channel pieces of its row
+// (pieces lane_in_row + LPR * i).  With C = 320 / 640 / 1280 that is 8 / 16 / 32 lanes and 5 pieces: every lane has five
+// 16-byte loads in flight and a wave covers 5 KB of rows per pass (one row per wave left 24 of 64 lanes idle at C = 320 and
+// a single load per lane in flight).  The sums are reduced over the row's lanes by a butterfly of log2(LPR) steps.
+template <typename T, int MAXV, int LPR>
 __global__ __launch_bounds__(256) void layernorm_kernel(const LnArgs a) {
-  const int lane = threadIdx.x & 63;
-  const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  constexpr int RPW = 64 / LPR;
+  const int lane = threadIdx.x & 63, lr = lane & (LPR - 1);
+  const long long row = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW + (lane / LPR);
   const long long total = (long long)a.images * a.rows;
-  if (row >= total) return;
-  const int img = (int)(row / a.rows);
-  const int r = (int)(row - (long long)img * a.rows);
+  const bool live = row < total;
+  const long long rr = live ? row : total - 1;               // idle lanes shadow the last row (no store): uniform shuffles
+  const int img = (int)(rr / a.rows);
+  const int r = (int)(rr - (long long)img * a.rows);
   const T* __restrict__ src = reinterpret_cast<const T*>(a.src) + img * a.src_img + (long long)r * a.C;
   T* __restrict__ out = reinterpret_cast<T*>(a.out) + img * a.out_img + (long long)r * a.C;
   const int V = a.C >> 3;
@@ -202,31 +207,40 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const LnArgs a) {
   float s = 0.f;
 #pragma unroll
   for (int i = 0; i < MAXV; ++i) {
-    const int v = lane + 64 * i;
+    const int v = lr + LPR * i;
     if (v < V) {
       unpack8<T>(ld16(src + v * 8), f[i]);
 #pragma unroll
       for (int j = 0; j < 8; ++j) s += f[i][j];
     }
   }
-  const float mean = wave_sum(s) / (float)a.C;
+#pragma unroll
+  for (int o = LPR / 2; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  const float mean = s / (float)a.C;
   float q = 0.f;
 #pragma unroll
   for (int i = 0; i < MAXV; ++i) {
-    const int v = lane + 64 * i;
+    const int v = lr + LPR * i;
     if (v < V) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) { const float d = f[i][j] - mean; q += d * d; }
     }
   }
-  const float rstd = rsqrtf(wave_sum(q) / (float)a.C + a.eps);
+#pragma unroll
+  for (int o = LPR / 2; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
+  const float rstd = rsqrtf(q / (float)a.C + a.eps);
+  if (!live) return;
 #pragma unroll
   for (int i = 0; i < MAXV; ++i) {
-    const int v = lane + 64 * i;
+    const int v = lr + LPR * i;
     if (v < V) {
-      float o[8];
+      float g[8], bt[8], o[8];
+      const f32x4 g0 = *reinterpret_cast<const f32x4*>(a.gamma + v * 8), g1 = *reinterpret_cast<const f32x4*>(a.gamma + v * 8 + 4);
+      const f32x4 b0 = *reinterpret_cast<const f32x4*>(a.beta + v * 8), b1 = *reinterpret_cast<const f32x4*>(a.beta + v * 8 + 4);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) o[j] = (f[i][j] - mean) * rstd * a.gamma[v * 8 + j] + a.beta[v * 8 + j];
+      for (int j = 0; j < 4; ++j) { g[j] = g0[j]; g[4 + j] = g1[j]; bt[j] = b0[j]; bt[4 + j] = b1[j]; }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] = (f[i][j] - mean) * rstd * g[j] + bt[j];
       st16(out + v * 8, pack8<T>(o));
     }
   }
@@ -249,13 +263,17 @@ static int launch_gn(const GnArgs& a, int batch, hipStream_t st) {
 template <typename T>
 static int launch_ln(const LnArgs& a, hipStream_t st) {
   const long long total = (long long)a.images * a.rows;
-  const unsigned blocks = (unsigned)((total + 3) / 4);
   const int V = a.C >> 3;
-  if (V <= 64) hipLaunchKernelGGL((layernorm_kernel<T, 1>), dim3(blocks), dim3(256), 0, st, a);
-  else if (V <= 128) hipLaunchKernelGGL((layernorm_kernel<T, 2>), dim3(blocks), dim3(256), 0, st, a);
-  else if (V <= 192) hipLaunchKernelGGL((layernorm_kernel<T, 3>), dim3(blocks), dim3(256), 0, st, a);
-  else if (V <= 320) hipLaunchKernelGGL((layernorm_kernel<T, 5>), dim3(blocks), dim3(256), 0, st, a);
+#define MOBI_LN(MAXV_, LPR_)                                                                                           \
+  hipLaunchKernelGGL((layernorm_kernel<T, MAXV_, LPR_>), dim3((unsigned)((total + 4 * (64 / LPR_) - 1) / (4 * (64 / LPR_)))), \
+                     dim3(256), 0, st, a)
+  if (V <= 8) MOBI_LN(1, 8);
+  else if (V <= 40) MOBI_LN(5, 8);                            // C <= 320
+  else if (V <= 80) MOBI_LN(5, 16);                           // C <= 640
+  else if (V <= 160) MOBI_LN(5, 32);                          // C <= 1280
+  else if (V <= 320) MOBI_LN(5, 64);                          // C <= 2560
   else return MOBI_ERR_UNSUPPORTED;
+#undef MOBI_LN
   MOBI_CHECK_LAUNCH();
   return MOBI_OK;
 }
@@ -292,7 +310,8 @@ extern "C" int mobi_layernorm(const mobi_layernorm_params* p, void* stream) {
   if (p->dtype != MOBI_F16 && p->dtype != MOBI_BF16) return MOBI_ERR_ARG;
   if (p->images <= 0 || p->rows_per_image <= 0 || p->channels <= 0 || (p->channels & 7)) return MOBI_ERR_UNSUPPORTED;
   if ((p->src_img_stride & 7) || (p->out_img_stride & 7)) return MOBI_ERR_ALIGN;
-  if ((reinterpret_cast<uintptr_t>(p->src) | reinterpret_cast<uintptr_t>(p->out)) & 15) return MOBI_ERR_ALIGN;
+  if ((reinterpret_cast<uintptr_t>(p->src) | reinterpret_cast<uintptr_t>(p->out) | reinterpret_cast<uintptr_t>(p->gamma) |
+       reinterpret_cast<uintptr_t>(p->beta)) & 15) return MOBI_ERR_ALIGN;
   LnArgs a;
   a.src = p->src; a.out = p->out; a.images = p->images; a.rows = p->rows_per_image; a.C = p->channels;
   const long long dense = (long long)p->rows_per_image * p->channels;
