@@ -59,10 +59,16 @@ class DDPM(nn.Module):
         if use_ema:
             raise NotImplementedError("EMA shadow weights are a training feature; MObI ships use_ema: False")
         self.v_posterior = v_posterior
+        self.loss_type, self.l_simple_weight, self.original_elbo_weight = loss_type, l_simple_weight, original_elbo_weight
+        if learn_logvar:
+            raise NotImplementedError("learn_logvar needs the backward pass (training row, not built)")
+        self.learn_logvar = learn_logvar
         if monitor is not None:
             self.monitor = monitor
         self.register_schedule(given_betas=given_betas, beta_schedule=beta_schedule, timesteps=timesteps,
                                linear_start=linear_start, linear_end=linear_end, cosine_s=cosine_s)
+        # (a plain tensor in the reference, indexed by a device-resident t: a buffer here so that it follows .to())
+        self.register_buffer("logvar", torch.full(fill_value=logvar_init, size=(self.num_timesteps,)), persistent=False)
         if ckpt_path is not None:
             self.init_from_ckpt(ckpt_path, ignore_keys=ignore_keys, only_model=load_only_unet)
 
@@ -122,6 +128,11 @@ class DDPM(nn.Module):
         self.register_buffer("posterior_mean_coef1", f32(betas * np.sqrt(alphas_cumprod_prev) / (1. - alphas_cumprod)))
         self.register_buffer("posterior_mean_coef2",
                              f32((1. - alphas_cumprod_prev) * np.sqrt(alphas) / (1. - alphas_cumprod)))
+        # weights of the variational-bound term (ddpm.py:169-179, eps-parameterisation), in the reference's fp32 tensor ops
+        lvlb = self.betas ** 2 / (2 * self.posterior_variance * f32(alphas) * (1 - self.alphas_cumprod))
+        lvlb[0] = lvlb[1]
+        self.register_buffer("lvlb_weights", lvlb, persistent=False)
+        assert not torch.isnan(self.lvlb_weights).all()
 
     @contextmanager
     def ema_scope(self, context=None):
@@ -137,6 +148,17 @@ class DDPM(nn.Module):
 
     def get_input(self, batch, k):
         return make_contiguous(batch["image"]), make_contiguous(batch["lidar"])
+
+
+    def get_loss(self, pred, target, mean=True):
+        """ddpm.py:289-303: elementwise |target - pred| or (target - pred)^2 (a [N] .. [N, 4, h, w] fp32 tensor on the
+        device), or its mean."""
+        if self.loss_type == "l1":
+            loss = (target - pred).abs()
+            return loss.mean() if mean else loss
+        if self.loss_type == "l2":
+            return F.mse_loss(target, pred) if mean else F.mse_loss(target, pred, reduction="none")
+        raise NotImplementedError("unknown loss type '{loss_type}'")
 
 
 class LatentDiffusion(DDPM):
@@ -303,6 +325,70 @@ class LatentDiffusion(DDPM):
         else:
             out["cond"] = {kk: cat_interleave([d[kk] for d in out["cond"]]) for kk in self.cond_stage_key}
         return out
+
+    # ---- loss side of the training / validation step (forward only) --------------------------------------------------
+    def shared_step(self, batch, **kwargs):
+        """ddpm.py:1036-1038: batch -> (loss, loss dict)."""
+        data = self.get_input(batch, self.first_stage_key)
+        return self(data["z"], data["cond"])
+
+    def forward(self, x, c, *args, **kwargs):
+        """ddpm.py:1040-1058: a random timestep per element, the conditioning (encoded here when the conditioning stage is
+        trainable), with probability `u_cond_percent` replaced by the learnt unconditional vectors; then `p_losses`."""
+        import random
+        t = torch.randint(0, self.num_timesteps, (x.shape[0],), device=self.device).long()
+        self.u_cond_prop = random.uniform(0, 1)
+        if self.model.conditioning_key is not None:
+            assert c is not None
+            if self.cond_stage_trainable:
+                c = self.get_learned_conditioning(c)
+        if self.u_cond_prop < self.u_cond_percent:
+            c = [self.learnable_vector.repeat(x.shape[0], 1, 1)]
+            if "ref_bbox" in self.cond_stage_key:
+                c.append(self.bbox_uncond_vector.repeat(x.shape[0], 1, 1))
+            c = torch.cat(c, dim=1)
+        return self.p_losses(x, c, t, *args, **kwargs)
+
+    @torch.no_grad()
+    def p_losses(self, x_start, cond, t, noise=None):
+        """ddpm.py:1177-1217 (eps-parameterisation): noise the 4 latent channels (`mobi_q_sample`), keep the inpainting
+        channels, one UNet evaluation on the engine, then
+          loss_simple = mean over (C, H, W) of get_loss(eps_hat, noise);   loss = l_simple_weight * mean(loss_simple /
+          exp(logvar[t]) + logvar[t]) + original_elbo_weight * mean(lvlb_weights[t] * loss_simple).
+        Forward only: the engine has no backward pass, hence no_grad."""
+        if self.first_stage_key == "inpaint":
+            noise = default(noise, lambda: torch.randn_like(x_start[:, :4, :, :]))
+            x_noisy = self.q_sample(x_start=x_start[:, :4, :, :], t=t, noise=noise)
+            x_noisy = torch.cat((x_noisy, x_start[:, 4:, :, :].float()), dim=1)
+        else:
+            noise = default(noise, lambda: torch.randn_like(x_start))
+            x_noisy = self.q_sample(x_start=x_start, t=t, noise=noise)
+        model_output = self.apply_model(x_noisy, t, cond)
+        prefix = "train" if self.training else "val"
+        target = noise.float()
+        loss_dict = {}
+        loss_simple = self.get_loss(model_output, target, mean=False).mean([1, 2, 3])
+        loss_dict.update({f"{prefix}/loss_simple": loss_simple.mean()})
+        logvar_t = self.logvar[t].to(self.device)
+        loss = loss_simple / torch.exp(logvar_t) + logvar_t
+        loss = self.l_simple_weight * loss.mean()
+        loss_vlb = self.get_loss(model_output, target, mean=False).mean(dim=(1, 2, 3))
+        loss_vlb = (self.lvlb_weights[t] * loss_vlb).mean()
+        loss_dict.update({f"{prefix}/loss_vlb": loss_vlb})
+        loss += (self.original_elbo_weight * loss_vlb)
+        loss_dict.update({f"{prefix}/loss": loss})
+        return loss, loss_dict
+
+    def validation_step(self, batch, batch_idx=0):
+        """ddpm.py:372-378 without the Lightning logger: the loss dict (and its `_ema` twin: use_ema is False)."""
+        _, loss_dict = self.shared_step(batch)
+        with self.ema_scope():
+            _, loss_dict_ema = self.shared_step(batch)
+        return {**loss_dict, **{k + "_ema": v for k, v in loss_dict_ema.items()}}
+
+    def training_step(self, batch, batch_idx=0):
+        raise NotImplementedError("the engine evaluates the training loss (shared_step) but has no backward pass: "
+                                  "SURVEY.md section 8(f) row 4 is not built")
 
     def apply_model(self, x_noisy, t, cond, return_ids=False):
         """x_noisy: fp32 [N, 9, h, w] or the un-concatenated list [x, inpaint_image, inpaint_mask]."""

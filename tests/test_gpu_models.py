@@ -449,3 +449,72 @@ def test_harness_flow_reference_spelling():
             assert set(k.split("/")[1] for k in lidar_metrics) == {"mse", "median_error"} and len(lidar_metrics) == 16
             assert all(k.startswith("test/") for k in lidar_metrics)
         assert not torch.equal(out["ddim"]["image_sample"], out["plms"]["image_sample"])
+
+
+def test_loss_side_of_the_training_step():
+    """`LatentDiffusion.p_losses` / `forward` / `shared_step` (reference ddpm.py:1036-1058, 1177-1217), forward only:
+    (1) the loss arithmetic against the REFERENCE's own p_losses (tests/golden/losses.npz: q_sample of the 4 latent channels
+        bit-exact, the three loss terms with l2 and l1, logvar and a non-zero ELBO weight) with the UNet replaced by the
+        golden's output;
+    (2) the whole step -- q_sample, UNet on the engine, losses -- against the CPU oracle's UNet on the same draw."""
+    _set(torch.float16)
+    from mobi_amd.ldm.models.diffusion.ddpm import LatentDiffusion
+    g = load("losses")
+    cfg = ounet.UNetConfig(model_channels=64, bbox_cond=True, use_lidar=True)
+    unet_cfg = {"target": "ldm.modules.diffusionmodules.openaimodel.UNetModel",
+                "params": dict(image_size=8, in_channels=9, out_channels=4, model_channels=64,
+                               attention_resolutions=[4, 2, 1], num_res_blocks=2, channel_mult=[1, 2, 4, 4],
+                               num_heads=8, use_spatial_transformer=True, transformer_depth=1, context_dim=768,
+                               legacy=False, bbox_cond=True, use_camera=True, use_lidar=True)}
+
+    def build(loss_type, elbo, logvar):
+        ld = LatentDiffusion(cond_stage_config="__is_unconditional__", unet_config=unet_cfg, linear_start=0.00085,
+                             linear_end=0.012, timesteps=1000, first_stage_key="inpaint", loss_type=loss_type,
+                             cond_stage_key=["ref_image", "ref_bbox"], image_size=8, channels=4, conditioning_key="crossattn",
+                             use_ema=False, use_camera=True, use_lidar=True, original_elbo_weight=elbo, logvar_init=logvar,
+                             u_cond_percent=0.2)
+        return ld.cuda().eval()
+    c = lambda t: t.cuda()
+    for loss_type, pre in (("l2", ""), ("l1", "l1_")):
+        ld = build(loss_type, 0.25, 0.3)
+        assert torch.equal(ld.lvlb_weights.cpu(), g["lvlb_weights"])                      # fp32 table, bit for bit
+        seen = {}
+
+        def fake(x_noisy, t, cond, seen=seen):
+            seen["x"] = x_noisy
+            return c(g["model_out"])
+        ld.apply_model = fake
+        loss, d = ld.p_losses(c(g["x_start"]), None, c(g["t"]), noise=c(g["noise"]))
+        assert torch.equal(seen["x"].cpu(), g["x_noisy"])                                 # q_sample + pass-through channels
+        for key in ("val/loss_simple", "val/loss_vlb", "val/loss"):
+            want = float(g[pre + key.replace("/", "__")])
+            assert abs(float(d[key]) - want) <= 2e-6 * abs(want), (loss_type, key)        # device reductions: summation order
+        assert abs(float(loss) - float(g[pre + "loss"])) <= 2e-6 * abs(float(g[pre + "loss"]))
+    # (2) end to end against the oracle's UNet
+    ld = build("l2", 0.0, 0.0)
+    sd = W.synth_state_dict(ounet.unet_param_shapes(cfg), 3)
+    ld.model.diffusion_model.load_state_dict(sd)
+    ld = ld.cuda()
+    N = 4
+    x0 = W.synth_input("ls.x", (N, 9, 8, 8))
+    ctx = W.synth_input("ls.c", (N, 2, 768))
+    noise = W.synth_input("ls.n", (N, 4, 8, 8))
+    t = torch.tensor([981, 1, 500, 21])
+    loss, d = ld.p_losses(c(x0), c(ctx), c(t), noise=c(noise))
+    sa, s1 = ld.sqrt_alphas_cumprod.cpu()[t].view(-1, 1, 1, 1), ld.sqrt_one_minus_alphas_cumprod.cpu()[t].view(-1, 1, 1, 1)
+    x_noisy = torch.cat([sa * x0[:, :4] + s1 * noise, x0[:, 4:]], 1)
+    eps = ounet.unet_forward(sd, cfg, x_noisy, t, ctx)
+    per = ((noise - eps) ** 2).mean([1, 2, 3])
+    assert abs(float(d["val/loss_simple"]) - float(per.mean())) <= 2 * TOL_NET[torch.float16] * float(per.mean())
+    assert abs(float(d["val/loss_vlb"]) - float((ld.lvlb_weights.cpu()[t] * per).mean())) <= 2 * TOL_NET[torch.float16] * float((ld.lvlb_weights.cpu()[t] * per).mean())
+    assert float(loss) == float(d["val/loss"]) == float(d["val/loss_simple"])            # logvar 0, ELBO weight 0
+    # forward(): random timesteps, unconditional substitution with probability u_cond_percent; shared_step needs a batch
+    torch.manual_seed(0)
+    z = c(x0)
+    out, dd = ld(z, c(ctx))
+    assert torch.isfinite(out) and set(dd) == {"val/loss_simple", "val/loss_vlb", "val/loss"} and 0.0 <= ld.u_cond_prop <= 1.0
+    with pytest.raises(NotImplementedError):
+        ld.training_step({}, 0)
+    with pytest.raises(NotImplementedError):
+        LatentDiffusion(cond_stage_config="__is_unconditional__", unet_config=unet_cfg, use_ema=False, learn_logvar=True,
+                        first_stage_key="inpaint", conditioning_key="crossattn", use_camera=True, use_lidar=True)
