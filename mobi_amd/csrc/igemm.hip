@@ -119,6 +119,7 @@ struct IgemmArgs {
   int wm;                  // waves along the pixel axis (2 or 4): block tile = 64*wm pixels
   int splits, nk_per;      // split-K: blockIdx.y owns k-tiles [y*nk_per, (y+1)*nk_per)
   float* split_ws;         // f32 [splits][M][n_packed] partial sums (NULL: single pass)
+  int ring_direct;         // 256 x 320 ring tiles: register epilogue (full tiles, row-major T output, bias OR per-image vector)
   int lin_window;          // direct-to-LDS kernel: window pixels are linear in the tap (no upsampling, <= 16 taps)
   int epi_direct;          // direct-to-LDS kernel: register epilogue (full tiles, row-major T output)
   int pp;                  // register-epilogue launch on the ping-pong kernel
@@ -504,6 +505,77 @@ __device__ __forceinline__ int direct_epilogue(const IgemmArgs& a, f32x4 (&acc)[
     }
   }
   return 2 * NT;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Register epilogue of the 256 x 320 ring tiles: a wave holds 128 pixels x NT * 16 channels = 32 NT accumulator
+// registers, so bias and residual cannot all sit in registers beside them.  Bias / per-image vector START the sums (the
+// kernel loads them before its k loop); here four passes of 32 pixels (pass k = 16-pixel tile pair k): the residual rows
+// of pass k + 1 are requested before pass k is converted and stored (two sets of NT registers).  Counted waits:
+// vector-memory operations retire in order, the wait before pass k leaves only the NT younger requests out.
+// ---------------------------------------------------------------------------------------------------------
+template <typename T, int NT, bool GEGLU>
+__device__ __forceinline__ void ring_register_epilogue(const IgemmArgs& a, f32x4 (&acc)[NT][8], int lane, int group, int nw0,
+                                                       int mw0) {
+  const int r16 = lane & 15, g4 = lane >> 4;
+  T* __restrict__ outT = reinterpret_cast<T*>(a.out);
+  const T* __restrict__ resid = reinterpret_cast<const T*>(a.residual);
+  const bool has_res = !GEGLU && a.residual;
+  u32x4 res[2][NT];                                            // (defined on every path: the untracked loads below are
+#pragma unroll                                                 //  pinned by in / out asm operands, which must not see undef)
+  for (int ni = 0; ni < NT; ++ni) res[0][ni] = res[1][ni] = u32x4{0u, 0u, 0u, 0u};
+  auto out_row = [&](int k) {                                  // pixel this lane stores in pass k
+    const int mi = GEGLU ? 2 * k + (g4 >> 1) : 2 * k + (g4 & 1);
+    return mw0 + mi * 16 + r16;
+  };
+  auto request_res = [&](int k, u32x4 (&r)[NT]) {
+    const int m = out_row(k);
+    const int img = m / a.hw_out, rem = m - img * a.hw_out;
+    const T* rowp = resid + (long long)(group * a.imgs_per_group + img) * a.res_img_stride + (long long)rem * a.cout + nw0 +
+                    8 * (g4 >> 1);
+#pragma unroll
+    for (int ni = 0; ni < NT; ++ni) r[ni] = vm_load16(rowp + ni * 16);
+  };
+  if (has_res) request_res(0, res[0]);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    if (has_res) {
+      // in flight, oldest first: rows of pass k | the NT stores of pass k - 1 | rows of pass k + 1 (requested now)
+      if (k + 1 < 4) request_res(k + 1, res[(k + 1) & 1]);
+      const bool both = k > 0 && k + 1 < 4;                    // (k is a literal once the loop is unrolled)
+      if (both) { if (NT == 5) asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }
+      else                  { if (NT == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
+    }
+    if constexpr (!GEGLU) {
+#pragma unroll
+      for (int ni = 0; ni < NT; ++ni) asm volatile("" : "+v"(res[k & 1][ni]));
+    }
+    const int m = out_row(k);
+    const int img = m / a.hw_out, rem = m - img * a.hw_out;
+    T* rowp = outT + (long long)(group * a.imgs_per_group + img) * a.out_img_stride + (long long)rem * a.cout;
+#pragma unroll
+    for (int ni = 0; ni < NT; ++ni) {
+      const f32x4 x = acc[ni][2 * k], y = acc[ni][2 * k + 1];
+      float xs[4] = {x[0], x[1], x[2], x[3]}, ys[4] = {y[0], y[1], y[2], y[3]};
+      if constexpr (GEGLU) MOBI_SWAP4("v_permlane32_swap_b32", xs, ys);
+      else MOBI_SWAP4("v_permlane16_swap_b32", xs, ys);
+      if constexpr (GEGLU) {
+        float o[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = xs[r] * gelu_erf_f(ys[r]);
+        vm_store8(rowp + (nw0 >> 1) + ni * 8 + 4 * (g4 & 1), pack4<T>(o));
+      } else {
+        float o[8] = {xs[0], xs[1], xs[2], xs[3], ys[0], ys[1], ys[2], ys[3]};
+        if (has_res) {
+          float rf[8];
+          unpack8<T>(res[k & 1][ni], rf);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) o[j] += rf[j];
+        }
+        vm_store16(rowp + nw0 + ni * 16 + 8 * (g4 >> 1), pack8<T>(o));
+      }
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1805,6 +1877,22 @@ __global__ __launch_bounds__(NW * 64, 2) void igemm_ring_kernel(const IgemmArgs 
     for (int j = 0; j < MT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int r16 = lane & 15, g4 = lane >> 4;
+  if constexpr (WIDE && MT == 8 && !TR) {
+    // register-epilogue launches: bias OR per-image vector start the sums (scale is 1; a wave's 128 pixels lie in one image)
+    if (a.ring_direct && (a.bias || a.rowvec)) {
+      const float* vec = a.bias;
+      if (a.rowvec) {
+        const int img = __builtin_amdgcn_readfirstlane((m0 + wm * 128) / a.hw_out);
+        vec = a.rowvec + (long long)(group * a.imgs_per_group + img) * a.rowvec_stride;
+      }
+#pragma unroll
+      for (int i = 0; i < NT; ++i) {
+        const f32x4 b = *reinterpret_cast<const f32x4*>(vec + n0 + wn * WAVE_N + i * 16 + g4 * 4);
+#pragma unroll
+        for (int j = 0; j < MT; ++j) acc[i][j] = b;
+      }
+    }
+  }
   const unsigned fsw = (((unsigned)g4 ^ ((0x1320u >> (((r16 >> 2) & 3) * 4)) & 3u)) << 4);
   const unsigned char* xrd = lds + (wm * MT * 16 + r16) * 64 + fsw;
   const unsigned char* wrd = lds + BM * 64 + (wn * WAVE_N + r16) * 64 + fsw;
@@ -1876,6 +1964,32 @@ __global__ __launch_bounds__(NW * 64, 2) void igemm_ring_kernel(const IgemmArgs 
   }
 #undef MOBI_RING_BARRIER
   MOBI_STAMP_AT(2);
+  if constexpr (WIDE && MT == 8 && !TR) {
+    if (a.ring_direct) {                                     // wave-uniform
+      // register epilogue: no LDS staging, no block barrier (the waves leave at their own pace); the accumulator layout is the
+      // ping-pong kernel's (channels x pixels), 64 pixels of the wave's 128 at a time.  Every request of the ring (also the
+      // all-zero ones past the k range) has to have landed before the wave ends.
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if constexpr (MT == 8) {
+        if (a.epilogue == MOBI_EPI_GEGLU) ring_register_epilogue<T, NT, true>(a, acc, lane, group, n0 + wn * WAVE_N, m0 + wm * 128);
+        else ring_register_epilogue<T, NT, false>(a, acc, lane, group, n0 + wn * WAVE_N, m0 + wm * 128);
+      }
+#if MOBI_STAMP
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      MOBI_STAMP_AT(3);
+      if (g_stamps && threadIdx.x == 0) {
+        unsigned long long* d = g_stamps + (size_t)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) * 8;
+        unsigned hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        d[4] = ((unsigned long long)xcc << 32) | hw;
+        d[5] = (unsigned long long)(ks_end - ks_begin);
+        d[6] = 1;
+      }
+#endif
+      return;
+    }
+  }
   // the ring becomes the epilogue's staging area: every request (also the all-zero ones) must have landed
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
@@ -2222,6 +2336,17 @@ static int igemm_prepare(const mobi_igemm_params* p, mobi::IgemmArgs& a) {
       a.tiles_n = (int)tn;
       a.sm = 0;
     }
+  }
+  {
+    const int bnw = (p->n_packed % 160) == 0 ? 320 : 256;
+    a.ring_direct = a.wide == 2 && p->out_mode == MOBI_OUT_ROWS && !a.split_ws && p->groups == 1 &&
+                    (!p->rowvec || (!p->bias && a.hw_out % 128 == 0)) && a.M % 256 == 0 && p->n_packed % bnw == 0 &&
+                    p->scale == 1.0f && !p->residual && tuning().ring_direct != 0;
+    // (with a residual the staged epilogue is as fast or a microsecond faster: 28.1 vs 29.2 us on 320 -> 320 1x1 at 64 x 64 x 16,
+    //  98.9 vs 100.2 on the 3x3; MOBI_IGEMM_RING_DIRECT=1 forces the register epilogue there too)
+    if (tuning().ring_direct == 1 && p->residual && a.wide == 2 && p->out_mode == MOBI_OUT_ROWS && !a.split_ws && p->groups == 1 &&
+        (!p->rowvec || (!p->bias && a.hw_out % 128 == 0)) && a.M % 256 == 0 && p->n_packed % bnw == 0 && p->scale == 1.0f)
+      a.ring_direct = 1;
   }
   return MOBI_OK;
 }

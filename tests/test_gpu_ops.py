@@ -575,6 +575,68 @@ def test_igemm_pingpong(ops, dtype, case, tune):
     assert _lib.load().mobi_igemm_kernel_variant(C.byref(p)) == 3
 
 
+# (images, h, w, cin, cin2, cout, k, residual, rowvec, geglu)
+RING_CASES = [
+    (2, 64, 64, 320, 0, 320, 1, True, False, False),          # 320-wide tiles (five 16-column MFMA tiles per wave), bias + residual
+    (2, 64, 64, 320, 0, 640, 3, True, True, False),           # 3x3, residual + per-image vector (the ResBlock conv)
+    (1, 128, 128, 128, 0, 256, 3, True, False, False),        # 256-wide tiles (four MFMA tiles per wave), rows of 128 pixels
+    (4, 32, 32, 128, 64, 320, 3, False, False, False),        # two sources, no residual
+    (2, 64, 64, 320, 0, 640, 1, False, False, True),          # GEGLU: 640 outputs = 1280 packed columns
+    (2, 32, 32, 256, 0, 256, 1, False, False, True),          # GEGLU on 256-wide tiles
+    (3, 16, 16, 192, 0, 320, 1, True, False, False),          # 768 pixels: three full 256-pixel tiles, 16 x 16 images
+]
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("case", RING_CASES, ids=[f"ring{i}" for i in range(len(RING_CASES))])
+def test_igemm_ring256_epilogues(ops, dtype, case, tune):
+    """The 256 x 320 (256) ring tiles with BOTH epilogues -- registers (bias / per-image vector start the sums, residual rows
+    double-buffered over four 32-pixel passes, GEGLU) and LDS-staged -- against a torch fp32 convolution and each other
+    (same fp32 sums, one rounding: the outputs differ by at most an ulp of the storage type)."""
+    import ctypes as C
+    from mobi_amd import _lib
+    n, h, w, cin, cin2, cout, k, res, rowvec, geglu = case
+    name = "ring." + ".".join(str(int(v)) for v in case)
+    xf, xd = rnd(name + ".x", (n, h, w, cin), dtype)
+    x2f, x2d = rnd(name + ".x2", (n, h, w, cin2), dtype) if cin2 else (None, None)
+    wf = torch.from_numpy(W.synth_param(name + ".weight", ((2 if geglu else 1) * cout, cin + cin2, k, k))).to(dtype).float()
+    bias = torch.from_numpy(W.synth_param(name + ".bias", ((2 if geglu else 1) * cout,)))
+    rf, rd = rnd(name + ".res", (n, h, w, cout), dtype) if res else (None, None)
+    rv = W.synth_input(name + ".rv", (n, cout)) if rowvec else None
+    ref = _conv_ref(xf if x2f is None else torch.cat([xf, x2f], 3), wf, None if rowvec else bias, 1, (k // 2, k // 2))
+    if geglu:
+        a_, g_ = ref.chunk(2, dim=-1)
+        ref = a_ * F.gelu(g_)
+    if rv is not None:
+        ref = ref + rv[:, None, None, :]
+    if rf is not None:
+        ref = ref + rf
+    tune.setenv("MOBI_IGEMM_WIDE", "2")
+    outs = {}
+    for direct in ("1", "0"):
+        tune.setenv("MOBI_IGEMM_RING_DIRECT", direct)
+        if geglu:
+            y = ops.linear(xd.view(n, h * w, cin), ops.pack_geglu(wf[:, :, 0, 0], bias, dtype, "cuda")).view(n, h, w, cout)
+        else:
+            pw = ops.pack_conv(wf, None if rowvec else bias, dtype, "cuda")
+            y = ops.igemm(xd, pw, x2=x2d, residual=rd, rowvec=None if rv is None else rv.cuda(), rowvec_has_bias=rowvec)
+        assert torch.isfinite(y.float()).all() and rel(y.float(), ref) < TOL[dtype], (case, direct)
+        outs[direct] = y.float()
+    ulp = 2.0 ** (-7 if dtype == torch.bfloat16 else -10)
+    assert float(((outs["1"] - outs["0"]).abs() / outs["0"].abs().clamp_min(1.0)).max()) <= 2 * ulp
+    p = _lib.IgemmParams()
+    p.src0, p.weight, p.out = 256, 256, 256
+    p.c0, p.c1, p.batch, p.hin, p.win, p.hout, p.wout = cin, cin2, n, h, w, h, w
+    if cin2:
+        p.src1 = 256
+    p.kh = p.kw = k
+    p.stride, p.pad_h, p.pad_w, p.groups = 1, k // 2, k // 2, 1
+    p.cout, p.n_packed = cout, (2 if geglu else 1) * cout
+    p.epilogue = _lib.EPI_GEGLU if geglu else _lib.EPI_NONE
+    p.scale, p.dtype = 1.0, _lib.MOBI_F16 if dtype == torch.float16 else _lib.MOBI_BF16
+    assert _lib.load().mobi_igemm_kernel_variant(C.byref(p)) == 5
+
+
 @pytest.mark.parametrize("dtype", DT)
 @pytest.mark.parametrize("n,t,c,heads,strided", [(3, 100, 320, 8, False), (2, 64, 640, 8, True), (2, 37, 1280, 8, False),
                                                  (1, 256, 64, 4, False)])
