@@ -584,6 +584,8 @@ RING_CASES = [
     (2, 64, 64, 320, 0, 640, 1, False, False, True),          # GEGLU: 640 outputs = 1280 packed columns
     (2, 32, 32, 256, 0, 256, 1, False, False, True),          # GEGLU on 256-wide tiles
     (3, 16, 16, 192, 0, 320, 1, True, False, False),          # 768 pixels: three full 256-pixel tiles, 16 x 16 images
+    (2, 128, 128, 96, 0, 960, 1, False, True, False),         # per-image vector, no residual, 3 column tiles x 128 row tiles, 3 k-steps
+    (1, 64, 64, 64, 0, 640, 3, False, False, False),          # k-steps that change tap every two steps (64 channels)
 ]
 
 
