@@ -120,6 +120,7 @@ struct IgemmArgs {
   int splits, nk_per;      // split-K: blockIdx.y owns k-tiles [y*nk_per, (y+1)*nk_per)
   float* split_ws;         // f32 [splits][M][n_packed] partial sums (NULL: single pass)
   int ring_direct;         // 256 x 320 ring tiles: register epilogue (full tiles, row-major T output, bias OR per-image vector)
+  int sm_direct;           // 128 x 160 ring tiles: register epilogue / register slab stores (full tiles)
   int lin_window;          // direct-to-LDS kernel: window pixels are linear in the tap (no upsampling, <= 16 taps)
   int epi_direct;          // direct-to-LDS kernel: register epilogue (full tiles, row-major T output)
   int pp;                  // register-epilogue launch on the ping-pong kernel
@@ -1964,6 +1965,32 @@ __global__ __launch_bounds__(NW * 64, 2) void igemm_ring_kernel(const IgemmArgs 
   }
 #undef MOBI_RING_BARRIER
   MOBI_STAMP_AT(2);
+  if constexpr (MT == 4 && !TR) {
+    if (a.sm_direct) {                                       // wave-uniform
+      // 128-pixel tiles, full: the wave tile is the ping-pong kernel's (64 pixels x NT * 16 channels), so are its register
+      // epilogue and its slab stores; no LDS staging, no block barrier
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // every request of the ring has landed before the wave ends
+      const int nw0 = n0 + wn * WAVE_N, mw0 = m0 + wm * 64;
+      if (a.split_ws) {
+        float* wsp = a.split_ws + (long long)blockIdx.y * a.M * a.n_packed;
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) {
+          float* rowp = wsp + (long long)(mw0 + mi * 16 + r16) * a.n_packed + nw0 + g4 * 4;
+#pragma unroll
+          for (int ni = 0; ni < NT; ++ni) vm_store16(rowp + ni * 16, __builtin_bit_cast(u32x4, acc[ni][mi]));
+        }
+      } else {
+        DirectEpiRegs<NT> q;
+#pragma unroll
+        for (int ni = 0; ni < NT; ++ni) { q.bias[ni] = u32x4{0u, 0u, 0u, 0u}; q.res[ni][0] = q.res[ni][1] = u32x4{0u, 0u, 0u, 0u}; }
+        direct_epilogue_request<T, NT>(a, q, lane, group, nw0, mw0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (a.epilogue == MOBI_EPI_GEGLU) direct_epilogue<T, NT, true>(a, acc, q, lane, group, nw0, mw0);
+        else direct_epilogue<T, NT, false>(a, acc, q, lane, group, nw0, mw0);
+      }
+      return;
+    }
+  }
   if constexpr (WIDE && MT == 8 && !TR) {
     if (a.ring_direct) {                                     // wave-uniform
       // register epilogue: no LDS staging, no block barrier (the waves leave at their own pace); the accumulator layout is the
@@ -2337,6 +2364,11 @@ static int igemm_prepare(const mobi_igemm_params* p, mobi::IgemmArgs& a) {
       a.sm = 0;
     }
   }
+  // 128 x 160 ring tiles: register epilogue / slab stores when every tile is full (the staged epilogue keeps ragged tiles,
+  // transposed / fp32 output, bias AND per-image vector)
+  a.sm_direct = (a.sm || a.wide == 1) && (p->out_mode == MOBI_OUT_ROWS || a.split_ws) && p->out_mode != MOBI_OUT_TRANSPOSED &&
+                p->groups == 1 && a.M % 128 == 0 && p->n_packed % (a.wide == 1 ? 2 * bn : bn) == 0 &&
+                (a.split_ws || !p->rowvec || (!p->bias && a.hw_out % 64 == 0)) && tuning().sm_direct != 0;
   {
     const int bnw = (p->n_packed % 160) == 0 ? 320 : 256;
     a.ring_direct = a.wide == 2 && p->out_mode == MOBI_OUT_ROWS && !a.split_ws && p->groups == 1 &&

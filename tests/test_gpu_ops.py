@@ -575,6 +575,60 @@ def test_igemm_pingpong(ops, dtype, case, tune):
     assert _lib.load().mobi_igemm_kernel_variant(C.byref(p)) == 3
 
 
+# (images, h, w, cin, cin2, cout, k, residual, rowvec, geglu, split)
+SM_CASES = [
+    (2, 16, 16, 640, 0, 320, 3, True, True, False, None),     # 512 pixels: four full 128-pixel tiles, residual + per-image vector
+    (8, 8, 8, 320, 0, 640, 1, True, False, False, None),      # 8 x 8 images: two images per tile, bias + residual
+    (2, 16, 16, 256, 64, 320, 3, False, False, False, None),  # two sources
+    (2, 16, 16, 320, 0, 320, 1, False, False, True, None),    # GEGLU (640 packed columns)
+    (2, 8, 8, 1280, 0, 320, 3, True, True, False, 5),         # split-K: fp32 slabs straight from the accumulators
+    (4, 8, 8, 640, 0, 1280, 1, True, False, False, 2),        # split-K, 1x1, 256-wide... 1280 = 8 x 160 column tiles
+    (1, 16, 8, 128, 0, 128, 3, True, False, False, None),     # 128-wide tiles (four 16-column MFMA tiles per wave)
+]
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("case", SM_CASES, ids=[f"sm{i}" for i in range(len(SM_CASES))])
+def test_igemm_ring128_epilogues(ops, dtype, case, tune):
+    """The 128 x 160 (128) ring tiles (small m) with the register epilogue / register slab stores and with the LDS-staged
+    epilogue: against a torch fp32 convolution, and bit for bit against each other (the same sums, the same rounding)."""
+    n, h, w, cin, cin2, cout, k, res, rowvec, geglu, split = case
+    name = "sm." + ".".join(str(v) for v in case)
+    xf, xd = rnd(name + ".x", (n, h, w, cin), dtype)
+    x2f, x2d = rnd(name + ".x2", (n, h, w, cin2), dtype) if cin2 else (None, None)
+    wf = torch.from_numpy(W.synth_param(name + ".weight", ((2 if geglu else 1) * cout, cin + cin2, k, k))).to(dtype).float()
+    bias = torch.from_numpy(W.synth_param(name + ".bias", ((2 if geglu else 1) * cout,)))
+    rf, rd = rnd(name + ".res", (n, h, w, cout), dtype) if res else (None, None)
+    rv = W.synth_input(name + ".rv", (n, cout)) if rowvec else None
+    ref = _conv_ref(xf if x2f is None else torch.cat([xf, x2f], 3), wf, None if rowvec else bias, 1, (k // 2, k // 2))
+    if geglu:
+        a_, g_ = ref.chunk(2, dim=-1)
+        ref = a_ * F.gelu(g_)
+    if rv is not None:
+        ref = ref + rv[:, None, None, :]
+    if rf is not None:
+        ref = ref + rf
+    tune.setenv("MOBI_IGEMM_WM", "2")
+    tune.setenv("MOBI_IGEMM_WIDE", "0")
+    outs = {}
+    for direct in ("1", "0"):
+        tune.setenv("MOBI_IGEMM_SM_DIRECT", direct)
+        if geglu:
+            y = ops.linear(xd.view(n, h * w, cin), ops.pack_geglu(wf[:, :, 0, 0], bias, dtype, "cuda")).view(n, h, w, cout)
+        else:
+            pw = ops.pack_conv(wf, None if rowvec else bias, dtype, "cuda")
+            y = ops.igemm(xd, pw, x2=x2d, residual=rd, rowvec=None if rv is None else rv.cuda(), rowvec_has_bias=rowvec,
+                          split_k=split)
+        assert torch.isfinite(y.float()).all() and rel(y.float(), ref) < TOL[dtype], (case, direct)
+        outs[direct] = y
+    if split:
+        assert torch.equal(outs["1"], outs["0"])                  # identical slabs, the same reduce launch
+    else:
+        ulp = 2.0 ** (-7 if dtype == torch.bfloat16 else -10)
+        d = (outs["1"].float() - outs["0"].float()).abs() / outs["0"].float().abs().clamp_min(1.0)
+        assert float(d.max()) <= 2 * ulp
+
+
 # (images, h, w, cin, cin2, cout, k, residual, rowvec, geglu)
 RING_CASES = [
     (2, 64, 64, 320, 0, 320, 1, True, False, False),          # 320-wide tiles (five 16-column MFMA tiles per wave), bias + residual
