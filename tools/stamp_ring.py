@@ -13,11 +13,15 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 # (images, hw, cin, cout, k, geglu, residual)
 SHAPES = [(16, 64, 320, 1280, 1, True, False), (16, 32, 640, 2560, 1, True, False), (16, 16, 1280, 5120, 1, True, False),
-          (16, 64, 320, 320, 1, False, True), (16, 64, 1280, 320, 1, False, True), (16, 64, 320, 320, 3, False, True)]
+          (16, 64, 320, 320, 1, False, True), (16, 64, 1280, 320, 1, False, True), (16, 64, 320, 320, 3, False, True),
+          # small m (mobi_nusc_256's launches, the 128 x 160 tiles)
+          (8, 32, 320, 320, 1, False, True), (8, 16, 640, 640, 1, False, True), (8, 8, 1280, 1280, 1, False, True),
+          (8, 16, 640, 640, 3, False, True), (8, 8, 1280, 1280, 3, False, True)]
 
 
 def main():
     os.environ["MOBI_HIPCC_FLAGS"] = (os.environ.get("MOBI_HIPCC_FLAGS", "") + " -DMOBI_STAMP=1").strip()
+    os.environ["MOBI_IGEMM_SM_DIRECT"] = os.environ["MOBI_IGEMM_RING_DIRECT"] = "0"      # the stamped (LDS-staged) epilogue
     from mobi_amd import build
     build.build(force=True, verbose=False)
     from mobi_amd import _lib, ops
@@ -69,9 +73,13 @@ def main():
             gaps += list(rows[1:, 0] - rows[:-1, 3])
         print(f"{'geglu' if geglu else 'conv'} {cin}->{cout} k{k} m={images * hw * hw}: event-timed {b2b:.1f} us back to back; "
               f"{len(s)} blocks x {int(s[:, 5].mean())} k-steps on {len(per_cu)} CUs ({per_cu.min()}-{per_cu.max()} blocks per CU) | "
-              f"in-kernel span {t[:, 3].max() - t0:.1f} us: entry->first step landed {np.mean(t[:, 1] - t[:, 0]):.2f}, "
-              f"k loop {np.mean(t[:, 2] - t[:, 1]):.2f} ({np.mean((t[:, 2] - t[:, 1]) / s[:, 5]):.3f} per step), "
-              f"drain + epilogue + stores {np.mean(t[:, 3] - t[:, 2]):.2f}, block end -> next block entry on the CU "
+              f"in-kernel span {t[:, 3].max() - t0:.1f} us: " +
+              (f"entry->first step landed {np.mean(t[:, 1] - t[:, 0]):.2f}, k loop {np.mean(t[:, 2] - t[:, 1]):.2f} "
+               f"({np.mean((t[:, 2] - t[:, 1]) / s[:, 5]):.3f} per step), " if (s[:, 1] != 0).all() else
+               f"entry -> end of the k loop {np.mean(t[:, 2] - t[:, 0]):.2f} ({np.mean((t[:, 2] - t[:, 0]) / s[:, 5]):.3f} per step incl. "
+               f"the first landing; four-wave geometry: no stamp in the loop), ") +
+              f"
+drain + epilogue + stores {np.mean(t[:, 3] - t[:, 2]):.2f}, block end -> next block entry on the CU "
               f"{np.mean(gaps) if gaps else 0:.2f} (median {np.median(gaps) if gaps else 0:.2f}), last entry at {t[:, 0].max() - t0:.1f}",
               flush=True)
     os.environ["MOBI_HIPCC_FLAGS"] = os.environ["MOBI_HIPCC_FLAGS"].replace("-DMOBI_STAMP=1", "").strip()
