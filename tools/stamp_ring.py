@@ -78,8 +78,7 @@ def main():
                f"({np.mean((t[:, 2] - t[:, 1]) / s[:, 5]):.3f} per step), " if (s[:, 1] != 0).all() else
                f"entry -> end of the k loop {np.mean(t[:, 2] - t[:, 0]):.2f} ({np.mean((t[:, 2] - t[:, 0]) / s[:, 5]):.3f} per step incl. "
                f"the first landing; four-wave geometry: no stamp in the loop), ") +
-              f"
-drain + epilogue + stores {np.mean(t[:, 3] - t[:, 2]):.2f}, block end -> next block entry on the CU "
+              f"drain + epilogue + stores {np.mean(t[:, 3] - t[:, 2]):.2f}, block end -> next block entry on the CU "
               f"{np.mean(gaps) if gaps else 0:.2f} (median {np.median(gaps) if gaps else 0:.2f}), last entry at {t[:, 0].max() - t0:.1f}",
               flush=True)
     os.environ["MOBI_HIPCC_FLAGS"] = os.environ["MOBI_HIPCC_FLAGS"].replace("-DMOBI_STAMP=1", "").strip()
