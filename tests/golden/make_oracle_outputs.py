@@ -1,0 +1,29 @@
+#!/usr/bin/env python3
+"""tests/golden/oracle_outputs.npz: the CPU oracle's outputs for the expensive GPU parity cases (tests/oracle_cases.py),
+computed here once instead of on the GPU box at every `pytest -m gpu` run.   python tests/golden/make_oracle_outputs.py"""
+import os
+import sys
+import time
+
+os.environ["MOBI_ORACLE_LIVE"] = "1"
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+import numpy as np                                          # noqa: E402
+from tests import oracle_cases as oc                       # noqa: E402
+
+
+def main():
+    out = {}
+    t0 = time.time()
+    out["prod_64_16"] = oc.prod_forward(64, 16, live=True).numpy()
+    print(f"prod 64x64 x 16: {time.time() - t0:.0f} s", flush=True)
+    out["prod_32_8"] = oc.prod_forward(32, 8, live=True).numpy()
+    out["full_width16"] = oc.full_width16(live=True).numpy()
+    for k, v in oc.trajectories10(live=True).items():
+        out["traj10_" + k] = v.numpy()
+    np.savez_compressed(oc.PATH, **out)
+    print(f"wrote {oc.PATH}: {sorted(out)} ({os.path.getsize(oc.PATH) / 1e6:.1f} MB, {time.time() - t0:.0f} s)")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,94 @@
+"""CPU-oracle outputs of the expensive GPU parity cases, computed ONCE: `tests/golden/oracle_outputs.npz` holds what these
+functions return (written by `python tests/golden/make_oracle_outputs.py`, minutes of CPU time), the `-m gpu` tests read
+it instead of spending ~5 of their 10 minutes in the oracle on the GPU box's host cores, and
+`tests/test_oracle_outputs_cpu.py` recomputes a sample of it live so that the file cannot drift from the oracle.
+A key that is missing from the file is computed live.  Test infrastructure only (imports `oracle/`)."""
+import functools
+import os
+
+import numpy as np
+import torch
+
+from oracle import sampler as osampler, unet as ounet, weights as W
+
+PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "oracle_outputs.npz")
+LIVE = os.environ.get("MOBI_ORACLE_LIVE") == "1"          # ignore the file (the generator, the CPU check)
+
+
+@functools.lru_cache(maxsize=None)
+def _file():
+    return dict(np.load(PATH)) if os.path.exists(PATH) and not LIVE else {}
+
+
+def _threads():
+    torch.set_num_threads(max(1, min(os.cpu_count() or 1, 32)))
+
+
+PROD_T = [981, 981, 741, 741, 501, 501, 261, 261, 21, 21, 1, 1, 901, 901, 481, 481]
+
+
+def prod_inputs(side, n):
+    return (W.synth_input(f"prod.x{side}", (n, 9, side, side)), W.synth_input(f"prod.c{side}", (n, 2, 768)),
+            torch.tensor(PROD_T[:n], dtype=torch.long))
+
+
+def prod_forward(side, n, pairs=None, live=False):
+    """Full-width UNet (seed 13) on the production batch, pair by pair -> [n, 4, side, side] (or the given pairs only)."""
+    key = f"prod_{side}_{n}"
+    if not live and pairs is None and key in _file():
+        return torch.from_numpy(_file()[key])
+    _threads()
+    cfg = ounet.UNetConfig()
+    sd = W.synth_state_dict(ounet.unet_param_shapes(cfg), 13)
+    x, ctx, t = prod_inputs(side, n)
+    idx = range(0, n, 2) if pairs is None else [2 * p for p in pairs]
+    return torch.cat([ounet.unet_forward(sd, cfg, x[i:i + 2], t[i:i + 2], ctx[i:i + 2]) for i in idx])
+
+
+def full_width16(live=False):
+    """Full-width UNet (seed 5), one pair at 16 x 16, t = 741."""
+    if not live and "full_width16" in _file():
+        return torch.from_numpy(_file()["full_width16"])
+    _threads()
+    cfg = ounet.UNetConfig()
+    sd = W.synth_state_dict(ounet.unet_param_shapes(cfg), 5)
+    return ounet.unet_forward(sd, cfg, W.synth_input("uf.x", (2, 9, 16, 16)), torch.tensor([741, 741], dtype=torch.long),
+                              W.synth_input("uf.c", (2, 2, 768)))
+
+
+def traj_inputs():
+    b, side = 4, 16
+    return dict(x_T=W.synth_input("smp.x_T", (b, 4, side, side)), inp=W.synth_input("smp.inpaint", (b, 4, side, side)),
+                msk=(W.synth_input("smp.mask", (b, 1, side, side)) > 0).float(), cond=W.synth_input("smp.cond", (b, 2, 768)),
+                uc=W.synth_input("smp.uc", (1, 2, 768)).repeat(b, 1, 1), x0=W.synth_input("smp.x0", (b, 4, side, side)),
+                cmask=(W.synth_input("smp.cmask", (b, 1, side, side)) > 0).float(),
+                mn=W.synth_input("smp.mn", (10, b, 4, side, side)), sn=W.synth_input("smp.sn", (10, b, 4, side, side)))
+
+
+def trajectories10(live=False, only=None):
+    """DDIM-10 / PLMS-10 finals with and without guidance, the DDIM intermediates' count, and mask-mode DDIM (eta 1) on the
+    reduced UNet (model_channels 64, seed 9): dict of tensors."""
+    keys = ["ddim_1.0", "ddim_5.0", "plms_1.0", "plms_5.0", "mask_eta1", "n_pred_x0"]
+    if not live and all("traj10_" + k in _file() for k in keys):
+        return {k: torch.from_numpy(_file()["traj10_" + k]) for k in keys}
+    _threads()
+    cfg = ounet.UNetConfig(model_channels=64)
+    sd = W.synth_state_dict(ounet.unet_param_shapes(cfg), 9)
+    i = traj_inputs()
+    eps = lambda x, t, c: ounet.unet_forward(sd, cfg, x, t, c)
+    rest = torch.cat([i["inp"], i["msk"]], 1)
+    sch = osampler.Schedule(10)
+    out = {}
+    for scale in (1.0, 5.0):
+        if only and f"ddim_{scale}" not in only:
+            continue
+        ref, rint = osampler.ddim_sample(eps, sch, i["cond"], i["x_T"], rest, scale=scale, uncond=i["uc"], log_every_t=3)
+        out[f"ddim_{scale}"] = ref
+        out["n_pred_x0"] = torch.tensor(len(rint["pred_x0"]))
+        if only:
+            continue
+        out[f"plms_{scale}"], _ = osampler.plms_sample(eps, sch, i["cond"], i["x_T"], rest, scale=scale, uncond=i["uc"], log_every_t=3)
+    if not only:
+        out["mask_eta1"], _ = osampler.ddim_sample(eps, osampler.Schedule(10, eta=1.0), i["cond"], i["x_T"], rest, mask=i["cmask"],
+                                                   x0=i["x0"], mask_noise=i["mn"], step_noise=i["sn"])
+    return out

@@ -50,16 +50,12 @@ def _threads():
 
 @functools.lru_cache(maxsize=None)
 def _full_width_case(side, n):
-    """(x, ctx, t, oracle output) of the full-width UNet, oracle evaluated pair by pair (computed once, shared by the
-    storage types)."""
-    _threads()
-    cfg = ounet.UNetConfig()
-    sd = W.synth_state_dict(ounet.unet_param_shapes(cfg), 13)
-    x = W.synth_input(f"prod.x{side}", (n, 9, side, side))
-    ctx = W.synth_input(f"prod.c{side}", (n, 2, 768))
-    t = torch.tensor([981, 981, 741, 741, 501, 501, 261, 261, 21, 21, 1, 1, 901, 901, 481, 481][:n], dtype=torch.long)
-    ref = torch.cat([ounet.unet_forward(sd, cfg, x[i:i + 2], t[i:i + 2], ctx[i:i + 2]) for i in range(0, n, 2)])
-    return x, ctx, t, ref
+    """(x, ctx, t, oracle output) of the full-width UNet, oracle evaluated pair by pair: read from
+    tests/golden/oracle_outputs.npz (tests/oracle_cases.py; tests/test_oracle_outputs_cpu.py re-derives a sample of it
+    live), computed here when the file lacks it."""
+    from tests import oracle_cases as oc
+    x, ctx, t = oc.prod_inputs(side, n)
+    return x, ctx, t, oc.prod_forward(side, n)
 
 
 @functools.lru_cache(maxsize=None)

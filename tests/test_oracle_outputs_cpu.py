@@ -1,0 +1,32 @@
+"""tests/golden/oracle_outputs.npz (the CPU oracle's outputs the `-m gpu` suite reads instead of recomputing them on the
+GPU box) against the oracle run live, on a sample sized for the CPU suite: one camera/lidar pair of the mobi_nusc_256
+production batch (full-width UNet, 32 x 32), the full-width 16 x 16 pair, and the DDIM-10 trajectory without guidance."""
+import os
+
+import numpy as np
+import torch
+
+from tests import oracle_cases as oc
+
+
+def _close(a, b):
+    # the same fp32 graph; thread count changes the order of a few reductions
+    return float((a - b).norm() / b.norm()) < 1e-5
+
+
+def test_file_holds_every_case():
+    f = dict(np.load(oc.PATH))
+    assert f["prod_64_16"].shape == (16, 4, 64, 64) and f["prod_32_8"].shape == (8, 4, 32, 32)
+    assert f["full_width16"].shape == (2, 4, 16, 16) and int(f["traj10_n_pred_x0"]) > 0
+    for k in ("ddim_1.0", "ddim_5.0", "plms_1.0", "plms_5.0", "mask_eta1"):
+        assert f["traj10_" + k].shape == (4, 4, 16, 16) and np.isfinite(f["traj10_" + k]).all()
+
+
+def test_sample_recomputed_live():
+    f = dict(np.load(oc.PATH))
+    pair = oc.prod_forward(32, 8, pairs=[2], live=True)                    # elements 4, 5 (t = 501); ~2 min: the 1.04 B
+    assert _close(pair, torch.from_numpy(f["prod_32_8"][4:6]))             # synthetic parameters dominate
+    if os.environ.get("MOBI_ORACLE_FULL") == "1":                          # (another parameter set: opt-in)
+        assert _close(oc.full_width16(live=True), torch.from_numpy(f["full_width16"]))
+    tr = oc.trajectories10(live=True, only=("ddim_1.0",))
+    assert _close(tr["ddim_1.0"], torch.from_numpy(f["traj10_ddim_1.0"])) and int(tr["n_pred_x0"]) == int(f["traj10_n_pred_x0"])
