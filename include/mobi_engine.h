@@ -108,6 +108,11 @@ typedef struct mobi_igemm_params {
                             + c%64 -- the taps of one 64-channel slice are consecutive k-tiles, so the
                             9 reads of a 3x3 window's pixels hit L2 instead of being re-fetched per
                             tap.  Needs C % 64 == 0 (and c0 % 64 == 0 with two sources).        */
+  const void* weight_tiled; /* optional second copy of W (k_order 0, groups 1, n_packed % 16 == 0, k % 32 == 0) as
+                            [n_packed / 16][k / 32] blocks of 1 KiB: block (p, s) is the LDS image of rows 16 p .. 16 p + 15,
+                            k 32 s .. 32 s + 31 -- row r at bytes 64 r, its four 16-byte chunks c at slot c ^ P[(r >> 2) & 3],
+                            P = {0, 2, 3, 1}.  The LDS-DMA main loops then fetch one contiguous KiB per request instead of
+                            sixteen 64-byte row segments (a CU's request path takes ~60 against ~25 B per clock).  NULL: W only. */
 } mobi_igemm_params;
 
 int mobi_igemm(const mobi_igemm_params* p, void* stream);

@@ -32,7 +32,8 @@ class IgemmParams(C.Structure):
                 ("pad_h", i32), ("pad_w", i32), ("src_img_stride", i64), ("weight", vp), ("groups", i32),
                 ("w_group_stride", i64), ("n_packed", i32), ("cout", i32), ("bias", vp), ("rowvec", vp), ("rowvec_stride", i32),
                 ("residual", vp), ("res_img_stride", i64), ("out", vp), ("out_img_stride", i64),
-                ("out_mode", i32), ("epilogue", i32), ("scale", f32), ("dtype", i32), ("split_k", i32), ("ws", vp), ("k_order", i32)]
+                ("out_mode", i32), ("epilogue", i32), ("scale", f32), ("dtype", i32), ("split_k", i32), ("ws", vp), ("k_order", i32),
+                ("weight_tiled", vp)]
 
 
 class GroupNormParams(C.Structure):

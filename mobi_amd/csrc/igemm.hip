@@ -121,6 +121,8 @@ struct IgemmArgs {
   float* split_ws;         // f32 [splits][M][n_packed] partial sums (NULL: single pass)
   int ring_direct;         // 256 x 320 ring tiles: register epilogue (full tiles, row-major T output, bias OR per-image vector)
   int sm_direct;           // 128 x 160 ring tiles: register epilogue / register slab stores (full tiles)
+  const void* w_tiled;     // W as 1-KiB request images (ring kernels), or NULL
+  int sm64;                // 128-pixel tiles on the 64-deep-step kernel (igemm_ring64_kernel)
   int lin_window;          // direct-to-LDS kernel: window pixels are linear in the tap (no upsampling, <= 16 taps)
   int epi_direct;          // direct-to-LDS kernel: register epilogue (full tiles, row-major T output)
   int pp;                  // register-epilogue launch on the ping-pong kernel
@@ -1782,7 +1784,8 @@ __global__ __launch_bounds__(NW * 64, 2) void igemm_ring_kernel(const IgemmArgs 
   const int tile_n = L % a.tiles_n, tile_m = L / a.tiles_n;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
   MOBI_STAMP_AT(0);
-  const T* wgt = reinterpret_cast<const T*>(a.weight) + (long long)group * a.w_group_stride;
+  const bool w_tiled = a.w_tiled != nullptr;                 // (wave-uniform) weights as 1-KiB request images
+  const T* wgt = w_tiled ? reinterpret_cast<const T*>(a.w_tiled) : reinterpret_cast<const T*>(a.weight) + (long long)group * a.w_group_stride;
   const __amdgpu_buffer_rsrc_t rx0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.src0), 0, a.src0_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rx1 =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.src1 ? a.src1 : a.src0), 0, a.src1 ? a.src1_bytes : 0, 0x00020000);
@@ -1811,6 +1814,9 @@ __global__ __launch_bounds__(NW * 64, 2) void igemm_ring_kernel(const IgemmArgs 
     const int piece = wave + NW * i;
     const int n = n0 + 16 * piece + rp;
     w_off[i] = (piece < WPIECES && n < a.n_packed) ? (unsigned)n * (unsigned)a.ktot * 2u + chunk16 : OOB;
+    // request images: piece (n0 / 16 + piece) starts at (k / 32) KiB times its index, a lane copies its own 16 bytes
+    if (w_tiled) w_off[i] = (piece < WPIECES && n0 + 16 * piece < a.n_packed)
+                                ? (unsigned)(n0 / 16 + piece) * (unsigned)(a.ktot >> 5) * 1024u + (unsigned)lane * 16u : OOB;
   }
   const int hlog = a.hin << a.up, wlog = a.win << a.up;
   // k range of this block in 32-deep steps (split-K: blockIdx.y owns 64-deep k-tiles [y * nk_per, (y + 1) * nk_per))
@@ -1849,7 +1855,7 @@ __global__ __launch_bounds__(NW * 64, 2) void igemm_ring_kernel(const IgemmArgs 
       if (src) __builtin_amdgcn_raw_ptr_buffer_load_lds(rx1, (lds_ptr_t)(st + 16 * (APW * wave_s + j) * 64), 16, vo, soff, 0, 0);
       else     __builtin_amdgcn_raw_ptr_buffer_load_lds(rx0, (lds_ptr_t)(st + 16 * (APW * wave_s + j) * 64), 16, vo, soff, 0, 0);
     }
-    const int kb = f_ks * 64;                                // byte offset of the step inside a weight row
+    const int kb = w_tiled ? f_ks * 1024 : f_ks * 64;        // byte offset of the step inside a weight row / a piece's images
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
       if (i == 2 && (NT != 5 || wave_s >= NW / 2)) break;    // a third piece exists for NT = 5 only (lower half of the waves)
@@ -1950,18 +1956,42 @@ __global__ __launch_bounds__(NW * 64, 2) void igemm_ring_kernel(const IgemmArgs 
     }
     if (!late) MOBI_RING_BARRIER();
   } else {
+#if MOBI_STAMP == 4                                           // shader cycles per phase of a k-step, per wave (tools/stamp_ring.py)
+    unsigned long long rp_t[6], rp_acc[5] = {0, 0, 0, 0, 0};
+#define MOBI_RP(i) rp_t[i] = __builtin_amdgcn_s_memtime()
+#else
+#define MOBI_RP(i) ((void)0)
+#endif
 #pragma clang loop unroll(disable)
     for (int s = ks_begin; s < ks_end; ++s) {
+      MOBI_RP(0);
       wait_step();
+      MOBI_RP(1);
       MOBI_RING_BARRIER();
+      MOBI_RP(2);
       frag_t xf[MT], wf[NT];
       read_frags(s, xf, wf);
       __builtin_amdgcn_sched_barrier(0);
       issue_step();                                          // step s + 3, behind the reads' latency
       __builtin_amdgcn_sched_barrier(0);
+      MOBI_RP(3);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      MOBI_RP(4);
       multiply(xf, wf);
+#if MOBI_STAMP == 4
+      asm volatile("s_nop 0" ::: "memory");
+      MOBI_RP(5);
+      if (s > ks_begin) for (int i = 0; i < 5; ++i) rp_acc[i] += rp_t[i + 1] - rp_t[i];
+#endif
     }
+#if MOBI_STAMP == 4
+    if (g_phase && lane == 0) {
+      unsigned long long* d = g_phase + ((size_t)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) * 8 + wave) * 8;
+      for (int i = 0; i < 5; ++i) d[i] = rp_acc[i];
+      d[5] = (unsigned long long)(ks_end - ks_begin - 1);
+    }
+#endif
+#undef MOBI_RP
   }
 #undef MOBI_RING_BARRIER
   MOBI_STAMP_AT(2);
@@ -2043,6 +2073,195 @@ __global__ __launch_bounds__(NW * 64, 2) void igemm_ring_kernel(const IgemmArgs 
     d[6] = 1;
   }
 #endif
+}
+
+// =========================================================================================================
+// SMALL-M main loop with 64-deep k-steps (launches of the 128-pixel geometry whose channel counts are multiples of 64):
+// the four-wave, 128 x (2 * WAVE_N) tile of igemm_ring_kernel, ONE block per CU, ring of four 64-deep k-slots of
+// 128-byte LDS rows.  Why: a CU's request path takes a request by its row segments -- 8 rows x 128 B go in at 42 B per
+// clock (four waves), 16 rows x 64 B (the 32-deep steps) at 21.5 (tools/probes/lds_dma_rate.hip) -- and the small
+// launches are bound by exactly that: of ~1,700 cycles per 32-deep step 1,130 are spent ISSUING the step's 4-5 requests per
+// wave, 357 in its 20 MFMAs (tools/phase_ring.py).  Here a step carries twice the MFMAs per barrier pair and its
+// activation requests cost half as much per byte.
+// LDS image of a slot: [row][8 x 16 B] (128-byte rows), chunk c of row r at position c ^ (r & 7) (conflict-free for
+// ds_read_b128: the ping-pong kernel's rule); a 1-KiB request is 8 rows, lane l fills position l & 7 of row l >> 3.
+// One raw s_barrier per k-step, three steps of prefetch, every wave issues R = 4 + NT requests per step (all-zero
+// pieces past its k range), counted waits.  Epilogues: the ring kernel's (registers / register slab stores for full tiles,
+// else LDS-staged through the drained ring).
+// =========================================================================================================
+template <typename T, int NT, bool TR>
+__global__ __launch_bounds__(256, 1) void igemm_ring64_kernel(const IgemmArgs a) {
+  typedef typename Vec8<T>::type frag_t;
+  constexpr int NW = 4, MT = 4, BM = 128, SL = 4;
+  constexpr int APW = BM / 8 / NW;                           // 4 activation requests per wave and k-step
+  constexpr int WAVE_N = NT * 16;
+  constexpr int BN = 2 * WAVE_N;                             // NT weight requests per wave and k-step
+  constexpr int SLOT = (BM + BN) * 128;
+  constexpr int RING = SL * SLOT;
+  constexpr int STAGE_BYTES = EpiGeom<32, TR, NT>::BYTES;
+  constexpr int LDS_BYTES = RING > NW * STAGE_BYTES ? RING : NW * STAGE_BYTES;
+  constexpr unsigned OOB = 0x80000000u;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
+  typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wave_s = __builtin_amdgcn_readfirstlane(wave);
+  const int wm = wave & 1, wn = wave >> 1;
+  const int group = blockIdx.z;
+  const int nblk = a.tiles_m * a.tiles_n;
+  const int L = xcd_remap(blockIdx.x, nblk);
+  const int tile_n = L % a.tiles_n, tile_m = L / a.tiles_n;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const T* wgt = reinterpret_cast<const T*>(a.weight) + (long long)group * a.w_group_stride;
+  const __amdgpu_buffer_rsrc_t rx0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.src0), 0, a.src0_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rx1 =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.src1 ? a.src1 : a.src0), 0, a.src1 ? a.src1_bytes : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(wgt), 0, a.w_bytes, 0x00020000);
+
+  // ---- request side: this lane fills position (lane & 7) of row (lane >> 3) of each 8-row piece ---------------------
+  const int rp = lane >> 3;
+  const unsigned chunk16 = (unsigned)((lane & 7) ^ rp) * 16u;
+  int x_base[APW], x_h[APW], x_w[APW];
+  bool x_ok[APW];
+#pragma unroll
+  for (int j = 0; j < APW; ++j) {
+    const int m = m0 + 8 * (APW * wave + j) + rp;
+    x_ok[j] = m < a.M;
+    const int mm = x_ok[j] ? m : 0;
+    const int img = mm / a.hw_out, rem = mm - img * a.hw_out;
+    const int ho = rem / a.wout, wo = rem - ho * a.wout;
+    x_base[j] = (group * a.imgs_per_group + img) * a.img_pix_stride;
+    x_h[j] = ho * a.stride - a.pad_h;
+    x_w[j] = wo * a.stride - a.pad_w;
+  }
+  unsigned w_off[NT];                                        // weight rows 8 * (wave + NW i) + rp of the tile
+#pragma unroll
+  for (int i = 0; i < NT; ++i) {
+    const int n = n0 + 8 * (wave + NW * i) + rp;
+    w_off[i] = n < a.n_packed ? (unsigned)n * (unsigned)a.ktot * 2u + chunk16 : OOB;
+  }
+  const int hlog = a.hin << a.up, wlog = a.win << a.up;
+  const int ks_all = a.ktot >> 6;                            // 64-deep steps; split-K: blockIdx.y owns [y nk_per, (y + 1) nk_per)
+  const int ks_begin = blockIdx.y * a.nk_per;
+  const int ks_end = min(ks_all, ks_begin + a.nk_per);
+  int u_c, u_tap, u_ky, u_kx;
+  {
+    const long long c_first = (long long)ks_begin * 64;
+    u_tap = (int)(c_first / a.C); u_c = (int)(c_first - (long long)u_tap * a.C);
+    u_ky = u_tap / a.kw; u_kx = u_tap - u_ky * a.kw;
+  }
+  unsigned f_row[APW];
+#pragma unroll
+  for (int j = 0; j < APW; ++j) f_row[j] = OOB;
+  int f_tap = -1, f_src = -1, f_ks = ks_begin;
+
+  auto issue_step = [&]() {
+    unsigned char* st = lds + (f_ks & (SL - 1)) * SLOT;
+    const bool live = f_ks < ks_end;
+    const int src = u_c >= a.c0 ? 1 : 0;
+    if (live && (u_tap != f_tap || src != f_src)) {
+      f_tap = u_tap; f_src = src;
+      const unsigned cs2 = (unsigned)(src ? a.c1 : a.c0) * 2u;
+#pragma unroll
+      for (int j = 0; j < APW; ++j) {
+        const int hi = x_h[j] + u_ky, wi = x_w[j] + u_kx;
+        const bool ok = x_ok[j] && (unsigned)hi < (unsigned)hlog && (unsigned)wi < (unsigned)wlog;
+        f_row[j] = ok ? (unsigned)(x_base[j] + (hi >> a.up) * a.win + (wi >> a.up)) * cs2 + chunk16 : OOB;
+      }
+    }
+    const int soff = (src ? u_c - a.c0 : u_c) * 2;
+#pragma unroll
+    for (int j = 0; j < APW; ++j) {
+      const unsigned vo = live ? f_row[j] : OOB;
+      if (src) __builtin_amdgcn_raw_ptr_buffer_load_lds(rx1, (lds_ptr_t)(st + 8 * (APW * wave_s + j) * 128), 16, vo, soff, 0, 0);
+      else     __builtin_amdgcn_raw_ptr_buffer_load_lds(rx0, (lds_ptr_t)(st + 8 * (APW * wave_s + j) * 128), 16, vo, soff, 0, 0);
+    }
+    const int kb = f_ks * 128;
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+      const unsigned vo = live ? w_off[i] : OOB;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr_t)(st + BM * 128 + 8 * (wave_s + NW * i) * 128), 16, vo, kb, 0, 0);
+    }
+    ++f_ks;
+    if (live) {
+      u_c += 64;
+      if (u_c >= a.C) { u_c = 0; ++u_tap; if (++u_kx == a.kw) { u_kx = 0; ++u_ky; } }
+    }
+  };
+  // own requests of the two youngest steps may stay in flight: R = 4 + NT
+  auto wait_step = [&]() {
+    if (NT == 5) asm volatile("s_waitcnt vmcnt(18)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+  };
+
+  f32x4 acc[NT][MT];
+#pragma unroll
+  for (int i = 0; i < NT; ++i)
+#pragma unroll
+    for (int j = 0; j < MT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int r16 = lane & 15, g4 = lane >> 4;
+  const unsigned char* xrd = lds + (wm * 64 + r16) * 128;
+  const unsigned char* wrd = lds + BM * 128 + (wn * WAVE_N + r16) * 128;
+
+  issue_step(); issue_step(); issue_step();
+#pragma clang loop unroll(disable)
+  for (int s = ks_begin; s < ks_end; ++s) {
+    wait_step();
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    const int so = (s & (SL - 1)) * SLOT;
+    frag_t xf[2][MT], wf[2][NT];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int sw = ((ks * 4 + g4) ^ (r16 & 7)) << 4;
+#pragma unroll
+      for (int mi = 0; mi < MT; ++mi) xf[ks][mi] = __builtin_bit_cast(frag_t, ld16(xrd + so + mi * 16 * 128 + sw));
+#pragma unroll
+      for (int ni = 0; ni < NT; ++ni) wf[ks][ni] = __builtin_bit_cast(frag_t, ld16(wrd + so + ni * 16 * 128 + sw));
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    issue_step();                                            // step s + 3, behind the reads' latency
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int ni = 0; ni < NT; ++ni)
+#pragma unroll
+        for (int mi = 0; mi < MT; ++mi)
+          acc[ni][mi] = TR ? mfma16(xf[ks][mi], wf[ks][ni], acc[ni][mi]) : mfma16(wf[ks][ni], xf[ks][mi], acc[ni][mi]);
+    __builtin_amdgcn_s_setprio(0);
+  }
+  if constexpr (!TR) {
+    if (a.sm_direct) {                                       // full tiles: registers -> memory (no staging, no block barrier)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      const int nw0 = n0 + wn * WAVE_N, mw0 = m0 + wm * 64;
+      if (a.split_ws) {
+        float* wsp = a.split_ws + (long long)blockIdx.y * a.M * a.n_packed;
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) {
+          float* rowp = wsp + (long long)(mw0 + mi * 16 + r16) * a.n_packed + nw0 + g4 * 4;
+#pragma unroll
+          for (int ni = 0; ni < NT; ++ni) vm_store16(rowp + ni * 16, __builtin_bit_cast(u32x4, acc[ni][mi]));
+        }
+      } else {
+        DirectEpiRegs<NT> q;
+#pragma unroll
+        for (int ni = 0; ni < NT; ++ni) { q.bias[ni] = u32x4{0u, 0u, 0u, 0u}; q.res[ni][0] = q.res[ni][1] = u32x4{0u, 0u, 0u, 0u}; }
+        direct_epilogue_request<T, NT>(a, q, lane, group, nw0, mw0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (a.epilogue == MOBI_EPI_GEGLU) direct_epilogue<T, NT, true>(a, acc, q, lane, group, nw0, mw0);
+        else direct_epilogue<T, NT, false>(a, acc, q, lane, group, nw0, mw0);
+      }
+      return;
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  float* stage = reinterpret_cast<float*>(lds) + wave * (STAGE_BYTES / 4);
+  igemm_epilogue<T, NT, TR, 32, true>(a, stage, acc, lane, group, n0 + wn * WAVE_N, m0 + wm * 64);
 }
 
 // split-K finish: sum the partial slabs, then the ordinary epilogue (bias, per-image vector, residual)
@@ -2163,6 +2382,12 @@ static int launch_igemm(const mobi_igemm_params* p, const IgemmArgs& a, int grou
   }
 #endif
   else if (a.wm == 4) { if (nt5) MOBI_IGEMM_BY_TR(5, 4); else MOBI_IGEMM_BY_TR(4, 4); }
+  else if (a.sm && a.sm64) {
+#define MOBI_SM64_LAUNCH(NT_, TR_) hipLaunchKernelGGL((igemm_ring64_kernel<T, NT_, TR_>), grid, dim3(256), 0, st, a)
+    if (nt5) { if (tr) MOBI_SM64_LAUNCH(5, true); else MOBI_SM64_LAUNCH(5, false); }
+    else     { if (tr) MOBI_SM64_LAUNCH(4, true); else MOBI_SM64_LAUNCH(4, false); }
+#undef MOBI_SM64_LAUNCH
+  }
   else if (a.sm) {
 #define MOBI_SM_LAUNCH(NT_, TR_) hipLaunchKernelGGL((igemm_ring_kernel<T, NT_, TR_, 4, 4>), grid, dim3(256), 0, st, a)
     if (nt5) { if (tr) MOBI_SM_LAUNCH(5, true); else MOBI_SM_LAUNCH(5, false); }
@@ -2364,6 +2589,15 @@ static int igemm_prepare(const mobi_igemm_params* p, mobi::IgemmArgs& a) {
       a.sm = 0;
     }
   }
+  // 64-deep steps for the 128-pixel geometry: channel runs of 64 (a k-step never straddles a tap or a source), >= 3 steps
+  // (one block per CU: only grids of at most one round of blocks -- with more, two co-resident blocks of the 32-deep ring win:
+  //  36.2 vs 45.3 us on 320 -> 320 3x3 at 32 x 32 x 8 split 4, tools/ab_sm64.py)
+  a.sm64 = a.sm && a.C % 64 == 0 && (p->c1 == 0 || p->c0 % 64 == 0) && a.nk_per >= 1 &&
+           (long long)a.tiles_m * a.tiles_n * a.splits * p->groups <= (long long)compute_units() && tuning().sm64 != 0;
+  if (tuning().sm64 == 1 && a.sm && a.C % 64 == 0 && (p->c1 == 0 || p->c0 % 64 == 0)) a.sm64 = 1;
+  a.w_tiled = (p->weight_tiled && !a.sm64 && (a.sm || a.wide) && p->groups == 1 && p->k_order == 0 && p->n_packed % 16 == 0 &&
+               a.ktot % 32 == 0 && !(reinterpret_cast<uintptr_t>(p->weight_tiled) & 15) && tuning().w_tiled != 0)
+                  ? p->weight_tiled : nullptr;
   // 128 x 160 ring tiles: register epilogue / slab stores when every tile is full (the staged epilogue keeps ragged tiles,
   // transposed / fp32 output, bias AND per-image vector)
   a.sm_direct = (a.sm || a.wide == 1) && (p->out_mode == MOBI_OUT_ROWS || a.split_ws) && p->out_mode != MOBI_OUT_TRANSPOSED &&

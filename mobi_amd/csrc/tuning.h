@@ -17,6 +17,8 @@ struct Tuning {
   int wide128;          // MOBI_IGEMM_WIDE128         1: route the 128 x 320 tiles where they fill the chip (A/B; measured slower)
   int ring_direct;      // MOBI_IGEMM_RING_DIRECT     0: 256 x 320 ring tiles always through the LDS-staged epilogue (A/B)
   int sm_direct;        // MOBI_IGEMM_SM_DIRECT       0: 128 x 160 ring tiles always through the LDS-staged epilogue (A/B)
+  int w_tiled;          // MOBI_IGEMM_WTILED          0: ring kernels fetch weights as row segments even when request images are given (A/B)
+  int sm64;             // MOBI_IGEMM_SM64            0: 128-pixel tiles always on the 32-deep-step ring kernel (A/B)
   int tka_mfma;         // MOBI_TKA_MFMA              0: two-key adapter on the vector-ALU kernel (A/B)
   int attn_nw;          // MOBI_ATTN_NW               4 | 8: waves per attention block
   int attn_sp;          // MOBI_ATTN_SP               1: software-pipelined attention kernel (dh 33..48)

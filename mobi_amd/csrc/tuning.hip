@@ -28,6 +28,8 @@ void read_env() {
   g_tuning.wide128 = env_int("MOBI_IGEMM_WIDE128");
   g_tuning.ring_direct = env_int("MOBI_IGEMM_RING_DIRECT");
   g_tuning.sm_direct = env_int("MOBI_IGEMM_SM_DIRECT");
+  g_tuning.w_tiled = env_int("MOBI_IGEMM_WTILED");
+  g_tuning.sm64 = env_int("MOBI_IGEMM_SM64");
   g_tuning.tka_mfma = env_int("MOBI_TKA_MFMA");
   g_tuning.attn_nw = env_int("MOBI_ATTN_NW");
   g_tuning.attn_sp = env_int("MOBI_ATTN_SP");

@@ -128,6 +128,32 @@ class Packed:
     n_packed: int
     geglu: bool = False
     k_order: int = 0                # 0: k = tap*C + c; 1: 64-channel-chunk major (mobi_igemm_params.k_order)
+    wt: Optional[torch.Tensor] = None   # the same matrix as 1-KiB request images (mobi_igemm_params.weight_tiled)
+
+    def __post_init__(self):
+        if self.wt is None and self.k_order == 0 and self.w.dim() == 2 and self.w.is_cuda and TILED_WEIGHTS:
+            self.wt = tile_weights(self.w)
+
+
+TILED_WEIGHTS = True
+_RING_PERM = (0, 2, 3, 1)              # 16-byte slot permutation of the ring kernels' LDS rows, per (row >> 2) & 3
+
+
+def tile_weights(w):
+    """T [n, k] (n % 16 == 0, k % 32 == 0) -> the same values as [n / 16][k / 32] blocks of 1 KiB, each block the LDS
+    image of a 16-row x 32-deep piece (row r holds its four 16-byte chunks c at slot c ^ P[(r >> 2) & 3]): ONE contiguous
+    KiB per LDS-DMA request instead of sixteen 64-byte row segments.  The request path of a CU takes 57-63 B per clock of
+    the former and 21-28 of the latter (tools/probes/lds_dma_rate.hip)."""
+    n, k = w.shape
+    if n % 16 or k % 32:
+        return None
+    v = w.reshape(n // 16, 16, k // 32, 4, 8)                                   # [piece, row, step, chunk, 8]
+    r = torch.arange(16, device=w.device)
+    perm = torch.tensor(_RING_PERM, device=w.device)[(r >> 2) & 3]              # [16]
+    src = torch.arange(4, device=w.device)[None, :] ^ perm[:, None]             # slot s of row r holds chunk s ^ P
+    v = v.permute(0, 2, 1, 3, 4)                                                # [piece, step, row, chunk, 8]
+    idx = src[None, None, :, :, None].expand(v.shape[0], v.shape[1], 16, 4, 8)
+    return torch.gather(v, 3, idx).contiguous()
 
 
 def pack_conv(weight, bias, dtype, device, chunk_major=False):
@@ -213,6 +239,7 @@ def igemm(x, pw: Packed, *, x2=None, stride=1, pad=None, upsample=False, hout=No
     s = _img_stride(x)
     p.src_img_stride = 0 if s == dense_in else s
     p.weight = _ptr(pw.w)
+    p.weight_tiled = None if weight_per_image else _ptr(pw.wt)
     p.groups = n if weight_per_image else 1
     p.w_group_stride = w_group_stride
     p.n_packed, p.cout = pw.n_packed, pw.cout

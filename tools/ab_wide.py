@@ -36,8 +36,10 @@ def main():
         # variants are timed INTERLEAVED, three rounds, best of each: the first kernel timed after a pause runs ~10 %
         # slower (clocks), which an A-then-B order books to A
         variants = (("routed", {}), ("pp", {"MOBI_IGEMM_WIDE": "0"}), ("w256", {"MOBI_IGEMM_WIDE": "2"}),
+                    ("w256 row-segment weights", {"MOBI_IGEMM_WIDE": "2", "MOBI_IGEMM_WTILED": "0"}),
                     ("w256 staged epi", {"MOBI_IGEMM_WIDE": "2", "MOBI_IGEMM_RING_DIRECT": "0"}),
-                    ("w128", {"MOBI_IGEMM_WIDE": "1"}), ("sm", {"MOBI_IGEMM_WM": "2", "MOBI_IGEMM_WIDE": "0"}))
+                    ("w128", {"MOBI_IGEMM_WIDE": "1"}), ("sm", {"MOBI_IGEMM_WM": "2", "MOBI_IGEMM_WIDE": "0"}),
+                    ("sm row-segment weights", {"MOBI_IGEMM_WM": "2", "MOBI_IGEMM_WIDE": "0", "MOBI_IGEMM_WTILED": "0"}))
         best, outs = {}, {}
         for rep in range(3):
             for tag, env in variants:
