@@ -1940,20 +1940,48 @@ __global__ __launch_bounds__(NW * 64, 2) void igemm_ring_kernel(const IgemmArgs 
     wait_step();
     MOBI_STAMP_AT(1);
     if (late) MOBI_RING_BARRIER();
+#if MOBI_STAMP == 4                                           // shader cycles per phase of a k-step, per wave (tools/phase_ring.py)
+    unsigned long long wp_t[8], wp_acc[7] = {0, 0, 0, 0, 0, 0, 0};
+#define MOBI_WP(i) wp_t[i] = __builtin_amdgcn_s_memtime()
+#else
+#define MOBI_WP(i) ((void)0)
+#endif
 #pragma clang loop unroll(disable)
     for (int s = ks_begin; s < ks_end; ++s) {
+      MOBI_WP(0);
       MOBI_RING_BARRIER();
+      MOBI_WP(1);
       frag_t xf[MT], wf[NT];
       read_frags(s, xf, wf);
       __builtin_amdgcn_sched_barrier(0);
       issue_step();
       __builtin_amdgcn_sched_barrier(0);
+      MOBI_WP(2);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      MOBI_WP(3);
       if (late) wait_step();
+      MOBI_WP(4);
       MOBI_RING_BARRIER();
+      MOBI_WP(5);
       multiply(xf, wf);
+#if MOBI_STAMP == 4
+      asm volatile("s_nop 0" ::: "memory");
+#endif
+      MOBI_WP(6);
       if (!late) wait_step();
+#if MOBI_STAMP == 4
+      MOBI_WP(7);
+      if (s > ks_begin) for (int i = 0; i < 7; ++i) wp_acc[i] += wp_t[i + 1] - wp_t[i];
+#endif
     }
+#if MOBI_STAMP == 4
+    if (g_phase && lane == 0) {
+      unsigned long long* d = g_phase + ((size_t)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) * 8 + wave) * 8;
+      for (int i = 0; i < 7; ++i) d[i] = wp_acc[i];
+      d[7] = (unsigned long long)(ks_end - ks_begin - 1);
+    }
+#endif
+#undef MOBI_WP
     if (!late) MOBI_RING_BARRIER();
   } else {
 #if MOBI_STAMP == 4                                           // shader cycles per phase of a k-step, per wave (tools/stamp_ring.py)
