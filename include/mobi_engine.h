@@ -31,7 +31,10 @@
 extern "C" {
 #endif
 
-#define MOBI_ABI_VERSION 1
+/* bumped whenever a parameter struct changes (2: mobi_attention_params.q_log2_scaled; 1 also covered the later
+ * additions mobi_igemm_params.weight_tiled and mobi_ddim_step_params.coef_dev): a caller built against another version
+ * must not call into this library -- check mobi_abi_version() == MOBI_ABI_VERSION next to the mobi_struct_size checks. */
+#define MOBI_ABI_VERSION 2
 
 enum { MOBI_OK = 0, MOBI_ERR_ARG = -1, MOBI_ERR_UNSUPPORTED = -2, MOBI_ERR_LAUNCH = -3, MOBI_ERR_ALIGN = -4 };
 enum { MOBI_F16 = 0, MOBI_BF16 = 1 };
@@ -182,6 +185,10 @@ typedef struct mobi_attention_params {
   float scale;
   int32_t dtype;
   int32_t v_layout;      /* 0: vt holds V transposed; 1: vt holds V row-major (q|k|v stacked projections)       */
+  int32_t q_log2_scaled; /* 1: q already carries scale * log2(e) (folded into the to_q weights when they were
+                            packed, attention.py:162,178): `scale` is then ignored and the kernels exponentiate
+                            q.k as a power of two directly; 0: the kernels scale q (one more rounding of q to T
+                            in the V row-major kernels)                                                        */
 } mobi_attention_params;
 int mobi_attention(const mobi_attention_params* p, void* stream);
 

@@ -11,6 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libmobi_hip.so")
 
 MOBI_F16, MOBI_BF16 = 0, 1
+ABI_VERSION = 2            # include/mobi_engine.h MOBI_ABI_VERSION
 EPI_NONE, EPI_GEGLU = 0, 1
 OUT_ROWS, OUT_TRANSPOSED, OUT_ROWS_F32 = 0, 1, 2
 ACT_NONE, ACT_SILU, ACT_GELU = 0, 1, 2
@@ -53,7 +54,7 @@ class AttentionParams(C.Structure):
                 ("vt", vp), ("vt_img_stride", i64), ("vt_row_stride", i32),
                 ("out", vp), ("out_img_stride", i64), ("out_row_stride", i32),
                 ("images", i32), ("heads", i32), ("dh", i32), ("tq", i32), ("tk", i32), ("scale", f32),
-                ("dtype", i32), ("v_layout", i32)]
+                ("dtype", i32), ("v_layout", i32), ("q_log2_scaled", i32)]
 
 
 class CtxAttentionParams(C.Structure):
@@ -184,6 +185,9 @@ def load():
         except AttributeError as e:
             raise EngineUnavailable(f"{LIB_PATH} does not export {name}") from e
         fn.restype, fn.argtypes = res, args
+    if lib.mobi_abi_version() != ABI_VERSION:
+        raise EngineUnavailable(f"ABI mismatch: {LIB_PATH} is version {lib.mobi_abi_version()}, the binding {ABI_VERSION} "
+                                "(include/mobi_engine.h MOBI_ABI_VERSION): rebuild with `python -m mobi_amd.build --force`")
     for sid, cls in STRUCT_IDS.items():
         want = lib.mobi_struct_size(sid)
         if want != C.sizeof(cls):

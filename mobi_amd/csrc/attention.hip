@@ -45,6 +45,16 @@
 #define MOBI_ATTN_DBUF 1   // two LDS images of the K / V tile: one barrier per key tile, the next tile is written while
 #endif                     // this one is still being multiplied (A/B: -DMOBI_ATTN_DBUF=0)
 
+#ifndef MOBI_ATTN_RDBG
+#define MOBI_ATTN_RDBG 0   // attention_rows_kernel, diagnosis only (wrong results): bit 0 = no exp / pack / OR, bit 1 = K / V tiles
+#endif                     // staged once, bit 2 = no P.V (reads + MFMAs), bit 3 = no S (reads + MFMAs), bit 4 = no barrier
+#ifndef MOBI_ATTN_PDBG
+#define MOBI_ATTN_PDBG 0   // attention_pipe_kernel, diagnosis only (wrong results): bit 0 = tiles staged in the prologue only,
+#endif                     // bit 1 = no barrier, bit 2 = no OR test / exact path
+#ifndef MOBI_ATTN_RVAR
+#define MOBI_ATTN_RVAR 0   // attention_rows_kernel A/B variants: bit 0 = next tile requested a whole step ahead
+#endif
+
 namespace mobi {
 
 struct AttnArgs {
@@ -53,7 +63,7 @@ struct AttnArgs {
   const void* vt; long long vt_img; int vt_row;      // v_layout 1: V rows [tk][vt_row]; 0: V^T rows [C][vt_row]
   void* out; long long out_img; int out_row;
   int heads, dh, tq, tk;
-  float scale;
+  float cexp;                // scale * log2(e), or 1 when q already carries it (mobi_attention_params.q_log2_scaled)
 };
 
 // VVEC: every V^T row start is 16-byte aligned (tk % 8 == 0 rows), the production case; the generic
@@ -246,7 +256,7 @@ __global__ __launch_bounds__(64 * NW, (WPS * 4) / NW) void attention_kernel(cons
 #pragma unroll
     for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
   float m_run = -INFINITY, l_run = 0.f;
-  const float cexp = a.scale * 1.4426950408889634f;
+  const float cexp = a.cexp;
 
   const int ntiles = (a.tk + 63) / 64;
   load_tile(0);
@@ -447,6 +457,767 @@ __global__ __launch_bounds__(64 * NW, (WPS * 4) / NW) void attention_kernel(cons
   }
 }
 
+// =========================================================================================================
+// attention_rows_kernel: the production kernel for V row-major (v_layout 1), head dims up to 80.
+//
+// Why a second kernel: SQ counters of attention_kernel on [16, 4096 x 4096, 8 x 40] show a 32-query x 64-key wave tile
+// costing ~1,100 cycles of instruction ISSUE on its SIMD (16 v_max3, 31 v_fma, 33 v_exp, 16 v_cvt_pk, 16 v_mov_b64, 18
+// s_nop, 22 LDS reads, staging) around 448 cycles of matrix pipe, and tools/probes/mfma_fill.hip shows that on this chip a
+// wave's vector instructions do issue in the shadow of its MFMAs: the loop is bound by the NUMBER of vector instructions.
+// This kernel keeps the tiling and the two LDS images of attention_kernel and removes vector instructions:
+//   * Q is multiplied by scale * log2(e) once, so an MFMA result is already an exponent of two;
+//   * the shift by the running maximum rides on the MFMA's C operand (sixteen registers holding -shift), so a score needs
+//     no FMA and the S accumulators no zeroing;
+//   * the shift is NOT the exact running maximum: it stays B below it... (B = bias) and is only raised when some
+//     probability of the tile reaches 2.0 -- one bit (bit 14) of the packed 16-bit word in BOTH storage types, so the test is
+//     an OR over the packed words (v_or3_b32: 8 per tile instead of 16 v_max3 + the per-tile rescale decision).  Softmax is
+//     shift-invariant, so the result is the same function; the shifted probabilities sit at most at 2.0 and typically at
+//     2^-B (bf16 keeps its 8 bits over the whole f32 exponent range; f16 stays normal down to 2^-14, B = 4).
+//   * the exact path (maximum of the tile, rescale of O, probabilities recomputed from the kept scores) runs on the first
+//     tile and whenever the test fires (a wave-uniform branch).
+// Per wave tile: 14 MFMA, 32 v_exp, 16 v_cvt_pk, 8 v_or3 + the LDS reads and the staging of the next tile.
+// =========================================================================================================
+template <typename T> struct AttnBias;
+template <> struct AttnBias<bf16_t> { static constexpr float value = 8.0f; };
+template <> struct AttnBias<f16_t> { static constexpr float value = 4.0f; };
+
+template <typename T>
+__device__ __forceinline__ unsigned pack2(float lo, float hi) {
+  typedef T T2 __attribute__((ext_vector_type(2)));
+  T2 v;
+  v[0] = (T)lo;
+  v[1] = (T)hi;
+  return __builtin_bit_cast(unsigned, v);
+}
+
+// QSH: the head dim leaves a padded channel in the last k-step (dh % 16 == 8: 8, 24, 40, 72); the shift then rides in
+// that channel of Q' against a column of ones in the K image instead of sixteen C-operand registers.
+template <typename T, int KS, int NW, bool QSH>
+__global__ __launch_bounds__(64 * NW, (KS <= 2 && (QSH || (KS & 1))) ? 4 : KS == 2 ? 3 : (KS == 3 && NW == 8 && QSH) ? 4 : KS == 3 ? 3 : 2)
+void attention_rows_kernel(const AttnArgs a) {
+  constexpr int NTHR = 64 * NW;
+  typedef typename Vec8<T>::type frag_t;
+  constexpr int DT = (KS + 1) / 2;
+  constexpr int KSTR = KS * 32 + 16;
+  constexpr int VSTR = (DT & 1) ? DT * 64 : DT * 64 + 64;
+  constexpr int K_BYTES = 64 * KSTR, V_BYTES = 64 * VSTR, IMG_BYTES = K_BYTES + V_BYTES;
+  constexpr int KP = (64 * KS * 2 + NTHR - 1) / NTHR;      // 16-byte pieces per thread, K tile and V tile alike
+  constexpr float BIAS = AttnBias<T>::value;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * IMG_BYTES];
+  unsigned char* ldsK = lds;
+  unsigned char* ldsV = lds + K_BYTES;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int ql = lane & 31, half = lane >> 5;
+  const int head = blockIdx.y, img = blockIdx.z;
+  const int q0 = blockIdx.x * (32 * NW) + wave * 32;
+  const int dh = a.dh;
+  // a padded channel of the P.V tile carries the denominator: dh is KS*16 - 8 (QSH) or KS*16, DT*32 is (KS + 1)/2 * 32
+  constexpr bool ONES = QSH || (KS & 1);
+
+  const T* __restrict__ qp = reinterpret_cast<const T*>(a.q) + img * a.q_img + head * dh;
+  const T* __restrict__ kp = reinterpret_cast<const T*>(a.k) + img * a.k_img + head * dh;
+  const T* __restrict__ vp = reinterpret_cast<const T*>(a.vt) + img * a.vt_img + (long long)head * dh;
+  T* __restrict__ op = reinterpret_cast<T*>(a.out) + img * a.out_img + head * dh;
+
+  // Q fragments, scaled once: an MFMA result is then the exponent of two of the probability
+  frag_t qf[KS];
+  {
+    const float cexp = a.cexp;
+    const int qrow = q0 + ql;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const int c = ks * 16 + half * 8;
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (qrow < a.tq && c < dh) v = ld16(qp + (long long)qrow * a.q_row + c);
+      frag_t f = __builtin_bit_cast(frag_t, v);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) f[j] = (T)((float)f[j] * cexp);          // cexp == 1 (q_log2_scaled): q bit for bit
+      qf[ks] = f;
+    }
+  }
+
+  u32x4 kr[KP], vr[KP];
+  unsigned koff[KP], voff[KP];
+  constexpr unsigned OOB = 0x80000000u;
+#pragma unroll
+  for (int i = 0; i < KP; ++i) {
+    const int p = tid + NTHR * i;
+    const int row = p / (KS * 2), pc = p - row * (KS * 2);
+    const bool on = row < 64 && pc * 8 < dh;
+    koff[i] = on ? (unsigned)(row * a.k_row + pc * 8) * 2u : OOB;
+    voff[i] = on ? (unsigned)(row * a.vt_row + pc * 8) * 2u : OOB;
+  }
+  const int k_bytes = ((a.tk - 1) * a.k_row + dh) * 2;
+  const int v_bytes = ((a.tk - 1) * a.vt_row + dh) * 2;
+  // channels [dh, KS*16) of every K row are written ONCE: zero, except channel dh = 1.0 when the shift rides in Q'
+  for (int p = tid; p < 64 * KS * 2; p += NTHR) {
+    const int row = p / (KS * 2), pc = p - row * (KS * 2);
+    if (pc * 8 >= dh) {
+      frag_t e;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) e[j] = (T)0.0f;
+      if (QSH && pc * 8 == dh) e[0] = (T)1.0f;
+#pragma unroll
+      for (int b = 0; b < 2; ++b) st16(ldsK + b * IMG_BYTES + row * KSTR + pc * 16, __builtin_bit_cast(u32x4, e));
+    }
+  }
+  // channels [dh, DT*32) of every V row are written ONCE: zero, except channel dh = 1.0 (the denominator column)
+  for (int p = tid; p < 64 * DT * 4; p += NTHR) {
+    const int row = p / (DT * 4), pc = p - row * (DT * 4);
+    if (pc * 8 >= dh) {
+      frag_t e;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) e[j] = (T)0.0f;
+      if (pc * 8 == dh) e[0] = (T)1.0f;
+#pragma unroll
+      for (int b = 0; b < 2; ++b) st16(ldsV + b * IMG_BYTES + row * VSTR + pc * 16, __builtin_bit_cast(u32x4, e));
+    }
+  }
+  auto load_tile = [&](int key0) {
+    const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(kp), 0, k_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(vp), 0, v_bytes, 0x00020000);
+    // the key tile's byte offset rides in the scalar offset of the request (wave-uniform): no per-tile address arithmetic
+    const unsigned ku = (unsigned)key0 * (unsigned)a.k_row * 2u, vu = (unsigned)key0 * (unsigned)a.vt_row * 2u;
+#pragma unroll
+    for (int i = 0; i < KP; ++i) kr[i] = __builtin_amdgcn_raw_buffer_load_b128(rk, koff[i], ku, 0);
+#pragma unroll
+    for (int i = 0; i < KP; ++i) vr[i] = __builtin_amdgcn_raw_buffer_load_b128(rv, voff[i], vu, 0);
+  };
+  auto store_tile = [&](int boff) {
+#pragma unroll
+    for (int i = 0; i < KP; ++i) {
+      const int p = tid + NTHR * i;
+      const int row = p / (KS * 2), pc = p - row * (KS * 2);
+      if (row < 64 && pc * 8 < dh) {
+        st16(ldsK + boff + row * KSTR + pc * 16, kr[i]);
+        st16(ldsV + boff + row * VSTR + pc * 16, vr[i]);
+      }
+    }
+  };
+
+  f32x16 o[DT];
+#pragma unroll
+  for (int d = 0; d < DT; ++d)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
+  f32x16 cm;                               // minus the shift of this lane's query column, in all sixteen registers
+#pragma unroll
+  for (int r = 0; r < 16; ++r) cm[r] = 0.f;
+  // QSH: lanes of the half that holds channel dh keep minus the shift in element dh % 8 (= 0) of the last Q' fragment
+  const bool qsh_lane = QSH && half == ((dh >> 3) & 1);
+  float l_run = 0.f;
+
+  const int ntiles = (a.tk + 63) / 64;
+  typedef __attribute__((address_space(3))) s16x4* lds4_t;
+  const int l16 = lane & 15, grp = lane >> 4;
+  const int k_lane = ql * KSTR + half * 16;
+  const int v_lane = (4 * half + (l16 >> 2)) * VSTR + (16 * (grp & 1) + 4 * (l16 & 3)) * 2;
+  const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+
+  // S'^T of one 32-key half from its LDS image (KS MFMAs), keys past the end masked
+  auto mask_half = [&](int key0, int kt, f32x16& sx) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int key = key0 + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+      if (key >= a.tk) sx[r] = -INFINITY;
+    }
+  };
+  auto scores_half = [&](auto ragged_tag, int boff, int key0, int kt, f32x16& sx) {
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const frag_t kf = __builtin_bit_cast(frag_t, ld16(ldsK + boff + k_lane + kt * 32 * KSTR + ks * 32));
+      sx = mfma32(kf, qf[ks], ks == 0 ? (QSH ? zero16 : cm) : sx);
+    }
+    if (decltype(ragged_tag)::value) mask_half(key0, kt, sx);
+  };
+  // the exact path for one half: its maximum per query column, the shift raised to (maximum - BIAS) -- set outright when
+  // nothing has been accumulated yet --, O rescaled, the other half's pending scores moved, the half's probabilities
+  auto raise_shift = [&](f32x16& sx, auto first_tag, auto pending_tag, f32x16& pending, unsigned (&pwh)[8]) {
+    constexpr bool first = decltype(first_tag)::value, has_pending = decltype(pending_tag)::value;
+    float mx = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sx[r]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    float d = mx + BIAS;
+    if (!first) d = fmaxf(d, 0.f);           // the shift only rises
+    if (QSH) {
+      // the shift is a value of the storage type: take the step its rounding actually makes
+      const float old_q = __shfl(qsh_lane ? (float)qf[KS - 1][0] : 0.f, ql + 32, 64);
+      const T new_q = (T)(old_q - d);
+      d = old_q - (float)new_q;
+      if (qsh_lane) qf[KS - 1][0] = new_q;
+    } else {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) cm[r] -= d;
+    }
+    if (!first) {
+      const float alpha = __builtin_amdgcn_exp2f(-d);
+      l_run *= alpha;
+#pragma unroll
+      for (int dd = 0; dd < DT; ++dd)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[dd][r] *= alpha;
+    }
+    if (has_pending) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) pending[r] -= d;
+    }
+    float psum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const float e0 = __builtin_amdgcn_exp2f(sx[2 * i] - d), e1 = __builtin_amdgcn_exp2f(sx[2 * i + 1] - d);
+      pwh[i] = pack2<T>(e0, e1);
+      if (!ONES) psum += e0 + e1;
+    }
+    if (!ONES) l_run += psum;
+  };
+
+  load_tile(0);
+  store_tile(0);
+  __syncthreads();
+  {
+    // the first shift, from the exact maximum of the first 32 keys (the loop then only tests; its first half-tile is
+    // computed once more there, so that the loop body has no first-step special case for the compiler to hoist on)
+    f32x16 s0;
+    unsigned pw0[8];
+    if (a.tk < 32) scores_half(std::true_type{}, 0, 0, 0, s0); else scores_half(std::false_type{}, 0, 0, 0, s0);
+    raise_shift(s0, std::true_type{}, std::false_type{}, s0, pw0);
+    if (!ONES) l_run = 0.f;
+  }
+  // A wave that waits on the busy matrix pipe holds up the vector issue of the SIMD's other waves too
+  // (tools/probes/mfma_fill.hip, 'split' rows), so MFMAs are issued with vector work of the SAME wave behind each:
+  //   S'(half 0)                      KS MFMAs alone
+  //   S'(half 1)      KS MFMAs, each followed by a share of half 0's exponentials / packing / OR test
+  //   P.V(half 0)   2 DT MFMAs, each followed by a share of half 1's
+  //   P.V(half 1)   2 DT MFMAs alone
+  // Each half has its own OR test right behind its exponentials (same basic block: with a branch in between hipcc sinks
+  // the exponentials out of the MFMA gaps) and before its P.V; O stays in the old shift's scale until a test fails.
+  // The ragged last tile runs a second copy of the body (RAGGED) with the masking, so the common one has no branch for it.
+  auto tile = [&](auto ragged_tag, int t) {
+    constexpr bool RAGGED = decltype(ragged_tag)::value;
+    const int key0 = t * 64;
+    const int boff = (t & 1) * IMG_BYTES;
+    const bool more = t + 1 < ntiles;
+    if (!QSH) asm volatile("" : "+v"(cm)); // sixteen live registers, not one value re-broadcast per MFMA
+    f32x16 s[2];
+    unsigned pw[2][8];
+    if constexpr (RAGGED) {
+      // the last, ragged tile: one half at a time on the exact path (masked scores, their maximum, probabilities), no
+      // speculation and no interleaving -- it runs once
+      s16x8 vr_[2][DT];
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt) {
+        scores_half(ragged_tag, boff, key0, kt, s[0]);
+        raise_shift(s[0], std::false_type{}, std::false_type{}, s[0], pw[0]);
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+          const unsigned char* vb = ldsV + boff + v_lane + (kt * 32 + st * 16) * VSTR;
+#pragma unroll
+          for (int d = 0; d < DT; ++d) {
+            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4_t)(vb + d * 64));
+            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4_t)(vb + d * 64 + 8 * VSTR));
+            vr_[st][d] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+          }
+        }
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+          const u32x4 pu = {pw[0][st * 4], pw[0][st * 4 + 1], pw[0][st * 4 + 2], pw[0][st * 4 + 3]};
+#pragma unroll
+          for (int d = 0; d < DT; ++d)
+            o[d] = mfma32(__builtin_bit_cast(frag_t, vr_[st][d]), __builtin_bit_cast(frag_t, pu), o[d]);
+        }
+      }
+      return;
+    }
+    frag_t kf1[KS];
+    scores_half(ragged_tag, boff, key0, 0, s[0]);
+    auto read_k1 = [&](int ks) { kf1[ks] = __builtin_bit_cast(frag_t, ld16(ldsK + boff + k_lane + 32 * KSTR + ks * 32)); };
+    read_k1(0);
+    if (KS > 1) read_k1(1);
+    __builtin_amdgcn_sched_barrier(0);
+    unsigned orr = 0u;
+    float psum = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      s[1] = mfma32(kf1[ks], qf[ks], ks == 0 ? (QSH ? zero16 : cm) : s[1]);
+      if (ks + 2 < KS) read_k1(ks + 2);
+#pragma unroll
+      for (int i = (8 * ks) / KS; i < (8 * (ks + 1)) / KS; ++i) {
+        const float e0 = __builtin_amdgcn_exp2f(s[0][2 * i]), e1 = __builtin_amdgcn_exp2f(s[0][2 * i + 1]);
+        pw[0][i] = pack2<T>(e0, e1);
+        orr |= pw[0][i];
+        if (!ONES) psum += e0 + e1;
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (!__all((orr & 0x40004000u) == 0u)) {
+      scores_half(ragged_tag, boff, key0, 0, s[0]);
+      raise_shift(s[0], std::false_type{}, std::true_type{}, s[1], pw[0]);
+    } else if (!ONES) {
+      l_run += psum;
+    }
+    if (more && !(MOBI_ATTN_RDBG & 2)) load_tile(key0 + 64);
+    // V^T fragments one 16-key group (2 DT reads) ahead of the MFMAs that use them
+    s16x8 vf[2][DT];
+    auto read_v = [&](int kt, int st) {
+      const unsigned char* vb = ldsV + boff + v_lane + (kt * 32 + st * 16) * VSTR;
+#pragma unroll
+      for (int d = 0; d < DT; ++d) {
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4_t)(vb + d * 64));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4_t)(vb + d * 64 + 8 * VSTR));
+        vf[st][d] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+      }
+    };
+    read_v(0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    orr = 0u;
+    psum = 0.f;
+#pragma unroll
+    for (int m = 0; m < 2 * DT; ++m) {
+      const int st = m / DT, d = m - st * DT;
+      const u32x4 pu = {pw[0][st * 4], pw[0][st * 4 + 1], pw[0][st * 4 + 2], pw[0][st * 4 + 3]};
+      o[d] = mfma32(__builtin_bit_cast(frag_t, vf[st][d]), __builtin_bit_cast(frag_t, pu), o[d]);
+      if (m == 0) read_v(0, 1);
+#pragma unroll
+      for (int i = (8 * m) / (2 * DT); i < (8 * (m + 1)) / (2 * DT); ++i) {
+        const float e0 = __builtin_amdgcn_exp2f(s[1][2 * i]), e1 = __builtin_amdgcn_exp2f(s[1][2 * i + 1]);
+        pw[1][i] = pack2<T>(e0, e1);
+        orr |= pw[1][i];
+        if (!ONES) psum += e0 + e1;
+      }
+      if (m == DT) read_v(1, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (!__all((orr & 0x40004000u) == 0u)) {
+      scores_half(ragged_tag, boff, key0, 1, s[1]);
+      raise_shift(s[1], std::false_type{}, std::false_type{}, s[1], pw[1]);
+    } else if (!ONES) {
+      l_run += psum;
+    }
+    if (more && !((MOBI_ATTN_RDBG & 2) && t > 0)) store_tile(IMG_BYTES - boff);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int m = 0; m < 2 * DT; ++m) {
+      const int st = m / DT, d = m - st * DT;
+      const u32x4 pu = {pw[1][st * 4], pw[1][st * 4 + 1], pw[1][st * 4 + 2], pw[1][st * 4 + 3]};
+      o[d] = mfma32(__builtin_bit_cast(frag_t, vf[st][d]), __builtin_bit_cast(frag_t, pu), o[d]);
+      if (m == 0) read_v(1, 1);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (!(MOBI_ATTN_RDBG & 16)) __syncthreads();
+  };
+  const int nfull = a.tk / 64;
+  for (int t = 0; t < nfull; ++t) tile(std::false_type{}, t);
+  if (nfull < ntiles) tile(std::true_type{}, nfull);
+
+  // ---- normalise and store: lane holds O^T[d][q] for d = 32 dt + 8 g + 4 half + (0..3) -------
+  if (ONES) {      // row dh of O^T sits in lane-half 0, register (dh % 32) / 2 of tile dh / 32
+    float lsum = 0.f;
+#pragma unroll
+    for (int d = 0; d < DT; ++d)
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        if (d * 32 + g * 8 == dh) lsum = o[d][g * 4];
+    l_run = half == 0 ? lsum : 0.f;
+  }
+  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  const float inv = 1.0f / l_tot;
+  const int qrow = q0 + ql;
+  if (qrow < a.tq) {
+    T* orow = op + (long long)qrow * a.out_row;
+#pragma unroll
+    for (int d = 0; d < DT; ++d)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int d0 = d * 32 + g * 8 + half * 4;
+        if (d0 < dh) {
+          float f[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) f[j] = o[d][g * 4 + j] * inv;
+          *reinterpret_cast<u32x2*>(orow + d0) = pack4<T>(f);
+        }
+      }
+  }
+}
+
+
+// =========================================================================================================
+// attention_pipe_kernel: attention_rows_kernel's arithmetic (Q' = Q * scale * log2 e, shift on the MFMA's C operand or in a
+// padded Q' channel, OR test on the packed probabilities) with the parts of DIFFERENT key tiles overlapped inside a wave.
+//
+// Why: ablations of attention_rows_kernel on [16, 4096 x 4096, 8 x 40] (tools/attn_lab.py, profiles/r03_attention_lab.txt):
+// removing the P.V MFMAs saves exactly their matrix-pipe time, removing the exponentials theirs -- with S(t) -> softmax(t)
+// -> P.V(t) in sequence a wave's time per tile is the SUM of its dependent latencies (~3,300 cycles at four waves per
+// SIMD) and the matrix pipe idles during the vector phase of all four.  Here step t of a wave issues
+//     S'(t+1) = K(t+1) . Q'^T   (2 KS MFMAs)   with the exponentials / packing / OR test of tile t dealt into their gaps,
+//     O^T += V^T(t) . P^T(t)    (4 DT MFMAs)   back to back (the SIMD's other wave has the vector pipe meanwhile),
+// all operand reads of the step requested up front, ONE barrier per key tile.  Two waves per SIMD.
+// LDS: three images (K tile + V tile), tile t in image t % 3: step t reads K(t+1) and V(t) (and K(t) on the exact path) and
+// writes tile t+2 -- requested from memory a whole step earlier -- into the image tile t-1 left at the last barrier.
+// =========================================================================================================
+template <typename T, int KS, int NW, bool QSH>
+__global__ __launch_bounds__(64 * NW, 2) void attention_pipe_kernel(const AttnArgs a) {
+  constexpr int NTHR = 64 * NW;
+  typedef typename Vec8<T>::type frag_t;
+  constexpr int DT = (KS + 1) / 2;
+  constexpr int KSTR = KS * 32 + 16;
+  constexpr int VSTR = (DT & 1) ? DT * 64 : DT * 64 + 64;
+  constexpr int K_BYTES = 64 * KSTR, V_BYTES = 64 * VSTR, IMG_BYTES = K_BYTES + V_BYTES;
+  constexpr int KP = (64 * KS * 2 + NTHR - 1) / NTHR;
+  constexpr int NSLOT = 4;
+  constexpr float BIAS = AttnBias<T>::value;
+  constexpr bool ONES = QSH || (KS & 1);
+  __shared__ __attribute__((aligned(16))) unsigned char lds[NSLOT * IMG_BYTES];
+  unsigned char* ldsK = lds;
+  unsigned char* ldsV = lds + K_BYTES;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int ql = lane & 31, half = lane >> 5;
+  const int head = blockIdx.y, img = blockIdx.z;
+  const int q0 = blockIdx.x * (32 * NW) + wave * 32;
+  const int dh = a.dh;
+
+  const T* __restrict__ qp = reinterpret_cast<const T*>(a.q) + img * a.q_img + head * dh;
+  const T* __restrict__ kp = reinterpret_cast<const T*>(a.k) + img * a.k_img + head * dh;
+  const T* __restrict__ vp = reinterpret_cast<const T*>(a.vt) + img * a.vt_img + (long long)head * dh;
+  T* __restrict__ op = reinterpret_cast<T*>(a.out) + img * a.out_img + head * dh;
+
+  frag_t qf[KS];
+  {
+    const float cexp = a.cexp;
+    const int qrow = q0 + ql;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const int c = ks * 16 + half * 8;
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (qrow < a.tq && c < dh) v = ld16(qp + (long long)qrow * a.q_row + c);
+      frag_t f = __builtin_bit_cast(frag_t, v);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) f[j] = (T)((float)f[j] * cexp);          // cexp == 1 (q_log2_scaled): q bit for bit
+      qf[ks] = f;
+    }
+  }
+
+  u32x4 kr[KP], vr[KP];
+  unsigned koff[KP], voff[KP];
+  constexpr unsigned OOB = 0x80000000u;
+#pragma unroll
+  for (int i = 0; i < KP; ++i) {
+    const int p = tid + NTHR * i;
+    const int row = p / (KS * 2), pc = p - row * (KS * 2);
+    const bool on = row < 64 && pc * 8 < dh;
+    koff[i] = on ? (unsigned)(row * a.k_row + pc * 8) * 2u : OOB;
+    voff[i] = on ? (unsigned)(row * a.vt_row + pc * 8) * 2u : OOB;
+  }
+  const int k_bytes = ((a.tk - 1) * a.k_row + dh) * 2;
+  const int v_bytes = ((a.tk - 1) * a.vt_row + dh) * 2;
+  // padded channels of the K rows (zero; channel dh = 1.0 when the shift rides in Q') and of the V rows (zero; channel
+  // dh = 1.0: the denominator column) are written ONCE into every image; the tile stores only touch channels < dh
+  for (int p = tid; p < 64 * KS * 2; p += NTHR) {
+    const int row = p / (KS * 2), pc = p - row * (KS * 2);
+    if (pc * 8 >= dh) {
+      frag_t e;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) e[j] = (T)0.0f;
+      if (QSH && pc * 8 == dh) e[0] = (T)1.0f;
+#pragma unroll
+      for (int b = 0; b < NSLOT; ++b) st16(ldsK + b * IMG_BYTES + row * KSTR + pc * 16, __builtin_bit_cast(u32x4, e));
+    }
+  }
+  for (int p = tid; p < 64 * DT * 4; p += NTHR) {
+    const int row = p / (DT * 4), pc = p - row * (DT * 4);
+    if (pc * 8 >= dh) {
+      frag_t e;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) e[j] = (T)0.0f;
+      if (pc * 8 == dh) e[0] = (T)1.0f;
+#pragma unroll
+      for (int b = 0; b < NSLOT; ++b) st16(ldsV + b * IMG_BYTES + row * VSTR + pc * 16, __builtin_bit_cast(u32x4, e));
+    }
+  }
+  const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(kp), 0, k_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(vp), 0, v_bytes, 0x00020000);
+  auto load_tile = [&](int key0) {
+    const unsigned ku = (unsigned)key0 * (unsigned)a.k_row * 2u, vu = (unsigned)key0 * (unsigned)a.vt_row * 2u;
+#pragma unroll
+    for (int i = 0; i < KP; ++i) kr[i] = __builtin_amdgcn_raw_buffer_load_b128(rk, koff[i], ku, 0);
+#pragma unroll
+    for (int i = 0; i < KP; ++i) vr[i] = __builtin_amdgcn_raw_buffer_load_b128(rv, voff[i], vu, 0);
+  };
+  auto store_tile = [&](int boff) {
+#pragma unroll
+    for (int i = 0; i < KP; ++i) {
+      const int p = tid + NTHR * i;
+      const int row = p / (KS * 2), pc = p - row * (KS * 2);
+      if (row < 64 && pc * 8 < dh) {
+        st16(ldsK + boff + row * KSTR + pc * 16, kr[i]);
+        st16(ldsV + boff + row * VSTR + pc * 16, vr[i]);
+      }
+    }
+  };
+#define MOBI_PIPE_BARRIER()                              \
+  do {                                                   \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   \
+    __builtin_amdgcn_sched_barrier(0);                   \
+    __builtin_amdgcn_s_barrier();                        \
+    __builtin_amdgcn_sched_barrier(0);                   \
+  } while (0)
+
+  f32x16 o[DT];
+#pragma unroll
+  for (int d = 0; d < DT; ++d)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
+  f32x16 cm;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) cm[r] = 0.f;
+  const bool qsh_lane = QSH && half == 1;     // channel dh = KS*16 - 8 sits in the upper half's fragment, element 0
+  float l_run = 0.f;
+  const int ntiles = (a.tk + 63) / 64;
+  const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+
+  typedef __attribute__((address_space(3))) s16x4* lds4_t;
+  const int l16 = lane & 15, grp = lane >> 4;
+  const int k_lane = ql * KSTR + half * 16;                                        // K fragment of (key ql, half)
+  const int v_lane = (4 * half + (l16 >> 2)) * VSTR + (16 * (grp & 1) + 4 * (l16 & 3)) * 2;
+
+  auto read_k = [&](int boff, frag_t (&kf)[2][KS]) {
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks)
+        kf[kt][ks] = __builtin_bit_cast(frag_t, ld16(ldsK + boff + k_lane + kt * 32 * KSTR + ks * 32));
+  };
+  auto scores = [&](frag_t (&kf)[2][KS], f32x16 (&sx)[2]) {
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) sx[kt] = mfma32(kf[kt][ks], qf[ks], ks == 0 ? (QSH ? zero16 : cm) : sx[kt]);
+  };
+  auto mask_ragged = [&](f32x16 (&sx)[2], int key0) {
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = key0 + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (key >= a.tk) sx[kt][r] = -INFINITY;
+      }
+  };
+
+  int slot0 = 0, slot1 = 1, slot2 = 2, slot3 = 3;                  // images of tiles t, t+1, t+2, t+3
+  // Operand fragments live in registers ACROSS steps and are refilled behind their last use ("rolling"): right after the
+  // P.V MFMA that consumed fragment i of V(t-1), fragment i of V(t) is requested into the same registers; right after an
+  // S MFMA, the same fragment of K(t+2).  A step therefore starts multiplying at once -- with the reads requested at the
+  // top of the step every wave of the block sat in the LDS latency together, the matrix pipe idle (stamps: 30 % of a step).
+  s16x8 vf[2][2][DT];                                               // V^T fragments of the tile whose P.V comes next
+  frag_t kf[2][KS];                                                 // K fragments of the tile whose S' comes next
+  auto read_v1 = [&](int boff, int i) {                             // fragment i = (kt, st, d) of the V tile in image boff
+    const int kt = i / (2 * DT), st = (i / DT) & 1, d = i % DT;
+    const unsigned char* vb = ldsV + boff + v_lane + (kt * 32 + st * 16) * VSTR;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4_t)(vb + d * 64));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4_t)(vb + d * 64 + 8 * VSTR));
+    vf[kt][st][d] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+  };
+  auto read_k1 = [&](int boff, int i) {
+    const int kt = i / KS, ks = i - kt * KS;
+    kf[kt][ks] = __builtin_bit_cast(frag_t, ld16(ldsK + boff + k_lane + kt * 32 * KSTR + ks * 32));
+  };
+  // one step: sc = S'(t) (in, complete), sn = S'(t+1) (out); pp = P(t-1) (in), pw = P(t) (out).
+  // MFMA i of the step: i < 4 DT: O^T += V^T(t-1) . P^T(t-1) (one accumulator's MFMAs DT apart); then the 2 KS of S'(t+1).
+  // EVERY MFMA is followed by its share of the tile's vector work in the wave's own stream: a wave that waits on the busy
+  // matrix pipe holds up the vector issue of the SIMD's other wave as well (tools/probes/mfma_fill.hip, 'split' rows).
+  auto step = [&](auto first_tag, int t, f32x16 (&sc)[2], f32x16 (&sn)[2], unsigned (&pp)[2][8], unsigned (&pw)[2][8]) {
+    constexpr bool FIRST = decltype(first_tag)::value;
+    const int key0 = t * 64;
+    const int b0 = slot0 * IMG_BYTES, b2 = slot2 * IMG_BYTES;
+    if (!(MOBI_ATTN_PDBG & 1)) {
+      if (t + 3 < ntiles) store_tile(slot3 * IMG_BYTES);    // requested one step ago (or in the prologue)
+      if (t + 4 < ntiles) load_tile(key0 + 256);
+    }
+    if (key0 + 64 > a.tk) mask_ragged(sc, key0);             // ragged last tile
+    if (!QSH) asm volatile("" : "+v"(cm));
+    __builtin_amdgcn_sched_barrier(0);
+    unsigned orr = 0u;
+    float psum = 0.f;
+    constexpr int NPV = FIRST ? 0 : 4 * DT, NG = NPV + 2 * KS;
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      if (g < NPV) {
+        const int kt = g / (2 * DT), st = (g / DT) & 1, d = g % DT;
+        const u32x4 pu = {pp[kt][st * 4], pp[kt][st * 4 + 1], pp[kt][st * 4 + 2], pp[kt][st * 4 + 3]};
+        o[d] = mfma32(__builtin_bit_cast(frag_t, vf[kt][st][d]), __builtin_bit_cast(frag_t, pu), o[d]);
+      } else {
+        const int kt = (g - NPV) / KS, ks = (g - NPV) - kt * KS;
+        sn[kt] = mfma32(kf[kt][ks], qf[ks], ks == 0 ? (QSH ? zero16 : cm) : sn[kt]);
+      }
+#pragma unroll
+      for (int pi = (16 * g) / NG; pi < (16 * (g + 1)) / NG; ++pi) {
+        const int pk = pi >> 3, i = pi & 7;
+        const float e0 = __builtin_amdgcn_exp2f(sc[pk][2 * i]), e1 = __builtin_amdgcn_exp2f(sc[pk][2 * i + 1]);
+        pw[pk][i] = pack2<T>(e0, e1);
+        orr |= pw[pk][i];
+        if (!ONES) psum += e0 + e1;
+      }
+      // refill behind the MFMA: V(t) for the next step's P.V, K(t+2) for its S'
+      if (g < NPV) {
+        read_v1(b0, g);
+      } else {
+        read_k1(b2, g - NPV);                               // (past the last tile: a stale image, the result is not used)
+        if (FIRST) {
+#pragma unroll
+          for (int i = (4 * DT * (g - NPV)) / (2 * KS); i < (4 * DT * (g - NPV + 1)) / (2 * KS); ++i) read_v1(b0, i);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    const bool fix = !(MOBI_ATTN_PDBG & 4) && !__all((orr & 0x40004000u) == 0u);
+    if (fix) {
+      // exact path (a probability reached 2.0): S'(t) once more from its LDS image, the tile's maximum per query
+      // column, the shift raised to (maximum - BIAS), O (tiles < t) rescaled, S'(t+1) moved to the new shift, P(t) recomputed
+      frag_t kc[2][KS];
+      read_k(b0, kc);
+      scores(kc, sc);
+      if (key0 + 64 > a.tk) mask_ragged(sc, key0);
+      float mx = -INFINITY;
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sc[kt][r]);
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      float d = fmaxf(mx + BIAS, 0.f);       // the shift only rises
+      if (QSH) {
+        // the shift is a value of the storage type: take the step its rounding actually makes
+        const float old_q = __shfl(qsh_lane ? (float)qf[KS - 1][0] : 0.f, ql + 32, 64);
+        const T new_q = (T)(old_q - d);
+        d = old_q - (float)new_q;
+        if (qsh_lane) qf[KS - 1][0] = new_q;
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) cm[r] -= d;
+      }
+      {
+        const float alpha = __builtin_amdgcn_exp2f(-d);
+        l_run *= alpha;
+#pragma unroll
+        for (int dd = 0; dd < DT; ++dd)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) o[dd][r] *= alpha;
+      }
+      psum = 0.f;
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sn[kt][r] -= d;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const float e0 = __builtin_amdgcn_exp2f(sc[kt][2 * i] - d), e1 = __builtin_amdgcn_exp2f(sc[kt][2 * i + 1] - d);
+          pw[kt][i] = pack2<T>(e0, e1);
+          if (!ONES) psum += e0 + e1;
+        }
+      }
+    }
+    if (!ONES) l_run += psum;
+    const int s_ = slot0;
+    slot0 = slot1;
+    slot1 = slot2;
+    slot2 = slot3;
+    slot3 = s_;
+    if (MOBI_ATTN_PDBG & 2) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); else MOBI_PIPE_BARRIER();
+  };
+
+  f32x16 sa[2], sb[2];
+  load_tile(0);
+  store_tile(0);
+  if (ntiles > 1) {
+    load_tile(64);
+    store_tile(IMG_BYTES);
+  }
+  if (ntiles > 2) {
+    load_tile(128);
+    store_tile(2 * IMG_BYTES);
+  }
+  if (ntiles > 3) load_tile(192);                            // stays in registers until step 0
+  MOBI_PIPE_BARRIER();
+  {
+    // S'(0), and the first shift from its exact maximum (every later step starts from a valid shift and only tests)
+    read_k(0, kf);
+    scores(kf, sa);
+    if (64 > a.tk) mask_ragged(sa, 0);
+    float mx = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sa[kt][r]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    float d = mx + BIAS;
+    if (QSH) {
+      const T new_q = (T)(-d);
+      d = -(float)new_q;
+      if (qsh_lane) qf[KS - 1][0] = new_q;
+    } else {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) cm[r] = -d;
+    }
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sa[kt][r] -= d;
+  }
+  read_k(IMG_BYTES, kf);                                     // K(1) for step 0
+  unsigned pa[2][8], pb[2][8];
+  step(std::true_type{}, 0, sa, sb, pb, pa);
+  int t = 1;
+  for (; t + 1 < ntiles; t += 2) {
+    step(std::false_type{}, t, sb, sa, pa, pb);
+    step(std::false_type{}, t + 1, sa, sb, pb, pa);
+  }
+  const bool odd_left = t < ntiles;                        // one more step, on the (sb, pa) -> pb roles
+  if (odd_left) step(std::false_type{}, t, sb, sa, pa, pb);
+  auto last_pv = [&](unsigned (&pl)[2][8]) {                 // the last tile's P.V (its fragments came in during the last step)
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int st = 0; st < 2; ++st) {
+        const u32x4 pu = {pl[kt][st * 4], pl[kt][st * 4 + 1], pl[kt][st * 4 + 2], pl[kt][st * 4 + 3]};
+#pragma unroll
+        for (int d = 0; d < DT; ++d)
+          o[d] = mfma32(__builtin_bit_cast(frag_t, vf[kt][st][d]), __builtin_bit_cast(frag_t, pu), o[d]);
+      }
+  };
+  if (odd_left) last_pv(pb); else last_pv(pa);
+#undef MOBI_PIPE_BARRIER
+
+  if (ONES) {
+    float lsum = 0.f;
+#pragma unroll
+    for (int d = 0; d < DT; ++d)
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        if (d * 32 + g * 8 == dh) lsum = o[d][g * 4];
+    l_run = half == 0 ? lsum : 0.f;
+  }
+  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  const float inv = 1.0f / l_tot;
+  const int qrow = q0 + ql;
+  if (qrow < a.tq) {
+    T* orow = op + (long long)qrow * a.out_row;
+#pragma unroll
+    for (int d = 0; d < DT; ++d)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int d0 = d * 32 + g * 8 + half * 4;
+        if (d0 < dh) {
+          float f[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) f[j] = o[d][g * 4 + j] * inv;
+          *reinterpret_cast<u32x2*>(orow + d0) = pack4<T>(f);
+        }
+      }
+  }
+}
+
+
 #ifdef MOBI_DEV   // development build only: the software-pipelined A/B alternative (measured slower, MOBI_ATTN_SP=1)
 // =========================================================================================================
 // SOFTWARE-PIPELINED variant of the 8-wave kernel (V row-major, one 16-byte K and V piece per thread and key tile,
@@ -556,7 +1327,7 @@ __global__ __launch_bounds__(512, 2) void attention_sp_kernel(const AttnArgs a) 
   f32x16 sa[2], sb[2];
   frag_t pa[2][2], pb[2][2];
   float m_run = -INFINITY, alpha = 1.f;
-  const float cexp = a.scale * 1.4426950408889634f;
+  const float cexp = a.cexp;
   const int ntiles = (a.tk + 63) / 64;
 
   load_tile(0);
@@ -755,6 +1526,33 @@ static int launch_attention_v(const mobi_attention_params* p, const AttnArgs& a,
     const long long blocks8 = (long long)((p->tq + 255) / 256) * p->heads * p->images;
     int nw8 = blocks8 >= 1024 && ks <= 5;             // measured -5.5 % on [16 | 8 images, 4096 x 4096, 8 x 40]
     if (tuning().attn_nw > 0) nw8 = ks <= 5 && tuning().attn_nw == 8;       // tests / A-B: 8 forces, 4 forbids
+    if (ks <= 5 && tuning().attn_v3 != 0) {           // the reduced-instruction kernel (MOBI_ATTN_V3=0: the kernel below)
+      dim3 gridr((p->tq + (nw8 ? 255 : 127)) / (nw8 ? 256 : 128), p->heads, p->images), blockr(nw8 ? 512 : 256);
+      const bool qsh = (p->dh & 15) != 0;             // a padded channel in the last k-step carries the shift
+      if (tuning().attn_v3 == 2 && ks == 3 && qsh && nw8) {      // A/B: the software-pipelined kernel (MOBI_ATTN_V3=2)
+        hipLaunchKernelGGL((attention_pipe_kernel<T, 3, 8, true>), gridr, blockr, 0, st, a);
+        MOBI_CHECK_LAUNCH();
+        return MOBI_OK;
+      }
+#define MOBI_ATTN_ROWS(KS_)                                                                              \
+  do {                                                                                                   \
+    if (qsh) {                                                                                           \
+      if (nw8) hipLaunchKernelGGL((attention_rows_kernel<T, KS_, 8, true>), gridr, blockr, 0, st, a);     \
+      else hipLaunchKernelGGL((attention_rows_kernel<T, KS_, 4, true>), gridr, blockr, 0, st, a);         \
+    } else {                                                                                             \
+      if (nw8) hipLaunchKernelGGL((attention_rows_kernel<T, KS_, 8, false>), gridr, blockr, 0, st, a);    \
+      else hipLaunchKernelGGL((attention_rows_kernel<T, KS_, 4, false>), gridr, blockr, 0, st, a);        \
+    }                                                                                                    \
+  } while (0)
+      if (ks <= 1) MOBI_ATTN_ROWS(1);
+      else if (ks == 2) MOBI_ATTN_ROWS(2);
+      else if (ks == 3) MOBI_ATTN_ROWS(3);
+      else if (ks == 4) MOBI_ATTN_ROWS(4);
+      else MOBI_ATTN_ROWS(5);
+#undef MOBI_ATTN_ROWS
+      MOBI_CHECK_LAUNCH();
+      return MOBI_OK;
+    }
     if (nw8) {
       dim3 grid8((p->tq + 255) / 256, p->heads, p->images), block8(512);
       // software-pipelined kernel (head dims 33..48): measured SLOWER than the kernel above (693 vs 620 us on
@@ -823,7 +1621,8 @@ extern "C" int mobi_attention(const mobi_attention_params* p, void* stream) {
   a.k = p->k; a.k_img = p->k_img_stride; a.k_row = p->k_row_stride;
   a.vt = p->vt; a.vt_img = p->vt_img_stride; a.vt_row = p->vt_row_stride;
   a.out = p->out; a.out_img = p->out_img_stride; a.out_row = p->out_row_stride;
-  a.heads = p->heads; a.dh = p->dh; a.tq = p->tq; a.tk = p->tk; a.scale = p->scale;
+  a.heads = p->heads; a.dh = p->dh; a.tq = p->tq; a.tk = p->tk;
+  a.cexp = p->q_log2_scaled ? 1.0f : p->scale * 1.4426950408889634f;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   return p->dtype == MOBI_F16 ? launch_attention<f16_t>(p, a, st) : launch_attention<bf16_t>(p, a, st);
 }

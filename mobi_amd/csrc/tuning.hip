@@ -33,6 +33,7 @@ void read_env() {
   g_tuning.tka_mfma = env_int("MOBI_TKA_MFMA");
   g_tuning.attn_nw = env_int("MOBI_ATTN_NW");
   g_tuning.attn_sp = env_int("MOBI_ATTN_SP");
+  g_tuning.attn_v3 = env_int("MOBI_ATTN_V3");
 }
 }  // namespace
 

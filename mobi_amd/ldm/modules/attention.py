@@ -83,34 +83,42 @@ class CrossAttention(nn.Module):
         self.to_out = nn.Sequential(Linear(inner_dim, query_dim), Marker())
 
     # -- packed projections ---------------------------------------------------------------
-    def _stacked(self, names):
+    def _stacked(self, names, fold_q=False):
         """One packed matrix for several projections of the same input (rows stacked in `names` order): the input
-        is read once and the launch count drops; attention reads q / k / v as column ranges of the result."""
+        is read once and the launch count drops; attention reads q / k / v as column ranges of the result.
+        fold_q: the to_q rows carry scale * log2(e) (fp32 masters multiplied before the single rounding to the storage
+        type), so the attention kernels exponentiate q.k as a power of two without touching q again
+        (mobi_attention_params.q_log2_scaled; `sim = einsum(q, k) * self.scale`, attention.py:178)."""
         mods = [getattr(self, n) for n in names]
         dtype = mods[0].packed().w.dtype
-        key = (names, dtype) + tuple(v for m in mods for v in (m.weight._version, m.weight.data_ptr()))
+        key = (names, fold_q, dtype) + tuple(v for m in mods for v in (m.weight._version, m.weight.data_ptr()))
         c = self.__dict__.setdefault("_stack_cache", {})
-        hit = c.get(names)
+        hit = c.get((names, fold_q))
         if hit is None or hit[0] != key:
-            w = torch.cat([m.weight.detach() for m in mods], dim=0)
+            ws = [m.weight.detach() for m in mods]
+            if fold_q:
+                assert names[0] == "to_q"
+                ws[0] = ws[0].float() * (self.scale * ops.LOG2E)
+            w = torch.cat([w_.float() for w_ in ws], dim=0) if fold_q else torch.cat(ws, dim=0)
             hit = (key, ops.pack_linear(w, None, dtype, w.device))
-            c[names] = hit
+            c[(names, fold_q)] = hit
         return hit[1]
 
     # -- forms of attention ------------------------------------------------------------------
     def self_attention(self, xn):
         """xn: normed tokens [N,T,C] -> attention output before to_out."""
         c = self.inner_dim
-        qkv = ops.linear(xn, self._stacked(("to_q", "to_k", "to_v")))
-        return ops.attention(qkv[..., :c], qkv[..., c:2 * c], qkv[..., 2 * c:], self.heads, self.scale, v_rows=True)
+        qkv = ops.linear(xn, self._stacked(("to_q", "to_k", "to_v"), fold_q=True))
+        return ops.attention(qkv[..., :c], qkv[..., c:2 * c], qkv[..., 2 * c:], self.heads, self.scale, v_rows=True,
+                             q_log2_scaled=True)
 
     def token_attention(self, xn, ctx):
         """Many queries against another token stream `ctx` [N,Tk,Cc] (engine tensor, may be a
         batch-strided view)."""
         c = self.inner_dim
-        q, kv = ops.concurrently(lambda: ops.linear(xn, self.to_q.packed()),
+        q, kv = ops.concurrently(lambda: ops.linear(xn, self._stacked(("to_q",), fold_q=True)),
                                  lambda: ops.linear(ctx, self._stacked(("to_k", "to_v"))))
-        return ops.attention(q, kv[..., :c], kv[..., c:], self.heads, self.scale, v_rows=True)
+        return ops.attention(q, kv[..., :c], kv[..., c:], self.heads, self.scale, v_rows=True, q_log2_scaled=True)
 
     def context_kv(self, context):
         """fp32 context [N,tk,Cc] -> (k, v) fp32 [N,tk,C]."""

@@ -324,9 +324,13 @@ def layernorm(x, gamma, beta, eps=1e-5):
     return out
 
 
-def attention(q, k, v, heads, scale, v_rows=False):
+LOG2E = 1.4426950408889634
+
+
+def attention(q, k, v, heads, scale, v_rows=False, q_log2_scaled=False):
     """q: [N, Tq, >=C] view (row stride may exceed C: stacked projections), k: [N, Tk, ...];
-    v_rows=False: v is V^T [N, C, Tk];  v_rows=True: v is [N, Tk, >=C] row-major like k.  -> out [N, Tq, C]."""
+    v_rows=False: v is V^T [N, C, Tk];  v_rows=True: v is [N, Tk, >=C] row-major like k.  -> out [N, Tq, C].
+    q_log2_scaled: q already carries scale * log2(e) (folded into the packed to_q weights); `scale` is then unused."""
     lib = _lib.load()
     n, tq = q.shape[0], q.shape[1]
     tk = k.shape[1]
@@ -338,6 +342,7 @@ def attention(q, k, v, heads, scale, v_rows=False):
     p.k, p.k_img_stride, p.k_row_stride = _ptr(k), k.stride(0), k.stride(1)
     p.vt, p.vt_img_stride, p.vt_row_stride = _ptr(v), v.stride(0), v.stride(1)
     p.v_layout = 1 if v_rows else 0
+    p.q_log2_scaled = 1 if q_log2_scaled else 0
     p.out, p.out_img_stride, p.out_row_stride = _ptr(out), out.stride(0), out.stride(1)
     for t_ in (q, k, v):
         assert t_.shape[2] == 1 or t_.stride(2) == 1

@@ -224,10 +224,63 @@ def test_attention(ops, dtype, heads, dh, tq, tk, v_rows, tune):
     sim = torch.einsum("bhid,bhjd->bhij", sp(qf), sp(kf)) * dh ** -0.5
     ref = torch.einsum("bhij,bhjd->bhid", sim.softmax(-1), sp(vf)).permute(0, 2, 1, 3).reshape(n, tq, c)
     assert rel(y.float(), ref) < TOL[dtype]
+    # q already carrying scale * log2(e) (what the transformer blocks do: folded into the packed to_q weights)
+    log2e = 1.4426950408889634
+    qsf = (qf * (dh ** -0.5 * log2e)).to(dtype)
+    sim2 = torch.einsum("bhid,bhjd->bhij", sp(qsf.float()), sp(kf)) / log2e
+    ref2 = torch.einsum("bhij,bhjd->bhid", sim2.softmax(-1), sp(vf)).permute(0, 2, 1, 3).reshape(n, tq, c)
+    y2 = ops.attention(qsf.cuda(), kd, vt, heads, 123.0, v_rows=v_rows, q_log2_scaled=True)
+    assert rel(y2.float(), ref2) < TOL[dtype]
     if v_rows and dh <= 80:
         tune.setenv("MOBI_ATTN_NW", "8")
         y8 = ops.attention(qd, kd, vt, heads, dh ** -0.5, v_rows=v_rows)
         assert rel(y8.float(), ref) < TOL[dtype]
+        # the kernel these launches ran on before attention_rows_kernel (still the one for V^T inputs and dh > 80)
+        tune.setenv("MOBI_ATTN_V3", "0")
+        for nw in ("4", "8"):
+            tune.setenv("MOBI_ATTN_NW", nw)
+            y0 = ops.attention(qd, kd, vt, heads, dh ** -0.5, v_rows=v_rows)
+            assert rel(y0.float(), ref) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("nw", ["4", "8"])
+@pytest.mark.parametrize("dh,tq,tk,kind", [(40, 300, 1000, "ramp"), (40, 256, 4096, "ramp"), (80, 130, 700, "ramp"),
+                                           (64, 70, 390, "ramp"), (48, 64, 512, "ramp"), (40, 96, 640, "huge"),
+                                           (80, 64, 320, "huge"), (32, 64, 256, "huge"), (40, 64, 200, "negative"),
+                                           (8, 40, 130, "ramp"), (24, 33, 257, "spike")])
+def test_attention_shift_path(ops, dtype, nw, dh, tq, tk, kind, tune):
+    """attention_rows_kernel keeps a shift below the running maximum and raises it only when a probability reaches 2.0
+    (the OR test on the packed words); these inputs make that exact path run often or at the extremes: scores that keep
+    rising along the keys ('ramp'), scores of magnitude ~1e3 ('huge': the speculative exp2 overflows), all scores far
+    below zero ('negative': the first tile must set the shift), one late dominant key ('spike')."""
+    n, heads = 2, 4
+    c = heads * dh
+    qf, _ = rnd(f"as.q{dh}.{tq}", (n, tq, c), dtype, 1.5)
+    kf, _ = rnd(f"as.k{dh}.{tk}", (n, tk, c), dtype, 1.5)
+    vf, vd = rnd(f"as.v{dh}.{tk}", (n, tk, c), dtype)
+    if kind == "ramp":
+        kf = kf * torch.linspace(0.2, 6.0, tk).view(1, tk, 1)
+    elif kind == "huge":
+        kf = kf * 60.0
+        qf = qf * 8.0
+    elif kind == "negative":
+        qf = qf.abs() + 1.0
+        kf = -(kf.abs() + 1.0) * 4.0
+    elif kind == "spike":
+        kf[:, tk - 3] = qf[:, 0:1].mean(1) * 9.0
+    qd, kd = qf.to(dtype).cuda(), kf.to(dtype).cuda()
+    qf, kf = qd.float().cpu(), kd.float().cpu()
+    sp = lambda t: t.reshape(n, -1, heads, dh).permute(0, 2, 1, 3)
+    sim = torch.einsum("bhid,bhjd->bhij", sp(qf).double(), sp(kf).double()) * dh ** -0.5
+    ref = torch.einsum("bhij,bhjd->bhid", sim.softmax(-1), sp(vf).double()).permute(0, 2, 1, 3).reshape(n, tq, c)
+    tune.setenv("MOBI_ATTN_NW", nw)
+    y = ops.attention(qd, kd, vd, heads, dh ** -0.5, v_rows=True)
+    assert torch.isfinite(y.float()).all()
+    # the kernel rounds Q' = Q * scale * log2(e) to the storage type once more (callers that fold the factor into to_q do
+    # not pay this: q_log2_scaled): 1.5 x the one-kernel bound; scores of ~1e3 ('huge') move by several units with it
+    tol = TOL[dtype] * (40 if kind == "huge" else 2.5 if kind in ("ramp", "spike") else 1.5)
+    assert rel(y.float(), ref) < tol
 
 
 @pytest.mark.parametrize("dtype", DT)
