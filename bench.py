@@ -43,7 +43,7 @@ WORKLOADS = {  # BASELINE.json configs[2] / configs[1]
     "mobi_nusc_512": dict(latent=64, objects=8, gflop_per_element=1021.9, gflop_skippable=78.0),
     "mobi_nusc_256": dict(latent=32, objects=4, gflop_per_element=209.7, gflop_skippable=19.5),
 }
-PMC_TRAFFIC = "r02_pmc_traffic.json"   # written by tools/pmc_summary.py from the --pmc passes of this round's build
+PMC_TRAFFIC = "r03_pmc_traffic.json"   # written by tools/pmc_summary.py from the --pmc passes of this round's build
 PEAK_TFLOPS = 2500.0          # dense bf16/fp16 MFMA, /opt/skills/guides/MI355X_MICROARCH.md
 
 
@@ -104,18 +104,27 @@ def stub_main(args, world, rank):
         time.sleep(0.002 * (1 + rank))           # rank-dependent: the MAX over ranks must win
     barrier()
     dt = time.perf_counter() - t0
+    ranks = None
     if world > 1:
+        own = dt
         tmax = torch.tensor([dt])
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
+        ranks = [None] * world
+        dist.all_gather_object(ranks, {"rank": rank, "local_rank": int(os.environ.get("LOCAL_RANK", "0")), "device": "cpu (stub)",
+                                       "ms_per_step": round(own / args.steps * 1e3, 3)})
     if rank == 0:
         elems = 16
-        print(json.dumps({"metric": "stub", "value": round(args.steps / dt * elems * world, 3), "unit": "stub element-forwards/s",
-                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-                          "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-                          "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-                          "config": {"workload": "stub (launcher test)", "parallelism": f"dp{world}"},
-                          "steps_per_s": round(args.steps / dt, 4)}))
+        line = {"metric": "stub", "value": round(args.steps / dt * elems * world, 3), "unit": "stub element-forwards/s",
+                "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+                "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                "config": {"workload": "stub (launcher test)", "parallelism": f"dp{world}"},
+                "steps_per_s": round(args.steps / dt, 4)}
+        if world > 1:
+            line.update(ranks_seen=dist.get_world_size(), backend=dist.get_backend(), ranks=ranks,
+                        ms_per_step_by_rank=[r["ms_per_step"] for r in ranks])
+        print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()
 
@@ -137,6 +146,8 @@ def main():
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end objects/s pass")
     ap.add_argument("--no-graph", action="store_true", help="issue every launch from the host (no HIP graph)")
     ap.add_argument("--no-plms-line", action="store_true", help="skip the PLMS + CFG 5 (shipped invocation) leg")
+    ap.add_argument("--no-fp16-line", action="store_true", help="skip the fp16-storage sub-record (the storage type that "
+                    "meets the 1e-3 end-to-end tolerance; only added to a bf16 run)")
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ:
@@ -223,10 +234,20 @@ def main():
         dt = time.perf_counter() - t0
         gpu_ms_per_step = ev0.elapsed_time(ev1) / args.steps
         host_ms_per_step = t_issued / args.steps * 1e3
+    dt_own = dt
+    ranks = None
     if world > 1:
         tmax = torch.tensor([dt], device=red_dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
+        # evidence per rank for the scaling runs: which device every rank ran on, its own step time, and the world size
+        # the collective backend itself reports
+        prop = torch.cuda.get_device_properties(device)
+        mine = {"rank": rank, "local_rank": local_rank, "device": prop.name, "pci_bus_id": getattr(prop, "pci_bus_id", None),
+                "uuid": str(getattr(prop, "uuid", "")), "ms_per_step": round(dt_own / args.steps * 1e3, 3),
+                "gpu_ms_per_step": round(gpu_ms_per_step, 3)}
+        ranks = [None] * world
+        dist.all_gather_object(ranks, mine)
     finite = bool(torch.isfinite(x).all())
 
     # ---- the shipped invocation (scripts/realism_test_bench.sh:95-102): PLMS, classifier-free guidance 5 -------
@@ -285,6 +306,8 @@ def main():
             move = lambda d: {k: move(v) if isinstance(v, dict) else v.to(device) for k, v in d.items()}
             return move(b)
 
+        gather_stat = {}
+
         def e2e(batch):
             data = model.get_input(batch, model.first_stage_key, force_c_encode=True, return_vae_rec=True)   # :416
             n = data["z"].shape[0]
@@ -299,7 +322,13 @@ def main():
             log = {k: log[k] for k in ("image_sample", "lidar_sample")}
             if backend != "nccl":
                 log = {k: v.cpu() for k, v in log.items()}
-            return mdist.gather_decoded(log, B * world)                 # the one collective of the path
+            torch.cuda.synchronize()
+            tg = time.perf_counter()
+            res = mdist.gather_decoded(log, B * world)                  # the one collective of the path
+            torch.cuda.synchronize()
+            gather_stat["s"] = time.perf_counter() - tg
+            gather_stat["bytes_per_rank"] = sum(v.numel() * v.element_size() for v in log.values())
+            return res
 
         with torch.no_grad():
             if args.warmup > 0:
@@ -400,6 +429,38 @@ def main():
             roofline["attention_ms_per_step"] = round(at["ms"], 3)
         roofline["igemm_ms_per_step"] = round(ig["ms"], 3)
         roofline["norm_ms_per_step"] = round(sum(kinds.get(k, {"ms": 0})["ms"] for k in ("groupnorm", "layernorm")), 3)
+        # every family of the step against ITS roof (matrix families: algorithmic FLOP/s over the dense peak; bandwidth
+        # families: algorithmic bytes/s over 8 TB/s), and the step if every launch ran at the better of its two roofs
+        fam = {}
+        for v, d in by_variant.items():
+            fam[f"igemm_{v}"] = {"ms": round(d["ms"], 3), "launches": d["launches"],
+                                 "tflops": round(d["flops"] / (d["ms"] * 1e-3) / 1e12, 1),
+                                 "frac": round(d["flops"] / (d["ms"] * 1e-3) / 1e12 / PEAK_TFLOPS, 4)}
+        for kname_, d in kinds.items():
+            if kname_ == "igemm" or d["ms"] <= 0:
+                continue
+            if d["flops"] > 0 and kname_ == "attention":
+                fam[kname_] = {"ms": round(d["ms"], 3), "launches": d["launches"],
+                               "tflops": round(d["flops"] / (d["ms"] * 1e-3) / 1e12, 1),
+                               "frac": round(d["flops"] / (d["ms"] * 1e-3) / 1e12 / PEAK_TFLOPS, 4)}
+            else:
+                fam[kname_] = {"ms": round(d["ms"], 3), "launches": d["launches"],
+                               "gb_s": round(d["bytes"] / (d["ms"] * 1e-3) / 1e9, 1),
+                               "frac": round(d["bytes"] / (d["ms"] * 1e-3) / 8.0e12, 4)}
+        roofline["families"] = fam
+        ideal = sum(max(flops / (PEAK_TFLOPS * 1e12), nb / 8.0e12) for _, flops, _, _, nb, _ in sink)
+        roofline["ms_per_step_every_launch_at_its_better_roof"] = round(ideal * 1e3, 3)
+        roofline["ms_per_step_sum_of_launches"] = round(sum(e0.elapsed_time(e1) for _, _, e0, e1, _, _ in sink), 3)
+        roofline["launches_per_step_all"] = len(sink)
+        if os.path.exists(pmc):
+            traffic = {}
+            for fam_k in ("igemm_ring_kernel", "igemm_pp_kernel", "attention_rows_kernel", "attention_kernel",
+                          "gn_stats_kernel", "gn_apply_kernel", "layernorm_kernel"):
+                rec = doc.get(fam_k)
+                if rec and doc.get("config") == run_cfg:
+                    traffic[fam_k] = round(rec["hbm_bytes_per_launch_corrected"])
+            if traffic:
+                roofline["traffic_by_kernel"] = traffic
 
     cpu_baseline = None
     if not args.no_cpu_baseline and rank == 0 and world == 1:
@@ -419,6 +480,40 @@ def main():
                         "sample": f"1 denoising step of 1 object (UNet batch 2) at latent {side}x{side}, fp32, "
                                   f"PyTorch CPU oracle of the reference graph, {cdt:.1f} s (second of two evaluations)"}
         del sd
+
+    # ---- the same step with fp16 storage: the storage type that meets the 1e-3 end-to-end tolerance ----------
+    fp16_line = None
+    if args.dtype == "bf16" and not args.no_fp16_line:
+        mobi_amd.set_engine_dtype(torch.float16)
+        s16 = DDIMSampler(model, graph=not args.no_graph)
+        s16.make_schedule(args.ddim_steps, ddim_eta=0.0, verbose=False)
+
+        def step16(x_, i):
+            index = total - 1 - (i % total)
+            step = int(steps_desc[i % total])
+            ts = torch.full((N,), step, device=device, dtype=torch.long)
+            return s16.p_sample_ddim(x_, cond, ts, index=index, unconditional_guidance_scale=args.cfg_scale,
+                                     unconditional_conditioning=uc if cfg else None, step_value=step, **kw)[0]
+
+        with torch.no_grad():
+            x16 = img
+            for i in range(max(args.warmup, 1)):
+                x16 = step16(x16, i)
+            barrier()
+            t0 = time.perf_counter()
+            for i in range(args.steps):
+                x16 = step16(x16, args.warmup + i)
+            barrier()
+            dt16 = time.perf_counter() - t0
+        if world > 1:
+            tmax = torch.tensor([dt16], device=red_dev)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dt16 = float(tmax.item())
+        fp16_line = {"dtype": "fp16", "steps": args.steps, "ms_per_step": round(dt16 / args.steps * 1e3, 3),
+                     "value": round(args.steps / dt16 * elems * world, 3), "unit": "UNet element-forwards/s",
+                     "finite": bool(torch.isfinite(x16).all())}
+        del s16
+        mobi_amd.set_engine_dtype(dtype)
 
     if rank == 0:
         steps_per_s = args.steps / dt
@@ -448,6 +543,18 @@ def main():
                           f"log_data (2 VAE decodes, range de-normalisation, uint8 collages on the device) + all-gather of the decoded samples")
         if plms_line:
             out["plms_cfg5"] = plms_line
+        if fp16_line:
+            out["fp16"] = fp16_line
+        out["headline_frac_of_peak"] = out["model_frac_of_peak"]     # the model-level fraction; roofline.frac is one kernel's
+        if world > 1:
+            out["ranks_seen"] = dist.get_world_size()
+            out["backend"] = dist.get_backend()
+            out["ranks"] = ranks
+            out["ms_per_step_by_rank"] = [r["ms_per_step"] for r in ranks]
+        if objects_per_s is not None and gather_stat:
+            out["all_gather"] = {"bytes_per_rank": int(gather_stat["bytes_per_rank"]),
+                                 "bytes_total": int(gather_stat["bytes_per_rank"]) * world,
+                                 "ms": round(gather_stat["s"] * 1e3, 3)}
         if roofline:
             out["roofline"] = roofline
         if cpu_baseline:

@@ -247,6 +247,13 @@ typedef struct mobi_skinny_linear_params {
 } mobi_skinny_linear_params;
 int mobi_skinny_linear(const mobi_skinny_linear_params* p, void* stream);
 
+/* out[m][n] = sum_k x[m][k] * w[n][k] (+ bias[n]), everything fp32, fp32 FMA chains (k ascending): the per-run folds of
+ * the conditioning tokens into per-image vectors (BasicTransformerBlock, attention.py:237-243 of the reference: the two
+ * bbox tokens' keys / values pushed through to_q^T and connector o to_out once per sampling run).  Row strides in
+ * elements; any m, n, k. */
+int mobi_linear_f32(const float* x, const float* w, const float* bias, float* out, int32_t m, int32_t n, int32_t k,
+                    int32_t x_stride, int32_t w_stride, int32_t out_stride, void* stream);
+
 /* LayerNorm over the last axis of fp32 rows (row strides in elements): the single-token mapper and its final_ln
  * (ldm/modules/encoders/xf.py:78-101, modules.py:153-168 of the reference). */
 int mobi_layernorm_rows_f32(const float* x, const float* gamma, const float* beta, float* out, int32_t rows, int32_t cols,

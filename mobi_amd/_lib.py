@@ -140,6 +140,7 @@ SYMBOLS = {
     "mobi_softmax_rows": (C.c_int, [vp, vp, i64, i32, i32, vp]),
     "mobi_skinny_linear": (C.c_int, [C.POINTER(SkinnyLinearParams), vp]),
     "mobi_layernorm_rows_f32": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, i32, f32, vp]),
+    "mobi_linear_f32": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
     "mobi_quick_gelu": (C.c_int, [vp, vp, i64, i32, vp]),
     "mobi_timestep_embedding": (C.c_int, [vp, vp, vp, i32, i32, vp]),
     "mobi_conv_small_cin": (C.c_int, [C.POINTER(ConvSmallCinParams), vp]),

@@ -108,6 +108,13 @@ class StepGraph:
         finally:
             if gc_was_on:
                 gc.enable()
+        # what the captured launches read of the transformer blocks' loop-invariant terms: this graph's own slot per block
+        # (keyed on self.ctx); checked before every run's first replay
+        self._term_ptrs = self._context_term_addresses()
+
+    def _context_term_addresses(self):
+        blocks = _context_blocks(self.sampler.model)
+        return None if blocks is None else [b.context_term_addresses(self.ctx) for b in blocks]
 
     @property
     def sampler(self):
@@ -144,13 +151,18 @@ class StepGraph:
             if self.cfg:
                 self.uncond.copy_(uncond)
             self._cond_id = cid
-            if self._warm:                       # loop-invariant context terms: recomputed in place, once per run
-                blocks = _context_blocks(self.sampler.model)
-                if blocks is None:
-                    self._body()                 # opaque model: one eager evaluation refreshes every cache
-                else:
-                    for b in blocks:
-                        b._context_terms(self.ctx)
+            if self._warm and _context_blocks(self.sampler.model) is None:
+                self._body()                     # opaque model: one eager evaluation refreshes every cache
+        if self._warm:
+            # loop-invariant context terms: every block's slot for THIS graph's token buffer is checked on every run (a hit
+            # costs a tuple compare) -- other users of the model have slots of their own, in-place weight edits move the
+            # key -- and recomputed IN PLACE when stale; the captured addresses must still be the slot's
+            blocks = _context_blocks(self.sampler.model)
+            if blocks is not None:
+                for b in blocks:
+                    b._context_terms(self.ctx)
+                if getattr(self, "_term_ptrs", None) is not None and self._context_term_addresses() != self._term_ptrs:
+                    raise RuntimeError("a transformer block's context-term buffers moved under a captured step graph")
         self._refs = (parts_extra, cond, uncond)  # keep the callers' tensors alive: their ids / addresses stay unique
 
     def run(self, x, step, coef_row=None, noise=None):

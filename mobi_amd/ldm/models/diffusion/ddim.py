@@ -146,11 +146,23 @@ class DDIMSampler(object):
         sigma = float(self.ddim_sigmas[index])
         if noise is None and sigma != 0.0:       # the reference draws at every step (ddim.py:209); it matters here only
             noise = noise_like(x.shape, x.device)
-        if self.use_graph and graph.usable(x) and isinstance(c, torch.Tensor):
-            if step_value is None:
-                step_value = int(t[0])           # (host sync; ddim_sampling passes the value it already has)
+        use_graph = self.use_graph and graph.usable(x) and isinstance(c, torch.Tensor)
+        if use_graph and step_value is None:
+            # called from outside the sampling loops (ddim_sampling / plms_sampling pass the value they already have and
+            # refresh the weights fingerprint once per run): one read-back of `t`; the captured step takes ONE timestep for
+            # the whole batch, so a ragged `t` stays on the eager path, which honours it; in-place parameter edits since
+            # the last call move the fingerprint and re-capture
+            tv = t.tolist()
+            if len(set(tv)) == 1:
+                step_value = int(tv[0])
+                self._weights_fp = graph.weights_fingerprint(self.model)
+            else:
+                use_graph = False
+        if use_graph:
             g = graph.get(self, "ddim", x, c, uncond, scale, kwargs, temperature=temperature, has_noise=sigma != 0.0)
+            self._last_step_was_graph = True
             return g.run(x, step_value, self._coef_table()[index], noise)
+        self._last_step_was_graph = False
         e_cond, e_uncond = self._eps(x, c, t, scale, uncond, kwargs)
         x_prev, pred_x0, _ = ops.ddim_step(
             x, e_cond, e_uncond=e_uncond, noise=noise, cfg_scale=float(scale),
@@ -166,6 +178,6 @@ class DDIMSampler(object):
         x = x.float().contiguous()
         x_prev, pred_x0 = self._step(x, c, t, index, temperature, unconditional_guidance_scale,
                                      unconditional_conditioning, noise, kwargs, step_value)
-        if self.use_graph and graph.usable(x) and isinstance(c, torch.Tensor):
+        if getattr(self, "_last_step_was_graph", False):
             return x_prev.clone(), pred_x0.clone()       # static graph outputs: hand out copies
         return x_prev, pred_x0

@@ -453,7 +453,8 @@ class LatentDiffusion(DDPM):
                 log["image_sample"] = image_sample
         if self.use_lidar:
             lidar_sample = self.decode_first_stage(h_lidar, module_name="lidar_stage_model", clamp=(-1., 1.))
-            log["lidar_sample"] = lidar_sample
+            if return_sample:                      # (not a key of the reference's dict: a 2-channel tensor would break
+                log["lidar_sample"] = lidar_sample  # consumers that turn every entry into a picture, main.py:341-387)
             lid = batch.get("lidar") if isinstance(batch, dict) else None
             if lid is None:
                 return log, lidar_metrics
@@ -478,7 +479,7 @@ class LatentDiffusion(DDPM):
             if return_sample:
                 log["range_sample_depth"] = depth
                 log["range_sample_int"] = smp[:, [1]]
-                log["range_sample_int_denorm"] = inten
+                log["range_sample_int_denorm"] = inten    # (opt-in like lidar_sample; the reference keeps it local)
                 if "range_mask" in lid:
                     log["range_bbox_mask"] = 1 - lid["range_mask"].to(dev)[:, [0]]
             if full and "width_crop" in lid:

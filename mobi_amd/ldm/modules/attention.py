@@ -20,6 +20,8 @@ Launch sequence of one transformer block (all HIP, include/mobi_engine.h):
              the lidar half against the UPDATED camera half (attention.py:257-261)
   ff         layernorm -> igemm GEGLU -> igemm (+ residual)
 """
+import weakref
+
 import torch
 import torch.nn as nn
 
@@ -230,56 +232,93 @@ class BasicTransformerBlock(nn.Module):
     def _context_terms(self, ctx):
         """Everything that depends on the conditioning tokens only -- attn2's per-image vector and the bbox
         adapter's keys / values -- is the same at every denoising step of a sampling run.  It is computed once
-        per context tensor (the cache holds a reference to the tensor, so its storage cannot be recycled, and
-        checks the tensor's version counter and the weights' versions) instead of once per UNet call."""
+        per context tensor (a slot per live tensor object, see below; the key checks the tensor's version counter and
+        the weights' versions) instead of once per UNet call."""
         ws = [self.attn2.to_v.weight, self.attn2.to_out[0].weight, self.attn2.to_out[0].bias, self.attn1.to_out[0].bias]
         if self.bbox_cond:
             ca = self.cond_adapter_attn
             ws += [ca.to_k.weight, ca.to_v.weight, ca.to_q.weight, ca.to_out[0].weight, ca.to_out[0].bias,
                    self.cond_adapter_connector.weight, self.cond_adapter_connector.bias,
                    self.cond_adapter_norm.weight, self.cond_adapter_norm.bias]
-        key = (id(ctx), ctx._version, ctx.data_ptr(), tuple(ctx.shape), tuple(w._version for w in ws),
+        key = (ctx._version, ctx.data_ptr(), tuple(ctx.shape), tuple(w._version for w in ws),
                ws[0].data_ptr(), self.attn2.to_v.skinny()[0].dtype)
-        c = self.__dict__.setdefault("_ctx_cache", {})
-        if c.get("key") != key:
-            c["key"], c["ctx"] = key, ctx
+        # ONE SLOT PER CONTEXT TENSOR (keyed on the tensor object, dropped when it dies): a step graph captures the
+        # addresses of its slot's buffers, so nothing else may write there -- a second graph (other batch, guidance or
+        # sampler kind), the PLMS sampler or an eager call with other tokens get slots of their own.  (With one shared
+        # slot a graph replayed after such a call read the other caller's terms, or freed memory.)
+        slots = self.__dict__.setdefault("_ctx_slots", {})
+        sid = id(ctx)
+        c = slots.get(sid)
+        if c is None or c["ref"]() is not ctx:
+            c = {"ref": weakref.ref(ctx, lambda _r, s_=slots, i_=sid: s_.pop(i_, None)), "key": None}
+            slots[sid] = c
+        if c["key"] != key:
+            c["key"] = key
             # (+ attn1.to_out's bias: the launch that adds this vector then passes no separate bias)
             ref_vec = self.attn2.single_token_vector(ctx[:, 0], extra_bias=self.attn1.to_out[0].bias)
             kv = self.cond_adapter_attn.context_kv(ctx) if self.bbox_cond else None
             adapter = self._two_key_terms(kv) if self.bbox_cond and ctx.shape[1] == 2 else None
-            # results live in PERSISTENT buffers, refreshed in place while their shapes stay the same: a denoising
-            # step captured in a HIP graph (mobi_amd/graph.py) keeps reading the same addresses across runs
+            # results live in PERSISTENT buffers, refreshed in place while their shapes stay the same (they do for one
+            # context tensor): a denoising step captured in a HIP graph (mobi_amd/graph.py) keeps reading these addresses
             for name, val in (("ref_vec", ref_vec), ("kv", kv), ("adapter", adapter)):
                 c[name] = _store_in_place(c.get(name), val)
         return c["ref_vec"], c["kv"], c["adapter"]
 
+    def context_term_addresses(self, ctx):
+        """Device addresses of the slot `ctx` owns (None if it has none): what a captured step reads."""
+        c = self.__dict__.get("_ctx_slots", {}).get(id(ctx))
+        if c is None or c["ref"]() is not ctx or c["key"] is None:
+            return None
+        flat = []
+        for name in ("ref_vec", "kv", "adapter"):
+            v = c.get(name)
+            for t in (v if isinstance(v, tuple) else (v,)):
+                flat.append(None if t is None else t.data_ptr())
+        return tuple(flat)
+
+    def _two_key_params(self):
+        """The parameter-only factors of the two-token fold below, prepared once per weight version on the host in fp64
+        (load-time work like the weight packs) and kept as fp32 device tensors:
+        W = connector o to_out [query, inner], b0 = Wc bo + bc, to_q^T [query, inner], gamma * scale, beta * scale, and
+        the head mask [H, inner]."""
+        ca, ln, con = self.cond_adapter_attn, self.cond_adapter_norm, self.cond_adapter_connector
+        ps = [ca.to_q.weight, ca.to_out[0].weight, ca.to_out[0].bias, con.weight, con.bias, ln.weight, ln.bias]
+        key = tuple(p._version for p in ps) + (ps[0].data_ptr(), ps[0].device)
+        c = self.__dict__.setdefault("_two_key_cache", {})
+        if c.get("key") != key:
+            d = lambda t: t.detach().double().cpu()
+            wq, wo, bo, wc, bc, gamma, beta = (d(p) for p in ps)
+            h, inner = ca.heads, wq.shape[0]
+            mask = torch.zeros(h, inner, dtype=torch.float64)
+            for i in range(h):
+                mask[i, i * (inner // h):(i + 1) * (inner // h)] = 1.0
+            f = lambda t: t.float().contiguous().to(ps[0].device)
+            c["key"], c["val"] = key, (f(wc @ wo), f(wc @ bo + bc), f(wq.t()), f(gamma * ca.scale), f(beta * ca.scale), f(mask))
+        return c["val"]
+
     def _two_key_terms(self, kv):
         """The bbox adapter (attention.py:237-243 of the reference: `x + connector(attn(norm(x), context))`) against
-        exactly TWO context tokens, folded into per-image vectors -- exact algebra, fp64 on the parameters:
+        exactly TWO context tokens, folded into per-image vectors -- exact algebra:
           softmax over two keys = sigmoid of the score difference:  p0 = sigmoid(scale * q_h . (k0 - k1)_h)
           q = to_q(LN(x)) has no bias, so  q_h . dk_h = LN(x) . (Wq_h^T dk_h) = rstd * (x . a_h - mean * sum a_h) + c_h
           attention output = v1 + p0 * (v0 - v1), pushed through W = connector o to_out:  b + sum_h p0_h * u_h
         so no [T, C] x [C, C] product is left: `ops.two_key_adapter` makes one pass over the tokens.
+        The token-dependent products run once per sampling run as fp32 FMA chains on the engine (`mobi_linear_f32`; round 2
+        had fp64 torch products here, i.e. rocBLAS kernels inside the product path): head h's slice of the key / value
+        difference, zero elsewhere, times to_q^T resp. W.
         Returns (a [N,H,C], a_sum [N,H], c [N,H], u [N,H,C], b [N,C]) fp32."""
-        ca, ln, con = self.cond_adapter_attn, self.cond_adapter_norm, self.cond_adapter_connector
-        k, v = kv[0].double(), kv[1].double()                                  # [N, 2, C]
-        n, _, ci = k.shape
-        h, dh = ca.heads, ci // ca.heads
-        wq = ca.to_q.weight.detach().double()                                  # [inner, query]
-        wo, bo = ca.to_out[0].weight.detach().double(), ca.to_out[0].bias.detach().double()
-        wc, bc = con.weight.detach().double(), con.bias.detach().double()
-        w = wc @ wo                                                            # [query, inner]
-        b0 = wc @ bo + bc
-        dk = (k[:, 0] - k[:, 1]).view(n, h, dh)
-        dv = (v[:, 0] - v[:, 1]).view(n, h, dh)
-        wt = torch.einsum("hdc,nhd->nhc", wq.view(h, dh, -1), dk)              # Wq_h^T dk_h: [N, H, query]
-        gamma, beta = ln.weight.detach().double(), ln.bias.detach().double()
-        a = wt * gamma * ca.scale
-        c = (wt * beta).sum(-1) * ca.scale
-        u = torch.einsum("chd,nhd->nhc", w.view(-1, h, dh), dv)                # W_h dv_h: [N, H, query]
-        b = v[:, 1] @ w.t() + b0
-        f = lambda t: t.float().contiguous()
-        return f(a), f(a.sum(-1)), f(c), f(u), f(b)
+        w, b0, wqt, gamma_s, beta_s, mask = self._two_key_params()
+        k, v = kv[0].float(), kv[1].float()                                    # [N, 2, inner]
+        n, _, inner = k.shape
+        h = self.cond_adapter_attn.heads
+        dk = ((k[:, 0] - k[:, 1])[:, None, :] * mask[None]).reshape(n * h, inner).contiguous()
+        dv = ((v[:, 0] - v[:, 1])[:, None, :] * mask[None]).reshape(n * h, inner).contiguous()
+        wt = ops.linear_f32(dk, wqt).view(n, h, -1)                            # Wq_h^T dk_h: [N, H, query]
+        a = (wt * gamma_s).contiguous()
+        c = (wt * beta_s).sum(-1).contiguous()
+        u = ops.linear_f32(dv, w).view(n, h, -1).contiguous()                  # W_h dv_h: [N, H, query]
+        b = ops.linear_f32(v[:, 1].contiguous(), w, b0)
+        return a, a.sum(-1).contiguous(), c, u, b
 
     def _forward(self, x, context=None):
         """x: engine tokens [N,T,C]; context: fp32 [N, n_ctx, context_dim]."""

@@ -418,6 +418,18 @@ def skinny_linear(x, w, bias=None, pre_act=ACT_NONE, post_act=ACT_NONE, out=None
     return out
 
 
+def linear_f32(x, w, bias=None):
+    """fp32 [m, k] x fp32 [n, k]^T (+ fp32 bias [n]) -> fp32 [m, n]; plain fp32 FMA chains (mobi_linear_f32)."""
+    lib = _lib.load()
+    assert x.dtype == w.dtype == torch.float32 and x.dim() == w.dim() == 2 and x.stride(1) == 1 and w.stride(1) == 1
+    assert x.shape[1] == w.shape[1] and (bias is None or (bias.dtype == torch.float32 and bias.is_contiguous()))
+    _dev(x), _dev(w)
+    out = torch.empty((x.shape[0], w.shape[0]), device=x.device, dtype=torch.float32)
+    _lib.check(lib.mobi_linear_f32(_ptr(x), _ptr(w), _ptr(bias), _ptr(out), x.shape[0], w.shape[0], x.shape[1], x.stride(0),
+                                   w.stride(0), out.stride(0), _stream()), "mobi_linear_f32")
+    return out
+
+
 def layernorm_rows_f32(x, gamma, beta, eps=1e-5):
     """fp32 [rows, cols] (row stride free) -> fp32 [rows, cols]."""
     lib = _lib.load()

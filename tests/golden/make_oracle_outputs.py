@@ -15,12 +15,26 @@ from tests import oracle_cases as oc                       # noqa: E402
 def main():
     out = {}
     t0 = time.time()
+    if "--add-vae512" in sys.argv:                      # keep what the file holds, add the 512 x 512 VAE cases only
+        out = dict(np.load(oc.PATH))
+        for lidar in (False, True):
+            m, d = oc.vae512(lidar, live=True)
+            tag = "lidar" if lidar else "camera"
+            out[f"vae512_{tag}_moments"], out[f"vae512_{tag}_decode"] = m.numpy(), d.numpy().astype(np.float16)
+            print(f"vae512 {tag}: {time.time() - t0:.0f} s", flush=True)
+        np.savez_compressed(oc.PATH, **out)
+        print(f"wrote {oc.PATH}: {sorted(out)} ({os.path.getsize(oc.PATH) / 1e6:.1f} MB)")
+        return
     out["prod_64_16"] = oc.prod_forward(64, 16, live=True).numpy()
     print(f"prod 64x64 x 16: {time.time() - t0:.0f} s", flush=True)
     out["prod_32_8"] = oc.prod_forward(32, 8, live=True).numpy()
     out["full_width16"] = oc.full_width16(live=True).numpy()
     for k, v in oc.trajectories10(live=True).items():
         out["traj10_" + k] = v.numpy()
+    for lidar in (False, True):
+        m, d = oc.vae512(lidar, live=True)
+        tag = "lidar" if lidar else "camera"
+        out[f"vae512_{tag}_moments"], out[f"vae512_{tag}_decode"] = m.numpy(), d.numpy().astype(np.float16)
     np.savez_compressed(oc.PATH, **out)
     print(f"wrote {oc.PATH}: {sorted(out)} ({os.path.getsize(oc.PATH) / 1e6:.1f} MB, {time.time() - t0:.0f} s)")
 

@@ -9,7 +9,7 @@ import os
 import numpy as np
 import torch
 
-from oracle import sampler as osampler, unet as ounet, weights as W
+from oracle import sampler as osampler, unet as ounet, vae as ovae, weights as W
 
 PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "oracle_outputs.npz")
 LIVE = os.environ.get("MOBI_ORACLE_LIVE") == "1"          # ignore the file (the generator, the CPU check)
@@ -92,3 +92,24 @@ def trajectories10(live=False, only=None):
         out["mask_eta1"], _ = osampler.ddim_sample(eps, osampler.Schedule(10, eta=1.0), i["cond"], i["x_T"], rest, mask=i["cmask"],
                                                    x0=i["x0"], mask_noise=i["mn"], step_noise=i["sn"])
     return out
+
+
+def vae512_inputs(lidar):
+    cfg = ovae.VAEConfig(in_channels=2 if lidar else 3, out_ch=2 if lidar else 3, ch=128, lidar_adapter=lidar)
+    x = W.synth_input(f"prod.vae512.{lidar}", (1, cfg.in_channels, 512, 512), kind="uniform")
+    z = W.synth_input(f"prod.vae512.z.{lidar}", (1, 4, 64, 64))
+    return cfg, x, z
+
+
+def vae512(lidar, live=False):
+    """ch = 128 VAE (seed 23) at the resolution `mobi_nusc_512` / `all-classes_512` run it (512 x 512: mid.attn_1 sees 4,096
+    tokens of 512 channels): encoder moments [1, 8, 64, 64] fp32 and the decoded picture (kept as fp16 in the file: 2.4e-4
+    of quantisation against tolerances of 5e-3 and more) -> (moments, picture)."""
+    tag = "lidar" if lidar else "camera"
+    km, kd = f"vae512_{tag}_moments", f"vae512_{tag}_decode"
+    if not live and km in _file() and kd in _file():
+        return torch.from_numpy(_file()[km]), torch.from_numpy(_file()[kd].astype(np.float32))
+    _threads()
+    cfg, x, z = vae512_inputs(lidar)
+    sd = W.synth_state_dict(ovae.vae_param_shapes(cfg), 23)
+    return ovae.encode_moments(sd, cfg, x), ovae.decode(sd, cfg, z)

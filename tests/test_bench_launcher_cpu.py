@@ -36,6 +36,21 @@ def test_gpus_flag_spawns_ranks():
     assert abs(out["value"] - out["steps_per_s"] * 16 * 2) / out["value"] < 0.02
 
 
+def test_eight_ranks_self_verifying_line():
+    """The line of an N > 1 run says what the collective backend saw: world size, one record per rank (rank, local rank,
+    device, its own step time); the headline time is the maximum of the per-rank times."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "3", "--warmup", "0"],
+                       env=_env(), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = _line(r.stdout)
+    assert out["n_gpus"] == 8 == out["ranks_seen"] and out["backend"] == "gloo"
+    assert [x["rank"] for x in out["ranks"]] == list(range(8)) and sorted(x["local_rank"] for x in out["ranks"]) == list(range(8))
+    per = out["ms_per_step_by_rank"]
+    assert len(per) == 8 and per[7] >= 15.9 and per[0] < per[7]          # rank r sleeps 2 (r + 1) ms per step
+    assert out["ms_per_step"] >= max(per) - 0.5
+    assert abs(out["value"] - out["steps_per_s"] * 16 * 8) / out["value"] < 0.02
+
+
 def test_under_external_torchrun_and_mismatch():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))

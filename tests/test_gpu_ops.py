@@ -836,3 +836,15 @@ def test_igemm_pingpong_split_k(ops, dtype, blocks, tune):
     p.cout, p.n_packed, p.scale = cout, cout, 1.0
     p.dtype = _lib.MOBI_F16 if dtype == torch.float16 else _lib.MOBI_BF16
     assert _lib.load().mobi_igemm_kernel_variant(C.byref(p)) == 3
+
+
+@pytest.mark.parametrize("m,n,k", [(1, 7, 5), (16, 320, 320), (128, 1280, 1280), (33, 100, 770), (2, 640, 64)])
+def test_linear_f32(ops, m, n, k):
+    """mobi_linear_f32: the per-run folds of the conditioning tokens (fp32 in, fp32 FMA chains, fp32 out) against fp64."""
+    x = W.synth_input(f"lf.x{m}.{k}", (m, k + 3))[:, :k].cuda()          # row stride > k
+    w = W.synth_input(f"lf.w{n}.{k}", (n, k)).cuda()
+    b = W.synth_input(f"lf.b{n}", (n,)).cuda()
+    ref = x.double().cpu() @ w.double().cpu().t() + b.double().cpu()
+    y = ops.linear_f32(x, w, b)
+    assert y.dtype == torch.float32 and rel(y, ref) < 2e-6
+    assert rel(ops.linear_f32(x, w), ref - b.double().cpu()) < 2e-6

@@ -163,6 +163,26 @@ def test_full_width_vae_256(dtype, lidar):
     check(rel_l2(vae.decode(z.cuda()).cpu(), ref_rec), TOL_VAE[dtype], f"vae128_{tag}_decode_{dtype}")
 
 
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("lidar", [False, True], ids=["camera", "lidar"])
+def test_full_width_vae_512(dtype, lidar):
+    """The VAEs as `mobi_nusc_512` / `all-classes_512` configure them (resolution 512: BASELINE configs 3-5): ch = 128, one
+    512 x 512 input -- mid.attn_1 runs on 4,096 tokens of 512 channels (single head), the first / last levels on 128
+    channels at 512 x 512 (the lidar adapter's 1 x 5 convolutions there).  Oracle outputs from
+    tests/golden/oracle_outputs.npz (tests/oracle_cases.py vae512)."""
+    _set(dtype)
+    from tests import oracle_cases as oc
+    cfg, x, z = oc.vae512_inputs(lidar)
+    ref_m, ref_rec = oc.vae512(lidar)
+    sd = W.synth_state_dict(ovae.vae_param_shapes(cfg), 23)
+    vae = _vae(cfg, res=512)
+    vae.load_state_dict(sd)
+    vae = vae.cuda()
+    tag = "lidar" if lidar else "camera"
+    check(rel_l2(vae.encode(x.cuda()).parameters.cpu(), ref_m), TOL_VAE[dtype], f"vae128_512_{tag}_encode_{dtype}")
+    check(rel_l2(vae.decode(z.cuda()).cpu(), ref_rec), TOL_VAE[dtype], f"vae128_512_{tag}_decode_{dtype}")
+
+
 def test_pingpong_race_screen():
     """tools/race_screen.py: seven ping-pong shapes x 60 repeats with odd persistent-block counts and an HBM-thrashing
     copy in between, every output bit for bit equal to the first."""

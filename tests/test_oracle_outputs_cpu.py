@@ -18,6 +18,9 @@ def test_file_holds_every_case():
     f = dict(np.load(oc.PATH))
     assert f["prod_64_16"].shape == (16, 4, 64, 64) and f["prod_32_8"].shape == (8, 4, 32, 32)
     assert f["full_width16"].shape == (2, 4, 16, 16) and int(f["traj10_n_pred_x0"]) > 0
+    for tag, ch in (("camera", 3), ("lidar", 2)):
+        assert f[f"vae512_{tag}_moments"].shape == (1, 8, 64, 64) and f[f"vae512_{tag}_decode"].shape == (1, ch, 512, 512)
+        assert np.isfinite(f[f"vae512_{tag}_moments"]).all() and np.isfinite(f[f"vae512_{tag}_decode"].astype(np.float32)).all()
     for k in ("ddim_1.0", "ddim_5.0", "plms_1.0", "plms_5.0", "mask_eta1"):
         assert f["traj10_" + k].shape == (4, 4, 16, 16) and np.isfinite(f["traj10_" + k]).all()
 
