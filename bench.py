@@ -439,7 +439,7 @@ def main():
         for kname_, d in kinds.items():
             if kname_ == "igemm" or d["ms"] <= 0:
                 continue
-            if d["flops"] > 0 and kname_ == "attention":
+            if d["flops"] > 0:
                 fam[kname_] = {"ms": round(d["ms"], 3), "launches": d["launches"],
                                "tflops": round(d["flops"] / (d["ms"] * 1e-3) / 1e12, 1),
                                "frac": round(d["flops"] / (d["ms"] * 1e-3) / 1e12 / PEAK_TFLOPS, 4)}
@@ -454,7 +454,7 @@ def main():
         roofline["launches_per_step_all"] = len(sink)
         if os.path.exists(pmc):
             traffic = {}
-            for fam_k in ("igemm_ring_kernel", "igemm_pp_kernel", "attention_rows_kernel", "attention_kernel",
+            for fam_k in ("igemm_ring_kernel", "igemm_pp_kernel", "attention_rows_kernel", "attention_kernel", "ff_geglu_kernel",
                           "gn_stats_kernel", "gn_apply_kernel", "layernorm_kernel"):
                 rec = doc.get(fam_k)
                 if rec and doc.get("config") == run_cfg:

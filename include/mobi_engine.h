@@ -192,6 +192,35 @@ typedef struct mobi_attention_params {
 } mobi_attention_params;
 int mobi_attention(const mobi_attention_params* p, void* stream);
 
+/* ---------------------------------------------------------------------------
+ * Fused GEGLU feed-forward (FeedForward / GEGLU, attention.py:38-65):
+ *   out = ((x W1v^T + b1v) * gelu_erf(x W1g^T + b1g)) W2^T + b2 (+ residual)
+ * in one launch; the hidden activation [rows][hidden] is never written.  c = 320
+ * (the 64 x 64 level of the UNet), hidden % 32 == 0.
+ * w_packed: mobi_ff_geglu_packed_bytes(c, hidden) bytes of "chunk images" (one
+ * chunk = 32 hidden units), every fragment 1 KiB = 64 lanes x 8 T in the lane order
+ * of the MFMA A operand (lane l: row l & 31, column group l >> 5):
+ *   first   [hidden/32][2 c/16 fragments]: fragment t c/16 + ks (t = 0 value rows, 1 gate
+ *           rows of GEGLU.proj.weight [2 hidden][c]): element j = W1[t hidden + 32 chunk +
+ *           (l & 31)][16 ks + 8 (l >> 5) + j];
+ *   then    [hidden/32][2 c/32 fragments + 1]: fragment 2 m + s: element j =
+ *           W2[32 m + (l & 31)][32 chunk + 16 s + 8 (j >> 2) + 4 (l >> 5) + (j & 3)]
+ *           (net[2].weight [c][hidden]; the unit order of the first product's accumulator),
+ *           the last KiB = the chunk's 32 value and 32 gate entries of GEGLU.proj.bias as fp32.
+ * ------------------------------------------------------------------------- */
+typedef struct mobi_ff_geglu_params {
+  const void* x;            /* T [rows][c], dense */
+  int64_t rows;
+  int32_t c, hidden;
+  const void* w_packed;
+  const float* b2;          /* [c] or NULL */
+  const void* residual;     /* T [rows][c] or NULL (may alias out) */
+  void* out;                /* T [rows][c] */
+  int32_t dtype;
+} mobi_ff_geglu_params;
+size_t mobi_ff_geglu_packed_bytes(int32_t c, int32_t hidden);
+int mobi_ff_geglu(const mobi_ff_geglu_params* p, void* stream);
+
 /* Attention against a handful of context tokens (tk <= 8): the bbox adapter
  * (attention.py:237-243, tk = 2).  k, v are fp32 [image][tk][heads*dh]. */
 typedef struct mobi_ctx_attention_params {

@@ -57,6 +57,11 @@ class AttentionParams(C.Structure):
                 ("dtype", i32), ("v_layout", i32), ("q_log2_scaled", i32)]
 
 
+class FfGegluParams(C.Structure):
+    _fields_ = [("x", vp), ("rows", i64), ("c", i32), ("hidden", i32), ("w_packed", vp), ("b2", vp), ("residual", vp),
+                ("out", vp), ("dtype", i32)]
+
+
 class CtxAttentionParams(C.Structure):
     _fields_ = [("q", vp), ("out", vp), ("k", vp), ("v", vp), ("images", i32), ("heads", i32), ("dh", i32),
                 ("tq", i32), ("tk", i32), ("scale", f32), ("dtype", i32)]
@@ -118,7 +123,8 @@ class ImagePrepareParams(C.Structure):
 
 STRUCT_IDS = {0: IgemmParams, 1: GroupNormParams, 2: LayerNormParams, 3: AttentionParams, 4: CtxAttentionParams,
               5: SkinnyLinearParams, 6: ConvSmallCinParams, 7: ConvSmallCoutParams, 8: DdimStepParams, 9: TwoKeyAdapterParams,
-              10: RangePasteParams, 11: LidarMetricsParams, 12: RangePrepareParams, 13: ImagePrepareParams}
+              10: RangePasteParams, 11: LidarMetricsParams, 12: RangePrepareParams, 13: ImagePrepareParams,
+              14: FfGegluParams}
 
 # every symbol include/mobi_engine.h declares: name -> (restype, argtypes)
 SYMBOLS = {
@@ -141,6 +147,8 @@ SYMBOLS = {
     "mobi_skinny_linear": (C.c_int, [C.POINTER(SkinnyLinearParams), vp]),
     "mobi_layernorm_rows_f32": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, i32, f32, vp]),
     "mobi_linear_f32": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
+    "mobi_ff_geglu": (C.c_int, [C.POINTER(FfGegluParams), vp]),
+    "mobi_ff_geglu_packed_bytes": (C.c_size_t, [i32, i32]),
     "mobi_quick_gelu": (C.c_int, [vp, vp, i64, i32, vp]),
     "mobi_timestep_embedding": (C.c_int, [vp, vp, vp, i32, i32, vp]),
     "mobi_conv_small_cin": (C.c_int, [C.POINTER(ConvSmallCinParams), vp]),

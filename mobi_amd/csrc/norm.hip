@@ -10,6 +10,7 @@
 //          E[x^2] - mean^2), then streams y = x * a[c] + b[c], optional SiLU.
 // Algorithmic bytes: 2 B read (stats) + 2 B read + 2 B written (apply) per element.
 #include "common.h"
+#include "tuning.h"
 
 namespace mobi {
 
@@ -180,6 +181,66 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const GnArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------
+// One-launch GroupNorm(+SiLU) for SMALL tensors: one block per (group, image) keeps the group's slab (hw x C/32 channels,
+// at most GN1_MAX elements of T) in LDS: read once, mean, variance about the mean (two passes over LDS, fixed order),
+// y = (x - mean) * rstd * gamma + beta, optional SiLU, written once.  The 16 x 16 / 8 x 8 levels of mobi_nusc_512 and every
+// level of mobi_nusc_256 qualify: there the two-launch form above is bound by its launches (7-8 us each), not by bytes.
+// Algorithmic bytes: 2 B read + 2 B written per element.
+constexpr int GN1_MAX = 32768;
+template <typename T>
+__global__ __launch_bounds__(256) void gn_fused_kernel(const GnArgs a) {
+  __shared__ unsigned slab[GN1_MAX / 2];               // channel pairs (C / 32 is even for every C % 64 == 0 ... see host)
+  __shared__ float s_red[8];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = blockIdx.x, img = blockIdx.y;
+  const int cpg = a.C / 32, hp = cpg >> 1;             // channels / channel pairs of the group
+  const int n2 = a.hw * hp;                            // pairs in the slab
+  const int c_first = g * cpg;
+  const T* __restrict__ s0 = reinterpret_cast<const T*>(a.src0) + (long long)img * a.hw * a.c0;
+  const T* __restrict__ s1 = a.src1 ? reinterpret_cast<const T*>(a.src1) + (long long)img * a.hw * a.c1 : nullptr;
+  typedef T T2 __attribute__((ext_vector_type(2)));
+  auto block_sum = [&](float v) {
+    v = wave_sum(v);
+    __syncthreads();                                   // (also orders this reduction behind the previous one's reads)
+    if (lane == 0) s_red[wave] = v;
+    __syncthreads();
+    return (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+  };
+  float sum = 0.f;
+  for (int d = tid; d < n2; d += 256) {
+    const int p = d / hp, j = d - p * hp;
+    const int c = c_first + 2 * j;
+    const T* src = c >= a.c0 ? s1 + (long long)p * a.c1 + (c - a.c0) : s0 + (long long)p * a.c0 + c;
+    const unsigned raw = *reinterpret_cast<const unsigned*>(src);
+    slab[d] = raw;
+    const T2 v = __builtin_bit_cast(T2, raw);
+    sum += (float)v[0] + (float)v[1];
+  }
+  const float n = (float)a.hw * (float)cpg;
+  const float mean = block_sum(sum) / n;
+  float sq = 0.f;
+  for (int d = tid; d < n2; d += 256) {
+    const T2 v = __builtin_bit_cast(T2, slab[d]);
+    const float d0 = (float)v[0] - mean, d1 = (float)v[1] - mean;
+    sq += d0 * d0 + d1 * d1;
+  }
+  const float rstd = rsqrtf(block_sum(sq) / n + a.eps);
+  T* __restrict__ out = reinterpret_cast<T*>(a.out) + (long long)img * a.hw * a.C;
+  for (int d = tid; d < n2; d += 256) {
+    const int p = d / hp, j = d - p * hp;
+    const int c = c_first + 2 * j;
+    const T2 v = __builtin_bit_cast(T2, slab[d]);
+    float y0 = ((float)v[0] - mean) * rstd * a.gamma[c] + a.beta[c];
+    float y1 = ((float)v[1] - mean) * rstd * a.gamma[c + 1] + a.beta[c + 1];
+    if (a.silu) { y0 = silu_f(y0); y1 = silu_f(y1); }
+    T2 o;
+    o[0] = (T)y0;
+    o[1] = (T)y1;
+    *reinterpret_cast<unsigned*>(out + (long long)p * a.C + c) = __builtin_bit_cast(unsigned, o);
+  }
+}
+
+// ---------------------------------------------------------------------------------------
 struct LnArgs {
   const void* src; void* out;
   int images, rows, C; long long src_img, out_img;
@@ -248,6 +309,13 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const LnArgs a) {
 
 template <typename T>
 static int launch_gn(const GnArgs& a, int batch, hipStream_t st) {
+  // small tensors: one launch, the group's slab in LDS (channel pairs: C / 32 even; both sources split at an even channel)
+  const int cpg = a.C / 32;
+  if (!(cpg & 1) && (long long)a.hw * cpg <= GN1_MAX && tuning().gn_fused != 0) {
+    hipLaunchKernelGGL((gn_fused_kernel<T>), dim3(32, batch), dim3(256), 0, st, a);
+    MOBI_CHECK_LAUNCH();
+    return MOBI_OK;
+  }
   hipLaunchKernelGGL((gn_stats_kernel<T>), dim3(a.chunks, batch), dim3(256), 0, st, a);
   MOBI_CHECK_LAUNCH();
   const long long vecs = (long long)a.hw * (a.C >> 3);

@@ -229,6 +229,7 @@ extern "C" size_t mobi_struct_size(int id) {
     case 11: return sizeof(mobi_lidar_metrics_params);
     case 12: return sizeof(mobi_range_prepare_params);
     case 13: return sizeof(mobi_image_prepare_params);
+    case 14: return sizeof(mobi_ff_geglu_params);
     default: return 0;
   }
 }

@@ -700,42 +700,29 @@ __global__ __launch_bounds__(256) void two_key_adapter_mfma_kernel(const mobi_tw
   }
 }
 
-// fp32 x fp32 -> fp32 small GEMM (x [m][k], w [n][k]): 16 x 64 output tile per block, k in LDS slabs of 32; each thread owns
-// one row and four columns (stride 16) and runs plain fp32 FMA chains in k order.  For the per-run context folds only.
+// fp32 x fp32 -> fp32 small GEMM (x [m][k], w [n][k]): 16 x 16 output tile per block (one output per thread, so that the
+// few rows of these folds still spread over hundreds of blocks), k in LDS slabs of 32, plain fp32 FMA chains in k order.
+// For the per-run context folds only.
 __global__ __launch_bounds__(256) void linear_f32_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                          const float* __restrict__ bias, float* __restrict__ out, int m,
                                                          int n, int k, int xs, int ws, int os) {
-  __shared__ float lx[16][33], lw[64][33];
+  __shared__ float lx[16][33], lw[16][33];
   const int tid = threadIdx.x, r = tid >> 4, c = tid & 15;
-  const int m0 = blockIdx.y * 16, n0 = blockIdx.x * 64;
-  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  const int m0 = blockIdx.y * 16, n0 = blockIdx.x * 16;
+  float acc = 0.f;
   for (int k0 = 0; k0 < k; k0 += 32) {
     for (int i = tid; i < 16 * 32; i += 256) {
       const int rr = i >> 5, kk = i & 31;
       lx[rr][kk] = (m0 + rr < m && k0 + kk < k) ? x[(long long)(m0 + rr) * xs + k0 + kk] : 0.f;
-    }
-    for (int i = tid; i < 64 * 32; i += 256) {
-      const int rr = i >> 5, kk = i & 31;
       lw[rr][kk] = (n0 + rr < n && k0 + kk < k) ? w[(long long)(n0 + rr) * ws + k0 + kk] : 0.f;
     }
     __syncthreads();
 #pragma unroll 8
-    for (int kk = 0; kk < 32; ++kk) {
-      const float xv = lx[r][kk];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) acc[j] = __builtin_fmaf(xv, lw[c + 16 * j][kk], acc[j]);
-    }
+    for (int kk = 0; kk < 32; ++kk) acc = __builtin_fmaf(lx[r][kk], lw[c][kk], acc);
     __syncthreads();
   }
-  if (m0 + r < m) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int col = n0 + c + 16 * j;
-      if (col < n) out[(long long)(m0 + r) * os + col] = acc[j] + (bias ? bias[col] : 0.f);
-    }
-  }
+  if (m0 + r < m && n0 + c < n) out[(long long)(m0 + r) * os + n0 + c] = acc + (bias ? bias[n0 + c] : 0.f);
 }
-
 }  // namespace mobi
 
 using namespace mobi;
@@ -759,7 +746,7 @@ extern "C" int mobi_linear_f32(const float* x, const float* w, const float* bias
   if (!x || !w || !out || m <= 0 || n <= 0 || k <= 0) return MOBI_ERR_ARG;
   if (x_stride < k || w_stride < k || out_stride < n) return MOBI_ERR_ARG;
   if ((m + 15) / 16 > 65535) return MOBI_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL(linear_f32_kernel, dim3((n + 63) / 64, (m + 15) / 16), dim3(256), 0, ST(stream), x, w, bias, out, m, n,
+  hipLaunchKernelGGL(linear_f32_kernel, dim3((n + 15) / 16, (m + 15) / 16), dim3(256), 0, ST(stream), x, w, bias, out, m, n,
                      k, x_stride, w_stride, out_stride);
   MOBI_CHECK_LAUNCH();
   return MOBI_OK;

@@ -34,6 +34,7 @@ void read_env() {
   g_tuning.attn_nw = env_int("MOBI_ATTN_NW");
   g_tuning.attn_sp = env_int("MOBI_ATTN_SP");
   g_tuning.attn_v3 = env_int("MOBI_ATTN_V3");
+  g_tuning.gn_fused = env_int("MOBI_GN_FUSED");
 }
 }  // namespace
 

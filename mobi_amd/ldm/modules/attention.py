@@ -20,14 +20,18 @@ Launch sequence of one transformer block (all HIP, include/mobi_engine.h):
              the lidar half against the UPDATED camera half (attention.py:257-261)
   ff         layernorm -> igemm GEGLU -> igemm (+ residual)
 """
+import os
 import weakref
 
 import torch
 import torch.nn as nn
 
-from ... import ops
+from ... import engine_dtype, ops
 from ..._lib import ACT_NONE
 from .diffusionmodules.util import Conv2d, GroupNorm32, LayerNorm, Linear, Marker, enter, leave, zero_module
+
+
+FUSED_FF = os.environ.get("MOBI_FUSED_FF", "1") != "0"      # A/B: 0 = GEGLU projection and output projection as two launches
 
 
 def _store_in_place(old, new):
@@ -67,7 +71,25 @@ class FeedForward(nn.Module):
         dim_out = dim if dim_out is None else dim_out
         self.net = nn.Sequential(GEGLU(dim, inner_dim), Marker(), Linear(inner_dim, dim_out))
 
+    def _fused(self):
+        """Chunk images of the pair for mobi_ff_geglu (C = 320: the output accumulators of a 32-row tile fit the registers),
+        or None; cached per weight version and storage type like the other packs."""
+        proj, out = self.net[0].proj, self.net[2]
+        c, hidden = out.weight.shape
+        if not (FUSED_FF and ops.ff_geglu_supported(c, hidden) and proj.weight.shape == (2 * hidden, c)):
+            return None
+        ps = (proj.weight, proj.bias, out.weight, out.bias)
+        key = tuple(p._version for p in ps) + (ps[0].data_ptr(), ps[0].device, engine_dtype())
+        cache = self.__dict__.setdefault("_fused_cache", {})
+        if cache.get("key") != key:
+            cache["key"], cache["val"] = key, ops.pack_ff_geglu(proj.weight, proj.bias, out.weight, out.bias, engine_dtype(),
+                                                                proj.weight.device)
+        return cache["val"]
+
     def forward(self, x, residual=None):
+        pf = self._fused() if x.is_contiguous() and (residual is None or residual.is_contiguous()) else None
+        if pf is not None:
+            return ops.ff_geglu(x, pf, residual=residual)        # one launch, the hidden activation never leaves the chip
         return ops.linear(self.net[0](x), self.net[2].packed(), residual=residual)
 
 

@@ -205,6 +205,69 @@ def pack_geglu(weight, bias, dtype, device):
     return Packed(wp.to(dtype).contiguous(), bp.contiguous(), 1, 1, cin, inner, n_packed, geglu=True)
 
 
+class PackedFf:
+    """Chunk images of a GEGLU feed-forward pair for mobi_ff_geglu (layout: include/mobi_engine.h)."""
+
+    def __init__(self, buf, b2, c, hidden, dtype):
+        self.buf, self.b2, self.c, self.hidden, self.dtype = buf, b2, c, hidden, dtype
+
+
+def ff_geglu_supported(c, hidden):
+    return c == 320 and hidden % 32 == 0
+
+
+def pack_ff_geglu(w1, b1, w2, b2, dtype, device):
+    """w1: GEGLU.proj.weight [2 hidden, c] (value rows, then gate rows), b1 [2 hidden]; w2: net[2].weight [c, hidden],
+    b2 [c] -> PackedFf.  Index arithmetic only (a gather of the fp32 masters, one rounding to the storage type)."""
+    two_h, c = w1.shape
+    hidden = two_h // 2
+    assert w2.shape == (c, hidden) and ff_geglu_supported(c, hidden)
+    ks_n, mt_n, nch = c // 16, c // 32, hidden // 32
+    w1 = w1.detach().to(device=device, dtype=torch.float32)
+    w2 = w2.detach().to(device=device, dtype=torch.float32)
+    ar = lambda n: torch.arange(n, device=device)
+    lane, j = ar(64), ar(8)
+    m_, h_ = lane & 31, lane >> 5
+    # first product: fragment (t, ks): rows t hidden + 32 chunk + m, columns 16 ks + 8 h + j
+    rows1 = (ar(2)[None, :, None, None] * hidden + ar(nch)[:, None, None, None] * 32 + m_[None, None, None, :])   # [nch,2,1,64]
+    cols1 = (ar(ks_n)[:, None, None] * 16 + h_[None, :, None] * 8 + j[None, None, :])                             # [KS,64,8]
+    img1 = w1[rows1.expand(nch, 2, ks_n, 64)[..., None], cols1[None, None]]                                      # [nch,2,KS,64,8]
+    # second product: fragment (m, s): rows 32 m + m_, units 32 chunk + 16 s + 8 (j >> 2) + 4 h + (j & 3)
+    rows2 = (ar(mt_n)[:, None, None] * 32 + m_[None, None, :])                                                    # [MT,1,64]
+    unit = (ar(2)[:, None, None] * 16 + ((j >> 2) * 8 + (j & 3))[None, None, :] + h_[None, :, None] * 4)           # [2,64,8]
+    cols2 = ar(nch)[:, None, None, None, None] * 32 + unit[None, None]                                            # [nch,1,2,64,8]
+    img2 = w2[rows2.expand(mt_n, 2, 64)[None, ..., None], cols2.expand(nch, mt_n, 2, 64, 8)]                      # [nch,MT,2,64,8]
+    esz = torch.empty((), dtype=dtype).element_size()
+    assert esz == 2
+    p1 = img1.to(dtype).contiguous().view(torch.uint8).reshape(nch, -1)
+    p2 = img2.to(dtype).contiguous().view(torch.uint8).reshape(nch, -1)
+    b1f = b1.detach().to(device=device, dtype=torch.float32)
+    bias = torch.zeros((nch, 256), device=device, dtype=torch.float32)
+    bias[:, :32] = b1f[:hidden].reshape(nch, 32)
+    bias[:, 32:64] = b1f[hidden:].reshape(nch, 32)
+    buf = torch.cat([p1.reshape(-1), torch.cat([p2, bias.view(torch.uint8).reshape(nch, -1)], dim=1).reshape(-1)]).contiguous()
+    assert buf.numel() == _lib.load().mobi_ff_geglu_packed_bytes(c, hidden)
+    return PackedFf(buf, None if b2 is None else b2.detach().to(device=device, dtype=torch.float32).contiguous(), c, hidden, dtype)
+
+
+def ff_geglu(x, pf: PackedFf, residual=None, out=None):
+    """x: T [..., c] dense -> out T [..., c] = GEGLU feed-forward (+ residual) in one launch (mobi_ff_geglu)."""
+    lib = _lib.load()
+    _dev(x)
+    assert x.is_contiguous() and x.shape[-1] == pf.c and x.dtype == pf.dtype
+    rows = x.numel() // pf.c
+    if out is None:
+        out = torch.empty_like(x)
+    assert out.is_contiguous() and out.shape == x.shape and (residual is None or (residual.is_contiguous() and residual.shape == x.shape))
+    p = _lib.FfGegluParams()
+    p.x, p.rows, p.c, p.hidden, p.w_packed, p.b2 = _ptr(x), rows, pf.c, pf.hidden, _ptr(pf.buf), _ptr(pf.b2)
+    p.residual, p.out, p.dtype = _ptr(residual), _ptr(out), _dt(x.dtype)
+    fl = 2.0 * rows * pf.c * (2 * pf.hidden) + 2.0 * rows * pf.hidden * pf.c
+    with _Timed("ff_geglu", fl, 2.0 * rows * pf.c * (3 if residual is not None else 2), f"rows={rows} c={pf.c} hidden={pf.hidden}"):
+        _lib.check(lib.mobi_ff_geglu(C.byref(p), _stream()), "mobi_ff_geglu")
+    return out
+
+
 # --------------------------------------------------------------------------------------
 # matrix-core ops
 # --------------------------------------------------------------------------------------
@@ -303,7 +366,8 @@ def groupnorm(x, gamma, beta, eps, silu, x2=None):
     p.src0, p.src1, p.c0, p.c1, p.batch, p.hw = _ptr(x), _ptr(x2), c0, c1, n, h * w
     p.gamma, p.beta, p.eps, p.silu = _ptr(gamma), _ptr(beta), eps, int(silu)
     p.out, p.ws, p.dtype = _ptr(out), _ptr(ws), _dt(x.dtype)
-    with _Timed("groupnorm", 0.0):
+    # algorithmic bytes: the tensor read once and written once (2 B per element each way)
+    with _Timed("groupnorm", 0.0, 2.0 * out.numel() * 2, f"n={n} hw={h * w} c={c0 + c1}"):
         _lib.check(lib.mobi_groupnorm(C.byref(p), _stream()), "mobi_groupnorm")
     return out
 
@@ -319,7 +383,7 @@ def layernorm(x, gamma, beta, eps=1e-5):
     p.src_img_stride = 0 if s == t * c else s
     p.out_img_stride = 0
     p.gamma, p.beta, p.eps, p.dtype = _ptr(gamma), _ptr(beta), eps, _dt(x.dtype)
-    with _Timed("layernorm", 0.0):
+    with _Timed("layernorm", 0.0, 2.0 * out.numel() * 2):
         _lib.check(lib.mobi_layernorm(C.byref(p), _stream()), "mobi_layernorm")
     return out
 

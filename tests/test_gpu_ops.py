@@ -55,8 +55,11 @@ def ops():
 @pytest.mark.parametrize("dtype", DT)
 @pytest.mark.parametrize("c0,c1,hw,silu", [(32, 0, 64, True), (320, 0, 4096, True), (320, 0, 4096, False),
                                            (1280, 1280, 64, True), (1280, 640, 256, True), (640, 320, 1024, True),
-                                           (64, 0, 17, True), (128, 0, 4096, True)])
-def test_groupnorm(ops, dtype, c0, c1, hw, silu):
+                                           (64, 0, 17, True), (128, 0, 4096, True), (1280, 0, 256, True),
+                                           (1920, 640, 64, False), (960, 960, 16, True)])
+def test_groupnorm(ops, dtype, c0, c1, hw, silu, tune):
+    """two-launch GroupNorm (statistics, apply) and, where a group's slab fits LDS, the one-launch kernel (gn_fused_kernel:
+    small tensors); both against fp32 torch."""
     h = int(math.isqrt(hw)) if int(math.isqrt(hw)) ** 2 == hw else 1
     w = hw // h
     xf, xd = rnd(f"gn{c0}.{c1}.{hw}", (2, h, w, c0), dtype, 2.0)
@@ -75,6 +78,9 @@ def test_groupnorm(ops, dtype, c0, c1, hw, silu):
     ref = F.silu(ref) if silu else ref
     assert y.shape == (2, h, w, C)
     assert rel(y.float().permute(0, 3, 1, 2), ref) < TOL[dtype]
+    tune.setenv("MOBI_GN_FUSED", "0")                        # the two-launch form on the shapes the fused kernel takes
+    y2 = ops.groupnorm(xd, g.cuda(), b.cuda(), 1e-5, silu, x2=x2d)
+    assert rel(y2.float().permute(0, 3, 1, 2), ref) < TOL[dtype]
 
 
 @pytest.mark.parametrize("dtype", DT)
@@ -848,3 +854,30 @@ def test_linear_f32(ops, m, n, k):
     y = ops.linear_f32(x, w, b)
     assert y.dtype == torch.float32 and rel(y, ref) < 2e-6
     assert rel(ops.linear_f32(x, w), ref - b.double().cpu()) < 2e-6
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("rows,hidden,residual", [(128, 1280, True), (65536, 1280, True), (300, 1280, False), (1, 64, True),
+                                                  (4096 + 17, 320, True)])
+def test_ff_geglu_fused(ops, dtype, rows, hidden, residual):
+    """mobi_ff_geglu: (x W1v^T + b1v) * gelu(x W1g^T + b1g) . W2^T + b2 + residual in one launch (C = 320) against fp32
+    torch with the hidden activation rounded to the storage type (as both engine paths do), and against the two-launch
+    path (GEGLU projection, then the output projection)."""
+    c = 320
+    xf, xd = rnd(f"ff.x{rows}", (rows, c), dtype)
+    rf, rd = rnd(f"ff.r{rows}", (rows, c), dtype)
+    w1 = torch.from_numpy(W.synth_param("ff.w1.weight", (2 * hidden, c))) * 2.0
+    b1 = torch.from_numpy(W.synth_param("ff.w1.bias", (2 * hidden,)))
+    w2 = torch.from_numpy(W.synth_param("ff.w2.weight", (c, hidden))) * 2.0
+    b2 = torch.from_numpy(W.synth_param("ff.w2.bias", (c,)))
+    pf = ops.pack_ff_geglu(w1, b1, w2, b2, dtype, "cuda")
+    y = ops.ff_geglu(xd, pf, residual=rd if residual else None)
+    w1r, w2r = w1.to(dtype).float(), w2.to(dtype).float()
+    h = F.linear(xf, w1r, b1)
+    h = (h[:, :hidden] * F.gelu(h[:, hidden:])).to(dtype).float()
+    ref = F.linear(h, w2r, b2) + (rf if residual else 0)
+    assert y.shape == (rows, c) and rel(y.float(), ref) < TOL[dtype]
+    # the two-launch path on the same inputs
+    g = ops.linear(xd.view(1, rows, c), ops.pack_geglu(w1, b1, dtype, "cuda"))
+    y2 = ops.linear(g, ops.pack_linear(w2, b2, dtype, "cuda"), residual=rd.view(1, rows, c) if residual else None)
+    assert rel(y.float(), y2.view(rows, c).float().cpu()) < TOL[dtype]

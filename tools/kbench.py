@@ -32,7 +32,7 @@ def timeit(fn, iters, warm=3):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("kind", choices=["attn", "conv", "linear", "gn", "ln", "tka"])
+    ap.add_argument("kind", choices=["attn", "conv", "linear", "gn", "ln", "tka", "ff"])
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--heads", type=int, default=8)
@@ -71,6 +71,26 @@ def main():
         us = timeit(lambda: ops.attention(q, k, vt, a.heads, a.dh ** -0.5, v_rows=a.v_rows), a.iters)
         fl = 4.0 * a.images * a.heads * a.t * a.t * a.dh
         print(f"attention heads={a.heads} dh={a.dh} T={a.t} images={a.images}: {us:.1f} us  {fl / us / 1e6:.1f} TFLOP/s")
+    elif a.kind == "ff":
+        # fused GEGLU feed-forward (mobi_ff_geglu) against the two launches it replaces
+        c, hidden = a.cin, 4 * a.cin
+        x, res = rn(a.rows, c), rn(a.rows, c)
+        w1 = torch.randn(2 * hidden, c, generator=g) / c ** 0.5
+        w2 = torch.randn(c, hidden, generator=g) / hidden ** 0.5
+        b1, b2 = torch.zeros(2 * hidden), torch.zeros(c)
+        pf = ops.pack_ff_geglu(w1, b1, w2, b2, dt, dev)
+        pg, po = ops.pack_geglu(w1, b1, dt, dev), ops.pack_linear(w2, b2, dt, dev)
+        x3, r3 = x.view(1, a.rows, c), res.view(1, a.rows, c)
+        fused = lambda: ops.ff_geglu(x, pf, residual=res)
+        two = lambda: ops.linear(ops.linear(x3, pg), po, residual=r3)
+        best = {}
+        for rep in range(3):
+            for tag, fn in (("fused", fused), ("two launches", two)):
+                best[tag] = min(best.get(tag, 1e30), timeit(fn, a.iters))
+        fl = 2.0 * a.rows * c * 2 * hidden + 2.0 * a.rows * hidden * c
+        d = float((fused().float() - two().view(a.rows, c).float()).norm() / two().float().norm())
+        print(f"ff_geglu rows={a.rows} c={c}: " + " | ".join(f"{t} {v:.1f} us {fl / v / 1e6:.0f} TFLOP/s" for t, v in best.items()) +
+              f" | rel diff {d:.2e}")
     elif a.kind == "conv":
         x = rn(a.images, a.hw, a.hw, a.cin)
         x2 = rn(a.images, a.hw, a.hw, a.cin2) if a.cin2 else None
