@@ -51,6 +51,12 @@
 #ifndef MOBI_ATTN_PDBG
 #define MOBI_ATTN_PDBG 0   // attention_pipe_kernel, diagnosis only (wrong results): bit 0 = tiles staged in the prologue only,
 #endif                     // bit 1 = no barrier, bit 2 = no OR test / exact path
+#ifndef MOBI_ATTN_HP_FD
+#define MOBI_ATTN_HP_FD 4  // attention_hp_kernel: operand fragments requested this many MFMA gaps ahead
+#endif
+#ifndef MOBI_ATTN_HP_NW6
+#define MOBI_ATTN_HP_NW6 1 // attention_hp_kernel: six-wave blocks (three waves per SIMD) for the big launches; 0: eight-wave
+#endif
 #ifndef MOBI_ATTN_RVAR
 #define MOBI_ATTN_RVAR 0   // attention_rows_kernel A/B variants: bit 0 = next tile requested a whole step ahead
 #endif
@@ -842,6 +848,392 @@ void attention_rows_kernel(const AttnArgs a) {
 }
 
 
+#ifdef MOBI_DEV   // development build only: two software-pipelined forms of attention_rows_kernel, both measured SLOWER
+// (profiles/r03_attention_lab_variants.txt; selectable with MOBI_ATTN_V3=2 / 3 for A/B runs, covered by the parity tests there)
+// =========================================================================================================
+// attention_hp_kernel: attention_rows_kernel's arithmetic and tiling as a half-tile software pipeline (see the comment at its
+// main loop).  The production kernel for V row-major, head dims up to 80.
+// =========================================================================================================
+template <typename T, int KS, int NW, bool QSH>
+__global__ __launch_bounds__(64 * NW, NW == 6 ? 3 : (KS <= 2 && (QSH || (KS & 1))) ? 4 : KS <= 3 ? 3 : 2)
+void attention_hp_kernel(const AttnArgs a) {
+  constexpr int NTHR = 64 * NW;
+  typedef typename Vec8<T>::type frag_t;
+  constexpr int DT = (KS + 1) / 2;
+  constexpr int KSTR = KS * 32 + 16;
+  constexpr int VSTR = (DT & 1) ? DT * 64 : DT * 64 + 64;
+  constexpr int K_BYTES = 64 * KSTR, V_BYTES = 64 * VSTR, IMG_BYTES = K_BYTES + V_BYTES;
+  constexpr int KP = (64 * KS * 2 + NTHR - 1) / NTHR;      // 16-byte pieces per thread, K tile and V tile alike
+  constexpr float BIAS = AttnBias<T>::value;
+  constexpr int NIMG = 3;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[NIMG * IMG_BYTES];
+  unsigned char* ldsK = lds;
+  unsigned char* ldsV = lds + K_BYTES;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int ql = lane & 31, half = lane >> 5;
+  const int head = blockIdx.y, img = blockIdx.z;
+  const int q0 = blockIdx.x * (32 * NW) + wave * 32;
+  const int dh = a.dh;
+  // a padded channel of the P.V tile carries the denominator: dh is KS*16 - 8 (QSH) or KS*16, DT*32 is (KS + 1)/2 * 32
+  constexpr bool ONES = QSH || (KS & 1);
+
+  const T* __restrict__ qp = reinterpret_cast<const T*>(a.q) + img * a.q_img + head * dh;
+  const T* __restrict__ kp = reinterpret_cast<const T*>(a.k) + img * a.k_img + head * dh;
+  const T* __restrict__ vp = reinterpret_cast<const T*>(a.vt) + img * a.vt_img + (long long)head * dh;
+  T* __restrict__ op = reinterpret_cast<T*>(a.out) + img * a.out_img + head * dh;
+
+  // Q fragments, scaled once: an MFMA result is then the exponent of two of the probability
+  frag_t qf[KS];
+  {
+    const float cexp = a.cexp;
+    const int qrow = q0 + ql;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const int c = ks * 16 + half * 8;
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (qrow < a.tq && c < dh) v = ld16(qp + (long long)qrow * a.q_row + c);
+      frag_t f = __builtin_bit_cast(frag_t, v);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) f[j] = (T)((float)f[j] * cexp);          // cexp == 1 (q_log2_scaled): q bit for bit
+      qf[ks] = f;
+    }
+  }
+
+  u32x4 kr[KP], vr[KP];
+  unsigned koff[KP], voff[KP];
+  constexpr unsigned OOB = 0x80000000u;
+#pragma unroll
+  for (int i = 0; i < KP; ++i) {
+    const int p = tid + NTHR * i;
+    const int row = p / (KS * 2), pc = p - row * (KS * 2);
+    const bool on = row < 64 && pc * 8 < dh;
+    koff[i] = on ? (unsigned)(row * a.k_row + pc * 8) * 2u : OOB;
+    voff[i] = on ? (unsigned)(row * a.vt_row + pc * 8) * 2u : OOB;
+  }
+  const int k_bytes = ((a.tk - 1) * a.k_row + dh) * 2;
+  const int v_bytes = ((a.tk - 1) * a.vt_row + dh) * 2;
+  // channels [dh, KS*16) of every K row are written ONCE: zero, except channel dh = 1.0 when the shift rides in Q'
+  for (int p = tid; p < 64 * KS * 2; p += NTHR) {
+    const int row = p / (KS * 2), pc = p - row * (KS * 2);
+    if (pc * 8 >= dh) {
+      frag_t e;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) e[j] = (T)0.0f;
+      if (QSH && pc * 8 == dh) e[0] = (T)1.0f;
+#pragma unroll
+      for (int b = 0; b < NIMG; ++b) st16(ldsK + b * IMG_BYTES + row * KSTR + pc * 16, __builtin_bit_cast(u32x4, e));
+    }
+  }
+  // channels [dh, DT*32) of every V row are written ONCE: zero, except channel dh = 1.0 (the denominator column)
+  for (int p = tid; p < 64 * DT * 4; p += NTHR) {
+    const int row = p / (DT * 4), pc = p - row * (DT * 4);
+    if (pc * 8 >= dh) {
+      frag_t e;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) e[j] = (T)0.0f;
+      if (pc * 8 == dh) e[0] = (T)1.0f;
+#pragma unroll
+      for (int b = 0; b < NIMG; ++b) st16(ldsV + b * IMG_BYTES + row * VSTR + pc * 16, __builtin_bit_cast(u32x4, e));
+    }
+  }
+  auto load_tile = [&](int key0) {
+    const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(kp), 0, k_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(vp), 0, v_bytes, 0x00020000);
+    // the key tile's byte offset rides in the scalar offset of the request (wave-uniform): no per-tile address arithmetic
+    const unsigned ku = (unsigned)key0 * (unsigned)a.k_row * 2u, vu = (unsigned)key0 * (unsigned)a.vt_row * 2u;
+#pragma unroll
+    for (int i = 0; i < KP; ++i) kr[i] = __builtin_amdgcn_raw_buffer_load_b128(rk, koff[i], ku, 0);
+#pragma unroll
+    for (int i = 0; i < KP; ++i) vr[i] = __builtin_amdgcn_raw_buffer_load_b128(rv, voff[i], vu, 0);
+  };
+  auto store_tile = [&](int boff) {
+#pragma unroll
+    for (int i = 0; i < KP; ++i) {
+      const int p = tid + NTHR * i;
+      const int row = p / (KS * 2), pc = p - row * (KS * 2);
+      if (row < 64 && pc * 8 < dh) {
+        st16(ldsK + boff + row * KSTR + pc * 16, kr[i]);
+        st16(ldsV + boff + row * VSTR + pc * 16, vr[i]);
+      }
+    }
+  };
+
+  f32x16 o[DT];
+#pragma unroll
+  for (int d = 0; d < DT; ++d)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
+  f32x16 cm;                               // minus the shift of this lane's query column, in all sixteen registers
+#pragma unroll
+  for (int r = 0; r < 16; ++r) cm[r] = 0.f;
+  // QSH: lanes of the half that holds channel dh keep minus the shift in element dh % 8 (= 0) of the last Q' fragment
+  const bool qsh_lane = QSH && half == ((dh >> 3) & 1);
+  float l_run = 0.f;
+
+  const int ntiles = (a.tk + 63) / 64;
+  typedef __attribute__((address_space(3))) s16x4* lds4_t;
+  const int l16 = lane & 15, grp = lane >> 4;
+  const int k_lane = ql * KSTR + half * 16;
+  const int v_lane = (4 * half + (l16 >> 2)) * VSTR + (16 * (grp & 1) + 4 * (l16 & 3)) * 2;
+  const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+
+  // S'^T of one 32-key half from its LDS image (KS MFMAs), keys past the end masked
+  auto mask_half = [&](int key0, int kt, f32x16& sx) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int key = key0 + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+      if (key >= a.tk) sx[r] = -INFINITY;
+    }
+  };
+  auto scores_half = [&](auto ragged_tag, int boff, int key0, int kt, f32x16& sx) {
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const frag_t kf = __builtin_bit_cast(frag_t, ld16(ldsK + boff + k_lane + kt * 32 * KSTR + ks * 32));
+      sx = mfma32(kf, qf[ks], ks == 0 ? (QSH ? zero16 : cm) : sx);
+    }
+    if (decltype(ragged_tag)::value) mask_half(key0, kt, sx);
+  };
+  // the exact path for one half: its maximum per query column, the shift raised to (maximum - BIAS) -- set outright when
+  // nothing has been accumulated yet --, O rescaled, the other half's pending scores moved, the half's probabilities
+  auto raise_shift = [&](f32x16& sx, auto first_tag, auto pending_tag, f32x16& pending, unsigned (&pwh)[8]) {
+    constexpr bool first = decltype(first_tag)::value, has_pending = decltype(pending_tag)::value;
+    float mx = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sx[r]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    float d = mx + BIAS;
+    if (!first) d = fmaxf(d, 0.f);           // the shift only rises
+    if (QSH) {
+      // the shift is a value of the storage type: take the step its rounding actually makes
+      const float old_q = __shfl(qsh_lane ? (float)qf[KS - 1][0] : 0.f, ql + 32, 64);
+      const T new_q = (T)(old_q - d);
+      d = old_q - (float)new_q;
+      if (qsh_lane) qf[KS - 1][0] = new_q;
+    } else {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) cm[r] -= d;
+    }
+    if (!first) {
+      const float alpha = __builtin_amdgcn_exp2f(-d);
+      l_run *= alpha;
+#pragma unroll
+      for (int dd = 0; dd < DT; ++dd)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[dd][r] *= alpha;
+    }
+    if (has_pending) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) pending[r] -= d;
+    }
+    float psum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const float e0 = __builtin_amdgcn_exp2f(sx[2 * i] - d), e1 = __builtin_amdgcn_exp2f(sx[2 * i + 1] - d);
+      pwh[i] = pack2<T>(e0, e1);
+      if (!ONES) psum += e0 + e1;
+    }
+    if (!ONES) l_run += psum;
+  };
+
+  // Half-tile software pipeline: one HALF-STEP multiplies P.V of the previous 32-key half (2 DT MFMAs) and S' of the next
+  // half (KS MFMAs) while the exponentials / packing / OR test of the current half run in their gaps -- no MFMA is issued
+  // without vector work of the same wave behind it (a wave that waits on the busy matrix pipe holds up the vector issue of
+  // the SIMD's other waves: tools/probes/mfma_fill.hip, 'split' rows; attention_rows_kernel leaves KS + 2 DT of its
+  // 2 KS + 4 DT MFMAs per tile bare).  Same registers as attention_rows_kernel (two 16-register score halves, two packed
+  // halves): four waves per SIMD.  Three LDS images: a half-step reads the previous tile's V and the next tile's K; ONE
+  // barrier per tile; the next tile is requested from memory a whole tile ahead.
+  auto first_shift = [&](f32x16& sx) {     // the first shift from the exact maximum of the first half; sx moved to it
+    float mx = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sx[r]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    float d = mx + BIAS;
+    if (QSH) {
+      const T new_q = (T)(-d);
+      d = -(float)new_q;
+      if (qsh_lane) qf[KS - 1][0] = new_q;
+    } else {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) cm[r] = -d;
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sx[r] -= d;
+  };
+#define MOBI_HP_BARRIER()                                \
+  do {                                                   \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   \
+    __builtin_amdgcn_sched_barrier(0);                   \
+    __builtin_amdgcn_s_barrier();                        \
+    __builtin_amdgcn_sched_barrier(0);                   \
+  } while (0)
+  auto pv_half = [&](int boff, int kt, const unsigned (&pw)[8]) {         // O^T += V^T . P^T of one half, bare (pipeline ends)
+    s16x8 vf[2][DT];
+#pragma unroll
+    for (int st = 0; st < 2; ++st) {
+      const unsigned char* vb = ldsV + boff + v_lane + (kt * 32 + st * 16) * VSTR;
+#pragma unroll
+      for (int d = 0; d < DT; ++d) {
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4_t)(vb + d * 64));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4_t)(vb + d * 64 + 8 * VSTR));
+        vf[st][d] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+      }
+    }
+#pragma unroll
+    for (int st = 0; st < 2; ++st) {
+      const u32x4 pu = {pw[st * 4], pw[st * 4 + 1], pw[st * 4 + 2], pw[st * 4 + 3]};
+#pragma unroll
+      for (int d = 0; d < DT; ++d) o[d] = mfma32(__builtin_bit_cast(frag_t, vf[st][d]), __builtin_bit_cast(frag_t, pu), o[d]);
+    }
+  };
+  // half-step of (tile t, half KT): sc = S'(t, KT) in, sn = S' of the next half out (NEXT), pp = P of the previous half in
+  // (PREV), pc = P(t, KT) out
+  auto half_step = [&](auto kt_tag, auto prev_tag, auto next_tag, int t, f32x16& sc, f32x16& sn, const unsigned (&pp)[8],
+                       unsigned (&pc)[8]) {
+    constexpr int KT = decltype(kt_tag)::value;
+    constexpr bool PREV = decltype(prev_tag)::value, NEXT = decltype(next_tag)::value;
+    const int key0 = t * 64;
+    const int bt = (t % 3) * IMG_BYTES;
+    const int bprev = KT == 0 ? ((t + 2) % 3) * IMG_BYTES : bt;          // the tile of the previous half
+    const int bnext = KT == 0 ? bt : ((t + 1) % 3) * IMG_BYTES;          // the tile of the next half
+    if (!QSH) asm volatile("" : "+v"(cm));
+    constexpr int NPV = PREV ? 2 * DT : 0, NS = NEXT ? KS : 0, NG = NPV + NS;
+    // operand fragment of gap g (the KS S' MFMAs spread evenly among the P.V ones), requested FD gaps ahead of its MFMA: at
+    // most FD + 1 fragments (4 registers each) are live -- with all of a half-step's fragments requested up front the
+    // kernel needs ~190 registers instead of 128
+    constexpr int FD = MOBI_ATTN_HP_FD;
+    auto is_s = [&](int g) { return NS > 0 && ((g + 1) * NS) / NG != (g * NS) / NG; };
+    auto read_frag = [&](int g) -> frag_t {
+      if (is_s(g)) {
+        const int ks = (g * NS) / NG;
+        return __builtin_bit_cast(frag_t, ld16(ldsK + bnext + k_lane + (KT ^ 1) * 32 * KSTR + ks * 32));
+      }
+      const int m = g - (g * NS) / NG, st = m / DT, d = m - st * DT;
+      const unsigned char* vb = ldsV + bprev + v_lane + ((KT ^ 1) * 32 + st * 16) * VSTR;
+      const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4_t)(vb + d * 64));
+      const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4_t)(vb + d * 64 + 8 * VSTR));
+      return __builtin_bit_cast(frag_t, (s16x8)__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+    };
+    frag_t fq[FD + 1];
+#pragma unroll
+    for (int g = 0; g < FD && g < NG; ++g) fq[g] = read_frag(g);
+    __builtin_amdgcn_sched_barrier(0);
+    unsigned orr = 0u;
+    float psum = 0.f;
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      if (g + FD < NG) fq[(g + FD) % (FD + 1)] = read_frag(g + FD);
+      const frag_t f = fq[g % (FD + 1)];
+      if (is_s(g)) {
+        const int ks = (g * NS) / NG;
+        sn = mfma32(f, qf[ks], ks == 0 ? (QSH ? zero16 : cm) : sn);
+      } else {
+        const int m = g - (g * NS) / NG, st = m / DT, d = m - st * DT;
+        const u32x4 pu = {pp[st * 4], pp[st * 4 + 1], pp[st * 4 + 2], pp[st * 4 + 3]};
+        o[d] = mfma32(f, __builtin_bit_cast(frag_t, pu), o[d]);
+      }
+#pragma unroll
+      for (int i = (8 * g) / NG; i < (8 * (g + 1)) / NG; ++i) {
+        const float e0 = __builtin_amdgcn_exp2f(sc[2 * i]), e1 = __builtin_amdgcn_exp2f(sc[2 * i + 1]);
+        pc[i] = pack2<T>(e0, e1);
+        orr |= pc[i];
+        if (!ONES) psum += e0 + e1;
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (!__all((orr & 0x40004000u) == 0u)) {
+      scores_half(std::false_type{}, bt, key0, KT, sc);
+      raise_shift(sc, std::false_type{}, next_tag, sn, pc);
+    } else if (!ONES) {
+      l_run += psum;
+    }
+  };
+
+  const int nfull = a.tk / 64;
+  load_tile(0);
+  store_tile(0);
+  if (ntiles > 1) load_tile(64);
+  __syncthreads();
+  f32x16 sA, sB;
+  unsigned pA[8], pB[8];
+  if (a.tk < 32) scores_half(std::true_type{}, 0, 0, 0, sA); else scores_half(std::false_type{}, 0, 0, 0, sA);
+  first_shift(sA);
+  // tile-level staging at the top of a tile: tile t+1 (in registers since the previous tile) into its image, tile t+2 requested
+  auto stage = [&](int t) {
+    if (t + 1 < ntiles) store_tile(((t + 1) % 3) * IMG_BYTES);
+    if (t + 2 < ntiles) load_tile((t + 2) * 64);
+  };
+  typedef std::integral_constant<int, 0> H0;
+  typedef std::integral_constant<int, 1> H1;
+  typedef std::true_type Y;
+  typedef std::false_type N;
+  // (first and last tile peeled: the steady-state loop has one straight-line version of each half-step)
+  if (nfull > 0) {
+    stage(0);
+    half_step(H0{}, N{}, Y{}, 0, sA, sB, pB, pA);
+    MOBI_HP_BARRIER();                       // tile t+1's image is complete; the image of tile t-1 is free
+    if (nfull > 1) {
+      half_step(H1{}, Y{}, Y{}, 0, sB, sA, pA, pB);
+      int t = 1;
+      for (; t + 1 < nfull; ++t) {
+        stage(t);
+        half_step(H0{}, Y{}, Y{}, t, sA, sB, pB, pA);
+        MOBI_HP_BARRIER();
+        half_step(H1{}, Y{}, Y{}, t, sB, sA, pA, pB);
+      }
+      stage(t);
+      half_step(H0{}, Y{}, Y{}, t, sA, sB, pB, pA);
+      MOBI_HP_BARRIER();
+      half_step(H1{}, Y{}, N{}, t, sB, sA, pA, pB);
+    } else {
+      half_step(H1{}, Y{}, N{}, 0, sB, sA, pA, pB);
+    }
+  }
+  if (nfull > 0) pv_half(((nfull - 1) % 3) * IMG_BYTES, 1, pB);           // the pipeline's last P.V
+  if (nfull < ntiles) {
+    // the ragged last tile: one half at a time on the exact path (masked scores, their maximum, probabilities)
+    const int t = nfull, key0 = t * 64, boff = (t % 3) * IMG_BYTES;
+    if (nfull > 0) MOBI_HP_BARRIER();        // (its image was written during the last full tile's first half-step)
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+      if (nfull > 0 || kt > 0) scores_half(std::true_type{}, boff, key0, kt, sA);
+      raise_shift(sA, std::false_type{}, std::false_type{}, sA, pA);
+      pv_half(boff, kt, pA);
+    }
+  }
+#undef MOBI_HP_BARRIER
+
+  // ---- normalise and store: lane holds O^T[d][q] for d = 32 dt + 8 g + 4 half + (0..3) -------
+  if (ONES) {      // row dh of O^T sits in lane-half 0, register (dh % 32) / 2 of tile dh / 32
+    float lsum = 0.f;
+#pragma unroll
+    for (int d = 0; d < DT; ++d)
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        if (d * 32 + g * 8 == dh) lsum = o[d][g * 4];
+    l_run = half == 0 ? lsum : 0.f;
+  }
+  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  const float inv = 1.0f / l_tot;
+  const int qrow = q0 + ql;
+  if (qrow < a.tq) {
+    T* orow = op + (long long)qrow * a.out_row;
+#pragma unroll
+    for (int d = 0; d < DT; ++d)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int d0 = d * 32 + g * 8 + half * 4;
+        if (d0 < dh) {
+          float f[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) f[j] = o[d][g * 4 + j] * inv;
+          *reinterpret_cast<u32x2*>(orow + d0) = pack4<T>(f);
+        }
+      }
+  }
+}
+
+
 // =========================================================================================================
 // attention_pipe_kernel: attention_rows_kernel's arithmetic (Q' = Q * scale * log2 e, shift on the MFMA's C operand or in a
 // padded Q' channel, OR test on the packed probabilities) with the parts of DIFFERENT key tiles overlapped inside a wave.
@@ -1218,6 +1610,8 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_pipe_kernel(const AttnAr
 }
 
 
+#endif  // MOBI_DEV (pipelined variants)
+
 #ifdef MOBI_DEV   // development build only: the software-pipelined A/B alternative (measured slower, MOBI_ATTN_SP=1)
 // =========================================================================================================
 // SOFTWARE-PIPELINED variant of the 8-wave kernel (V row-major, one 16-byte K and V piece per thread and key tile,
@@ -1529,27 +1923,49 @@ static int launch_attention_v(const mobi_attention_params* p, const AttnArgs& a,
     if (ks <= 5 && tuning().attn_v3 != 0) {           // the reduced-instruction kernel (MOBI_ATTN_V3=0: the kernel below)
       dim3 gridr((p->tq + (nw8 ? 255 : 127)) / (nw8 ? 256 : 128), p->heads, p->images), blockr(nw8 ? 512 : 256);
       const bool qsh = (p->dh & 15) != 0;             // a padded channel in the last k-step carries the shift
+#ifdef MOBI_DEV
       if (tuning().attn_v3 == 2 && ks == 3 && qsh && nw8) {      // A/B: the software-pipelined kernel (MOBI_ATTN_V3=2)
         hipLaunchKernelGGL((attention_pipe_kernel<T, 3, 8, true>), gridr, blockr, 0, st, a);
         MOBI_CHECK_LAUNCH();
         return MOBI_OK;
       }
-#define MOBI_ATTN_ROWS(KS_)                                                                              \
+#endif
+#define MOBI_ATTN_ROWS_K(KERNEL_, KS_)                                                                   \
   do {                                                                                                   \
     if (qsh) {                                                                                           \
-      if (nw8) hipLaunchKernelGGL((attention_rows_kernel<T, KS_, 8, true>), gridr, blockr, 0, st, a);     \
-      else hipLaunchKernelGGL((attention_rows_kernel<T, KS_, 4, true>), gridr, blockr, 0, st, a);         \
+      if (nw8) hipLaunchKernelGGL((KERNEL_<T, KS_, 8, true>), gridr, blockr, 0, st, a);                   \
+      else hipLaunchKernelGGL((KERNEL_<T, KS_, 4, true>), gridr, blockr, 0, st, a);                       \
     } else {                                                                                             \
-      if (nw8) hipLaunchKernelGGL((attention_rows_kernel<T, KS_, 8, false>), gridr, blockr, 0, st, a);    \
-      else hipLaunchKernelGGL((attention_rows_kernel<T, KS_, 4, false>), gridr, blockr, 0, st, a);        \
+      if (nw8) hipLaunchKernelGGL((KERNEL_<T, KS_, 8, false>), gridr, blockr, 0, st, a);                  \
+      else hipLaunchKernelGGL((KERNEL_<T, KS_, 4, false>), gridr, blockr, 0, st, a);                      \
     }                                                                                                    \
   } while (0)
+#ifdef MOBI_DEV
+#define MOBI_ATTN_ROWS(KS_)                                                                              \
+  do {                                                                                                   \
+    if (tuning().attn_v3 == 3 && qsh) {           /* A/B: the half-tile pipeline (padded head dims only) */ \
+      if (nw8 && KS_ <= 3 && MOBI_ATTN_HP_NW6) {                                                         \
+        dim3 grid6((p->tq + 191) / 192, p->heads, p->images), block6(384);                               \
+        hipLaunchKernelGGL((attention_hp_kernel<T, KS_, 6, true>), grid6, block6, 0, st, a);             \
+      } else if (nw8) {                                                                                  \
+        hipLaunchKernelGGL((attention_hp_kernel<T, KS_, 8, true>), gridr, blockr, 0, st, a);             \
+      } else {                                                                                           \
+        hipLaunchKernelGGL((attention_hp_kernel<T, KS_, 4, true>), gridr, blockr, 0, st, a);             \
+      }                                                                                                  \
+    } else {                                                                                             \
+      MOBI_ATTN_ROWS_K(attention_rows_kernel, KS_);                                                      \
+    }                                                                                                    \
+  } while (0)
+#else
+#define MOBI_ATTN_ROWS(KS_) MOBI_ATTN_ROWS_K(attention_rows_kernel, KS_)
+#endif
       if (ks <= 1) MOBI_ATTN_ROWS(1);
       else if (ks == 2) MOBI_ATTN_ROWS(2);
       else if (ks == 3) MOBI_ATTN_ROWS(3);
       else if (ks == 4) MOBI_ATTN_ROWS(4);
       else MOBI_ATTN_ROWS(5);
 #undef MOBI_ATTN_ROWS
+#undef MOBI_ATTN_ROWS_K
       MOBI_CHECK_LAUNCH();
       return MOBI_OK;
     }
