@@ -1103,13 +1103,19 @@ void attention_hp_kernel(const AttnArgs a) {
     // kernel needs ~190 registers instead of 128
     constexpr int FD = MOBI_ATTN_HP_FD;
     auto is_s = [&](int g) { return NS > 0 && ((g + 1) * NS) / NG != (g * NS) / NG; };
+    // (ONE address register per operand and half-step, every fragment at an immediate offset from it: computed per
+    //  fragment the addresses cost 36 vector instructions per tile -- SQ_INSTS_VALU 120 M against 84 M per launch)
+    int kofs = bnext + k_lane, vofs = bprev + v_lane;
+    asm volatile("" : "+v"(kofs), "+v"(vofs));
+    const unsigned char* kbase = ldsK + kofs;
+    const unsigned char* vbase = ldsV + vofs;
     auto read_frag = [&](int g) -> frag_t {
       if (is_s(g)) {
         const int ks = (g * NS) / NG;
-        return __builtin_bit_cast(frag_t, ld16(ldsK + bnext + k_lane + (KT ^ 1) * 32 * KSTR + ks * 32));
+        return __builtin_bit_cast(frag_t, ld16(kbase + ((KT ^ 1) * 32 * KSTR + ks * 32)));
       }
       const int m = g - (g * NS) / NG, st = m / DT, d = m - st * DT;
-      const unsigned char* vb = ldsV + bprev + v_lane + ((KT ^ 1) * 32 + st * 16) * VSTR;
+      const unsigned char* vb = vbase + (((KT ^ 1) * 32 + st * 16) * VSTR);
       const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4_t)(vb + d * 64));
       const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4_t)(vb + d * 64 + 8 * VSTR));
       return __builtin_bit_cast(frag_t, (s16x8)__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));

@@ -1,7 +1,7 @@
 #!/bin/bash
 # SQ counters of the 64x64-level attention launch (one --pmc pass per counter group; no trace domains beside them)
 set -u
-OUT=gpurun_out/pmc_attn
+OUT=gpurun_out/pmc_attn${MOBI_ATTN_V3:+_v3_$MOBI_ATTN_V3}      # (export MOBI_ATTN_V3=0 first for the kernel of rounds 1-2)
 mkdir -p $OUT
 export TMPDIR=/tmp
 i=0
@@ -15,9 +15,11 @@ done
 python - <<'PY'
 import csv, glob, collections
 acc = collections.defaultdict(lambda: [0.0, 0])
-for f in glob.glob('gpurun_out/pmc_attn/p*/**/*counter_collection.csv', recursive=True):
+import os
+out = 'gpurun_out/pmc_attn' + ('_v3_' + os.environ['MOBI_ATTN_V3'] if os.environ.get('MOBI_ATTN_V3') else '')
+for f in glob.glob(out + '/p*/**/*counter_collection.csv', recursive=True):
     for r in csv.DictReader(open(f)):
-        if 'attention_kernel' not in r['Kernel_Name']: continue
+        if 'attention_' not in r['Kernel_Name']: continue
         a = acc[r['Counter_Name']]; a[0] += float(r['Counter_Value']); a[1] += 1
 for k, (v, n) in sorted(acc.items()):
     print(f"{k:32s} {v / n:16.0f} per launch ({n} launches)")
