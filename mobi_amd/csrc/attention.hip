@@ -58,7 +58,7 @@
 #define MOBI_ATTN_HP_NW6 1 // attention_hp_kernel: six-wave blocks (three waves per SIMD) for the big launches; 0: eight-wave
 #endif
 #ifndef MOBI_ATTN_RVAR
-#define MOBI_ATTN_RVAR 0   // attention_rows_kernel A/B variants: bit 0 = next tile requested a whole step ahead
+#define MOBI_ATTN_RVAR 0   // attention_rows_kernel A/B variants: bit 1 = bf16 storage keeps the per-half OR test
 #endif
 
 namespace mobi {
@@ -520,6 +520,9 @@ void attention_rows_kernel(const AttnArgs a) {
   const int dh = a.dh;
   // a padded channel of the P.V tile carries the denominator: dh is KS*16 - 8 (QSH) or KS*16, DT*32 is (KS + 1)/2 * 32
   constexpr bool ONES = QSH || (KS & 1);
+  // (no test: bf16 storage, padded head dims -- the other instantiations would not fit their register budget with both passes;
+  //  RVAR bit 1 keeps the test everywhere, A/B)
+  constexpr bool TEST = !std::is_same<T, bf16_t>::value || !QSH || (MOBI_ATTN_RVAR & 2);
 
   const T* __restrict__ qp = reinterpret_cast<const T*>(a.q) + img * a.q_img + head * dh;
   const T* __restrict__ kp = reinterpret_cast<const T*>(a.k) + img * a.k_img + head * dh;
@@ -679,18 +682,6 @@ void attention_rows_kernel(const AttnArgs a) {
     if (!ONES) l_run += psum;
   };
 
-  load_tile(0);
-  store_tile(0);
-  __syncthreads();
-  {
-    // the first shift, from the exact maximum of the first 32 keys (the loop then only tests; its first half-tile is
-    // computed once more there, so that the loop body has no first-step special case for the compiler to hoist on)
-    f32x16 s0;
-    unsigned pw0[8];
-    if (a.tk < 32) scores_half(std::true_type{}, 0, 0, 0, s0); else scores_half(std::false_type{}, 0, 0, 0, s0);
-    raise_shift(s0, std::true_type{}, std::false_type{}, s0, pw0);
-    if (!ONES) l_run = 0.f;
-  }
   // A wave that waits on the busy matrix pipe holds up the vector issue of the SIMD's other waves too
   // (tools/probes/mfma_fill.hip, 'split' rows), so MFMAs are issued with vector work of the SAME wave behind each:
   //   S'(half 0)                      KS MFMAs alone
@@ -700,8 +691,8 @@ void attention_rows_kernel(const AttnArgs a) {
   // Each half has its own OR test right behind its exponentials (same basic block: with a branch in between hipcc sinks
   // the exponentials out of the MFMA gaps) and before its P.V; O stays in the old shift's scale until a test fails.
   // The ragged last tile runs a second copy of the body (RAGGED) with the masking, so the common one has no branch for it.
-  auto tile = [&](auto ragged_tag, int t) {
-    constexpr bool RAGGED = decltype(ragged_tag)::value;
+  auto tile = [&](auto ragged_tag, auto test_tag, int t) {
+    constexpr bool RAGGED = decltype(ragged_tag)::value, TESTED = decltype(test_tag)::value;
     const int key0 = t * 64;
     const int boff = (t & 1) * IMG_BYTES;
     const bool more = t + 1 < ntiles;
@@ -752,12 +743,12 @@ void attention_rows_kernel(const AttnArgs a) {
       for (int i = (8 * ks) / KS; i < (8 * (ks + 1)) / KS; ++i) {
         const float e0 = __builtin_amdgcn_exp2f(s[0][2 * i]), e1 = __builtin_amdgcn_exp2f(s[0][2 * i + 1]);
         pw[0][i] = pack2<T>(e0, e1);
-        orr |= pw[0][i];
+        if (TESTED) orr |= pw[0][i];
         if (!ONES) psum += e0 + e1;
       }
       __builtin_amdgcn_sched_barrier(0);
     }
-    if (!__all((orr & 0x40004000u) == 0u)) {
+    if (TESTED && !__all((orr & 0x40004000u) == 0u)) {
       scores_half(ragged_tag, boff, key0, 0, s[0]);
       raise_shift(s[0], std::false_type{}, std::true_type{}, s[1], pw[0]);
     } else if (!ONES) {
@@ -789,13 +780,13 @@ void attention_rows_kernel(const AttnArgs a) {
       for (int i = (8 * m) / (2 * DT); i < (8 * (m + 1)) / (2 * DT); ++i) {
         const float e0 = __builtin_amdgcn_exp2f(s[1][2 * i]), e1 = __builtin_amdgcn_exp2f(s[1][2 * i + 1]);
         pw[1][i] = pack2<T>(e0, e1);
-        orr |= pw[1][i];
+        if (TESTED) orr |= pw[1][i];
         if (!ONES) psum += e0 + e1;
       }
       if (m == DT) read_v(1, 0);
       __builtin_amdgcn_sched_barrier(0);
     }
-    if (!__all((orr & 0x40004000u) == 0u)) {
+    if (TESTED && !__all((orr & 0x40004000u) == 0u)) {
       scores_half(ragged_tag, boff, key0, 1, s[1]);
       raise_shift(s[1], std::false_type{}, std::false_type{}, s[1], pw[1]);
     } else if (!ONES) {
@@ -813,21 +804,58 @@ void attention_rows_kernel(const AttnArgs a) {
     }
     if (!(MOBI_ATTN_RDBG & 16)) __syncthreads();
   };
+  // TEST (fp16 storage): the OR test per half-tile keeps every probability below 2.0 (fp16 ends at 65504).  bf16 storage has
+  // fp32's exponent range: the shift of the first 32 keys stays for the whole row (softmax is shift-invariant, a probability
+  // may be 2^100), the per-tile test, its 8 OR instructions and its branches are gone, and an overflow -- a score more than
+  // ~120 octaves above that first maximum -- shows in the denominator (inf / nan / 0) at the end: the block then repeats its
+  // pass WITH the test (block-uniform decision), which raises the shift as it goes.
   const int nfull = a.tk / 64;
-  for (int t = 0; t < nfull; ++t) tile(std::false_type{}, t);
-  if (nfull < ntiles) tile(std::true_type{}, nfull);
-
-  // ---- normalise and store: lane holds O^T[d][q] for d = 32 dt + 8 g + 4 half + (0..3) -------
-  if (ONES) {      // row dh of O^T sits in lane-half 0, register (dh % 32) / 2 of tile dh / 32
-    float lsum = 0.f;
+  float l_tot = 0.f;
+  for (int attempt = 0; attempt < 2; ++attempt) {
+    const bool tested = TEST || attempt == 1;
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+    {
+      // the first shift, from the exact maximum of the first 32 keys (the loop then only tests; its first half-tile is
+      // computed once more there, so that the loop body has no first-step special case for the compiler to hoist on)
+      f32x16 s0;
+      unsigned pw0[8];
+      if (a.tk < 32) scores_half(std::true_type{}, 0, 0, 0, s0); else scores_half(std::false_type{}, 0, 0, 0, s0);
+      raise_shift(s0, std::true_type{}, std::false_type{}, s0, pw0);
+      if (!ONES) l_run = 0.f;
+    }
+    if (tested) {
+      for (int t = 0; t < nfull; ++t) tile(std::false_type{}, std::true_type{}, t);
+    } else {
+      for (int t = 0; t < nfull; ++t) tile(std::false_type{}, std::false_type{}, t);
+    }
+    if (nfull < ntiles) tile(std::true_type{}, std::true_type{}, nfull);
+    // the denominator: row dh of O^T (lane-half 0, register (dh % 32) / 2 of tile dh / 32) or the running sum
+    if (ONES) {
+      float lsum = 0.f;
+#pragma unroll
+      for (int d = 0; d < DT; ++d)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          if (d * 32 + g * 8 == dh) lsum = o[d][g * 4];
+      l_run = half == 0 ? lsum : 0.f;
+    }
+    l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    if (tested) break;
+    const bool bad = !(l_tot > 0.f && l_tot < 1.0e30f);
+    if (!__syncthreads_or(bad ? 1 : 0)) break;
 #pragma unroll
     for (int d = 0; d < DT; ++d)
 #pragma unroll
-      for (int g = 0; g < 4; ++g)
-        if (d * 32 + g * 8 == dh) lsum = o[d][g * 4];
-    l_run = half == 0 ? lsum : 0.f;
+      for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) cm[r] = 0.f;
+    if (qsh_lane) qf[KS - 1][0] = (T)0.0f;
+    l_run = 0.f;
   }
-  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+
+  // ---- normalise and store: lane holds O^T[d][q] for d = 32 dt + 8 g + 4 half + (0..3) -------
   const float inv = 1.0f / l_tot;
   const int qrow = q0 + ql;
   if (qrow < a.tq) {
