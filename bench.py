@@ -455,7 +455,7 @@ def main():
         if os.path.exists(pmc):
             traffic = {}
             for fam_k in ("igemm_ring_kernel", "igemm_pp_kernel", "attention_rows_kernel", "attention_kernel", "ff_geglu_kernel",
-                          "gn_stats_kernel", "gn_apply_kernel", "layernorm_kernel"):
+                          "gn_regs_kernel", "gn_stats_kernel", "gn_apply_kernel", "layernorm_kernel"):
                 rec = doc.get(fam_k)
                 if rec and doc.get("config") == run_cfg:
                     traffic[fam_k] = round(rec["hbm_bytes_per_launch_corrected"])

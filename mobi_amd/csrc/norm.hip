@@ -2,13 +2,17 @@
 // 16-byte accesses, fp32 statistics (the reference's GroupNorm32 computes in fp32,
 // ldm/modules/diffusionmodules/util.py:214-216).
 //
-// GroupNorm runs as two launches:
-//   stats: grid (chunks, images); each block sweeps a chunk of pixels with every thread owning
+// GroupNorm has three forms (launch_gn picks; MOBI_GN_FUSED = 0 / 1 force the second / third for A/Bs):
+//   registers (gn_regs_kernel): one launch, a block owns 1 / 2 / 4 adjacent groups of one image and keeps them in
+//          registers; 2 B read + 2 B written per element.  Every shape of the denoising step except the 64 x 64 level's
+//          640- and 960-channel inputs;
+//   two launches: stats: grid (chunks, images); each block sweeps a chunk of pixels with every thread owning
 //          a fixed 8-channel column, folds per-channel sums into the 32 groups through LDS in
 //          a fixed order (deterministic) and writes one (sum, sumsq) pair per group;
-//   apply: every block first combines its image's chunk partials in fp64 (cancellation-safe
+//          apply: every block first combines its image's chunk partials in fp64 (cancellation-safe
 //          E[x^2] - mean^2), then streams y = x * a[c] + b[c], optional SiLU.
-// Algorithmic bytes: 2 B read (stats) + 2 B read + 2 B written (apply) per element.
+//          2 B read (stats) + 2 B read + 2 B written (apply) per element; fully coalesced 16-byte accesses;
+//   LDS (gn_fused_kernel): one launch, one block per (group, image), the slab in LDS (kept for A/Bs).
 #include "common.h"
 #include "tuning.h"
 
@@ -241,6 +245,244 @@ __global__ __launch_bounds__(256) void gn_fused_kernel(const GnArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------
+// One-launch GroupNorm(+SiLU) with the slab in REGISTERS: a block owns GB adjacent groups of one image (GB = 1 / 2 / 4, the
+// smallest count whose channels are whole pieces of PW = 8 or 4 channels: a pixel's segment is GB * C / 32 contiguous
+// channels) and every thread keeps its pieces -- a FIXED column `col` of the segment, pixels slot, slot + SLOTS, ... -- in
+// ITEMS x PW / 2 registers: all loads of the block are in flight at once, the tensor is read once and written once.  A
+// column lies in at most two groups (C / 32 >= PW): its first `k` channels belong to group g0, the rest to g0 + 1.
+// Statistics: fp32 mean, then the variance about the mean (from registers), both reduced in a fixed order (per-thread
+// partials in LDS by group, one wave slice per group, then the slices).  The (group block, image) -> workgroup map hands
+// each XCD whole images: the cache lines neighbouring blocks share are fetched from HBM into ONE L2.
+// Algorithmic bytes: 2 B read + 2 B written per element.
+struct GnRegsGeom { int gb, ppr, slots; };               // groups per block, pieces per pixel segment, pixel slots
+
+template <typename T, int THREADS, int ITEMS, int PW>
+__global__ __launch_bounds__(THREADS) void gn_regs_kernel(const GnArgs a, const GnRegsGeom geo) {
+  constexpr int NW = THREADS / 64, PR = PW / 2;
+  __shared__ float s_part[4][THREADS];                    // per-thread partial of each of the block's groups
+  __shared__ float s_wave[NW];
+  __shared__ float s_stat[2][4];                          // mean, rstd of the block's groups
+  __shared__ __attribute__((aligned(16))) float s_sc[4 * 80], s_sh[4 * 80];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int GB = geo.gb, PPR = geo.ppr, SLOTS = geo.slots;
+  const int cpg = a.C / 32, ngb = 32 / GB;
+  // workgroup -> (image, group block): XCD x (= id % 8) takes the contiguous range x * n / 8 ... of the work list
+  const int nblk = (int)gridDim.x;
+  int w = (int)blockIdx.x;
+  if (!(nblk & 7)) w = (w & 7) * (nblk >> 3) + (w >> 3);
+  const int img = w / ngb, gblk = w - img * ngb;
+  const int c_first = gblk * GB * cpg;                    // first channel of the block's segment (a multiple of PW)
+
+  const int slot = tid / PPR, col = tid - slot * PPR;
+  const bool live = slot < SLOTS;
+  const int cb = col * PW;                                // channel offset inside the segment
+  const int g0 = cb / cpg;
+  const int k = min(PW, (g0 + 1) * cpg - cb);             // channels of this column that lie in group g0
+  const int c = c_first + cb;
+  const bool second = c >= a.c0;
+  const int cs = second ? a.c1 : a.c0;
+  const T* __restrict__ src = second ? reinterpret_cast<const T*>(a.src1) + (long long)img * a.hw * a.c1 + (c - a.c0)
+                                     : reinterpret_cast<const T*>(a.src0) + (long long)img * a.hw * a.c0 + c;
+  typedef unsigned piece_t __attribute__((ext_vector_type(PR)));
+  typedef T T2 __attribute__((ext_vector_type(2)));
+  unsigned raw[ITEMS][PR];
+#pragma unroll
+  for (int i = 0; i < ITEMS; ++i) {
+    const int p = slot + i * SLOTS;
+    piece_t r = piece_t(0u);
+    if (live && p < a.hw) r = *reinterpret_cast<const piece_t*>(src + (long long)p * cs);
+#pragma unroll
+    for (int j = 0; j < PR; ++j) raw[i][j] = r[j];
+  }
+  auto unpack = [&](const unsigned (&r)[PR], float (&f)[PW]) {
+#pragma unroll
+    for (int j = 0; j < PR; ++j) {
+      const T2 v = __builtin_bit_cast(T2, r[j]);
+      f[2 * j] = (float)v[0];
+      f[2 * j + 1] = (float)v[1];
+    }
+  };
+  // (the packed pieces are what stays in registers between the passes: without the pins the compiler keeps the unpacked
+  // floats of the first pass alive, twice the registers)
+  auto pin = [&]() {
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i)
+#pragma unroll
+      for (int j = 0; j < PR; ++j) asm volatile("" : "+v"(raw[i][j]));
+  };
+  // sum over the block's threads of (lo -> group g0, hi -> group g0 + 1), fixed order; result for every group in s_stat[which]
+  auto reduce = [&](float lo, float hi, int which, float scale, bool to_rstd) {
+    __syncthreads();
+    for (int g = 0; g < GB; ++g) s_part[g][tid] = g == g0 ? lo : (g == g0 + 1 ? hi : 0.f);
+    __syncthreads();
+    {
+      const int g = wave % GB, part = wave / GB, parts = NW / GB, len = THREADS / parts;
+      float v = 0.f;
+      for (int t = part * len + lane; t < (part + 1) * len; t += 64) v += s_part[g][t];
+      v = wave_sum(v);
+      if (lane == 0) s_wave[wave] = v;
+    }
+    __syncthreads();
+    if (tid < GB) {
+      float v = 0.f;
+      for (int part = 0; part < NW / GB; ++part) v += s_wave[part * GB + tid];
+      v *= scale;
+      s_stat[which][tid] = to_rstd ? rsqrtf(v + a.eps) : v;
+    }
+    __syncthreads();
+  };
+  const float inv_n = 1.f / ((float)a.hw * (float)cpg);
+  // per-channel accumulators over the thread's pixels (one add / one fma per element), split into the two groups once
+  auto split = [&](const float (&acc)[PW], float& lo, float& hi) {
+    lo = 0.f; hi = 0.f;
+#pragma unroll
+    for (int j = 0; j < PW; ++j) { lo += j < k ? acc[j] : 0.f; hi += j < k ? 0.f : acc[j]; }
+  };
+  {
+    float acc[PW];
+#pragma unroll
+    for (int j = 0; j < PW; ++j) acc[j] = 0.f;
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) {
+      float f[PW];
+      unpack(raw[i], f);
+#pragma unroll
+      for (int j = 0; j < PW; ++j) acc[j] += f[j];
+    }
+    float lo, hi;
+    split(acc, lo, hi);
+    reduce(lo, hi, 0, inv_n, false);
+  }
+  pin();
+  {
+    const float m_lo = s_stat[0][g0], m_hi = s_stat[0][min(g0 + 1, GB - 1)];
+    float acc[PW], m[PW];
+#pragma unroll
+    for (int j = 0; j < PW; ++j) { acc[j] = 0.f; m[j] = j < k ? m_lo : m_hi; }
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) {
+      if (live && slot + i * SLOTS < a.hw) {
+        float f[PW];
+        unpack(raw[i], f);
+#pragma unroll
+        for (int j = 0; j < PW; ++j) {
+          const float d = f[j] - m[j];
+          acc[j] += d * d;
+        }
+      }
+    }
+    float lo, hi;
+    split(acc, lo, hi);
+    reduce(lo, hi, 1, inv_n, true);
+  }
+  pin();
+  // y = x * sc[c] + sh[c]
+  for (int cc = tid; cc < GB * cpg; cc += THREADS) {
+    const int g = cc / cpg;
+    const float sc = s_stat[1][g] * a.gamma[c_first + cc];
+    s_sc[cc] = sc;
+    s_sh[cc] = a.beta[c_first + cc] - s_stat[0][g] * sc;
+  }
+  __syncthreads();
+  if (!live) return;
+  T* __restrict__ out = reinterpret_cast<T*>(a.out) + (long long)img * a.hw * a.C + c;
+  float sc[PW], sh[PW];
+#pragma unroll
+  for (int j = 0; j < PW; j += 4) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(s_sc + cb + j), u = *reinterpret_cast<const f32x4*>(s_sh + cb + j);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { sc[j + e] = v[e]; sh[j + e] = u[e]; }
+  }
+#pragma unroll
+  for (int i = 0; i < ITEMS; ++i) {
+    const int p = slot + i * SLOTS;
+    if (p < a.hw) {
+      float f[PW];
+      unpack(raw[i], f);
+#pragma unroll
+      for (int j = 0; j < PW; ++j) {
+        f[j] = f[j] * sc[j] + sh[j];
+        if (a.silu) f[j] = silu_f(f[j]);
+      }
+      piece_t o;
+#pragma unroll
+      for (int j = 0; j < PR; ++j) {
+        T2 v;
+        v[0] = (T)f[2 * j];
+        v[1] = (T)f[2 * j + 1];
+        o[j] = __builtin_bit_cast(unsigned, v);
+      }
+      *reinterpret_cast<piece_t*>(out + (long long)p * a.C) = o;
+    }
+  }
+}
+
+// geometry of the register form for (C, hw): 16-byte pieces when a thread then holds at most 16 of them, else 8-byte pieces
+// (half the groups per block, up to 24 per thread); false when the tensor does not qualify (odd C / 32, or too many
+// pieces per thread: the 64 x 64 level's 960-channel input)
+static bool gn_regs_geometry(int C, int hw, int batch, GnRegsGeom* geo, int* threads, int* items, int* pw_out) {
+  const int cpg = C / 32;
+  if (cpg < 8 || (cpg & 1)) return false;
+  static const int steps8[] = {1, 2, 3, 4, 6, 8, 12, 16};
+  static const int steps4[] = {8, 12, 16, 24};
+  bool found = false;
+  for (int pw = 8; pw >= 4; pw >>= 1) {
+    int gb = 1;
+    while (gb <= 4 && ((gb * cpg) & (pw - 1))) gb <<= 1;
+    if (gb > 4) continue;
+    if (pw == 8) while (gb * cpg < 32 && gb < 4) gb <<= 1;       // segments of at least 64 bytes
+    const int ppr = gb * cpg / pw;
+    if (gb * cpg > 4 * 80) continue;
+    const long long pieces = (long long)hw * ppr;
+    const int th = pieces >= 2048 ? 1024 : 256;
+    if (pw == 4 && th != 1024) continue;
+    const int slots = th / ppr;
+    if (slots < 1) continue;
+    const int it = (hw + slots - 1) / slots;
+    int pick = 0;
+    if (pw == 8) { for (int s : steps8) if (s >= it) { pick = s; break; } }
+    else         { for (int s : steps4) if (s >= it) { pick = s; break; } }
+    if (!pick) continue;
+    if (th == 1024 && pick >= 12 && 32 / gb * batch > 256) continue;   // one such block per CU: a second round of blocks loses
+    // 16-byte pieces unless the 8-byte form (half the groups per block) is what gives every CU a block
+    if (found && !(32 / geo->gb * batch < 256 && 32 / gb * batch > 32 / geo->gb * batch)) continue;
+    geo->gb = gb; geo->ppr = ppr; geo->slots = slots;
+    *threads = th; *items = pick; *pw_out = pw;
+    found = true;
+  }
+  return found;
+}
+
+template <typename T>
+static bool launch_gn_regs(const GnArgs& a, int batch, hipStream_t st) {
+  GnRegsGeom geo;
+  int th, it, pw;
+  if (!gn_regs_geometry(a.C, a.hw, batch, &geo, &th, &it, &pw)) return false;
+  const dim3 grid((unsigned)(32 / geo.gb * batch));
+#define MOBI_GNR(TH_, IT_, PW_) hipLaunchKernelGGL((gn_regs_kernel<T, TH_, IT_, PW_>), grid, dim3(TH_), 0, st, a, geo)
+  if (pw == 4) {
+    switch (it) {
+      case 8: MOBI_GNR(1024, 8, 4); break;   case 12: MOBI_GNR(1024, 12, 4); break;
+      case 16: MOBI_GNR(1024, 16, 4); break; default: MOBI_GNR(1024, 24, 4); break;
+    }
+  } else if (th == 256) {
+    switch (it) {
+      case 1: MOBI_GNR(256, 1, 8); break;   case 2: MOBI_GNR(256, 2, 8); break;   case 3: MOBI_GNR(256, 3, 8); break;
+      case 4: MOBI_GNR(256, 4, 8); break;   case 6: MOBI_GNR(256, 6, 8); break;   case 8: MOBI_GNR(256, 8, 8); break;
+      case 12: MOBI_GNR(256, 12, 8); break; default: MOBI_GNR(256, 16, 8); break;
+    }
+  } else {
+    switch (it) {
+      case 1: MOBI_GNR(1024, 1, 8); break;   case 2: MOBI_GNR(1024, 2, 8); break;   case 3: MOBI_GNR(1024, 3, 8); break;
+      case 4: MOBI_GNR(1024, 4, 8); break;   case 6: MOBI_GNR(1024, 6, 8); break;   case 8: MOBI_GNR(1024, 8, 8); break;
+      case 12: MOBI_GNR(1024, 12, 8); break; default: MOBI_GNR(1024, 16, 8); break;
+    }
+  }
+#undef MOBI_GNR
+  return true;
+}
+
+// ---------------------------------------------------------------------------------------
 struct LnArgs {
   const void* src; void* out;
   int images, rows, C; long long src_img, out_img;
@@ -311,7 +553,12 @@ template <typename T>
 static int launch_gn(const GnArgs& a, int batch, hipStream_t st) {
   // small tensors: one launch, the group's slab in LDS (channel pairs: C / 32 even; both sources split at an even channel)
   const int cpg = a.C / 32;
-  if (!(cpg & 1) && (long long)a.hw * cpg <= GN1_MAX && tuning().gn_fused != 0) {
+  const int mode = tuning().gn_fused;                   // 0: two launches; 1: the LDS form where it fits; else registers first
+  if (mode != 0 && mode != 1 && launch_gn_regs<T>(a, batch, st)) {
+    MOBI_CHECK_LAUNCH();
+    return MOBI_OK;
+  }
+  if (!(cpg & 1) && (long long)a.hw * cpg <= GN1_MAX && mode != 0) {
     hipLaunchKernelGGL((gn_fused_kernel<T>), dim3(32, batch), dim3(256), 0, st, a);
     MOBI_CHECK_LAUNCH();
     return MOBI_OK;

@@ -151,18 +151,19 @@ class StepGraph:
             if self.cfg:
                 self.uncond.copy_(uncond)
             self._cond_id = cid
-            if self._warm and _context_blocks(self.sampler.model) is None:
-                self._body()                     # opaque model: one eager evaluation refreshes every cache
-        if self._warm:
-            # loop-invariant context terms: every block's slot for THIS graph's token buffer is checked on every run (a hit
-            # costs a tuple compare) -- other users of the model have slots of their own, in-place weight edits move the
-            # key -- and recomputed IN PLACE when stale; the captured addresses must still be the slot's
-            blocks = _context_blocks(self.sampler.model)
-            if blocks is not None:
-                for b in blocks:
-                    b._context_terms(self.ctx)
-                if getattr(self, "_term_ptrs", None) is not None and self._context_term_addresses() != self._term_ptrs:
-                    raise RuntimeError("a transformer block's context-term buffers moved under a captured step graph")
+            if self._warm:
+                # loop-invariant context terms: recomputed IN PLACE in this graph's own slot of every block (keyed on
+                # self.ctx: other users of the model -- another graph, the PLMS sampler, eager calls -- have slots of their
+                # own and cannot change what the captured launches read; weight changes make a new graph, see `get`); the
+                # captured addresses must still be the slots'
+                blocks = _context_blocks(self.sampler.model)
+                if blocks is None:
+                    self._body()                 # opaque model: one eager evaluation refreshes every cache
+                else:
+                    for b in blocks:
+                        b._context_terms(self.ctx)
+                    if getattr(self, "_term_ptrs", None) is not None and self._context_term_addresses() != self._term_ptrs:
+                        raise RuntimeError("a transformer block's context-term buffers moved under a captured step graph")
         self._refs = (parts_extra, cond, uncond)  # keep the callers' tensors alive: their ids / addresses stay unique
 
     def run(self, x, step, coef_row=None, noise=None):

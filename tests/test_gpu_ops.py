@@ -56,10 +56,14 @@ def ops():
 @pytest.mark.parametrize("c0,c1,hw,silu", [(32, 0, 64, True), (320, 0, 4096, True), (320, 0, 4096, False),
                                            (1280, 1280, 64, True), (1280, 640, 256, True), (640, 320, 1024, True),
                                            (64, 0, 17, True), (128, 0, 4096, True), (1280, 0, 256, True),
-                                           (1920, 640, 64, False), (960, 960, 16, True)])
+                                           (1920, 640, 64, False), (960, 960, 16, True), (640, 0, 1024, True),
+                                           (320, 0, 1024, True), (640, 0, 100, True), (1280, 0, 77, False),
+                                           (1280, 640, 1024, True), (320, 320, 4096, True)])
 def test_groupnorm(ops, dtype, c0, c1, hw, silu, tune):
-    """two-launch GroupNorm (statistics, apply) and, where a group's slab fits LDS, the one-launch kernel (gn_fused_kernel:
-    small tensors); both against fp32 torch."""
+    """The three forms of GroupNorm against fp32 torch: one launch with the slab in registers (gn_regs_kernel: 16- and
+    8-byte pieces, segments that straddle the two sources, ragged pixel counts), one launch with the slab in LDS
+    (gn_fused_kernel, MOBI_GN_FUSED=1) and the two-launch form (statistics, apply; MOBI_GN_FUSED=0 and every shape the
+    one-launch forms do not take)."""
     h = int(math.isqrt(hw)) if int(math.isqrt(hw)) ** 2 == hw else 1
     w = hw // h
     xf, xd = rnd(f"gn{c0}.{c1}.{hw}", (2, h, w, c0), dtype, 2.0)
@@ -81,6 +85,9 @@ def test_groupnorm(ops, dtype, c0, c1, hw, silu, tune):
     tune.setenv("MOBI_GN_FUSED", "0")                        # the two-launch form on the shapes the fused kernel takes
     y2 = ops.groupnorm(xd, g.cuda(), b.cuda(), 1e-5, silu, x2=x2d)
     assert rel(y2.float().permute(0, 3, 1, 2), ref) < TOL[dtype]
+    tune.setenv("MOBI_GN_FUSED", "1")
+    y3 = ops.groupnorm(xd, g.cuda(), b.cuda(), 1e-5, silu, x2=x2d)
+    assert rel(y3.float().permute(0, 3, 1, 2), ref) < TOL[dtype]
 
 
 @pytest.mark.parametrize("dtype", DT)
