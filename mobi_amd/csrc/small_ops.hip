@@ -700,6 +700,193 @@ __global__ __launch_bounds__(256) void two_key_adapter_mfma_kernel(const mobi_tw
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// The same two products with the token rows in REGISTERS (C = 320 / 640: the 64 x 64 and 32 x 32 levels).  A lane
+// loads its token's row as the MFMA fragments it is multiplied as -- token lane & 15, channels 32 f + 8 (lane >> 4) .. + 7
+// of k-block f -- straight from global memory (64-byte segments, each row read once, every load of a 16-token tile in
+// flight at once) and keeps them.  The update product is issued as two 16-row halves per 32 channels whose table rows are
+// ordered so that the accumulator registers a lane receives are the channels of the fragment it holds: A row m of half s
+// is channel 32 f + 8 (m >> 2) + 4 s + (m & 3), so lane (token, q) gets channels 32 f + 8 q + 4 s + j.  x + b + update is
+// then packed in place and stored as the same 16-byte pieces: no x tile in LDS (the kernel above: 128 C bytes of its
+// 196 C), which leaves 68 C bytes of tables -- 23 / 46 KB: three / two blocks per CU.
+// ---------------------------------------------------------------------------------------------------------
+template <typename T, int NF>
+__global__ __launch_bounds__(256) void two_key_adapter_regs_kernel(const mobi_two_key_adapter_params p, int rows_per_block) {
+  typedef typename Vec8<T>::type frag_t;
+  constexpr int C = 32 * NF;
+  constexpr int AST = C * 2 + 16;                   // bytes per table row (hi or lo): odd multiple of 16, conflict-free reads
+  // a: T [9][C] hi, lo (rows >= heads are zero; row 8 is what MFMA rows 8..15 read); u: T [C + 1][8] hi, lo (U^T, heads
+  // contiguous; entry C is zero: what the lanes that supply k >= 8 read)
+  __shared__ __attribute__((aligned(16))) unsigned char tkr_lds[2 * 9 * AST + 2 * (C + 1) * 16 + (C + 8) * 4];
+  const int H = p.heads;
+  unsigned char* s_ahi = tkr_lds;
+  unsigned char* s_alo = s_ahi + 9 * AST;
+  unsigned char* s_uhi = s_alo + 9 * AST;
+  unsigned char* s_ulo = s_uhi + (C + 1) * 16;
+  float* s_b = reinterpret_cast<float*>(s_ulo + (C + 1) * 16);    // [C]
+  float* s_asum = s_b + C;                          // [8] sums of the split table rows
+  const int img = blockIdx.y;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r16 = lane & 15, g4 = lane >> 4;
+  {
+    const float* ga = p.a + (long long)img * H * C;
+    const float* gu = p.u + (long long)img * H * C;
+    // every load of the block in flight at once (the staging is a latency chain otherwise: 64 C bytes per block behind one
+    // or two loads per thread); conflict-free LDS writes: a as four channels of one head per thread (8 bytes, consecutive
+    // lanes consecutive), u as the eight heads of one channel per thread (one 16-byte entry)
+#pragma unroll
+    for (int i0 = 0; i0 < 2 * C; i0 += 256) {
+      const int i = i0 + tid;                       // (2 C is a multiple of 64, not of 256: the last step is partial)
+      const int h = i / (C / 4), c = (i - h * (C / 4)) * 4;
+      if (i < 2 * C) {
+        f32x4 va = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (h < H) va = *reinterpret_cast<const f32x4*>(ga + h * C + c);
+        float lo[4], hi[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const T t = (T)va[e]; hi[e] = (float)t; lo[e] = va[e] - hi[e]; }
+        *reinterpret_cast<u32x2*>(s_ahi + h * AST + c * 2) = pack4<T>(hi);
+        *reinterpret_cast<u32x2*>(s_alo + h * AST + c * 2) = pack4<T>(lo);
+      }
+    }
+#pragma unroll
+    for (int c0 = 0; c0 < C; c0 += 256) {
+      const int c = c0 + tid;
+      if (c < C) {
+        float hi[8], lo[8];
+#pragma unroll
+        for (int h = 0; h < 8; ++h) {
+          const float v = h < H ? gu[h * C + c] : 0.f;
+          const T t = (T)v;
+          hi[h] = (float)t;
+          lo[h] = v - hi[h];
+        }
+        st16(s_uhi + c * 16, pack8<T>(hi));
+        st16(s_ulo + c * 16, pack8<T>(lo));
+      }
+    }
+    for (int c = tid; c < C; c += 256) {
+      s_b[c] = p.b[(long long)img * C + c];
+      *reinterpret_cast<T*>(s_ahi + 8 * AST + c * 2) = (T)0.0f;
+      *reinterpret_cast<T*>(s_alo + 8 * AST + c * 2) = (T)0.0f;
+    }
+    if (tid < 8) {
+      *reinterpret_cast<T*>(s_uhi + C * 16 + tid * 2) = (T)0.0f;
+      *reinterpret_cast<T*>(s_ulo + C * 16 + tid * 2) = (T)0.0f;
+    }
+  }
+  __syncthreads();
+  {                                                 // sums of the numbers the matrix product will use: 32 threads per head
+    const int h = tid >> 5, l = tid & 31;
+    float sum = 0.f;
+    for (int c = l; c < C; c += 32)
+      sum += (float)*reinterpret_cast<const T*>(s_ahi + h * AST + c * 2) + (float)*reinterpret_cast<const T*>(s_alo + h * AST + c * 2);
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+    if (l == 0) s_asum[h] = sum;
+  }
+  __syncthreads();
+  float a_sum[4], cc[4];                            // the lane's four heads: 4 g4 .. 4 g4 + 3 (g4 < 2)
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int h = 4 * g4 + j;
+    a_sum[j] = h < 8 ? s_asum[h] : 0.f;
+    cc[j] = h < H ? p.c[img * H + h] : 0.f;
+  }
+  const long long ximg = p.x_img_stride ? p.x_img_stride : (long long)p.rows_per_image * C;
+  const long long oimg = p.out_img_stride ? p.out_img_stride : (long long)p.rows_per_image * C;
+  const T* __restrict__ xb = reinterpret_cast<const T*>(p.x) + img * ximg;
+  T* __restrict__ ob = reinterpret_cast<T*>(p.out) + img * oimg;
+  const int r_begin = blockIdx.x * rows_per_block;
+  const int r_end = min(p.rows_per_image, r_begin + rows_per_block);
+  const float inv_c = 1.0f / (float)C;
+  const int a_off = min(r16, 8) * AST + 16 * g4;    // this lane's table row of the logits product (byte offset)
+  // update row r16 of half 0 is channel 8 (r16 >> 2) + (r16 & 3) of the 32-channel block; lanes beyond k = 7 read zeros
+  const int u_off = g4 == 0 ? (8 * (r16 >> 2) + (r16 & 3)) * 16 : C * 16;
+  const int u_step = g4 == 0 ? 16 : 0;              // (bytes per channel)
+
+  for (int r0 = r_begin + 16 * wave; r0 < r_end; r0 += 64) {
+    const int row = r0 + r16;
+    const bool live = row < r_end;
+    const T* __restrict__ xr = xb + (long long)(live ? row : r_end - 1) * C + 8 * g4;
+    unsigned xf[NF][4];
+#pragma unroll
+    for (int f = 0; f < NF; ++f) {
+      const u32x4 v = ld16(xr + 32 * f);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) xf[f][e] = v[e];
+    }
+    auto frag = [&](int f) { return __builtin_bit_cast(frag_t, u32x4{xf[f][0], xf[f][1], xf[f][2], xf[f][3]}); };
+    // ---- logits + LayerNorm sums --------------------------------------------------------------------------------
+    f32x4 lg = f32x4{0.f, 0.f, 0.f, 0.f};
+    float sx = 0.f, sxx = 0.f;
+#pragma unroll
+    for (int f = 0; f < NF; ++f) {
+      const frag_t x8 = frag(f);
+      const frag_t ah = __builtin_bit_cast(frag_t, ld16(s_ahi + a_off + 64 * f));
+      const frag_t al = __builtin_bit_cast(frag_t, ld16(s_alo + a_off + 64 * f));
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { const float v = (float)x8[j]; sx += v; sxx += v * v; }
+      lg = mfma16(ah, x8, lg);
+      lg = mfma16(al, x8, lg);
+    }
+    // (the packed rows are what stays in registers: without the pins the compiler keeps the unpacked floats of the
+    //  statistics alive for the final add, three times the registers)
+#pragma unroll
+    for (int f = 0; f < NF; ++f)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) asm volatile("" : "+v"(xf[f][e]));
+    sx += __shfl_xor(sx, 16, 64); sx += __shfl_xor(sx, 32, 64);            // the four k-chunk lanes of a token
+    sxx += __shfl_xor(sxx, 16, 64); sxx += __shfl_xor(sxx, 32, 64);
+    const float mean = sx * inv_c;
+    float var = sxx * inv_c - mean * mean;
+    var = var < 0.f ? 0.f : var;
+    const float rstd = rsqrtf(var + p.eps);
+    float g[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float z = rstd * (lg[j] - mean * a_sum[j]) + cc[j];
+      g[j] = 1.0f / (1.0f + __expf(-z));
+    }
+    // gates of heads 4..7 live 16 lanes further on: bring them to the g4 = 0 lanes, which supply k = 0..7
+    float gh[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) gh[j] = __shfl_down(g[j], 16, 64);
+    frag_t gf, gl;                                  // gates and their rounding remainders (the product stays ~16-bit)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      gf[j] = g4 == 0 ? (T)g[j] : (T)0.0f;
+      gf[4 + j] = g4 == 0 ? (T)gh[j] : (T)0.0f;
+      gl[j] = g4 == 0 ? (T)(g[j] - (float)gf[j]) : (T)0.0f;
+      gl[4 + j] = g4 == 0 ? (T)(gh[j] - (float)gf[4 + j]) : (T)0.0f;
+    }
+    // ---- update, final add, store ---------------------------------------------------------------------------------
+    T* __restrict__ orow = ob + (long long)row * C + 8 * g4;
+#pragma unroll
+    for (int f = 0; f < NF; ++f) {
+      f32x4 d[2];
+#pragma unroll
+      for (int s_ = 0; s_ < 2; ++s_) {
+        const frag_t uh = __builtin_bit_cast(frag_t, ld16(s_uhi + u_off + (32 * f + 4 * s_) * u_step));
+        const frag_t ul = __builtin_bit_cast(frag_t, ld16(s_ulo + u_off + (32 * f + 4 * s_) * u_step));
+        d[s_] = f32x4{0.f, 0.f, 0.f, 0.f};
+        d[s_] = mfma16(uh, gf, d[s_]);
+        d[s_] = mfma16(ul, gf, d[s_]);
+        d[s_] = mfma16(uh, gl, d[s_]);
+      }
+      const frag_t x8 = frag(f);
+      const f32x4 b0 = *reinterpret_cast<const f32x4*>(s_b + 32 * f + 8 * g4);
+      const f32x4 b1 = *reinterpret_cast<const f32x4*>(s_b + 32 * f + 8 * g4 + 4);
+      float o[8];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        o[j] = (float)x8[j] + b0[j] + d[0][j];
+        o[4 + j] = (float)x8[4 + j] + b1[j] + d[1][j];
+      }
+      if (live) st16(orow + 32 * f, pack8<T>(o));
+    }
+  }
+}
+
 // fp32 x fp32 -> fp32 small GEMM (x [m][k], w [n][k]): 16 x 16 output tile per block (one output per thread, so that the
 // few rows of these folds still spread over hundreds of blocks), k in LDS slabs of 32, plain fp32 FMA chains in k order.
 // For the per-run context folds only.
@@ -784,7 +971,26 @@ extern "C" int mobi_two_key_adapter(const mobi_two_key_adapter_params* p, void* 
        reinterpret_cast<uintptr_t>(p->u) | reinterpret_cast<uintptr_t>(p->b)) & 15) return MOBI_ERR_ALIGN;
   // (measured, tools/kbench.py tka: C = 320 at 64 x 64 x 16 37.0 vs 67.3 us; at C = 640 its 127 KB of LDS leave one block
   //  per CU and it loses, 39.8 vs 36.8 us: the vector-ALU kernel keeps the wider levels; MOBI_TKA_MFMA=1 forces it to 640)
-  if ((p->channels & 31) == 0 && p->channels <= (mobi::tuning().tka_mfma == 1 ? 640 : 320) && mobi::tuning().tka_mfma != 0) {
+  const int tka = mobi::tuning().tka_mfma;          // unset: token rows in registers; 2 / 1: the LDS-tile kernel (to 320 / 640); 0: VALU
+  // (C = 1280 stays on the vector-ALU kernel: 16 x 16 and 8 x 8 tokens per image are a fixed cost of table staging plus
+  //  one tile per wave either way -- 20.8 us there, 21.5 us as a 40-block unrolled register kernel, profiles/r03_tka_lab.txt)
+  if (tka != 0 && tka != 1 && tka != 2 && (p->channels == 320 || p->channels == 640)) {
+    // 16 rows per wave and tile, 64 per block at least; about 512 blocks over the launch (the tables are staged per block)
+    long long rows = ((long long)p->rows_per_image * p->images + 511) / 512;
+    rows = (rows + 15) / 16 * 16;
+    if (rows < 64) rows = 64;
+    if (mobi::tuning().tka_rows > 0) rows = (mobi::tuning().tka_rows + 15) / 16 * 16;
+    if (rows > p->rows_per_image) rows = (p->rows_per_image + 15) / 16 * 16;
+    const dim3 g2((unsigned)((p->rows_per_image + rows - 1) / rows), (unsigned)p->images);
+#define MOBI_TKR(T_, NF_) hipLaunchKernelGGL((two_key_adapter_regs_kernel<T_, NF_>), g2, dim3(256), 0, ST(stream), *p, (int)rows)
+    const int NF = p->channels / 32;
+    if (p->dtype == MOBI_F16) { if (NF == 10) MOBI_TKR(f16_t, 10); else MOBI_TKR(f16_t, 20); }
+    else                      { if (NF == 10) MOBI_TKR(bf16_t, 10); else MOBI_TKR(bf16_t, 20); }
+#undef MOBI_TKR
+    MOBI_CHECK_LAUNCH();
+    return MOBI_OK;
+  }
+  if ((p->channels & 31) == 0 && p->channels <= (tka == 1 ? 640 : 320) && tka != 0) {
     // matrix-core kernel: blocks of 64 rows (16 per wave) x k; about 512 blocks over the launch (tables re-staged per block)
     const int C = p->channels;
     long long rows = ((long long)p->rows_per_image * p->images + 511) / 512;
@@ -803,6 +1009,7 @@ extern "C" int mobi_two_key_adapter(const mobi_two_key_adapter_params* p, void* 
   long long rpb = ((long long)p->rows_per_image * p->images + 1023) / 1024;
   rpb = (rpb + 3) / 4 * 4;
   if (rpb < 8) rpb = 8;
+  if (mobi::tuning().tka_rows > 0) rpb = (mobi::tuning().tka_rows + 3) / 4 * 4;
   if (rpb > p->rows_per_image) rpb = (p->rows_per_image + 3) / 4 * 4;
   const dim3 grid((unsigned)((p->rows_per_image + rpb - 1) / rpb), (unsigned)p->images);
   const int V = p->channels >> 3;

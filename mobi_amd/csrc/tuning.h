@@ -19,9 +19,10 @@ struct Tuning {
   int sm_direct;        // MOBI_IGEMM_SM_DIRECT       0: 128 x 160 ring tiles always through the LDS-staged epilogue (A/B)
   int w_tiled;          // MOBI_IGEMM_WTILED          0: ring kernels fetch weights as row segments even when request images are given (A/B)
   int sm64;             // MOBI_IGEMM_SM64            0: 128-pixel tiles always on the 32-deep-step ring kernel (A/B)
-  int tka_mfma;         // MOBI_TKA_MFMA              0: two-key adapter on the vector-ALU kernel (A/B)
+  int tka_mfma;         // MOBI_TKA_MFMA              0: two-key adapter on the vector-ALU kernel; 2 / 1: the LDS-tile kernel to C = 320 / 640 (A/B)
   int attn_nw;          // MOBI_ATTN_NW               4 | 8: waves per attention block
   int attn_sp;          // MOBI_ATTN_SP               1: software-pipelined attention kernel (dh 33..48)
+  int tka_rows;         // MOBI_TKA_ROWS              rows per block of the register two-key adapter kernel (sweeps)
   int gn_fused;         // MOBI_GN_FUSED              0: two-launch GroupNorm; 1: one launch, slab in LDS, where it fits (A/B)
   int attn_v3;          // MOBI_ATTN_V3               0: V row-major launches stay on attention_kernel (A/B); development build: 2 / 3 = the
                         //                            software-pipelined variants of attention_rows_kernel

@@ -762,10 +762,10 @@ def test_igemm_ring256_epilogues(ops, dtype, case, tune):
 @pytest.mark.parametrize("dtype", DT)
 @pytest.mark.parametrize("n,t,c,heads,strided", [(3, 100, 320, 8, False), (2, 64, 640, 8, True), (2, 37, 1280, 8, False),
                                                  (1, 256, 64, 4, False)])
-def test_two_key_adapter(ops, dtype, n, t, c, heads, strided):
-    """One-pass bbox adapter kernel (LayerNorm statistics, per-head gate logits, gated per-image vectors) against the
-    same formula in torch fp32; ragged token counts, three channel widths (1 / 2 / 3 chunks per lane), a
-    batch-strided view updated in place."""
+def test_two_key_adapter(ops, dtype, n, t, c, heads, strided, tune):
+    """One-pass bbox adapter kernels (LayerNorm statistics, per-head gate logits, gated per-image vectors: token rows in
+    registers at C = 320 / 640, the LDS-tile and vector-ALU kernels elsewhere and under MOBI_TKA_MFMA) against the same
+    formula in torch fp32; ragged token counts, three channel widths, a batch-strided view updated in place."""
     name = f"tka.{n}.{t}.{c}.{heads}"
     full = 2 * n if strided else n
     xf, xd = rnd(name + ".x", (full, t, c), dtype, scale=2.0)
@@ -781,10 +781,16 @@ def test_two_key_adapter(ops, dtype, n, t, c, heads, strided):
     view = xd[::2] if strided else xd
     y = ops.two_key_adapter(view, a.cuda(), a.sum(-1).contiguous().cuda(), cc.cuda(), u.cuda(), b.cuda(), 1e-5)
     assert rel(y.float(), ref) < TOL[dtype]
+    x0 = xd.clone()
     y2 = ops.two_key_adapter(view, a.cuda(), a.sum(-1).contiguous().cuda(), cc.cuda(), u.cuda(), b.cuda(), 1e-5, out=view)
     assert y2.data_ptr() == view.data_ptr() and torch.equal(y2, y)
     if strided:                                                        # the partner images are untouched
         assert torch.equal(xd[1::2].float().cpu(), xf[1::2])
+    for form in ("0", "1"):                                            # the vector-ALU and the LDS-tile kernels on the same shapes
+        tune.setenv("MOBI_TKA_MFMA", form)
+        y3 = ops.two_key_adapter(x0[::2] if strided else x0, a.cuda(), a.sum(-1).contiguous().cuda(), cc.cuda(), u.cuda(),
+                                 b.cuda(), 1e-5)
+        assert rel(y3.float(), ref) < TOL[dtype], form
 
 
 @pytest.mark.parametrize("dtype", DT)
