@@ -63,6 +63,20 @@
 
 namespace mobi {
 
+// Workgroup -> (query block, head, image).  The hardware deals consecutive workgroup ids (x fastest) round-robin to the eight
+// XCDs; left alone, the query blocks of one (head, image) -- which all stream the same K / V panel -- land on eight different
+// L2s and each fetches the panel from HBM (measured: 378 MB per [16, 4096 x 4096, 8 x 40] launch against 168 MB of
+// operands).  xcd_remap hands every XCD a contiguous range of the (image, head, query block) list instead.
+__device__ __forceinline__ void attn_block(int xcd_map, int& qblk, int& head, int& img) {
+  const int gx = (int)gridDim.x, gy = (int)gridDim.y;
+  const int lin = (int)blockIdx.x + gx * ((int)blockIdx.y + gy * (int)blockIdx.z);
+  const int L = xcd_map ? xcd_remap(lin, gx * gy * (int)gridDim.z) : lin;
+  qblk = L % gx;
+  const int hi = L / gx;
+  head = hi % gy;
+  img = hi / gy;
+}
+
 struct AttnArgs {
   const void* q; long long q_img; int q_row;
   const void* k; long long k_img; int k_row;
@@ -70,6 +84,7 @@ struct AttnArgs {
   void* out; long long out_img; int out_row;
   int heads, dh, tq, tk;
   float cexp;                // scale * log2(e), or 1 when q already carries it (mobi_attention_params.q_log2_scaled)
+  int xcd_map;               // workgroup ids re-dealt so that the query blocks of a (head, image) share one XCD's L2
 };
 
 // VVEC: every V^T row start is 16-byte aligned (tk % 8 == 0 rows), the production case; the generic
@@ -101,8 +116,9 @@ __global__ __launch_bounds__(64 * NW, (WPS * 4) / NW) void attention_kernel(cons
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int ql = lane & 31, half = lane >> 5;
-  const int head = blockIdx.y, img = blockIdx.z;
-  const int q0 = blockIdx.x * (32 * NW) + wave * 32;
+  int qblk, head, img;
+  attn_block(a.xcd_map, qblk, head, img);
+  const int q0 = qblk * (32 * NW) + wave * 32;
   const int dh = a.dh;
   // When the head dim leaves a padded row in the P.V tile (dh < 32*DT: dh = 40, 80, ...; not 64, 160) that
   // row of V^T is filled with ones, so the matrix core accumulates the softmax denominator
@@ -515,8 +531,9 @@ void attention_rows_kernel(const AttnArgs a) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int ql = lane & 31, half = lane >> 5;
-  const int head = blockIdx.y, img = blockIdx.z;
-  const int q0 = blockIdx.x * (32 * NW) + wave * 32;
+  int qblk, head, img;
+  attn_block(a.xcd_map, qblk, head, img);
+  const int q0 = qblk * (32 * NW) + wave * 32;
   const int dh = a.dh;
   // a padded channel of the P.V tile carries the denominator: dh is KS*16 - 8 (QSH) or KS*16, DT*32 is (KS + 1)/2 * 32
   constexpr bool ONES = QSH || (KS & 1);
@@ -900,8 +917,9 @@ void attention_hp_kernel(const AttnArgs a) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int ql = lane & 31, half = lane >> 5;
-  const int head = blockIdx.y, img = blockIdx.z;
-  const int q0 = blockIdx.x * (32 * NW) + wave * 32;
+  int qblk, head, img;
+  attn_block(a.xcd_map, qblk, head, img);
+  const int q0 = qblk * (32 * NW) + wave * 32;
   const int dh = a.dh;
   // a padded channel of the P.V tile carries the denominator: dh is KS*16 - 8 (QSH) or KS*16, DT*32 is (KS + 1)/2 * 32
   constexpr bool ONES = QSH || (KS & 1);
@@ -1300,8 +1318,9 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_pipe_kernel(const AttnAr
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int ql = lane & 31, half = lane >> 5;
-  const int head = blockIdx.y, img = blockIdx.z;
-  const int q0 = blockIdx.x * (32 * NW) + wave * 32;
+  int qblk, head, img;
+  attn_block(a.xcd_map, qblk, head, img);
+  const int q0 = qblk * (32 * NW) + wave * 32;
   const int dh = a.dh;
 
   const T* __restrict__ qp = reinterpret_cast<const T*>(a.q) + img * a.q_img + head * dh;
@@ -1686,8 +1705,9 @@ __global__ __launch_bounds__(512, 2) void attention_sp_kernel(const AttnArgs a) 
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int ql = lane & 31, half = lane >> 5;
-  const int head = blockIdx.y, img = blockIdx.z;
-  const int q0 = blockIdx.x * 256 + wave * 32;
+  int qblk, head, img;
+  attn_block(a.xcd_map, qblk, head, img);
+  const int q0 = qblk * 256 + wave * 32;
   const int dh = a.dh;
 
   const T* __restrict__ qp = reinterpret_cast<const T*>(a.q) + img * a.q_img + head * dh;
@@ -2073,6 +2093,7 @@ extern "C" int mobi_attention(const mobi_attention_params* p, void* stream) {
   a.out = p->out; a.out_img = p->out_img_stride; a.out_row = p->out_row_stride;
   a.heads = p->heads; a.dh = p->dh; a.tq = p->tq; a.tk = p->tk;
   a.cexp = p->q_log2_scaled ? 1.0f : p->scale * 1.4426950408889634f;
+  a.xcd_map = tuning().attn_xcd != 0;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   return p->dtype == MOBI_F16 ? launch_attention<f16_t>(p, a, st) : launch_attention<bf16_t>(p, a, st);
 }
