@@ -70,7 +70,8 @@ class CtxAttentionParams(C.Structure):
 class TwoKeyAdapterParams(C.Structure):
     _fields_ = [("x", vp), ("out", vp), ("x_img_stride", i64), ("out_img_stride", i64), ("a", vp), ("a_sum", vp),
                 ("c", vp), ("u", vp), ("b", vp), ("images", i32), ("rows_per_image", i32), ("channels", i32),
-                ("heads", i32), ("eps", f32), ("dtype", i32)]
+                ("heads", i32), ("eps", f32), ("dtype", i32), ("ln_out", vp * 2), ("ln_gamma", vp * 2), ("ln_beta", vp * 2),
+                ("ln_eps", f32)]
 
 
 class SkinnyLinearParams(C.Structure):
@@ -143,6 +144,7 @@ SYMBOLS = {
     "mobi_attention": (C.c_int, [C.POINTER(AttentionParams), vp]),
     "mobi_ctx_attention": (C.c_int, [C.POINTER(CtxAttentionParams), vp]),
     "mobi_two_key_adapter": (C.c_int, [C.POINTER(TwoKeyAdapterParams), vp]),
+    "mobi_two_key_adapter_fuses_ln": (C.c_int, [i32]),
     "mobi_softmax_rows": (C.c_int, [vp, vp, i64, i32, i32, vp]),
     "mobi_skinny_linear": (C.c_int, [C.POINTER(SkinnyLinearParams), vp]),
     "mobi_layernorm_rows_f32": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, i32, f32, vp]),

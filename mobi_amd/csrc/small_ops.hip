@@ -717,7 +717,7 @@ __global__ __launch_bounds__(256) void two_key_adapter_regs_kernel(const mobi_tw
   constexpr int AST = C * 2 + 16;                   // bytes per table row (hi or lo): odd multiple of 16, conflict-free reads
   // a: T [9][C] hi, lo (rows >= heads are zero; row 8 is what MFMA rows 8..15 read); u: T [C + 1][8] hi, lo (U^T, heads
   // contiguous; entry C is zero: what the lanes that supply k >= 8 read)
-  __shared__ __attribute__((aligned(16))) unsigned char tkr_lds[2 * 9 * AST + 2 * (C + 1) * 16 + (C + 8) * 4];
+  __shared__ __attribute__((aligned(16))) unsigned char tkr_lds[2 * 9 * AST + 2 * (C + 1) * 16 + (C + 8) * 4 + 2 * C * 4];
   const int H = p.heads;
   unsigned char* s_ahi = tkr_lds;
   unsigned char* s_alo = s_ahi + 9 * AST;
@@ -725,6 +725,9 @@ __global__ __launch_bounds__(256) void two_key_adapter_regs_kernel(const mobi_tw
   unsigned char* s_ulo = s_uhi + (C + 1) * 16;
   float* s_b = reinterpret_cast<float*>(s_ulo + (C + 1) * 16);    // [C]
   float* s_asum = s_b + C;                          // [8] sums of the split table rows
+  float* s_lg = s_asum + 8;                         // [C] gamma, [C] beta of this image's second-result LayerNorm
+  float* s_lb = s_lg + C;
+  const bool ln2 = p.ln_out[0] != nullptr;          // (uniform)
   const int img = blockIdx.y;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r16 = lane & 15, g4 = lane >> 4;
@@ -768,6 +771,11 @@ __global__ __launch_bounds__(256) void two_key_adapter_regs_kernel(const mobi_tw
       s_b[c] = p.b[(long long)img * C + c];
       *reinterpret_cast<T*>(s_ahi + 8 * AST + c * 2) = (T)0.0f;
       *reinterpret_cast<T*>(s_alo + 8 * AST + c * 2) = (T)0.0f;
+    }
+    if (ln2) {
+      const float* lg = (blockIdx.y & 1) ? p.ln_gamma[1] : p.ln_gamma[0];
+      const float* lb = (blockIdx.y & 1) ? p.ln_beta[1] : p.ln_beta[0];
+      for (int c = tid; c < C; c += 256) { s_lg[c] = lg[c]; s_lb[c] = lb[c]; }
     }
     if (tid < 8) {
       *reinterpret_cast<T*>(s_uhi + C * 16 + tid * 2) = (T)0.0f;
@@ -882,7 +890,45 @@ __global__ __launch_bounds__(256) void two_key_adapter_regs_kernel(const mobi_tw
         o[j] = (float)x8[j] + b0[j] + d[0][j];
         o[4 + j] = (float)x8[4 + j] + b1[j] + d[1][j];
       }
-      if (live) st16(orow + 32 * f, pack8<T>(o));
+      const u32x4 packed = pack8<T>(o);
+      if (live) st16(orow + 32 * f, packed);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) xf[f][e] = packed[e];          // the stored (rounded) row: what a LayerNorm launch would read
+    }
+    if (!ln2) continue;
+    // ---- second result: LayerNorm of the stored row (mean, variance about the mean: layernorm_kernel's arithmetic) ------
+    float s1 = 0.f;
+#pragma unroll
+    for (int f = 0; f < NF; ++f) {
+      const frag_t x8 = frag(f);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s1 += (float)x8[j];
+    }
+    s1 += __shfl_xor(s1, 16, 64); s1 += __shfl_xor(s1, 32, 64);
+    const float mean2 = s1 * inv_c;
+    float q2 = 0.f;
+#pragma unroll
+    for (int f = 0; f < NF; ++f) {
+      const frag_t x8 = frag(f);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { const float dd = (float)x8[j] - mean2; q2 += dd * dd; }
+    }
+    q2 += __shfl_xor(q2, 16, 64); q2 += __shfl_xor(q2, 32, 64);
+    const float rstd2 = rsqrtf(q2 * inv_c + p.ln_eps);
+    T* __restrict__ lrow = reinterpret_cast<T*>((img & 1) ? p.ln_out[1] : p.ln_out[0]) +
+                           ((long long)(img >> 1) * p.rows_per_image + row) * C + 8 * g4;
+#pragma unroll
+    for (int f = 0; f < NF; ++f) {
+      const frag_t x8 = frag(f);
+      const f32x4 g0 = *reinterpret_cast<const f32x4*>(s_lg + 32 * f + 8 * g4), g1 = *reinterpret_cast<const f32x4*>(s_lg + 32 * f + 8 * g4 + 4);
+      const f32x4 h0 = *reinterpret_cast<const f32x4*>(s_lb + 32 * f + 8 * g4), h1 = *reinterpret_cast<const f32x4*>(s_lb + 32 * f + 8 * g4 + 4);
+      float o[8];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        o[j] = ((float)x8[j] - mean2) * rstd2 * g0[j] + h0[j];
+        o[4 + j] = ((float)x8[4 + j] - mean2) * rstd2 * g1[j] + h1[j];
+      }
+      if (live) st16(lrow + 32 * f, pack8<T>(o));
     }
   }
 }
@@ -961,6 +1007,11 @@ extern "C" int mobi_ctx_attention(const mobi_ctx_attention_params* p, void* stre
   return MOBI_OK;
 }
 
+extern "C" int mobi_two_key_adapter_fuses_ln(int32_t channels) {
+  const int tka = mobi::tuning().tka_mfma;
+  return tka != 0 && tka != 1 && tka != 2 && (channels == 320 || channels == 640);
+}
+
 extern "C" int mobi_two_key_adapter(const mobi_two_key_adapter_params* p, void* stream) {
   using namespace mobi;
   if (!p || !p->x || !p->out || !p->a || !p->a_sum || !p->c || !p->u || !p->b) return MOBI_ERR_ARG;
@@ -972,6 +1023,11 @@ extern "C" int mobi_two_key_adapter(const mobi_two_key_adapter_params* p, void* 
   // (measured, tools/kbench.py tka: C = 320 at 64 x 64 x 16 37.0 vs 67.3 us; at C = 640 its 127 KB of LDS leave one block
   //  per CU and it loses, 39.8 vs 36.8 us: the vector-ALU kernel keeps the wider levels; MOBI_TKA_MFMA=1 forces it to 640)
   const int tka = mobi::tuning().tka_mfma;          // unset: token rows in registers; 2 / 1: the LDS-tile kernel (to 320 / 640); 0: VALU
+  if (p->ln_out[0]) {
+    if (!mobi_two_key_adapter_fuses_ln(p->channels)) return MOBI_ERR_UNSUPPORTED;
+    if (!p->ln_out[1] || !p->ln_gamma[0] || !p->ln_gamma[1] || !p->ln_beta[0] || !p->ln_beta[1] || (p->images & 1)) return MOBI_ERR_ARG;
+    if ((reinterpret_cast<uintptr_t>(p->ln_out[0]) | reinterpret_cast<uintptr_t>(p->ln_out[1])) & 15) return MOBI_ERR_ALIGN;
+  }
   // (C = 1280 stays on the vector-ALU kernel: 16 x 16 and 8 x 8 tokens per image are a fixed cost of table staging plus
   //  one tile per wave either way -- 20.8 us there, 21.5 us as a 40-block unrolled register kernel, profiles/r03_tka_lab.txt)
   if (tka != 0 && tka != 1 && tka != 2 && (p->channels == 320 || p->channels == 640)) {

@@ -32,6 +32,7 @@ from .diffusionmodules.util import Conv2d, GroupNorm32, LayerNorm, Linear, Marke
 
 
 FUSED_FF = os.environ.get("MOBI_FUSED_FF", "1") != "0"      # A/B: 0 = GEGLU projection and output projection as two launches
+FUSED_LN = os.environ.get("MOBI_FUSED_LN", "1") != "0"      # A/B: 0 = the cross-modal LayerNorms as launches of their own
 
 
 def _store_in_place(old, new):
@@ -350,8 +351,18 @@ class BasicTransformerBlock(nn.Module):
         a = self.attn1.self_attention(self._ln(self.norm1, x))
         x = ops.linear(a, self.attn1.to_out[0].packed(), residual=x, rowvec=ref_vec, rowvec_has_bias=True)
 
+        ln_cam = ln_lidar = None
         if self.bbox_cond and adapter is not None:
-            x = ops.two_key_adapter(x, *adapter, eps=self.cond_adapter_norm.eps, out=x)
+            nc, nl = (self.cross_modal_norm_camera, self.cross_modal_norm_lidar) if self.multimodal else (None, None)
+            if (FUSED_LN and self.multimodal and x.shape[0] % 2 == 0 and nc.eps == nl.eps
+                    and ops.two_key_adapter_fuses_ln(x.shape[2])):
+                # the adapter kernel holds each result row in registers: it also writes the two LayerNorms the cross-modal
+                # step reads next (camera norm of the even images, lidar norm of the odd ones -- the camera update below
+                # does not touch the lidar rows)
+                x, (ln_cam, ln_lidar) = ops.two_key_adapter(x, *adapter, eps=self.cond_adapter_norm.eps, out=x,
+                                                            ln_pair=(nc.affine(), nl.affine(), nc.eps))
+            else:
+                x = ops.two_key_adapter(x, *adapter, eps=self.cond_adapter_norm.eps, out=x)
         elif self.bbox_cond:
             ca = self.cond_adapter_attn
             q = ops.linear(self._ln(self.cond_adapter_norm, x), ca.to_q.packed())
@@ -363,10 +374,12 @@ class BasicTransformerBlock(nn.Module):
             if x.shape[0] % 2:
                 raise ValueError("multimodal blocks need camera/lidar samples interleaved on an even batch")
             xc, xl = x[::2], x[1::2]
-            a = self.cross_modal_attn_camera.attend(self._ln(self.cross_modal_norm_camera, xc), context=xl)
+            a = self.cross_modal_attn_camera.attend(self._ln(self.cross_modal_norm_camera, xc) if ln_cam is None else ln_cam,
+                                                    context=xl)
             ops.linear(a, self._folded(self.cross_modal_attn_camera, self.cross_modal_connector_camera, "cam"),
                        residual=xc, out=xc)
-            a = self.cross_modal_attn_lidar.attend(self._ln(self.cross_modal_norm_lidar, xl), context=xc)
+            a = self.cross_modal_attn_lidar.attend(self._ln(self.cross_modal_norm_lidar, xl) if ln_lidar is None else ln_lidar,
+                                                   context=xc)
             ops.linear(a, self._folded(self.cross_modal_attn_lidar, self.cross_modal_connector_lidar, "lidar"),
                        residual=xl, out=xl)
 

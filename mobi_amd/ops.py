@@ -429,10 +429,17 @@ def ctx_attention(q, k, v, heads, scale):
     return out
 
 
-def two_key_adapter(x, a, a_sum, c, u, b, eps, out=None):
+def two_key_adapter_fuses_ln(channels):
+    """Whether mobi_two_key_adapter writes the pair of LayerNorm results (`ln_pair`) at this width."""
+    return bool(_lib.load().mobi_two_key_adapter_fuses_ln(int(channels)))
+
+
+def two_key_adapter(x, a, a_sum, c, u, b, eps, out=None, ln_pair=None):
     """x: [N, T, C] tokens (T storage type, possibly a batch-strided view); a, u: fp32 [N, H, C]; a_sum, c: fp32 [N, H];
     b: fp32 [N, C].  Returns x + b + sum_h sigmoid(rstd * (x . a_h - mean * a_sum_h) + c_h) * u_h with the token's
-    LayerNorm statistics (include/mobi_engine.h, mobi_two_key_adapter); out=x updates in place."""
+    LayerNorm statistics (include/mobi_engine.h, mobi_two_key_adapter); out=x updates in place.
+    ln_pair = ((gamma0, beta0), (gamma1, beta1), eps): also returns (LN_0 of the even images, LN_1 of the odd images) of
+    the result, [N / 2, T, C] each -- what the cross-modal step normalises next (two_key_adapter_fuses_ln(C) must hold)."""
     lib = _lib.load()
     n, t, ch = x.shape
     if out is None:
@@ -447,9 +454,22 @@ def two_key_adapter(x, a, a_sum, c, u, b, eps, out=None):
     p.out_img_stride = 0 if so == t * ch else so
     p.a, p.a_sum, p.c, p.u, p.b = _ptr(a), _ptr(a_sum), _ptr(c), _ptr(u), _ptr(b)
     p.images, p.rows_per_image, p.channels, p.heads, p.eps, p.dtype = n, t, ch, a.shape[1], eps, _dt(x.dtype)
-    with _Timed("two_key_adapter", 0.0, 2.0 * x.numel() * 2):
+    lns = None
+    nbytes = 2.0 * x.numel() * 2
+    if ln_pair is not None:
+        (g0, b0), (g1, b1), ln_eps = ln_pair
+        assert n % 2 == 0
+        for tns in (g0, b0, g1, b1):
+            assert tns.dtype == torch.float32 and tns.is_contiguous() and tns.numel() == ch
+        lns = (torch.empty((n // 2, t, ch), device=x.device, dtype=x.dtype),
+               torch.empty((n // 2, t, ch), device=x.device, dtype=x.dtype))
+        for i, (tn, g, bb) in enumerate(((lns[0], g0, b0), (lns[1], g1, b1))):
+            p.ln_out[i], p.ln_gamma[i], p.ln_beta[i] = _ptr(tn), _ptr(g), _ptr(bb)
+        p.ln_eps = ln_eps
+        nbytes += x.numel() * 2
+    with _Timed("two_key_adapter", 0.0, nbytes):
         _lib.check(lib.mobi_two_key_adapter(C.byref(p), _stream()), "mobi_two_key_adapter")
-    return out
+    return out if lns is None else (out, lns)
 
 
 def softmax_rows(s, dtype):

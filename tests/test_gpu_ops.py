@@ -794,6 +794,33 @@ def test_two_key_adapter(ops, dtype, n, t, c, heads, strided, tune):
 
 
 @pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("n,t,c", [(4, 100, 320), (2, 64, 640), (6, 16, 640)])
+def test_two_key_adapter_layernorm_pair(ops, dtype, n, t, c, tune):
+    """The adapter kernel's second result: LayerNorm of the result rows, even images with one (gamma, beta), odd images with
+    another, against mobi_layernorm on the stored result (same rounded input: only the summation order differs) and against
+    fp32 torch; the first result is unchanged by asking for the second; widths / tunings without the fused form say so."""
+    name = f"tkaln.{n}.{t}.{c}"
+    xf, xd = rnd(name + ".x", (n, t, c), dtype, scale=2.0)
+    a = (W.synth_input(name + ".a", (n, 8, c)) * 0.05).cuda()
+    u, b, cc = (W.synth_input(name + k, s).cuda() for k, s in ((".u", (n, 8, c)), (".b", (n, c)), (".c", (n, 8))))
+    gb = [(torch.from_numpy(W.synth_param(f"{name}.g{i}", (c,))).cuda(), torch.from_numpy(W.synth_param(f"{name}.b{i}", (c,))).cuda())
+          for i in range(2)]
+    assert ops.two_key_adapter_fuses_ln(c) and not ops.two_key_adapter_fuses_ln(1280)
+    y = ops.two_key_adapter(xd, a, a.sum(-1).contiguous(), cc, u, b, 1e-5)
+    y2, (l0, l1) = ops.two_key_adapter(xd, a, a.sum(-1).contiguous(), cc, u, b, 1e-5, ln_pair=(gb[0], gb[1], 1e-5))
+    assert torch.equal(y, y2) and l0.shape == l1.shape == (n // 2, t, c)
+    for got, half, (g, bt) in ((l0, y[0::2], gb[0]), (l1, y[1::2], gb[1])):
+        ref = F.layer_norm(half.float(), (c,), g, bt, 1e-5)
+        assert rel(got.float(), ref) < TOL[dtype]
+        sep = ops.layernorm(half.contiguous(), g, bt, 1e-5)
+        assert rel(got.float(), sep.float()) < TOL[dtype] / 4 and float((got.float() - sep.float()).abs().max()) < 0.07
+    tune.setenv("MOBI_TKA_MFMA", "0")
+    assert not ops.two_key_adapter_fuses_ln(c)
+    with pytest.raises(Exception):
+        ops.two_key_adapter(xd, a, a.sum(-1).contiguous(), cc, u, b, 1e-5, ln_pair=(gb[0], gb[1], 1e-5))
+
+
+@pytest.mark.parametrize("dtype", DT)
 def test_igemm_pingpong_upsample_and_stride(ops, dtype, tune):
     """Nearest-x2 upsampling on the load side and a stride-2 convolution through the ping-pong kernel."""
     tune.setenv("MOBI_IGEMM_WM", "4")
