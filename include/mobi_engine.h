@@ -194,7 +194,7 @@ int mobi_attention(const mobi_attention_params* p, void* stream);
 
 /* ---------------------------------------------------------------------------
  * Fused GEGLU feed-forward (FeedForward / GEGLU, attention.py:38-65):
- *   out = ((x W1v^T + b1v) * gelu_erf(x W1g^T + b1g)) W2^T + b2 (+ residual)
+ *   out = ((x' W1v^T + b1v) * gelu_erf(x' W1g^T + b1g)) W2^T + b2 (+ residual),  x' = x or LayerNorm(x)
  * in one launch; the hidden activation [rows][hidden] is never written.  c = 320
  * (the 64 x 64 level of the UNet), hidden % 32 == 0.
  * w_packed: mobi_ff_geglu_packed_bytes(c, hidden) bytes of "chunk images" (one
@@ -217,6 +217,9 @@ typedef struct mobi_ff_geglu_params {
   const void* residual;     /* T [rows][c] or NULL (may alias out) */
   void* out;                /* T [rows][c] */
   int32_t dtype;
+  /* Optional LayerNorm of x over the c channels, applied in the kernel before the first product (norm3 of
+   * BasicTransformerBlock, attention.py:270: x + ff(norm3(x)); `residual` is then x): f32 [c] each, eps.  NULL: none. */
+  const float* ln_gamma; const float* ln_beta; float ln_eps;
 } mobi_ff_geglu_params;
 size_t mobi_ff_geglu_packed_bytes(int32_t c, int32_t hidden);
 int mobi_ff_geglu(const mobi_ff_geglu_params* p, void* stream);

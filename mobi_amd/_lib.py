@@ -59,7 +59,7 @@ class AttentionParams(C.Structure):
 
 class FfGegluParams(C.Structure):
     _fields_ = [("x", vp), ("rows", i64), ("c", i32), ("hidden", i32), ("w_packed", vp), ("b2", vp), ("residual", vp),
-                ("out", vp), ("dtype", i32)]
+                ("out", vp), ("dtype", i32), ("ln_gamma", vp), ("ln_beta", vp), ("ln_eps", f32)]
 
 
 class CtxAttentionParams(C.Structure):

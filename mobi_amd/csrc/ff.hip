@@ -37,6 +37,9 @@ struct FfArgs {
   void* out;
   long long rows;
   int chunks;
+  const float* ln_gamma;    // LayerNorm over the C channels applied to x first (fp32 [C] each), or NULL
+  const float* ln_beta;
+  float ln_eps;
 };
 
 template <typename T, int C>
@@ -60,6 +63,38 @@ __global__ __launch_bounds__(256, 1) void ff_geglu_kernel(const FfArgs a) {
   frag_t xf[KS];
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks) xf[ks] = __builtin_bit_cast(frag_t, ld16(xp + ks * 16 + half * 8));
+  if (a.ln_gamma) {
+    // LayerNorm of the token rows in the registers they are multiplied from (norm3 of the transformer block: the launch
+    // that would write LN(x) and the second read of it go away; `residual` is then x itself).  A row's channels lie in
+    // lanes ql and ql + 32: mean, then the variance about the mean (layernorm_kernel's arithmetic), the result rounded
+    // to the storage type as that kernel's output would be.
+    float s1 = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s1 += (float)xf[ks][j];
+    s1 += __shfl_xor(s1, 32, 64);
+    const float mean = s1 * (1.0f / C);
+    float q = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { const float d = (float)xf[ks][j] - mean; q += d * d; }
+    q += __shfl_xor(q, 32, 64);
+    const float rstd = rsqrtf(q * (1.0f / C) + a.ln_eps);
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const f32x4 g0 = *reinterpret_cast<const f32x4*>(a.ln_gamma + ks * 16 + half * 8);
+      const f32x4 g1 = *reinterpret_cast<const f32x4*>(a.ln_gamma + ks * 16 + half * 8 + 4);
+      const f32x4 h0 = *reinterpret_cast<const f32x4*>(a.ln_beta + ks * 16 + half * 8);
+      const f32x4 h1 = *reinterpret_cast<const f32x4*>(a.ln_beta + ks * 16 + half * 8 + 4);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        xf[ks][j] = (T)(((float)xf[ks][j] - mean) * rstd * g0[j] + h0[j]);
+        xf[ks][4 + j] = (T)(((float)xf[ks][4 + j] - mean) * rstd * g1[j] + h1[j]);
+      }
+    }
+  }
 
   const int nch = (MOBI_FF_DBG & 16) ? 2 : a.chunks;      // (bit 4: two chunks only -- what the prologue and the epilogue cost)
   const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.w1p), 0, nch * W1_SLOT, 0x00020000);
@@ -293,12 +328,15 @@ extern "C" int mobi_ff_geglu(const mobi_ff_geglu_params* p, void* stream) {
   if (p->dtype != MOBI_F16 && p->dtype != MOBI_BF16) return MOBI_ERR_ARG;
   if (p->rows <= 0 || p->hidden <= 0 || (p->hidden & 31)) return MOBI_ERR_ARG;
   if (p->c != 320) return MOBI_ERR_UNSUPPORTED;          // the output accumulators of one 32-row tile must fit the registers
+  if (p->ln_gamma && (!p->ln_beta || ((reinterpret_cast<uintptr_t>(p->ln_gamma) | reinterpret_cast<uintptr_t>(p->ln_beta)) & 15)))
+    return p->ln_beta ? MOBI_ERR_ALIGN : MOBI_ERR_ARG;
   if ((reinterpret_cast<uintptr_t>(p->x) | reinterpret_cast<uintptr_t>(p->w_packed) | reinterpret_cast<uintptr_t>(p->out) |
        reinterpret_cast<uintptr_t>(p->residual) | reinterpret_cast<uintptr_t>(p->b2)) & 15) return MOBI_ERR_ALIGN;
   const long long blocks = (p->rows + 127) / 128;
   if (blocks > 0x7fffffffLL) return MOBI_ERR_UNSUPPORTED;
   FfArgs a;
   a.x = p->x; a.b2 = p->b2; a.residual = p->residual; a.out = p->out; a.rows = p->rows; a.chunks = p->hidden / 32;
+  a.ln_gamma = p->ln_gamma; a.ln_beta = p->ln_gamma ? p->ln_beta : nullptr; a.ln_eps = p->ln_eps;
   a.w1p = p->w_packed;
   a.w2p = reinterpret_cast<const unsigned char*>(p->w_packed) + (size_t)a.chunks * (2 * (p->c / 16)) * 1024;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);

@@ -87,10 +87,18 @@ class FeedForward(nn.Module):
                                                                 proj.weight.device)
         return cache["val"]
 
-    def forward(self, x, residual=None):
+    def forward(self, x, residual=None, norm=None):
+        """norm: the LayerNorm module applied to x first (the transformer block's norm3); the one-launch kernel normalises
+        the rows in the registers it multiplies them from, elsewhere it is a launch of its own."""
         pf = self._fused() if x.is_contiguous() and (residual is None or residual.is_contiguous()) else None
-        if pf is not None:
-            return ops.ff_geglu(x, pf, residual=residual)        # one launch, the hidden activation never leaves the chip
+        if pf is not None:                                       # one launch, the hidden activation never leaves the chip
+            if norm is not None and FUSED_LN:
+                return ops.ff_geglu(x, pf, residual=residual, ln=(*norm.affine(), norm.eps))
+            if norm is not None:
+                x = ops.layernorm(x, *norm.affine(), norm.eps)
+            return ops.ff_geglu(x, pf, residual=residual)
+        if norm is not None:
+            x = ops.layernorm(x, *norm.affine(), norm.eps)
         return ops.linear(self.net[0](x), self.net[2].packed(), residual=residual)
 
 
@@ -383,7 +391,7 @@ class BasicTransformerBlock(nn.Module):
             ops.linear(a, self._folded(self.cross_modal_attn_lidar, self.cross_modal_connector_lidar, "lidar"),
                        residual=xl, out=xl)
 
-        return self.ff(self._ln(self.norm3, x), residual=x)
+        return self.ff(x, residual=x, norm=self.norm3)
 
 
 class SpatialTransformer(nn.Module):

@@ -250,8 +250,9 @@ def pack_ff_geglu(w1, b1, w2, b2, dtype, device):
     return PackedFf(buf, None if b2 is None else b2.detach().to(device=device, dtype=torch.float32).contiguous(), c, hidden, dtype)
 
 
-def ff_geglu(x, pf: PackedFf, residual=None, out=None):
-    """x: T [..., c] dense -> out T [..., c] = GEGLU feed-forward (+ residual) in one launch (mobi_ff_geglu)."""
+def ff_geglu(x, pf: PackedFf, residual=None, out=None, ln=None):
+    """x: T [..., c] dense -> out T [..., c] = GEGLU feed-forward (+ residual) in one launch (mobi_ff_geglu).
+    ln = (gamma, beta, eps): the feed-forward of LayerNorm(x) (the kernel normalises the rows it holds in registers)."""
     lib = _lib.load()
     _dev(x)
     assert x.is_contiguous() and x.shape[-1] == pf.c and x.dtype == pf.dtype
@@ -262,8 +263,13 @@ def ff_geglu(x, pf: PackedFf, residual=None, out=None):
     p = _lib.FfGegluParams()
     p.x, p.rows, p.c, p.hidden, p.w_packed, p.b2 = _ptr(x), rows, pf.c, pf.hidden, _ptr(pf.buf), _ptr(pf.b2)
     p.residual, p.out, p.dtype = _ptr(residual), _ptr(out), _dt(x.dtype)
+    if ln is not None:
+        g, b, eps = ln
+        assert g.dtype == b.dtype == torch.float32 and g.numel() == b.numel() == pf.c and g.is_contiguous() and b.is_contiguous()
+        p.ln_gamma, p.ln_beta, p.ln_eps = _ptr(g), _ptr(b), eps
     fl = 2.0 * rows * pf.c * (2 * pf.hidden) + 2.0 * rows * pf.hidden * pf.c
-    with _Timed("ff_geglu", fl, 2.0 * rows * pf.c * (3 if residual is not None else 2), f"rows={rows} c={pf.c} hidden={pf.hidden}"):
+    reads = 1 + (residual is not None and (ln is None or residual.data_ptr() != x.data_ptr()))
+    with _Timed("ff_geglu", fl, 2.0 * rows * pf.c * (reads + 1), f"rows={rows} c={pf.c} hidden={pf.hidden}"):
         _lib.check(lib.mobi_ff_geglu(C.byref(p), _stream()), "mobi_ff_geglu")
     return out
 

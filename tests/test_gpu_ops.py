@@ -921,3 +921,10 @@ def test_ff_geglu_fused(ops, dtype, rows, hidden, residual):
     g = ops.linear(xd.view(1, rows, c), ops.pack_geglu(w1, b1, dtype, "cuda"))
     y2 = ops.linear(g, ops.pack_linear(w2, b2, dtype, "cuda"), residual=rd.view(1, rows, c) if residual else None)
     assert rel(y.float(), y2.view(rows, c).float().cpu()) < TOL[dtype]
+    # LayerNorm of x inside the kernel (norm3) against LayerNorm as a launch of its own followed by the same kernel
+    gam = torch.from_numpy(W.synth_param("ff.ln.weight", (c,))).cuda()
+    bet = torch.from_numpy(W.synth_param("ff.ln.bias", (c,))).cuda()
+    xs = (xd.float() * 1.7 + 0.4).to(dtype)
+    y3 = ops.ff_geglu(xs, pf, residual=xs if residual else None, ln=(gam, bet, 1e-5))
+    y4 = ops.ff_geglu(ops.layernorm(xs.view(1, rows, c), gam, bet, 1e-5).view(rows, c), pf, residual=xs if residual else None)
+    assert rel(y3.float(), y4.float()) < TOL[dtype] / 2
