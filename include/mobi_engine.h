@@ -218,7 +218,7 @@ typedef struct mobi_ff_geglu_params {
   void* out;                /* T [rows][c] */
   int32_t dtype;
   /* Optional LayerNorm of x over the c channels, applied in the kernel before the first product (norm3 of
-   * BasicTransformerBlock, attention.py:270: x + ff(norm3(x)); `residual` is then x): f32 [c] each, eps.  NULL: none. */
+   * BasicTransformerBlock, attention.py:265: ff(norm3(x)) + x; `residual` is then x): f32 [c] each, eps.  NULL: none. */
   const float* ln_gamma; const float* ln_beta; float ln_eps;
 } mobi_ff_geglu_params;
 size_t mobi_ff_geglu_packed_bytes(int32_t c, int32_t hidden);
