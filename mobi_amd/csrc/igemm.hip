@@ -114,6 +114,9 @@ struct IgemmArgs {
   int out_mode, epilogue;
   float scale;
   int tiles_m, tiles_n;
+  int n_major;             // work list walks the pixel tiles of one channel tile first: an XCD (a contiguous range of the
+                           // list) then streams ITS slice of the weights instead of all of them (launches whose weights
+                           // outweigh their activations: the 16 x 16 / 8 x 8 levels)
   int src0_bytes, src1_bytes, w_bytes, fast, glds;
   int k_order;             // 0: k = tap*C + c;  1: k = (c/64)*taps*64 + tap*64 + c%64 (FAST shapes only)   // buffer extents for the FAST path's descriptors
   int wm;                  // waves along the pixel axis (2 or 4): block tile = 64*wm pixels
@@ -130,6 +133,11 @@ struct IgemmArgs {
   int wide;                // ring kernel with eight waves: 2 = 256 x 320 (256) tiles, 1 = 128 x 320 (256) tiles
   int hw_shift, w_shift;   // log2(hw_out), log2(wout) when both are powers of two (ping-pong kernel), else -1
 };
+
+__device__ __forceinline__ void tile_of(const IgemmArgs& a, int L, int& tile_m, int& tile_n) {
+  if (a.n_major) { tile_m = L % a.tiles_m; tile_n = L / a.tiles_m; }
+  else           { tile_n = L % a.tiles_n; tile_m = L / a.tiles_n; }
+}
 
 // 8 consecutive floats through two 16-byte accesses (LDS stage rows, bias, per-image vectors)
 __device__ __forceinline__ void ld8f(const float* p, float (&f)[8]) {
@@ -724,8 +732,8 @@ __global__ __launch_bounds__(128 * WM, 2) void igemm_kernel(const IgemmArgs a) {
 
   const int nblk = a.tiles_m * a.tiles_n;
   const int L = xcd_remap(blockIdx.x, nblk);
-  const int tile_n = L % a.tiles_n;
-  const int tile_m = L / a.tiles_n;
+  int tile_m, tile_n;
+  tile_of(a, L, tile_m, tile_n);
   const int m0 = tile_m * BM;
   const int n0 = tile_n * BN;
 
@@ -1048,7 +1056,8 @@ __global__ __launch_bounds__(512, 2) void igemm_glds_kernel(const IgemmArgs a) {
 
   auto set_fetch_tile = [&]() {
     const int L = xcd_remap(f_bid, nblk);
-    const int tile_n = L % a.tiles_n, tile_m = L / a.tiles_n;
+    int tile_m, tile_n;
+    tile_of(a, L, tile_m, tile_n);
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     x_okm = 0;
 #pragma unroll
@@ -1185,7 +1194,9 @@ __global__ __launch_bounds__(512, 2) void igemm_glds_kernel(const IgemmArgs a) {
       for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int L = xcd_remap(bid, nblk);
-    const int nw0 = (L % a.tiles_n) * BN + wn * WAVE_N, mw0 = (L / a.tiles_n) * BM + wm * 64;
+    int tm_, tn_;
+    tile_of(a, L, tm_, tn_);
+    const int nw0 = tn_ * BN + wn * WAVE_N, mw0 = tm_ * BM + wm * 64;
     int mk_req = 0;
     if constexpr (DIRECT) {                                  // bias / residual rows of this output tile: in flight
       vm_issued += direct_epilogue_request<T, NT>(a, dq, lane, group, nw0, mw0);      // for the whole k loop
@@ -1357,7 +1368,8 @@ __global__ __launch_bounds__(512, 2) void igemm_pp_kernel(const IgemmArgs a) {
 
   auto set_fetch_tile = [&]() {
     const int L = xcd_remap(f_bid, nblk);
-    const int tile_n = L % a.tiles_n, tile_m = L / a.tiles_n;
+    int tile_m, tile_n;
+    tile_of(a, L, tile_m, tile_n);
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     {
       const int m = m0 + 8 * wave + rloc;                    // < M: every tile is full
@@ -1520,7 +1532,9 @@ __global__ __launch_bounds__(512, 2) void igemm_pp_kernel(const IgemmArgs a) {
   int ahead = 0;                                             // requested k-tiles not yet multiplied
   {
     const int L0 = xcd_remap(blockIdx.x, nblk);
-    const int nw0 = (L0 % a.tiles_n) * BN + wn * WAVE_N, mw0 = (L0 / a.tiles_n) * BM + wm * 64;
+    int tm_, tn_;
+    tile_of(a, L0, tm_, tn_);
+    const int nw0 = tn_ * BN + wn * WAVE_N, mw0 = tm_ * BM + wm * 64;
     u32x4 bv[NT];
     if (has_vec) { request_vec(bv, nw0, mw0); vm_issued += NT; }
     set_fetch_tile();
@@ -1548,7 +1562,9 @@ __global__ __launch_bounds__(512, 2) void igemm_pp_kernel(const IgemmArgs a) {
 #endif
   for (int bid = blockIdx.x; bid < nblk; bid += gridDim.x) {
     const int L = xcd_remap(bid, nblk);
-    const int nw0 = (L % a.tiles_n) * BN + wn * WAVE_N, mw0 = (L / a.tiles_n) * BM + wm * 64;
+    int tm_, tn_;
+    tile_of(a, L, tm_, tn_);
+    const int nw0 = tn_ * BN + wn * WAVE_N, mw0 = tm_ * BM + wm * 64;
     for (int kt = 0; kt < nk; ++kt) {
       const unsigned char* st = lds + c_slot * STAGE;
       const unsigned char* xb = st + (wm * 64 + r16) * 128;
@@ -1781,7 +1797,8 @@ __global__ __launch_bounds__(NW * 64, 2) void igemm_ring_kernel(const IgemmArgs 
   const int group = blockIdx.z;
   const int nblk = a.tiles_m * a.tiles_n;
   const int L = xcd_remap(blockIdx.x, nblk);
-  const int tile_n = L % a.tiles_n, tile_m = L / a.tiles_n;
+  int tile_m, tile_n;
+  tile_of(a, L, tile_m, tile_n);
   const int m0 = tile_m * BM, n0 = tile_n * BN;
   MOBI_STAMP_AT(0);
   const bool w_tiled = a.w_tiled != nullptr;                 // (wave-uniform) weights as 1-KiB request images
@@ -2138,7 +2155,8 @@ __global__ __launch_bounds__(256, 1) void igemm_ring64_kernel(const IgemmArgs a)
   const int group = blockIdx.z;
   const int nblk = a.tiles_m * a.tiles_n;
   const int L = xcd_remap(blockIdx.x, nblk);
-  const int tile_n = L % a.tiles_n, tile_m = L / a.tiles_n;
+  int tile_m, tile_n;
+  tile_of(a, L, tile_m, tile_n);
   const int m0 = tile_m * BM, n0 = tile_n * BN;
   const T* wgt = reinterpret_cast<const T*>(a.weight) + (long long)group * a.w_group_stride;
   const __amdgpu_buffer_rsrc_t rx0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.src0), 0, a.src0_bytes, 0x00020000);
@@ -2616,6 +2634,17 @@ static int igemm_prepare(const mobi_igemm_params* p, mobi::IgemmArgs& a) {
       a.tiles_n = (int)tn;
       a.sm = 0;
     }
+  }
+  // order of the work list (tile_of): by channel tile when a 1 x 1 launch's weights outweigh the activations it reads --
+  // every XCD's L2 then fetches its slice of the weights and all of the (smaller) activations instead of all of the weights
+  // and its slice of the activations.  Measured (tools/ab_nmajor.sh): the 16 x 16 level's GEGLU projection (26 MB of weights,
+  // 10.5 MB of activations) 219-223 against 233-237 us; 3 x 3 convolutions LOSE 3-6 % (143.7 vs 139.5 us at 1280 -> 1280,
+  // 16 x 16: nine taps re-read the whole activation tensor through every L2), so they keep the pixel-major order.
+  {
+    const long long wbytes = (long long)p->n_packed * a.ktot * 2;
+    const long long abytes = (long long)p->batch * p->hin * p->win * a.C * 2;
+    a.n_major = p->groups == 1 && a.tiles_n >= 2 && p->kh * p->kw == 1 && wbytes > abytes && tuning().n_major != 0;
+    if (tuning().n_major == 1 && p->groups == 1) a.n_major = 1;
   }
   // 64-deep steps for the 128-pixel geometry: channel runs of 64 (a k-step never straddles a tap or a source), >= 3 steps
   // (one block per CU: only grids of at most one round of blocks -- with more, two co-resident blocks of the 32-deep ring win:

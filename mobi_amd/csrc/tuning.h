@@ -18,6 +18,7 @@ struct Tuning {
   int ring_direct;      // MOBI_IGEMM_RING_DIRECT     0: 256 x 320 ring tiles always through the LDS-staged epilogue (A/B)
   int sm_direct;        // MOBI_IGEMM_SM_DIRECT       0: 128 x 160 ring tiles always through the LDS-staged epilogue (A/B)
   int w_tiled;          // MOBI_IGEMM_WTILED          0: ring kernels fetch weights as row segments even when request images are given (A/B)
+  int n_major;          // MOBI_IGEMM_N_MAJOR         0: igemm work lists always walk the channel tiles of a pixel tile first (A/B); 1: never
   int sm64;             // MOBI_IGEMM_SM64            0: 128-pixel tiles always on the 32-deep-step ring kernel (A/B)
   int tka_mfma;         // MOBI_TKA_MFMA              0: two-key adapter on the vector-ALU kernel; 2 / 1: the LDS-tile kernel to C = 320 / 640 (A/B)
   int attn_nw;          // MOBI_ATTN_NW               4 | 8: waves per attention block
