@@ -117,7 +117,7 @@ def test_unet_vs_oracle(dtype, mc, side, batch, cam_only):
 
 
 @pytest.mark.parametrize("dtype", DT)
-def test_unet_full_width(dtype):
+def test_unet_full_width(dtype, monkeypatch):
     """mobi_nusc_512's UNet (model_channels 320: head dims 40 / 80 / 160, 1.04 B parameters) at a
     16x16 latent, batch 2 (one camera/lidar pair), against the CPU oracle."""
     _set(dtype)
@@ -133,6 +133,16 @@ def test_unet_full_width(dtype):
     del sd
     y = net.cuda()(x.cuda(), t.cuda(), context=ctx.cuda())
     assert rel_l2(y.cpu(), ref) < TOL_NET[dtype]
+    # the same network with the one-launch feed-forward (+ norm3 inside it) at the 320-channel level: production takes it
+    # from 24576 token rows on (mobi_amd/ldm/modules/attention.py), this latent has 512
+    from mobi_amd.ldm.modules import attention as A
+    monkeypatch.setattr(A, "FUSED_FF_MIN_ROWS", 0)
+    seen = []
+    orig = A.ops.ff_geglu
+    monkeypatch.setattr(A.ops, "ff_geglu", lambda *a, **k: (seen.append(k.get("ln") is not None), orig(*a, **k))[1])
+    y2 = net(x.cuda(), t.cuda(), context=ctx.cuda())
+    assert seen and all(seen)
+    assert rel_l2(y2.cpu(), ref) < TOL_NET[dtype]
 
 
 @pytest.mark.parametrize("dtype", DT)
