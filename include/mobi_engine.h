@@ -258,7 +258,7 @@ typedef struct mobi_two_key_adapter_params {
   /* Optional second result: the LayerNorm of the RESULT rows as the cross-modal step reads it next (attention.py:
    * cross_modal_norm_camera on the even images, cross_modal_norm_lidar on the odd ones).  Image i goes to ln_out[i & 1]
    * at image index i >> 1 (T [images / 2][token][channels], dense) with ln_gamma / ln_beta [i & 1] (f32 [channels]).
-   * ln_out[0] == NULL: none.  Served where mobi_two_key_adapter_fuses_ln(channels) says so (MOBI_ERR_UNSUPPORTED
+   * ln_out[0] == NULL: none.  Served where mobi_two_key_adapter_fuses_ln(channels, images * rows_per_image) says so (MOBI_ERR_UNSUPPORTED
    * otherwise: the caller then runs mobi_layernorm on the two halves). */
   void* ln_out[2];
   const float* ln_gamma[2];
@@ -266,7 +266,7 @@ typedef struct mobi_two_key_adapter_params {
   float ln_eps;
 } mobi_two_key_adapter_params;
 int mobi_two_key_adapter(const mobi_two_key_adapter_params* p, void* stream);
-int mobi_two_key_adapter_fuses_ln(int32_t channels);   /* 1: this build / tuning writes ln_out for that width */
+int mobi_two_key_adapter_fuses_ln(int32_t channels, int64_t total_rows);   /* 1: this build / tuning writes ln_out for that width and images * rows_per_image */
 
 /* Row softmax fp32 -> T (AttnBlock, model.py:189-190). */
 int mobi_softmax_rows(const float* src, void* out, int64_t rows, int32_t cols, int32_t dtype, void* stream);

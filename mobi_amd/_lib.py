@@ -144,7 +144,7 @@ SYMBOLS = {
     "mobi_attention": (C.c_int, [C.POINTER(AttentionParams), vp]),
     "mobi_ctx_attention": (C.c_int, [C.POINTER(CtxAttentionParams), vp]),
     "mobi_two_key_adapter": (C.c_int, [C.POINTER(TwoKeyAdapterParams), vp]),
-    "mobi_two_key_adapter_fuses_ln": (C.c_int, [i32]),
+    "mobi_two_key_adapter_fuses_ln": (C.c_int, [i32, i64]),
     "mobi_softmax_rows": (C.c_int, [vp, vp, i64, i32, i32, vp]),
     "mobi_skinny_linear": (C.c_int, [C.POINTER(SkinnyLinearParams), vp]),
     "mobi_layernorm_rows_f32": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, i32, f32, vp]),

@@ -134,10 +134,14 @@ struct IgemmArgs {
   int hw_shift, w_shift;   // log2(hw_out), log2(wout) when both are powers of two (ping-pong kernel), else -1
 };
 
-__device__ __forceinline__ void tile_of(const IgemmArgs& a, int L, int& tile_m, int& tile_n) {
-  if (a.n_major) { tile_m = L % a.tiles_m; tile_n = L / a.tiles_m; }
-  else           { tile_n = L % a.tiles_n; tile_m = L / a.tiles_n; }
-}
+// (a macro, not a function of `a`: a reference to the kernel-argument struct makes the compiler keep a copy of it in scratch)
+// (the ping-pong kernel, at its register limit, always walks pixel-major: igemm_prepare leaves n_major 0 for it)
+#define MOBI_TILE_OF_M(L_, tile_m_, tile_n_) const int tile_n_ = (L_) % a.tiles_n, tile_m_ = (L_) / a.tiles_n
+#define MOBI_TILE_OF(L_, tile_m_, tile_n_)                                                     \
+  const int tdiv_##tile_m_ = __builtin_amdgcn_readfirstlane(a.n_major ? a.tiles_m : a.tiles_n); \
+  const int tq_##tile_m_ = (L_) / tdiv_##tile_m_, tr_##tile_m_ = (L_) - tq_##tile_m_ * tdiv_##tile_m_; \
+  const int tile_m_ = a.n_major ? tr_##tile_m_ : tq_##tile_m_;                                 \
+  const int tile_n_ = a.n_major ? tq_##tile_m_ : tr_##tile_m_
 
 // 8 consecutive floats through two 16-byte accesses (LDS stage rows, bias, per-image vectors)
 __device__ __forceinline__ void ld8f(const float* p, float (&f)[8]) {
@@ -732,8 +736,7 @@ __global__ __launch_bounds__(128 * WM, 2) void igemm_kernel(const IgemmArgs a) {
 
   const int nblk = a.tiles_m * a.tiles_n;
   const int L = xcd_remap(blockIdx.x, nblk);
-  int tile_m, tile_n;
-  tile_of(a, L, tile_m, tile_n);
+  MOBI_TILE_OF(L, tile_m, tile_n);
   const int m0 = tile_m * BM;
   const int n0 = tile_n * BN;
 
@@ -1056,8 +1059,7 @@ __global__ __launch_bounds__(512, 2) void igemm_glds_kernel(const IgemmArgs a) {
 
   auto set_fetch_tile = [&]() {
     const int L = xcd_remap(f_bid, nblk);
-    int tile_m, tile_n;
-    tile_of(a, L, tile_m, tile_n);
+    MOBI_TILE_OF(L, tile_m, tile_n);
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     x_okm = 0;
 #pragma unroll
@@ -1194,8 +1196,7 @@ __global__ __launch_bounds__(512, 2) void igemm_glds_kernel(const IgemmArgs a) {
       for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int L = xcd_remap(bid, nblk);
-    int tm_, tn_;
-    tile_of(a, L, tm_, tn_);
+    MOBI_TILE_OF(L, tm_, tn_);
     const int nw0 = tn_ * BN + wn * WAVE_N, mw0 = tm_ * BM + wm * 64;
     int mk_req = 0;
     if constexpr (DIRECT) {                                  // bias / residual rows of this output tile: in flight
@@ -1368,8 +1369,7 @@ __global__ __launch_bounds__(512, 2) void igemm_pp_kernel(const IgemmArgs a) {
 
   auto set_fetch_tile = [&]() {
     const int L = xcd_remap(f_bid, nblk);
-    int tile_m, tile_n;
-    tile_of(a, L, tile_m, tile_n);
+    MOBI_TILE_OF_M(L, tile_m, tile_n);
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     {
       const int m = m0 + 8 * wave + rloc;                    // < M: every tile is full
@@ -1532,8 +1532,7 @@ __global__ __launch_bounds__(512, 2) void igemm_pp_kernel(const IgemmArgs a) {
   int ahead = 0;                                             // requested k-tiles not yet multiplied
   {
     const int L0 = xcd_remap(blockIdx.x, nblk);
-    int tm_, tn_;
-    tile_of(a, L0, tm_, tn_);
+    MOBI_TILE_OF_M(L0, tm_, tn_);
     const int nw0 = tn_ * BN + wn * WAVE_N, mw0 = tm_ * BM + wm * 64;
     u32x4 bv[NT];
     if (has_vec) { request_vec(bv, nw0, mw0); vm_issued += NT; }
@@ -1562,8 +1561,7 @@ __global__ __launch_bounds__(512, 2) void igemm_pp_kernel(const IgemmArgs a) {
 #endif
   for (int bid = blockIdx.x; bid < nblk; bid += gridDim.x) {
     const int L = xcd_remap(bid, nblk);
-    int tm_, tn_;
-    tile_of(a, L, tm_, tn_);
+    MOBI_TILE_OF_M(L, tm_, tn_);
     const int nw0 = tn_ * BN + wn * WAVE_N, mw0 = tm_ * BM + wm * 64;
     for (int kt = 0; kt < nk; ++kt) {
       const unsigned char* st = lds + c_slot * STAGE;
@@ -1797,8 +1795,7 @@ __global__ __launch_bounds__(NW * 64, 2) void igemm_ring_kernel(const IgemmArgs 
   const int group = blockIdx.z;
   const int nblk = a.tiles_m * a.tiles_n;
   const int L = xcd_remap(blockIdx.x, nblk);
-  int tile_m, tile_n;
-  tile_of(a, L, tile_m, tile_n);
+  MOBI_TILE_OF(L, tile_m, tile_n);
   const int m0 = tile_m * BM, n0 = tile_n * BN;
   MOBI_STAMP_AT(0);
   const bool w_tiled = a.w_tiled != nullptr;                 // (wave-uniform) weights as 1-KiB request images
@@ -2155,8 +2152,7 @@ __global__ __launch_bounds__(256, 1) void igemm_ring64_kernel(const IgemmArgs a)
   const int group = blockIdx.z;
   const int nblk = a.tiles_m * a.tiles_n;
   const int L = xcd_remap(blockIdx.x, nblk);
-  int tile_m, tile_n;
-  tile_of(a, L, tile_m, tile_n);
+  MOBI_TILE_OF(L, tile_m, tile_n);
   const int m0 = tile_m * BM, n0 = tile_n * BN;
   const T* wgt = reinterpret_cast<const T*>(a.weight) + (long long)group * a.w_group_stride;
   const __amdgpu_buffer_rsrc_t rx0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.src0), 0, a.src0_bytes, 0x00020000);
@@ -2645,6 +2641,7 @@ static int igemm_prepare(const mobi_igemm_params* p, mobi::IgemmArgs& a) {
     const long long abytes = (long long)p->batch * p->hin * p->win * a.C * 2;
     a.n_major = p->groups == 1 && a.tiles_n >= 2 && p->kh * p->kw == 1 && wbytes > abytes && tuning().n_major != 0;
     if (tuning().n_major == 1 && p->groups == 1) a.n_major = 1;
+    if (!a.wide && a.wm == 4 && a.fast && a.glds && a.pp) a.n_major = 0;      // the ping-pong kernel's launches
   }
   // 64-deep steps for the 128-pixel geometry: channel runs of 64 (a k-step never straddles a tap or a source), >= 3 steps
   // (one block per CU: only grids of at most one round of blocks -- with more, two co-resident blocks of the 32-deep ring win:

@@ -1007,9 +1007,13 @@ extern "C" int mobi_ctx_attention(const mobi_ctx_attention_params* p, void* stre
   return MOBI_OK;
 }
 
-extern "C" int mobi_two_key_adapter_fuses_ln(int32_t channels) {
+// the register kernel's launches: C = 320 / 640 and enough token rows to spread its 64-row blocks over the chip (measured,
+// tools/tka_lab.py --nusc256: 8 x 256 tokens at C = 640: 11.3-12.7 us against 8.4 us on the vector-ALU kernel; 8 x 1024 at C = 320:
+// 8.9 against 12.3)
+extern "C" int mobi_two_key_adapter_fuses_ln(int32_t channels, int64_t total_rows) {
   const int tka = mobi::tuning().tka_mfma;
-  return tka != 0 && tka != 1 && tka != 2 && (channels == 320 || channels == 640);
+  if (tka == 0 || tka == 1 || tka == 2) return 0;
+  return (channels == 320 && total_rows >= 1024) || (channels == 640 && total_rows >= 4096);
 }
 
 extern "C" int mobi_two_key_adapter(const mobi_two_key_adapter_params* p, void* stream) {
@@ -1024,13 +1028,13 @@ extern "C" int mobi_two_key_adapter(const mobi_two_key_adapter_params* p, void* 
   //  per CU and it loses, 39.8 vs 36.8 us: the vector-ALU kernel keeps the wider levels; MOBI_TKA_MFMA=1 forces it to 640)
   const int tka = mobi::tuning().tka_mfma;          // unset: token rows in registers; 2 / 1: the LDS-tile kernel (to 320 / 640); 0: VALU
   if (p->ln_out[0]) {
-    if (!mobi_two_key_adapter_fuses_ln(p->channels)) return MOBI_ERR_UNSUPPORTED;
+    if (!mobi_two_key_adapter_fuses_ln(p->channels, (int64_t)p->images * p->rows_per_image)) return MOBI_ERR_UNSUPPORTED;
     if (!p->ln_out[1] || !p->ln_gamma[0] || !p->ln_gamma[1] || !p->ln_beta[0] || !p->ln_beta[1] || (p->images & 1)) return MOBI_ERR_ARG;
     if ((reinterpret_cast<uintptr_t>(p->ln_out[0]) | reinterpret_cast<uintptr_t>(p->ln_out[1])) & 15) return MOBI_ERR_ALIGN;
   }
   // (C = 1280 stays on the vector-ALU kernel: 16 x 16 and 8 x 8 tokens per image are a fixed cost of table staging plus
   //  one tile per wave either way -- 20.8 us there, 21.5 us as a 40-block unrolled register kernel, profiles/r03_tka_lab.txt)
-  if (tka != 0 && tka != 1 && tka != 2 && (p->channels == 320 || p->channels == 640)) {
+  if (mobi_two_key_adapter_fuses_ln(p->channels, (int64_t)p->images * p->rows_per_image)) {
     // 16 rows per wave and tile, 64 per block at least; about 512 blocks over the launch (the tables are staged per block)
     long long rows = ((long long)p->rows_per_image * p->images + 511) / 512;
     rows = (rows + 15) / 16 * 16;

@@ -368,7 +368,7 @@ class BasicTransformerBlock(nn.Module):
         if self.bbox_cond and adapter is not None:
             nc, nl = (self.cross_modal_norm_camera, self.cross_modal_norm_lidar) if self.multimodal else (None, None)
             if (FUSED_LN and self.multimodal and x.shape[0] % 2 == 0 and nc.eps == nl.eps
-                    and ops.two_key_adapter_fuses_ln(x.shape[2])):
+                    and ops.two_key_adapter_fuses_ln(x.shape[2], x.shape[0] * x.shape[1])):
                 # the adapter kernel holds each result row in registers: it also writes the two LayerNorms the cross-modal
                 # step reads next (camera norm of the even images, lidar norm of the odd ones -- the camera update below
                 # does not touch the lidar rows)

@@ -435,9 +435,9 @@ def ctx_attention(q, k, v, heads, scale):
     return out
 
 
-def two_key_adapter_fuses_ln(channels):
-    """Whether mobi_two_key_adapter writes the pair of LayerNorm results (`ln_pair`) at this width."""
-    return bool(_lib.load().mobi_two_key_adapter_fuses_ln(int(channels)))
+def two_key_adapter_fuses_ln(channels, total_rows):
+    """Whether mobi_two_key_adapter writes the pair of LayerNorm results (`ln_pair`) at this width and row count."""
+    return bool(_lib.load().mobi_two_key_adapter_fuses_ln(int(channels), int(total_rows)))
 
 
 def two_key_adapter(x, a, a_sum, c, u, b, eps, out=None, ln_pair=None):
@@ -445,7 +445,7 @@ def two_key_adapter(x, a, a_sum, c, u, b, eps, out=None, ln_pair=None):
     b: fp32 [N, C].  Returns x + b + sum_h sigmoid(rstd * (x . a_h - mean * a_sum_h) + c_h) * u_h with the token's
     LayerNorm statistics (include/mobi_engine.h, mobi_two_key_adapter); out=x updates in place.
     ln_pair = ((gamma0, beta0), (gamma1, beta1), eps): also returns (LN_0 of the even images, LN_1 of the odd images) of
-    the result, [N / 2, T, C] each -- what the cross-modal step normalises next (two_key_adapter_fuses_ln(C) must hold)."""
+    the result, [N / 2, T, C] each -- what the cross-modal step normalises next (two_key_adapter_fuses_ln(C, N * T) must hold)."""
     lib = _lib.load()
     n, t, ch = x.shape
     if out is None:

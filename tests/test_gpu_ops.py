@@ -761,6 +761,7 @@ def test_igemm_ring256_epilogues(ops, dtype, case, tune):
 
 @pytest.mark.parametrize("dtype", DT)
 @pytest.mark.parametrize("n,t,c,heads,strided", [(3, 100, 320, 8, False), (2, 64, 640, 8, True), (2, 37, 1280, 8, False),
+                                                 (3, 401, 320, 8, False), (2, 2101, 640, 8, True),
                                                  (1, 256, 64, 4, False)])
 def test_two_key_adapter(ops, dtype, n, t, c, heads, strided, tune):
     """One-pass bbox adapter kernels (LayerNorm statistics, per-head gate logits, gated per-image vectors: token rows in
@@ -794,7 +795,7 @@ def test_two_key_adapter(ops, dtype, n, t, c, heads, strided, tune):
 
 
 @pytest.mark.parametrize("dtype", DT)
-@pytest.mark.parametrize("n,t,c", [(4, 100, 320), (2, 64, 640), (6, 16, 640)])
+@pytest.mark.parametrize("n,t,c", [(4, 300, 320), (2, 2048, 640), (6, 700, 640)])
 def test_two_key_adapter_layernorm_pair(ops, dtype, n, t, c, tune):
     """The adapter kernel's second result: LayerNorm of the result rows, even images with one (gamma, beta), odd images with
     another, against mobi_layernorm on the stored result (same rounded input: only the summation order differs) and against
@@ -805,7 +806,8 @@ def test_two_key_adapter_layernorm_pair(ops, dtype, n, t, c, tune):
     u, b, cc = (W.synth_input(name + k, s).cuda() for k, s in ((".u", (n, 8, c)), (".b", (n, c)), (".c", (n, 8))))
     gb = [(torch.from_numpy(W.synth_param(f"{name}.g{i}", (c,))).cuda(), torch.from_numpy(W.synth_param(f"{name}.b{i}", (c,))).cuda())
           for i in range(2)]
-    assert ops.two_key_adapter_fuses_ln(c) and not ops.two_key_adapter_fuses_ln(1280)
+    assert ops.two_key_adapter_fuses_ln(c, n * t) and not ops.two_key_adapter_fuses_ln(1280, n * t)
+    assert not ops.two_key_adapter_fuses_ln(c, 512)                     # too few rows: the vector-ALU kernel's launch
     y = ops.two_key_adapter(xd, a, a.sum(-1).contiguous(), cc, u, b, 1e-5)
     y2, (l0, l1) = ops.two_key_adapter(xd, a, a.sum(-1).contiguous(), cc, u, b, 1e-5, ln_pair=(gb[0], gb[1], 1e-5))
     assert torch.equal(y, y2) and l0.shape == l1.shape == (n // 2, t, c)
@@ -815,7 +817,7 @@ def test_two_key_adapter_layernorm_pair(ops, dtype, n, t, c, tune):
         sep = ops.layernorm(half.contiguous(), g, bt, 1e-5)
         assert rel(got.float(), sep.float()) < TOL[dtype] / 4 and float((got.float() - sep.float()).abs().max()) < 0.07
     tune.setenv("MOBI_TKA_MFMA", "0")
-    assert not ops.two_key_adapter_fuses_ln(c)
+    assert not ops.two_key_adapter_fuses_ln(c, n * t)
     with pytest.raises(Exception):
         ops.two_key_adapter(xd, a, a.sum(-1).contiguous(), cc, u, b, 1e-5, ln_pair=(gb[0], gb[1], 1e-5))
 

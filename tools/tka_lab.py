@@ -15,6 +15,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from tools.gn_lab import timeit  # noqa: E402
 
 SHAPES_512 = [(4096, 320, 5), (1024, 640, 6), (256, 1280, 5), (64, 1280, 1)]   # tokens per image, C, launches per step
+SHAPES_256 = [(1024, 320, 5), (256, 640, 6), (64, 1280, 5), (16, 1280, 1)]
 
 
 def main():
@@ -24,6 +25,7 @@ def main():
     ap.add_argument("--iters", type=int, default=24)
     ap.add_argument("--rows", default="", help="comma list of MOBI_TKA_ROWS values to sweep for the register kernel")
     ap.add_argument("--valu-rows", default="", help="the same for the vector-ALU kernel")
+    ap.add_argument("--nusc256", action="store_true", help="the shapes of mobi_nusc_256 (use with --images 8)")
     a = ap.parse_args()
     from mobi_amd import _lib, build, ops
     build.build(verbose=False)
@@ -34,7 +36,7 @@ def main():
     forms += [(f"valu/{r}", {"MOBI_TKA_ROWS": r, "MOBI_TKA_MFMA": "0"}) for r in a.valu_rows.split(",") if r]
     total = {t: 0.0 for t, _ in forms}
     print(f"two-key adapter, {a.images} images, {a.dtype}; us per launch (GB/s at 2 B read + 2 B written per element)")
-    for t, c, n in SHAPES_512:
+    for t, c, n in (SHAPES_256 if a.nusc256 else SHAPES_512):
         mb = a.images * t * c * 2 / 1e6
         copies = max(2, min(12, int(600 / mb)))
         xs = [(torch.randn(a.images, t, c, generator=g) * 1.5 + 0.3).to("cuda").to(dt) for _ in range(2)]
