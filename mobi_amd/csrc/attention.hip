@@ -537,9 +537,11 @@ void attention_rows_kernel(const AttnArgs a) {
   const int dh = a.dh;
   // a padded channel of the P.V tile carries the denominator: dh is KS*16 - 8 (QSH) or KS*16, DT*32 is (KS + 1)/2 * 32
   constexpr bool ONES = QSH || (KS & 1);
-  // (no test: bf16 storage, padded head dims -- the other instantiations would not fit their register budget with both passes;
-  //  RVAR bit 1 keeps the test everywhere, A/B)
-  constexpr bool TEST = !std::is_same<T, bf16_t>::value || !QSH || (MOBI_ATTN_RVAR & 2);
+  // (no test on padded head dims, both storage types: the first pass keeps the shift of the first 32 keys and an overflow --
+  //  a probability beyond fp32's / fp16's range -- shows in the denominator; fp16 has 2^20 of headroom above that shift,
+  //  i.e. a later score may exceed the first 32 keys' maximum by 13.9 nats before the block repeats its pass with the test.
+  //  The other instantiations would not fit their register budget with both passes; RVAR bit 1 keeps the test everywhere, A/B)
+  constexpr bool TEST = !QSH || (MOBI_ATTN_RVAR & 2) || (std::is_same<T, f16_t>::value && (MOBI_ATTN_RVAR & 4));
 
   const T* __restrict__ qp = reinterpret_cast<const T*>(a.q) + img * a.q_img + head * dh;
   const T* __restrict__ kp = reinterpret_cast<const T*>(a.k) + img * a.k_img + head * dh;
