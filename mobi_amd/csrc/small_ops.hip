@@ -300,6 +300,80 @@ __global__ __launch_bounds__(256) void conv_small_cout_kernel(const mobi_conv_sm
     }
 }
 
+// The same convolution on the matrix cores (cin % 32 == 0, w % 16 == 0, at most 8 output channels: the output convolutions
+// of the UNet, 320 -> 4 at 64 x 64, and of the VAE decoders, 128 -> 3 / 2 at 512 x 512).  The kernel above reads the 9 x cin
+// weights of all output channels once per PIXEL (1.5 GB of cache traffic per UNet call, 119 us); here they sit in LDS as
+// MFMA 16x16x32 A-operand images (8 weight rows + a zero row that the upper 8 lanes read), a wave owns 16 consecutive pixels
+// of an image row per tile, and a lane loads its pixel's 32-channel pieces of each tap straight from global memory as the B
+// fragments (taps outside the image: zeros).  D[channel][pixel] lands with 16 consecutive pixels of a channel in 16 lanes:
+// 64-byte runs of the fp32 NCHW output.
+template <typename T, int KSTEPS>                         // KSTEPS = cin / 32 (10: cin 320, 4: cin 128)
+__global__ __launch_bounds__(256) void conv_small_cout_mfma_kernel(const mobi_conv_small_cout_params a, int tiles_per_wave) {
+  typedef typename Vec8<T>::type frag_t;
+  constexpr int CIN = 32 * KSTEPS;
+  constexpr int ROW = 64;                                  // bytes per weight row and 32-deep step
+  extern __shared__ __attribute__((aligned(16))) unsigned char csm_lds[];     // [taps][KSTEPS][9 rows][64 B]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r16 = lane & 15, g4 = lane >> 4;
+  const int taps = a.kh * a.kw, K = taps * CIN;
+  {
+    const T* __restrict__ w = reinterpret_cast<const T*>(a.weight);
+    const int pieces = taps * KSTEPS * 9 * 4;               // 16-byte pieces
+    for (int i = tid; i < pieces; i += 256) {
+      const int ch = i & 3, row = (i >> 2) % 9, st = (i >> 2) / 9;          // st = tap * KSTEPS + step
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (row < a.cout) v = ld16(w + (long long)row * K + st * 32 + ch * 8);
+      st16(csm_lds + (st * 9 + row) * ROW + ch * 16, v);
+    }
+  }
+  __syncthreads();
+  const int tiles_x = a.w >> 4;
+  const long long hw = (long long)a.h * a.w;
+  const long long tiles = (long long)a.batch * a.h * tiles_x;
+  const unsigned char* wrd = csm_lds + min(r16, 8) * ROW + g4 * 16;
+  const long long t_begin = ((long long)blockIdx.x * 4 + wave) * tiles_per_wave;
+  for (long long t = t_begin; t < t_begin + tiles_per_wave && t < tiles; ++t) {
+    const int tx = (int)(t % tiles_x);
+    const long long ry = t / tiles_x;
+    const int y = (int)(ry % a.h), img = (int)(ry / a.h);
+    const int x = tx * 16 + r16;
+    const T* __restrict__ src = reinterpret_cast<const T*>(a.src) + (long long)img * hw * CIN + 8 * g4;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    u32x4 cur[KSTEPS], nxt[KSTEPS];
+    auto fetch = [&](int tap, u32x4 (&dst)[KSTEPS]) {
+      const int ky = tap / a.kw, kx = tap - ky * a.kw;
+      const int yy = y + ky - a.pad_h, xx = x + kx - a.pad_w;
+      const bool ok = tap < taps && yy >= 0 && yy < a.h && xx >= 0 && xx < a.w;
+      const T* __restrict__ row = src + ((long long)(ok ? yy : y) * a.w + (ok ? xx : x)) * CIN;
+#pragma unroll
+      for (int s_ = 0; s_ < KSTEPS; ++s_) {
+        dst[s_] = ld16(row + 32 * s_);
+        if (!ok) dst[s_] = u32x4{0u, 0u, 0u, 0u};
+      }
+    };
+    fetch(0, cur);
+    for (int tap = 0; tap < taps; ++tap) {
+      fetch(tap + 1, nxt);                                  // (past the last tap: a valid address, zeros, unused)
+      const unsigned char* wt = wrd + tap * (KSTEPS * 9 * ROW);
+#pragma unroll
+      for (int s_ = 0; s_ < KSTEPS; ++s_)
+        acc = mfma16(__builtin_bit_cast(frag_t, ld16(wt + s_ * 9 * ROW)), __builtin_bit_cast(frag_t, cur[s_]), acc);
+#pragma unroll
+      for (int s_ = 0; s_ < KSTEPS; ++s_) cur[s_] = nxt[s_];
+    }
+    // lane (pixel r16, g4) holds output channels 4 g4 .. 4 g4 + 3
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int ch = 4 * g4 + j;
+      if (ch < a.cout) {
+        float v = acc[j] + (a.bias ? a.bias[ch] : 0.f);
+        if (a.clamp) v = fminf(fmaxf(v, a.clamp_lo), a.clamp_hi);
+        a.out[((long long)img * a.cout + ch) * hw + (long long)y * a.w + x] = v;
+      }
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------
 // layout converters
 // ---------------------------------------------------------------------------------------
@@ -1134,6 +1208,21 @@ extern "C" int mobi_conv_small_cout(const mobi_conv_small_cout_params* p, void* 
   if (p->cout <= 0 || p->cout > 8 || p->cin <= 0 || (p->cin & 7)) return MOBI_ERR_UNSUPPORTED;
   if ((reinterpret_cast<uintptr_t>(p->src) | reinterpret_cast<uintptr_t>(p->weight)) & 15) return MOBI_ERR_ALIGN;
   const long long pixels = (long long)p->batch * p->h * p->w;
+  if ((p->cin == 320 || p->cin == 128) && (p->w & 15) == 0 && p->kh * p->kw <= 9 && mobi::tuning().cout_mfma != 0) {
+    // matrix-core form: 16-pixel tiles, about 512 blocks of four waves over the launch (the weights are staged per block)
+    const long long tiles = pixels / 16;
+    long long tpw = (tiles + 2047) / 2048;
+    if (tpw < 1) tpw = 1;
+    const unsigned blocks = (unsigned)((tiles + 4 * tpw - 1) / (4 * tpw));
+    const size_t lds = (size_t)p->kh * p->kw * (p->cin / 32) * 9 * 64;
+#define MOBI_CSM(T_, KS_) \
+  hipLaunchKernelGGL((conv_small_cout_mfma_kernel<T_, KS_>), dim3(blocks), dim3(256), lds, ST(stream), *p, (int)tpw)   /* < 64 KB */
+    if (p->dtype == MOBI_F16) { if (p->cin == 320) MOBI_CSM(f16_t, 10); else MOBI_CSM(f16_t, 4); }
+    else                      { if (p->cin == 320) MOBI_CSM(bf16_t, 10); else MOBI_CSM(bf16_t, 4); }
+#undef MOBI_CSM
+    MOBI_CHECK_LAUNCH();
+    return MOBI_OK;
+  }
   const unsigned blocks = (unsigned)((pixels + 3) / 4);
   if (p->dtype == MOBI_F16) hipLaunchKernelGGL((conv_small_cout_kernel<f16_t>), dim3(blocks), dim3(256), 0, ST(stream), *p);
   else hipLaunchKernelGGL((conv_small_cout_kernel<bf16_t>), dim3(blocks), dim3(256), 0, ST(stream), *p);

@@ -412,6 +412,29 @@ def test_small_convs(ops, dtype):
     assert rel(y, F.conv2d(xf.permute(0, 3, 1, 2), wl, None, padding=(0, 2))) < 1e-4
 
 
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("cin,cout,h,w,kh,kw,clamp", [(320, 4, 9, 32, 3, 3, None), (128, 3, 5, 48, 3, 3, (-1.0, 1.0)),
+                                                     (128, 2, 6, 16, 1, 5, None), (320, 8, 3, 16, 3, 3, None)])
+def test_conv_small_cout_matrix_core_form(ops, dtype, cin, cout, h, w, kh, kw, clamp, tune):
+    """The few-output-channel convolution on the matrix cores (cin 320 / 128, w % 16 == 0: the UNet's and the VAE decoders'
+    output convolutions) against fp32 torch and against the one-wave-per-pixel kernel (MOBI_COUT_MFMA=0); borders on all
+    four sides, the 1 x 5 lidar tap shape, clamp, 2 / 3 / 4 / 8 output channels."""
+    name = f"csm.{cin}.{cout}.{h}.{w}.{kh}{kw}"
+    xf, xd = rnd(name + ".x", (3, h, w, cin), dtype)
+    wt = torch.from_numpy(W.synth_param(name + ".weight", (cout, cin, kh, kw))).to(dtype).float()
+    bias = torch.from_numpy(W.synth_param(name + ".bias", (cout,)))
+    pw = ops.pack_conv(wt, bias, dtype, "cuda")
+    pad = (kh // 2, kw // 2)
+    y = ops.conv_small_cout(xd, pw, pad=pad, clamp=clamp)
+    ref = F.conv2d(xf.permute(0, 3, 1, 2), wt, bias, padding=pad)
+    if clamp:
+        ref = ref.clamp(*clamp)
+    assert y.shape == ref.shape and y.dtype == torch.float32 and rel(y, ref) < 2e-5 * (1 if dtype == torch.float16 else 1)
+    tune.setenv("MOBI_COUT_MFMA", "0")
+    y0 = ops.conv_small_cout(xd, pw, pad=pad, clamp=clamp)
+    assert rel(y, y0) < 2e-5
+
+
 def test_layout_and_index_ops_bit_exact(ops):
     x = W.synth_input("l.x", (2, 40, 5, 7))
     for dtype in DT:
