@@ -83,6 +83,104 @@ __global__ __launch_bounds__(256) void skinny_linear_kernel(const mobi_skinny_li
     }
 }
 
+// The same layer on the matrix cores (k % 32 == 0).  The vector-ALU kernel above spends m FMAs per weight element and keeps two
+// 16-byte weight loads in flight per wave: 27-100 us per launch of the time-embedding chain (0.16 ms per denoising step).  Here
+// the fp32 rows are split into three T pieces (hi + mid + lo = x to 24 bits for bf16, more for fp16: the products are exact,
+// the sums fp32 -- within 1e-6 of the fp32 FMA chain) and staged in LDS as MFMA 16x16x32 A-operand images per 512-deep k chunk; a
+// block owns 16 output columns, its four waves take every fourth 32-deep step, a lane loads its column's 8 weights of a step
+// straight from global memory (all of the chunk's loads in flight), three MFMAs per step, partial sums folded through LDS
+// in wave order.  The weights are the traffic: 45 MB for the batched emb_layers projection.
+// WIDE (many columns: the batched projection): a block owns 64 columns, 16 per wave, every wave walks all steps of a chunk --
+// the staging of x (SiLU, split: the same for every block) is shared by four times the columns.  Otherwise a block owns 16
+// columns and its four waves take every fourth step (few columns: more blocks, shorter chains).
+template <typename T, bool WIDE>
+__global__ __launch_bounds__(256) void skinny_linear_mfma_kernel(const mobi_skinny_linear_params a) {
+  typedef typename Vec8<T>::type frag_t;
+  constexpr int KC = 512, STEPS = KC / 32, SPW = WIDE ? STEPS : STEPS / 4;     // steps per chunk / per wave and chunk
+  __shared__ __attribute__((aligned(16))) unsigned char xs[3 * STEPS * 1024];     // [piece][step][row][64 B]
+  __shared__ float part[WIDE ? 1 : 4][64][4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r16 = lane & 15, g4 = lane >> 4;
+  const int n = WIDE ? (blockIdx.x * 4 + wave) * 16 + r16 : blockIdx.x * 16 + r16;
+  const bool n_ok = n < a.n;
+  const T* __restrict__ wrow = reinterpret_cast<const T*>(a.weight) + (long long)(n_ok ? n : 0) * a.k + 8 * g4;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  for (int k0 = 0; k0 < a.k; k0 += KC) {
+    const int steps = min(STEPS, (a.k - k0) >> 5);
+    // this wave's weight pieces of the chunk: requested before the staging barrier, consumed behind it
+    u32x4 wf[SPW];
+#pragma unroll
+    for (int i = 0; i < SPW; ++i) {
+      const int st = WIDE ? i : wave + 4 * i;
+      wf[i] = u32x4{0u, 0u, 0u, 0u};
+      if (st < steps && n_ok) wf[i] = ld16(wrow + k0 + 32 * st);
+    }
+    __syncthreads();                                                  // (the previous chunk's images are read)
+    for (int i = tid; i < 16 * (KC / 8); i += 256) {                   // (row, 8 consecutive k): split and store three 16-byte pieces
+      const int m = i / (KC / 8), kq = (i - m * (KC / 8)) * 8;
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = 0.f;
+      if (m < a.m && k0 + kq < a.k) {
+        const f32x4 lo4 = *reinterpret_cast<const f32x4*>(a.x + (long long)m * a.x_row_stride + k0 + kq);
+        const f32x4 hi4 = *reinterpret_cast<const f32x4*>(a.x + (long long)m * a.x_row_stride + k0 + kq + 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { v[j] = lo4[j]; v[4 + j] = hi4[j]; }
+        if (a.pre_act == MOBI_ACT_SILU) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] = silu_f(v[j]);
+        }
+      }
+      float p0[8], p1[8], p2[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const T h = (T)v[j];
+        const float r1 = v[j] - (float)h;
+        const T md = (T)r1;
+        p0[j] = (float)h; p1[j] = (float)md; p2[j] = r1 - (float)md;
+      }
+      unsigned char* dst = xs + ((kq >> 5) * 16 + m) * 64 + ((kq >> 3) & 3) * 16;
+      st16(dst, pack8<T>(p0));
+      st16(dst + STEPS * 1024, pack8<T>(p1));
+      st16(dst + 2 * STEPS * 1024, pack8<T>(p2));
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < SPW; ++i) {
+      const int st = WIDE ? i : wave + 4 * i;
+      if (st < steps) {                                               // (wave-uniform)
+        const unsigned char* img = xs + (st * 16 + r16) * 64 + g4 * 16;
+        const frag_t w8 = __builtin_bit_cast(frag_t, wf[i]);
+        acc = mfma16(__builtin_bit_cast(frag_t, ld16(img)), w8, acc);
+        acc = mfma16(__builtin_bit_cast(frag_t, ld16(img + STEPS * 1024)), w8, acc);
+        acc = mfma16(__builtin_bit_cast(frag_t, ld16(img + 2 * STEPS * 1024)), w8, acc);
+      }
+    }
+  }
+  // lane (column r16, g4) holds rows 4 g4 .. 4 g4 + 3; without WIDE the four waves' partial sums are folded in wave order
+  if constexpr (!WIDE) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) part[wave][lane][j] = acc[j];
+    __syncthreads();
+    if (wave != 0) return;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[j] = (part[0][lane][j] + part[1][lane][j]) + (part[2][lane][j] + part[3][lane][j]);
+  }
+  if (n_ok) {
+    const float bias = a.bias ? a.bias[n] : 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int m = 4 * g4 + j;
+      if (m < a.m) {
+        float o = acc[j] + bias;
+        if (a.post_act == MOBI_ACT_SILU) o = silu_f(o);
+        else if (a.post_act == MOBI_ACT_GELU) o = gelu_erf_f(o);
+        a.out[(long long)m * a.out_row_stride + n] = o;
+      }
+    }
+  }
+}
+
 // LayerNorm over the last axis of a few fp32 rows (the token mapper / bbox MLP work on ONE fp32 token per image): one wave
 // per row, two passes in registers (mean, then centred variance), torch's formula (x - mean) * rsqrt(var + eps) * g + b
 __global__ void layernorm_rows_f32_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
@@ -1042,6 +1140,18 @@ extern "C" int mobi_skinny_linear(const mobi_skinny_linear_params* p, void* stre
   if ((p->k & 7) || (p->x_row_stride & 3)) return MOBI_ERR_UNSUPPORTED;
   if ((reinterpret_cast<uintptr_t>(p->x) | reinterpret_cast<uintptr_t>(p->weight)) & 15) return MOBI_ERR_ALIGN;
   const unsigned blocks = (unsigned)((p->n + 15) / 16);
+  if ((p->k & 31) == 0 && mobi::tuning().skinny_mfma != 0) {
+    if (p->n >= 8192) {                               // 64 columns per block: at least 128 blocks
+      const unsigned wblocks = (unsigned)((p->n + 63) / 64);
+      if (p->dtype == MOBI_F16) hipLaunchKernelGGL((skinny_linear_mfma_kernel<f16_t, true>), dim3(wblocks), dim3(256), 0, ST(stream), *p);
+      else hipLaunchKernelGGL((skinny_linear_mfma_kernel<bf16_t, true>), dim3(wblocks), dim3(256), 0, ST(stream), *p);
+    } else {
+      if (p->dtype == MOBI_F16) hipLaunchKernelGGL((skinny_linear_mfma_kernel<f16_t, false>), dim3(blocks), dim3(256), 0, ST(stream), *p);
+      else hipLaunchKernelGGL((skinny_linear_mfma_kernel<bf16_t, false>), dim3(blocks), dim3(256), 0, ST(stream), *p);
+    }
+    MOBI_CHECK_LAUNCH();
+    return MOBI_OK;
+  }
   if (p->dtype == MOBI_F16) hipLaunchKernelGGL((skinny_linear_kernel<f16_t>), dim3(blocks), dim3(256), 0, ST(stream), *p);
   else hipLaunchKernelGGL((skinny_linear_kernel<bf16_t>), dim3(blocks), dim3(256), 0, ST(stream), *p);
   MOBI_CHECK_LAUNCH();

@@ -370,7 +370,7 @@ def test_ctx_attention(ops, dtype, tk):
 
 # ---------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("dtype", DT)
-def test_skinny_linear_and_timestep_embedding(ops, dtype):
+def test_skinny_linear_and_timestep_embedding(ops, dtype, tune):
     from mobi_amd._lib import ACT_SILU
     from mobi_amd.ldm.modules.diffusionmodules.util import timestep_embedding
     from oracle.unet import timestep_embedding as ref_temb
@@ -380,6 +380,20 @@ def test_skinny_linear_and_timestep_embedding(ops, dtype):
     y = ops.skinny_linear(x.cuda()[:, 0], wf.to(dtype).cuda(), b.cuda(), pre_act=ACT_SILU, post_act=ACT_SILU)
     ref = F.silu(F.linear(F.silu(x[:, 0]), wf, b))
     assert rel(y, ref) < 2e-5
+    # the matrix-core forms (k % 32 == 0: 16 columns per block; n >= 8192: 64 per block) and the vector-ALU kernel (other k,
+    # MOBI_SKINNY_MFMA=0) on ragged column counts, 1 / 3 / 16 rows, GELU behind, k beyond one 512-deep chunk
+    for m, k, n, post in ((16, 1280, 8203, 0), (3, 1280, 1283, 2), (1, 352, 77, 0), (16, 328, 40, 0)):
+        xs = W.synth_input(f"s2.x{m}.{k}", (m, k))
+        ws = torch.from_numpy(W.synth_param(f"s2.w{k}.{n}", (n, k))).to(dtype)
+        bs = torch.from_numpy(W.synth_param(f"s2.b{n}", (n,)))
+        ref2 = F.linear(xs.double(), ws.double(), bs.double())
+        ref2 = F.gelu(ref2) if post == 2 else ref2
+        for env in (None, "0"):
+            if env is not None:
+                tune.setenv("MOBI_SKINNY_MFMA", env)
+            y2 = ops.skinny_linear(xs.cuda(), ws.cuda(), bs.cuda(), post_act=post)
+            assert y2.shape == (m, n) and rel(y2.double(), ref2) < 2e-6, (m, k, n, env)
+        tune.delenv("MOBI_SKINNY_MFMA")
     t = torch.tensor([1, 21, 500, 981, 999], dtype=torch.long)
     e = timestep_embedding(t.cuda(), 320)
     assert rel(e, ref_temb(t, 320)) < 1e-6
