@@ -37,6 +37,22 @@ def main():
               f"(median {gs[len(gs) // 2] / 1e3:.2f} us, p90 {gs[int(len(gs) * 0.9)] / 1e3:.2f} us, max {gs[-1] / 1e3:.1f} us)")
         if n_per_step:
             print(f"   per step of {n_per_step} launches: busy {busy / len(run) * n_per_step / 1e6:.3f} ms, gaps {sum(gaps) / len(run) * n_per_step / 1e6:.3f} ms")
+        # in-graph time by kernel (template arguments stripped), per step
+        if n_per_step:
+            fam = {}
+            for s0, e0, name in run:
+                k = name.split("<")[0].split("(")[0]
+                k = k[k.find("mobi"):] if "mobi" in k else k
+                import re as _re
+                k = _re.sub(r"^_ZN4mobi\d+", "", k)
+                k = _re.sub(r"I(DF16_|DF16b).*", "", k)
+                v = fam.setdefault(k[:48], [0, 0])
+                v[0] += 1
+                v[1] += e0 - s0
+            steps = len(run) / n_per_step
+            print(f"   in-graph time by kernel, per step ({steps:.2f} steps in the run):")
+            for k, v in sorted(fam.items(), key=lambda kv: -kv[1][1]):
+                print(f"      {k:48s} {v[0] / steps:7.1f} launches {v[1] / steps / 1e6:8.3f} ms  avg {v[1] / v[0] / 1e3:7.1f} us")
         # gaps by the kernel that FOLLOWS
         by = {}
         for (a, b), g in zip(zip(run, run[1:]), gaps):
