@@ -2618,6 +2618,9 @@ static int igemm_prepare(const mobi_igemm_params* p, mobi::IgemmArgs& a) {
     };
     const long long t256 = ((a.M + 255) / 256) * tn * a.splits, t128 = ((a.M + 127) / 128) * tn * a.splits;
     int pick = tuning().wide > 0 ? tuning().wide : (fills(t256) ? 2 : (fills(t128) && tuning().wide128 == 1 ? 1 : 0));
+    // a channel tile that is half padding or more (128 output channels in a 256-wide tile: the VAEs' 128-channel levels)
+    // loses to the ping-pong kernel's 256 x 128 tile: 878 vs 1160 us on 128 -> 128 3x3 at 512 x 512 x 8 (tools/kbench.py conv)
+    if (tuning().wide <= 0 && pick == 2 && p->n_packed * 2 <= bnw && a.pp) pick = 0;
 #ifndef MOBI_DEV
     // launches of the 256-pixel geometry that the ping-pong kernel's register epilogue does not take (transposed / fp32
     // output, ragged tiles, bias AND per-image vector, per-image weights): the ring kernel's LDS-staged epilogue does
