@@ -81,7 +81,7 @@ def main():
               f"HIP-event brackets on the same box.  `roofline.achieved` = {roof['achieved']} TFLOP/s = {roof['gflop_per_launch']} GFLOP "
               f"(algorithmic 2*M*N*K) / that launch time; frac {roof['frac']}.  igemm time per step by main loop: "
               f"{roof['igemm_ms_by_variant']}.", "`__amd_rocclr_copyBuffer` rows are the one-off weight upload / packing, not per-step work.", ""]
-    for fam in ("igemm_pp_kernel", "igemm_ring_kernel", "attention_kernel"):
+    for fam in ("igemm_pp_kernel", "igemm_ring_kernel", "attention_rows_kernel", "attention_kernel", "gn_regs_kernel"):
         rec = pmc.get(fam)
         if rec:
             lines.append(f"HBM traffic of `{fam}` (`{tag}_pmc_traffic.json`, FETCH_SIZE x 2 + WRITE_SIZE, separate `--pmc` passes): "
@@ -91,8 +91,11 @@ def main():
               f"* `{tag}_launches_one_step.tsv` (`..._nusc256.tsv`) kind, GFLOP, us, algorithmic MB, kernel variant and shape of every launch of one step",
               f"* `{tag}_pmc_traffic.json` per-kernel-family FETCH_SIZE / WRITE_SIZE (tools/pmc_summary.py)",
               f"* `{tag}_error_table.txt` measured rel-L2 of every parity assertion of `pytest -m gpu` (MOBI_RECORD_ERRORS)",
-              f"* `{tag}_ab_wide.txt` interleaved best-of-3 A/B of the igemm main loops per shape (tools/ab_wide.py)",
-              f"* `{tag}_splitk_sweep_*.txt` graph-timed split-K / main-loop sweep of the small-m shapes (tools/sweep_split.py)"]
+              f"* `{tag}_graph_breakdown.txt` per-kernel time INSIDE the replayed step graph, both workloads (tools/graph_gaps.py)",
+              f"* `{tag}_attention_*.txt` attention lab: ablations, variants, SQ counters; `{tag}_mfma_fill_probe.txt`",
+              f"* `{tag}_gn_lab.txt`, `{tag}_tka_lab.txt`, `{tag}_ff_lab.txt` graph-timed per-shape A/Bs of the GroupNorm / two-key adapter / "
+              "feed-forward kernels; `*_ab_*.txt` interleaved whole-step A/Bs (tools/ab_step.sh) and per-shape A/Bs",
+              f"* the igemm main-loop A/Bs and split-K sweeps of the untouched kernels are round 2's (`r02_ab_wide.txt`, `r02_splitk_sweep_*.txt`)"]
     with open(os.path.join(dst, f"{tag}_README.md"), "w") as f:
         f.write("\n".join(lines) + "\n")
     print("\n".join(lines[:16]))
