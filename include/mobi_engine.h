@@ -258,8 +258,8 @@ typedef struct mobi_two_key_adapter_params {
   /* Optional second result: the LayerNorm of the RESULT rows as the cross-modal step reads it next (attention.py:
    * cross_modal_norm_camera on the even images, cross_modal_norm_lidar on the odd ones).  Image i goes to ln_out[i & 1]
    * at image index i >> 1 (T [images / 2][token][channels], dense) with ln_gamma / ln_beta [i & 1] (f32 [channels]).
-   * ln_out[0] == NULL: none.  Served where mobi_two_key_adapter_fuses_ln(channels, images * rows_per_image) says so (MOBI_ERR_UNSUPPORTED
-   * otherwise: the caller then runs mobi_layernorm on the two halves). */
+   * ln_out[0] == NULL: none.  Served where mobi_two_key_adapter_fuses_ln(channels, images * rows_per_image) says so: every
+   * launch of the default routing (MOBI_ERR_UNSUPPORTED otherwise: the caller then runs mobi_layernorm on the two halves). */
   void* ln_out[2];
   const float* ln_gamma[2];
   const float* ln_beta[2];

@@ -540,11 +540,14 @@ static inline unsigned grid_for(long long total, int block, long long cap = 6553
 // ---------------------------------------------------------------------------------------
 template <typename T, int MAXV>
 __global__ __launch_bounds__(256) void two_key_adapter_kernel(const mobi_two_key_adapter_params p, int rows_per_block) {
-  __shared__ __attribute__((aligned(16))) float tk_lds[17 * 512 * MAXV];      // C <= 512 * MAXV
+  __shared__ __attribute__((aligned(16))) float tk_lds[19 * 512 * MAXV];      // C <= 512 * MAXV (17 C tables + 2 C for the second result)
   const int C = p.channels, H = p.heads, V = C >> 3;
   float* s_a = tk_lds;                     // [H][C]
   float* s_u = tk_lds + 8 * C;             // [H][C]
   float* s_b = tk_lds + 16 * C;            // [C]
+  float* s_lg = tk_lds + 17 * C;           // [C] gamma, [C] beta of the second result's LayerNorm (natural channel order)
+  float* s_lb = tk_lds + 18 * C;
+  const bool ln2 = p.ln_out[0] != nullptr; // (uniform)
   const int img = blockIdx.y;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   // LDS image of a table row: the FIRST four floats of every 8-channel group, then the SECOND four (a lane reads
@@ -564,6 +567,11 @@ __global__ __launch_bounds__(256) void two_key_adapter_kernel(const mobi_two_key
       reinterpret_cast<f32x4*>(s_u)[d] = h < H ? gu[i] : z;
     }
     for (int q = tid; q < Q; q += 256) reinterpret_cast<f32x4*>(s_b)[(q & 1) * (Q >> 1) + (q >> 1)] = gb[q];
+    if (ln2) {
+      const float* lg = (img & 1) ? p.ln_gamma[1] : p.ln_gamma[0];
+      const float* lb = (img & 1) ? p.ln_beta[1] : p.ln_beta[0];
+      for (int c = tid; c < C; c += 256) { s_lg[c] = lg[c]; s_lb[c] = lb[c]; }
+    }
   }
   float a_sum[8], cc[8];
 #pragma unroll
@@ -679,7 +687,50 @@ __global__ __launch_bounds__(256) void two_key_adapter_kernel(const mobi_two_key
 #pragma unroll
           for (int j = 0; j < 4; ++j) { o[j] += g[h] * u0[j]; o[4 + j] += g[h] * u1[j]; }
         }
-        st16(ob + (long long)r * C + v * 8, pack8<T>(o));
+        const u32x4 packed = pack8<T>(o);
+        st16(ob + (long long)r * C + v * 8, packed);
+        cur[i] = packed;                                     // the stored (rounded) row: what a LayerNorm launch would read
+      }
+    }
+    if (ln2) {
+      // second result (see two_key_adapter_regs_kernel): LayerNorm of the stored row, mean then variance about the mean
+      float s1 = 0.f;
+#pragma unroll
+      for (int i = 0; i < MAXV; ++i)
+        if (lane + 64 * i < V) {
+          float f[8];
+          unpack8<T>(cur[i], f);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) s1 += f[j];
+        }
+      const float mean2 = wave_sum(s1) * inv_c;
+      float q2 = 0.f;
+#pragma unroll
+      for (int i = 0; i < MAXV; ++i)
+        if (lane + 64 * i < V) {
+          float f[8];
+          unpack8<T>(cur[i], f);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) { const float d = f[j] - mean2; q2 += d * d; }
+        }
+      const float rstd2 = rsqrtf(wave_sum(q2) * inv_c + p.ln_eps);
+      T* __restrict__ lrow = reinterpret_cast<T*>((img & 1) ? p.ln_out[1] : p.ln_out[0]) +
+                             ((long long)(img >> 1) * p.rows_per_image + r) * C;
+#pragma unroll
+      for (int i = 0; i < MAXV; ++i) {
+        const int v = lane + 64 * i;
+        if (v < V) {
+          float f[8], o[8];
+          unpack8<T>(cur[i], f);
+          const f32x4 g0 = *reinterpret_cast<const f32x4*>(s_lg + v * 8), g1 = *reinterpret_cast<const f32x4*>(s_lg + v * 8 + 4);
+          const f32x4 h0 = *reinterpret_cast<const f32x4*>(s_lb + v * 8), h1 = *reinterpret_cast<const f32x4*>(s_lb + v * 8 + 4);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            o[j] = (f[j] - mean2) * rstd2 * g0[j] + h0[j];
+            o[4 + j] = (f[4 + j] - mean2) * rstd2 * g1[j] + h1[j];
+          }
+          st16(lrow + v * 8, pack8<T>(o));
+        }
       }
     }
 #pragma unroll
@@ -1194,10 +1245,18 @@ extern "C" int mobi_ctx_attention(const mobi_ctx_attention_params* p, void* stre
 // the register kernel's launches: C = 320 / 640 and enough token rows to spread its 64-row blocks over the chip (measured,
 // tools/tka_lab.py --nusc256: 8 x 256 tokens at C = 640: 11.3-12.7 us against 8.4 us on the vector-ALU kernel; 8 x 1024 at C = 320:
 // 8.9 against 12.3)
-extern "C" int mobi_two_key_adapter_fuses_ln(int32_t channels, int64_t total_rows) {
+static int tka_regs_launch(int32_t channels, int64_t total_rows) {
   const int tka = mobi::tuning().tka_mfma;
   if (tka == 0 || tka == 1 || tka == 2) return 0;
   return (channels == 320 && total_rows >= 1024) || (channels == 640 && total_rows >= 4096);
+}
+// the second result (ln_out) is written by the register kernel and by the vector-ALU kernel, i.e. by every launch of the
+// default routing; not by the LDS-tile kernel the A/B settings MOBI_TKA_MFMA=1 / 2 route C <= 640 / 320 to
+extern "C" int mobi_two_key_adapter_fuses_ln(int32_t channels, int64_t total_rows) {
+  if (channels <= 0 || (channels & 7) || channels > 1536 || total_rows <= 0) return 0;
+  const int tka = mobi::tuning().tka_mfma;
+  if ((tka == 1 || tka == 2) && (channels & 31) == 0 && channels <= (tka == 1 ? 640 : 320)) return 0;
+  return 1;
 }
 
 extern "C" int mobi_two_key_adapter(const mobi_two_key_adapter_params* p, void* stream) {
@@ -1218,7 +1277,7 @@ extern "C" int mobi_two_key_adapter(const mobi_two_key_adapter_params* p, void* 
   }
   // (C = 1280 stays on the vector-ALU kernel: 16 x 16 and 8 x 8 tokens per image are a fixed cost of table staging plus
   //  one tile per wave either way -- 20.8 us there, 21.5 us as a 40-block unrolled register kernel, profiles/r03_tka_lab.txt)
-  if (mobi_two_key_adapter_fuses_ln(p->channels, (int64_t)p->images * p->rows_per_image)) {
+  if (tka_regs_launch(p->channels, (int64_t)p->images * p->rows_per_image)) {
     // 16 rows per wave and tile, 64 per block at least; about 512 blocks over the launch (the tables are staged per block)
     long long rows = ((long long)p->rows_per_image * p->images + 511) / 512;
     rows = (rows + 15) / 16 * 16;
@@ -1234,7 +1293,7 @@ extern "C" int mobi_two_key_adapter(const mobi_two_key_adapter_params* p, void* 
     MOBI_CHECK_LAUNCH();
     return MOBI_OK;
   }
-  if ((p->channels & 31) == 0 && p->channels <= (tka == 1 ? 640 : 320) && tka != 0) {
+  if ((tka == 1 || tka == 2) && (p->channels & 31) == 0 && p->channels <= (tka == 1 ? 640 : 320)) {      // A/B only
     // matrix-core kernel: blocks of 64 rows (16 per wave) x k; about 512 blocks over the launch (tables re-staged per block)
     const int C = p->channels;
     long long rows = ((long long)p->rows_per_image * p->images + 511) / 512;

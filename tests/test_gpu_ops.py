@@ -832,19 +832,20 @@ def test_two_key_adapter(ops, dtype, n, t, c, heads, strided, tune):
 
 
 @pytest.mark.parametrize("dtype", DT)
-@pytest.mark.parametrize("n,t,c", [(4, 300, 320), (2, 2048, 640), (6, 700, 640)])
+@pytest.mark.parametrize("n,t,c", [(4, 300, 320), (2, 2048, 640), (6, 700, 640), (4, 37, 1280), (2, 100, 640), (2, 50, 320),
+                                   (2, 33, 64)])
 def test_two_key_adapter_layernorm_pair(ops, dtype, n, t, c, tune):
-    """The adapter kernel's second result: LayerNorm of the result rows, even images with one (gamma, beta), odd images with
+    """The adapter kernels' second result: LayerNorm of the result rows, even images with one (gamma, beta), odd images with
     another, against mobi_layernorm on the stored result (same rounded input: only the summation order differs) and against
-    fp32 torch; the first result is unchanged by asking for the second; widths / tunings without the fused form say so."""
+    fp32 torch; the first result is unchanged by asking for the second; register kernel (C = 320 / 640 with enough rows) and
+    vector-ALU kernel (every other shape, MOBI_TKA_MFMA=0); the A/B-only LDS-tile kernel says it does not."""
     name = f"tkaln.{n}.{t}.{c}"
     xf, xd = rnd(name + ".x", (n, t, c), dtype, scale=2.0)
     a = (W.synth_input(name + ".a", (n, 8, c)) * 0.05).cuda()
     u, b, cc = (W.synth_input(name + k, s).cuda() for k, s in ((".u", (n, 8, c)), (".b", (n, c)), (".c", (n, 8))))
     gb = [(torch.from_numpy(W.synth_param(f"{name}.g{i}", (c,))).cuda(), torch.from_numpy(W.synth_param(f"{name}.b{i}", (c,))).cuda())
           for i in range(2)]
-    assert ops.two_key_adapter_fuses_ln(c, n * t) and not ops.two_key_adapter_fuses_ln(1280, n * t)
-    assert not ops.two_key_adapter_fuses_ln(c, 512)                     # too few rows: the vector-ALU kernel's launch
+    assert ops.two_key_adapter_fuses_ln(c, n * t)                       # the register kernel or the vector-ALU kernel: both write it
     y = ops.two_key_adapter(xd, a, a.sum(-1).contiguous(), cc, u, b, 1e-5)
     y2, (l0, l1) = ops.two_key_adapter(xd, a, a.sum(-1).contiguous(), cc, u, b, 1e-5, ln_pair=(gb[0], gb[1], 1e-5))
     assert torch.equal(y, y2) and l0.shape == l1.shape == (n // 2, t, c)
@@ -853,10 +854,16 @@ def test_two_key_adapter_layernorm_pair(ops, dtype, n, t, c, tune):
         assert rel(got.float(), ref) < TOL[dtype]
         sep = ops.layernorm(half.contiguous(), g, bt, 1e-5)
         assert rel(got.float(), sep.float()) < TOL[dtype] / 4 and float((got.float() - sep.float()).abs().max()) < 0.07
-    tune.setenv("MOBI_TKA_MFMA", "0")
-    assert not ops.two_key_adapter_fuses_ln(c, n * t)
-    with pytest.raises(Exception):
-        ops.two_key_adapter(xd, a, a.sum(-1).contiguous(), cc, u, b, 1e-5, ln_pair=(gb[0], gb[1], 1e-5))
+    tune.setenv("MOBI_TKA_MFMA", "0")                                   # the vector-ALU kernel on every shape
+    assert ops.two_key_adapter_fuses_ln(c, n * t)
+    y3, (m0, m1) = ops.two_key_adapter(xd, a, a.sum(-1).contiguous(), cc, u, b, 1e-5, ln_pair=(gb[0], gb[1], 1e-5))
+    for got, half, (g, bt) in ((m0, y3[0::2], gb[0]), (m1, y3[1::2], gb[1])):
+        assert rel(got.float(), F.layer_norm(half.float(), (c,), g, bt, 1e-5)) < TOL[dtype]
+    tune.setenv("MOBI_TKA_MFMA", "1")                                   # the LDS-tile kernel (A/B only) does not write it
+    if c % 32 == 0 and c <= 640:
+        assert not ops.two_key_adapter_fuses_ln(c, n * t)
+        with pytest.raises(Exception):
+            ops.two_key_adapter(xd, a, a.sum(-1).contiguous(), cc, u, b, 1e-5, ln_pair=(gb[0], gb[1], 1e-5))
 
 
 @pytest.mark.parametrize("dtype", DT)
