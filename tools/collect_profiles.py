@@ -86,7 +86,10 @@ def main():
         if rec:
             lines.append(f"HBM traffic of `{fam}` (`{tag}_pmc_traffic.json`, FETCH_SIZE x 2 + WRITE_SIZE, separate `--pmc` passes): "
                          f"{rec['hbm_bytes_per_launch_corrected'] / 1e6:.1f} MB per launch over {rec['launches']} launches.")
-    lines += ["", "Files:",
+    lines += ["", "Box spread: the pool's boxes fall into two groups about 6 % apart (clocks under load); the same build measured "
+              "19.49-19.52 ms per step on a fast one (`r03_ab_fused_ln.txt`, third block) and 20.7-20.9 on the slow one this set comes from; "
+              "every A/B in this directory is interleaved on one box.",
+              "", "Files:",
               f"* `{tag}_unet512_b16_bf16_kernel_stats.csv` rocprofv3 stats; `{tag}_bench_unet512_b16_bf16.json` bench line of the same box",
               f"* `{tag}_launches_one_step.tsv` (`..._nusc256.tsv`) kind, GFLOP, us, algorithmic MB, kernel variant and shape of every launch of one step",
               f"* `{tag}_pmc_traffic.json` per-kernel-family FETCH_SIZE / WRITE_SIZE (tools/pmc_summary.py)",
