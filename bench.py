@@ -102,11 +102,11 @@ def stub_main(args, world, rank):
     for _ in range(args.steps):
         a = torch.tanh(a @ a)
         time.sleep(0.002 * (1 + rank))           # rank-dependent: the MAX over ranks must win
+    own = time.perf_counter() - t0               # this rank's own K steps (before it waits for the others)
     barrier()
     dt = time.perf_counter() - t0
     ranks = None
     if world > 1:
-        own = dt
         tmax = torch.tensor([dt])
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
@@ -230,11 +230,12 @@ def main():
             x = one_step(x, args.warmup + i)
         ev1.record()
         t_issued = time.perf_counter() - t0            # host time to issue K steps (the GPU may still be running)
+        torch.cuda.synchronize()
+        dt_own = time.perf_counter() - t0              # this rank's own K steps (before it waits for the others)
         barrier()
         dt = time.perf_counter() - t0
         gpu_ms_per_step = ev0.elapsed_time(ev1) / args.steps
         host_ms_per_step = t_issued / args.steps * 1e3
-    dt_own = dt
     ranks = None
     if world > 1:
         tmax = torch.tensor([dt], device=red_dev)
