@@ -31,10 +31,13 @@
 extern "C" {
 #endif
 
-/* bumped whenever a parameter struct changes (2: mobi_attention_params.q_log2_scaled; 1 also covered the later
- * additions mobi_igemm_params.weight_tiled and mobi_ddim_step_params.coef_dev): a caller built against another version
- * must not call into this library -- check mobi_abi_version() == MOBI_ABI_VERSION next to the mobi_struct_size checks. */
-#define MOBI_ABI_VERSION 2
+/* bumped whenever a parameter struct OR a function signature changes: a caller built against another version must
+ * not call into this library -- check mobi_abi_version() == MOBI_ABI_VERSION next to the mobi_struct_size checks.
+ *   1  first layout (later also mobi_igemm_params.weight_tiled, mobi_ddim_step_params.coef_dev)
+ *   2  mobi_attention_params.q_log2_scaled; mobi_two_key_adapter_params.ln_out / ln_gamma / ln_beta / ln_eps;
+ *      mobi_ff_geglu_params (struct id 14); mobi_two_key_adapter_fuses_ln(channels, total_rows)
+ *   3  mobi_row_chain_params / mobi_chain_op (struct ids 15, 16), mobi_row_chain* */
+#define MOBI_ABI_VERSION 3
 
 enum { MOBI_OK = 0, MOBI_ERR_ARG = -1, MOBI_ERR_UNSUPPORTED = -2, MOBI_ERR_LAUNCH = -3, MOBI_ERR_ALIGN = -4 };
 enum { MOBI_F16 = 0, MOBI_BF16 = 1 };
@@ -44,7 +47,8 @@ const char* mobi_error_string(int code);
 /* sizeof() of a parameter struct as the library was compiled; bindings compare it with
  * their own layout before the first call.  id: 0 igemm, 1 groupnorm, 2 layernorm,
  * 3 attention, 4 ctx_attention, 5 skinny_linear, 6 conv_small_cin, 7 conv_small_cout,
- * 8 ddim_step, 9 two_key_adapter, 10 range_paste, 11 lidar_metrics.  Returns 0 for an unknown id. */
+ * 8 ddim_step, 9 two_key_adapter, 10 range_paste, 11 lidar_metrics, 12 range_prepare, 13 image_prepare, 14 ff_geglu,
+ * 15 row_chain, 16 chain_op.  Returns 0 for an unknown id. */
 size_t mobi_struct_size(int id);
 /* Development hook: the library reads its MOBI_* A/B environment variables once, at the first launch
  * (mobi_amd/csrc/tuning.h lists them); this re-reads them.  Not needed by a product caller. */
@@ -223,6 +227,72 @@ typedef struct mobi_ff_geglu_params {
 } mobi_ff_geglu_params;
 size_t mobi_ff_geglu_packed_bytes(int32_t c, int32_t hidden);
 int mobi_ff_geglu(const mobi_ff_geglu_params* p, void* stream);
+
+/* ---------------------------------------------------------------------------
+ * Row-resident chain of C -> C linear layers over token rows (C = 320: the
+ * 64 x 64 level of the UNet; `mobi_nusc_256`'s 32 x 32 level), one launch.
+ * Replaces the launches BETWEEN the attention kernels of a transformer block
+ * (BasicTransformerBlock._forward, attention.py:230-266 of the reference), whose
+ * [rows][C] results otherwise make an HBM round trip each:
+ *   after attn1:   x = to_out(a) + attn2 vector + x            (:234-235)
+ *                  x = x + cond_adapter(...)                   (:237-243, the two-key fold of mobi_two_key_adapter)
+ *                  q = cross_modal_attn_*.to_q(LayerNorm(x)), k | v = to_k | to_v(x of the partner)   (:249-261)
+ *   after the camera's cross-modal attention:  x_cam = x_cam + connector(to_out(a));  k | v of the lidar's attention
+ *   before attn1:  t = proj_in(GroupNorm(x)) (:306-307), q | k | v = attn1.to_*(LayerNorm(t))        (:234)
+ * A wave keeps 32 token rows in registers as MFMA 32x32x16 B fragments (lane l: row l & 31, channels
+ * 16 ks + 8 (l >> 5) + 0..7 of fragment ks) and runs a PROGRAM of operations on them; weights stream through an
+ * LDS ring as 20-KiB chunk images.  A block = 4 waves = 128 rows of one image: rows_per_image % 128 == 0.
+ *
+ * Weight image of one product (mobi_row_chain_weight_bytes() = 200 KiB for a [320][320] matrix W, out = W x):
+ *   [chunk c < 10][fragment f < 20][lane l < 64][8 T],  f = 10 kk + m  (kk < 2, m < 10):
+ *   element j = W[32 m + tau(l & 31)][16 (2 c + kk) + 8 (l >> 5) + j],  tau(i) = i with bits 2 and 3 swapped
+ *   (so that the accumulator registers a lane receives are the channels of the fragments it holds).
+ *
+ * Operations (code):
+ *   MOBI_CH_LOAD_S    s <- rows of p0 (T; image index img / img_div, strides in elements)
+ *   MOBI_CH_LOAD_R    r <- rows of p0
+ *   MOBI_CH_AFFINE_S  s <- s * bias[img][ch] + svec[img][ch]   (f32 [images][C] each: GroupNorm folded to scale / shift)
+ *   MOBI_CH_COPY      s <- r
+ *   MOBI_CH_ROWSTATS  (rs, cs) <- (rstd, -rstd * mean) of r over the C channels (eps)
+ *   MOBI_CH_PRODUCT   v = W s (p0 = weight image, p1 = the NEXT product's image or NULL: prefetched);
+ *                     flags FOLD: v = rs * v + cs * svec[ch] (LayerNorm folded into W: W' = W diag(gamma),
+ *                                 svec = row sums of the ROUNDED W', bias = W beta);
+ *                     v += bias[(img / bias_img_div) * bias_img_stride + ch] (f32, required: zeros where the layer has none);
+ *                     RESID: v += r;   TO_R: r <- round(v);   STORE: dst rows <- round(v)
+ *   MOBI_CH_ADAPTER   r <- two-key adapter of r (the tables of mobi_two_key_adapter_params, fields ad_*), STORE optional
+ *   MOBI_CH_STORE_R   dst rows <- r
+ * nprog = 2: even images run prog[0], odd images prog[1] (camera / lidar rows of the interleaved batch).
+ * ------------------------------------------------------------------------- */
+enum { MOBI_CH_LOAD_S = 0, MOBI_CH_LOAD_R = 1, MOBI_CH_AFFINE_S = 2, MOBI_CH_COPY = 3, MOBI_CH_ROWSTATS = 4,
+       MOBI_CH_PRODUCT = 5, MOBI_CH_ADAPTER = 6, MOBI_CH_STORE_R = 7 };
+enum { MOBI_CH_FOLD = 1, MOBI_CH_RESID = 2, MOBI_CH_TO_R = 4, MOBI_CH_STORE = 8 };
+#define MOBI_CHAIN_MAX_OPS 10
+typedef struct mobi_chain_op {
+  int32_t code, flags;
+  const void* p0;                 /* LOAD_*: T tensor;  PRODUCT: weight image */
+  const void* p1;                 /* PRODUCT: the next product's weight image, or NULL */
+  const float* bias;              /* PRODUCT: f32 bias;  AFFINE_S: f32 scale [images][C] */
+  const float* svec;              /* PRODUCT + FOLD: f32 [C];  AFFINE_S: f32 shift [images][C] */
+  void* dst;                      /* T rows (PRODUCT + STORE, ADAPTER + STORE, STORE_R) */
+  int64_t img_stride, row_stride;           /* of p0 (LOAD_*), elements */
+  int64_t dst_img_stride, dst_row_stride;   /* of dst, elements */
+  int64_t bias_img_stride;                  /* elements; 0: one vector for all images */
+  int32_t img_div, dst_img_div, bias_img_div;   /* image index = img / div (0 is read as 1) */
+  float eps;                                /* ROWSTATS */
+} mobi_chain_op;
+typedef struct mobi_row_chain_params {
+  int32_t dtype, channels;        /* channels == 320 */
+  int32_t images, rows_per_image; /* rows_per_image % 128 == 0 */
+  int32_t nprog;                  /* 1 or 2 */
+  int32_t nops[2];
+  mobi_chain_op prog[2][MOBI_CHAIN_MAX_OPS];
+  /* MOBI_CH_ADAPTER tables (as mobi_two_key_adapter_params: a, u f32 [image][heads][C]; a_sum, c f32 [image][heads]; b f32 [image][C]) */
+  const float* ad_a; const float* ad_a_sum; const float* ad_c; const float* ad_u; const float* ad_b;
+  int32_t ad_heads; float ad_eps;
+} mobi_row_chain_params;
+size_t mobi_row_chain_weight_bytes(int32_t channels);
+int mobi_row_chain_supported(int32_t channels, int32_t rows_per_image);
+int mobi_row_chain(const mobi_row_chain_params* p, void* stream);
 
 /* Attention against a handful of context tokens (tk <= 8): the bbox adapter
  * (attention.py:237-243, tk = 2).  k, v are fp32 [image][tk][heads*dh]. */

@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libmobi_hip.so")
 
 MOBI_F16, MOBI_BF16 = 0, 1
-ABI_VERSION = 2            # include/mobi_engine.h MOBI_ABI_VERSION
+ABI_VERSION = 3            # include/mobi_engine.h MOBI_ABI_VERSION
 EPI_NONE, EPI_GEGLU = 0, 1
 OUT_ROWS, OUT_TRANSPOSED, OUT_ROWS_F32 = 0, 1, 2
 ACT_NONE, ACT_SILU, ACT_GELU = 0, 1, 2
@@ -60,6 +60,23 @@ class AttentionParams(C.Structure):
 class FfGegluParams(C.Structure):
     _fields_ = [("x", vp), ("rows", i64), ("c", i32), ("hidden", i32), ("w_packed", vp), ("b2", vp), ("residual", vp),
                 ("out", vp), ("dtype", i32), ("ln_gamma", vp), ("ln_beta", vp), ("ln_eps", f32)]
+
+
+CH_LOAD_S, CH_LOAD_R, CH_AFFINE_S, CH_COPY, CH_ROWSTATS, CH_PRODUCT, CH_ADAPTER, CH_STORE_R = range(8)
+CH_FOLD, CH_RESID, CH_TO_R, CH_STORE = 1, 2, 4, 8
+CHAIN_MAX_OPS = 10
+
+
+class ChainOp(C.Structure):
+    _fields_ = [("code", i32), ("flags", i32), ("p0", vp), ("p1", vp), ("bias", vp), ("svec", vp), ("dst", vp),
+                ("img_stride", i64), ("row_stride", i64), ("dst_img_stride", i64), ("dst_row_stride", i64),
+                ("bias_img_stride", i64), ("img_div", i32), ("dst_img_div", i32), ("bias_img_div", i32), ("eps", f32)]
+
+
+class RowChainParams(C.Structure):
+    _fields_ = [("dtype", i32), ("channels", i32), ("images", i32), ("rows_per_image", i32), ("nprog", i32),
+                ("nops", i32 * 2), ("prog", (ChainOp * CHAIN_MAX_OPS) * 2), ("ad_a", vp), ("ad_a_sum", vp), ("ad_c", vp),
+                ("ad_u", vp), ("ad_b", vp), ("ad_heads", i32), ("ad_eps", f32)]
 
 
 class CtxAttentionParams(C.Structure):
@@ -125,7 +142,7 @@ class ImagePrepareParams(C.Structure):
 STRUCT_IDS = {0: IgemmParams, 1: GroupNormParams, 2: LayerNormParams, 3: AttentionParams, 4: CtxAttentionParams,
               5: SkinnyLinearParams, 6: ConvSmallCinParams, 7: ConvSmallCoutParams, 8: DdimStepParams, 9: TwoKeyAdapterParams,
               10: RangePasteParams, 11: LidarMetricsParams, 12: RangePrepareParams, 13: ImagePrepareParams,
-              14: FfGegluParams}
+              14: FfGegluParams, 15: RowChainParams, 16: ChainOp}
 
 # every symbol include/mobi_engine.h declares: name -> (restype, argtypes)
 SYMBOLS = {
@@ -151,6 +168,9 @@ SYMBOLS = {
     "mobi_linear_f32": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
     "mobi_ff_geglu": (C.c_int, [C.POINTER(FfGegluParams), vp]),
     "mobi_ff_geglu_packed_bytes": (C.c_size_t, [i32, i32]),
+    "mobi_row_chain": (C.c_int, [C.POINTER(RowChainParams), vp]),
+    "mobi_row_chain_weight_bytes": (C.c_size_t, [i32]),
+    "mobi_row_chain_supported": (C.c_int, [i32, i32]),
     "mobi_quick_gelu": (C.c_int, [vp, vp, i64, i32, vp]),
     "mobi_timestep_embedding": (C.c_int, [vp, vp, vp, i32, i32, vp]),
     "mobi_conv_small_cin": (C.c_int, [C.POINTER(ConvSmallCinParams), vp]),

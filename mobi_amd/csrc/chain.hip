@@ -1,0 +1,453 @@
+// Row-resident chain of C -> C linear layers for gfx950 (C = 320), include/mobi_engine.h mobi_row_chain:
+// the launches BETWEEN the attention kernels of a transformer block (BasicTransformerBlock._forward, attention.py:230-266
+// of the reference) as one kernel each -- to_out (+ residual + attn2 vector) -> two-key bbox adapter -> cross-modal
+// LayerNorm -> to_q / to_k / to_v, and connector o to_out (+ residual) -> the partner's to_k / to_v -- so that the
+// [rows][C] intermediates never make an HBM round trip.
+//
+// Structure = ff.hip's: a wave holds 32 token rows as the B fragments of MFMA 32x32x16 (lane l: row l & 31, channels
+// 16 ks + 8 (l >> 5) + 0..7 of fragment ks), weights are the A operand, streamed through an LDS ring as ready-made 1-KiB
+// fragment images by LDS-DMA (no VGPR staging), D^T[channel][row] accumulates in fp32.  The rows of every weight image
+// are permuted (tau: bits 2 and 3 of the row index swapped) so that the accumulator registers a lane receives ARE the
+// channels of the fragments it holds: acc[m][8 (ks & 1) + j] <-> fragment ks = 2 m + .., element j.  A product's result
+// therefore becomes the next product's operand by a conversion in registers, and everything row-wise (residual, bias,
+// LayerNorm statistics, the adapter's gates) is lane-local plus one exchange between lanes l and l + 32.
+//
+// LayerNorm in front of a projection is FOLDED into it (exact algebra): LN(x) W^T = rstd (x (W diag gamma)^T - mean s) +
+// W beta, s = row sums of the rounded W diag gamma -- the product reads the raw rows, the epilogue applies two scalars per
+// row; no normalised copy of the row exists, not even in registers.
+//
+// A block = 4 waves (one per SIMD: ~400 registers) = 128 rows of ONE image; the program (a short list of operations,
+// mobi_chain_op) is interpreted with uniform branches, every product is the same unrolled 200-MFMA body.
+// Weight ring: NSLOT slots of one chunk (20 KiB = 2 k-steps x 10 output tiles); the requests of chunk g + NSLOT - 1 are
+// issued behind the barrier that opens chunk g (all waves are then done with chunk g - 1, whose slot it takes); a wave
+// waits for its OWN requests with a counted vmcnt, the barrier publishes everybody's.
+#include "common.h"
+
+namespace mobi {
+namespace {
+
+constexpr int CH_C = 320, CH_KS = CH_C / 16, CH_MT = CH_C / 32;
+constexpr int CH_NCH = CH_KS / 2;                 // chunks per product
+constexpr int CH_FR = 2 * CH_MT;                  // fragments per chunk
+constexpr int CH_CHUNK = CH_FR * 1024;
+constexpr int CH_NSLOT = 6, CH_D = CH_NSLOT - 1;
+constexpr int CH_RPW = CH_FR / 4;                 // requests per wave and chunk
+constexpr int CH_AST = CH_C * 2 + 16;             // bytes per row of the adapter's logit tables
+constexpr int CH_TAB_A = 9 * CH_AST, CH_TAB_U = (CH_C + 1) * 16;
+constexpr int CH_TAB = 2 * CH_TAB_A + 2 * CH_TAB_U + CH_C * 4 + 64;
+constexpr int CH_QD = 6;                          // fragment queue depth
+static_assert(CH_FR % 4 == 0, "chunk pieces are dealt to four waves");
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+__device__ __forceinline__ void wait_vm(int groups) {
+  // all but the `groups` youngest request groups (CH_RPW requests each) of this wave have landed
+  switch (groups) {
+    case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    case 1: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(1 * CH_RPW) : "memory"); break;
+    case 2: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * CH_RPW) : "memory"); break;
+    case 3: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * CH_RPW) : "memory"); break;
+    default: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * CH_RPW) : "memory"); break;
+  }
+}
+
+}  // namespace
+
+template <typename T>
+__global__ __launch_bounds__(256, 1) void row_chain_kernel(const mobi_row_chain_params a) {
+  typedef typename Vec8<T>::type frag_t;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[CH_NSLOT * CH_CHUNK + CH_TAB];
+  unsigned char* ring = lds;
+  unsigned char* s_ahi = lds + CH_NSLOT * CH_CHUNK;
+  unsigned char* s_alo = s_ahi + CH_TAB_A;
+  unsigned char* s_uhi = s_alo + CH_TAB_A;
+  unsigned char* s_ulo = s_uhi + CH_TAB_U;
+  float* s_b = reinterpret_cast<float*>(s_ulo + CH_TAB_U);      // [C]
+  float* s_asum = s_b + CH_C;                                   // [8]
+  float* s_cc = s_asum + 8;                                     // [8]
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ql = lane & 31, half = lane >> 5;
+  const int tiles = a.rows_per_image / 128;
+  const int img = blockIdx.x / tiles, tile = blockIdx.x - img * tiles;
+  const int kind = a.nprog == 2 ? (img & 1) : 0;
+  const int nops = a.nops[kind];
+  const long long row = (long long)tile * 128 + wave * 32 + ql;          // within the image
+  const unsigned lane16 = (unsigned)lane * 16u;
+  const int ch_lane = 8 * half;                                           // + 16 ks + j
+
+  // ---- adapter tables of this image (two_key_adapter_regs_kernel's split tables, small_ops.hip) ------------------------
+  if (a.ad_a) {
+    const int H = a.ad_heads;
+    const float* ga = a.ad_a + (long long)img * H * CH_C;
+    const float* gu = a.ad_u + (long long)img * H * CH_C;
+#pragma unroll
+    for (int i0 = 0; i0 < 2 * CH_C; i0 += 256) {
+      const int i = i0 + tid;
+      const int hh = i / (CH_C / 4), c = (i - hh * (CH_C / 4)) * 4;
+      if (i < 2 * CH_C) {
+        f32x4 va = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (hh < H) va = *reinterpret_cast<const f32x4*>(ga + hh * CH_C + c);
+        float lo[4], hi[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const T t = (T)va[e]; hi[e] = (float)t; lo[e] = va[e] - hi[e]; }
+        *reinterpret_cast<u32x2*>(s_ahi + hh * CH_AST + c * 2) = pack4<T>(hi);
+        *reinterpret_cast<u32x2*>(s_alo + hh * CH_AST + c * 2) = pack4<T>(lo);
+      }
+    }
+#pragma unroll
+    for (int c0 = 0; c0 < CH_C; c0 += 256) {
+      const int c = c0 + tid;
+      if (c < CH_C) {
+        float hi[8], lo[8];
+#pragma unroll
+        for (int hh = 0; hh < 8; ++hh) {
+          const float v = hh < H ? gu[hh * CH_C + c] : 0.f;
+          const T t = (T)v;
+          hi[hh] = (float)t;
+          lo[hh] = v - hi[hh];
+        }
+        st16(s_uhi + c * 16, pack8<T>(hi));
+        st16(s_ulo + c * 16, pack8<T>(lo));
+      }
+    }
+    for (int c = tid; c < CH_C; c += 256) {
+      s_b[c] = a.ad_b[(long long)img * CH_C + c];
+      *reinterpret_cast<T*>(s_ahi + 8 * CH_AST + c * 2) = (T)0.0f;
+      *reinterpret_cast<T*>(s_alo + 8 * CH_AST + c * 2) = (T)0.0f;
+    }
+    if (tid < 8) {
+      *reinterpret_cast<T*>(s_uhi + CH_C * 16 + tid * 2) = (T)0.0f;
+      *reinterpret_cast<T*>(s_ulo + CH_C * 16 + tid * 2) = (T)0.0f;
+      s_cc[tid] = tid < H ? a.ad_c[img * H + tid] : 0.f;
+    }
+    __syncthreads();
+    {                                               // sums of the numbers the logit product will use: 32 threads per head
+      const int hh = tid >> 5, l = tid & 31;
+      float sum = 0.f;
+      for (int c = l; c < CH_C; c += 32)
+        sum += (float)*reinterpret_cast<const T*>(s_ahi + hh * CH_AST + c * 2) + (float)*reinterpret_cast<const T*>(s_alo + hh * CH_AST + c * 2);
+#pragma unroll
+      for (int o = 16; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+      if (l == 0) s_asum[hh] = sum;
+    }
+    __syncthreads();
+  }
+
+  frag_t xs[CH_KS], xr[CH_KS];
+  f32x16 acc[CH_MT];
+#pragma unroll
+  for (int ks = 0; ks < CH_KS; ++ks) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { xs[ks][j] = (T)0.0f; xr[ks][j] = (T)0.0f; }
+  }
+  float rs = 1.0f, cs = 0.0f;
+
+  // ---- weight ring state (uniform) ------------------------------------------------------------------------------
+  int pend = 0;            // chunks requested and not yet consumed
+  int slot_c = 0;          // slot of the next chunk to consume
+  int slot_q = 0;          // slot of the next chunk to request
+  auto request = [&](const __amdgpu_buffer_rsrc_t& r, int chunk) {
+#pragma unroll
+    for (int i = 0; i < CH_RPW; ++i) {
+      const int p = wave + 4 * i;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_ptr_t)(ring + slot_q * CH_CHUNK + p * 1024), 16, lane16,
+                                               chunk * CH_CHUNK + p * 1024, 0, 0);
+    }
+    slot_q = slot_q + 1 == CH_NSLOT ? 0 : slot_q + 1;
+    ++pend;
+  };
+
+  auto row_ptr = [&](const void* base, long long img_stride, long long row_stride, int div) -> const T* {
+    const int ii = div > 1 ? img / div : img;
+    return reinterpret_cast<const T*>(base) + ii * img_stride + row * row_stride + ch_lane;
+  };
+
+  // ---- a product's epilogue --------------------------------------------------------------------------------------
+  auto epilogue = [&](auto fold_, auto resid_, auto to_r_, auto store_, const mobi_chain_op& op) {
+    constexpr bool FOLD = decltype(fold_)::value, RESID = decltype(resid_)::value, TO_R = decltype(to_r_)::value,
+                   STORE = decltype(store_)::value;
+    const float* bias = op.bias + (long long)(op.bias_img_div > 1 ? img / op.bias_img_div : img) * op.bias_img_stride + ch_lane;
+    const float* sv = FOLD ? op.svec + ch_lane : nullptr;
+    T* dst = STORE ? const_cast<T*>(row_ptr(op.dst, op.dst_img_stride, op.dst_row_stride, op.dst_img_div)) : nullptr;
+#pragma unroll
+    for (int ks = 0; ks < CH_KS; ++ks) {
+      const int m = ks >> 1, o = 8 * (ks & 1);
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = acc[m][o + j];
+      if (FOLD) {
+        const f32x4 s0 = *reinterpret_cast<const f32x4*>(sv + 16 * ks), s1 = *reinterpret_cast<const f32x4*>(sv + 16 * ks + 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          v[j] = rs * v[j] + cs * s0[j];
+          v[4 + j] = rs * v[4 + j] + cs * s1[j];
+        }
+      }
+      {
+        const f32x4 b0 = *reinterpret_cast<const f32x4*>(bias + 16 * ks), b1 = *reinterpret_cast<const f32x4*>(bias + 16 * ks + 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          v[j] += b0[j];
+          v[4 + j] += b1[j];
+        }
+      }
+      if (RESID) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] += (float)xr[ks][j];
+      }
+      const u32x4 packed = pack8<T>(v);
+      if (TO_R) xr[ks] = __builtin_bit_cast(frag_t, packed);
+      if (STORE) st16(dst + 16 * ks, packed);
+    }
+  };
+
+  // ---- the program ---------------------------------------------------------------------------------------------------
+  for (int oi = 0; oi < nops; ++oi) {
+    const mobi_chain_op& op = a.prog[kind][oi];
+    const int code = op.code;
+    if (code == MOBI_CH_LOAD_S) {
+      const T* p = row_ptr(op.p0, op.img_stride, op.row_stride, op.img_div);
+#pragma unroll
+      for (int ks = 0; ks < CH_KS; ++ks) xs[ks] = __builtin_bit_cast(frag_t, ld16(p + 16 * ks));
+    } else if (code == MOBI_CH_LOAD_R) {
+      const T* p = row_ptr(op.p0, op.img_stride, op.row_stride, op.img_div);
+#pragma unroll
+      for (int ks = 0; ks < CH_KS; ++ks) xr[ks] = __builtin_bit_cast(frag_t, ld16(p + 16 * ks));
+    } else if (code == MOBI_CH_AFFINE_S) {
+      const float* sc = op.bias + (long long)img * CH_C + ch_lane;
+      const float* sh = op.svec + (long long)img * CH_C + ch_lane;
+#pragma unroll
+      for (int ks = 0; ks < CH_KS; ++ks) {
+        const f32x4 a0 = *reinterpret_cast<const f32x4*>(sc + 16 * ks), a1 = *reinterpret_cast<const f32x4*>(sc + 16 * ks + 4);
+        const f32x4 h0 = *reinterpret_cast<const f32x4*>(sh + 16 * ks), h1 = *reinterpret_cast<const f32x4*>(sh + 16 * ks + 4);
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          v[j] = (float)xs[ks][j] * a0[j] + h0[j];
+          v[4 + j] = (float)xs[ks][4 + j] * a1[j] + h1[j];
+        }
+        xs[ks] = __builtin_bit_cast(frag_t, pack8<T>(v));
+      }
+    } else if (code == MOBI_CH_COPY) {
+#pragma unroll
+      for (int ks = 0; ks < CH_KS; ++ks) xs[ks] = xr[ks];
+    } else if (code == MOBI_CH_STORE_R) {
+      T* dst = const_cast<T*>(row_ptr(op.dst, op.dst_img_stride, op.dst_row_stride, op.dst_img_div));
+#pragma unroll
+      for (int ks = 0; ks < CH_KS; ++ks) st16(dst + 16 * ks, __builtin_bit_cast(u32x4, xr[ks]));
+    } else if (code == MOBI_CH_ROWSTATS) {
+      // mean, then the variance about the mean from the registers (layernorm_kernel's arithmetic); a row's channels lie
+      // in lanes ql and ql + 32
+      float s1 = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < CH_KS; ++ks)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s1 += (float)xr[ks][j];
+      s1 += __shfl_xor(s1, 32, 64);
+      const float mean = s1 * (1.0f / CH_C);
+      float q = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < CH_KS; ++ks)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const float d = (float)xr[ks][j] - mean; q += d * d; }
+      q += __shfl_xor(q, 32, 64);
+      rs = rsqrtf(q * (1.0f / CH_C) + op.eps);
+      cs = -rs * mean;
+    } else if (code == MOBI_CH_ADAPTER) {
+      // x + b + sum_h sigmoid(rstd (x . a_h - mean sum a_h) + c_h) u_h  (mobi_two_key_adapter; tables split hi + lo)
+      f32x16 lg;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) lg[r] = 0.f;
+      float sx = 0.f, sxx = 0.f;
+      const int a_off = (ql < 8 ? ql : 8) * CH_AST + 16 * half;
+#pragma unroll
+      for (int ks = 0; ks < CH_KS; ++ks) {
+        const frag_t ah = __builtin_bit_cast(frag_t, ld16(s_ahi + a_off + 32 * ks));
+        const frag_t al = __builtin_bit_cast(frag_t, ld16(s_alo + a_off + 32 * ks));
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const float v = (float)xr[ks][j]; sx += v; sxx += v * v; }
+        lg = mfma32(ah, xr[ks], lg);
+        lg = mfma32(al, xr[ks], lg);
+      }
+      sx += __shfl_xor(sx, 32, 64);
+      sxx += __shfl_xor(sxx, 32, 64);
+      const float mean = sx * (1.0f / CH_C);
+      float var = sxx * (1.0f / CH_C) - mean * mean;
+      var = var < 0.f ? 0.f : var;
+      const float rstd = rsqrtf(var + a.ad_eps);
+      // lane (ql, half) holds heads 4 half + j in lg[j]
+      float g[4], gh[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float z = rstd * (lg[j] - mean * s_asum[4 * half + j]) + s_cc[4 * half + j];
+        g[j] = 1.0f / (1.0f + __expf(-z));
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) gh[j] = __shfl_down(g[j], 32, 64);          // heads 4..7 to the half-0 lanes (k = 0..7)
+      frag_t gf, gl;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        gf[j] = half == 0 ? (T)g[j] : (T)0.0f;
+        gf[4 + j] = half == 0 ? (T)gh[j] : (T)0.0f;
+        gl[j] = half == 0 ? (T)(g[j] - (float)gf[j]) : (T)0.0f;
+        gl[4 + j] = half == 0 ? (T)(gh[j] - (float)gf[4 + j]) : (T)0.0f;
+      }
+      // update: A row i of tile m is channel 32 m + tau(i); k = heads (lanes of half 1 supply zeros)
+      const int ti = (ql & 0x13) | ((ql & 4) << 1) | ((ql & 8) >> 1);
+      const int u_off = half == 0 ? ti * 16 : CH_C * 16;
+      const int u_step = half == 0 ? 32 * 16 : 0;
+      T* dst = (op.flags & MOBI_CH_STORE) ? const_cast<T*>(row_ptr(op.dst, op.dst_img_stride, op.dst_row_stride, op.dst_img_div)) : nullptr;
+#pragma unroll
+      for (int m = 0; m < CH_MT; ++m) {
+        const frag_t uh = __builtin_bit_cast(frag_t, ld16(s_uhi + u_off + m * u_step));
+        const frag_t ul = __builtin_bit_cast(frag_t, ld16(s_ulo + u_off + m * u_step));
+        f32x16 d;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) d[r] = 0.f;
+        d = mfma32(uh, gf, d);
+        d = mfma32(ul, gf, d);
+        d = mfma32(uh, gl, d);
+#pragma unroll
+        for (int k2 = 0; k2 < 2; ++k2) {
+          const int ks = 2 * m + k2;
+          const f32x4 b0 = *reinterpret_cast<const f32x4*>(s_b + 16 * ks + ch_lane);
+          const f32x4 b1 = *reinterpret_cast<const f32x4*>(s_b + 16 * ks + ch_lane + 4);
+          float v[8];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            v[j] = (float)xr[ks][j] + b0[j] + d[8 * k2 + j];
+            v[4 + j] = (float)xr[ks][4 + j] + b1[j] + d[8 * k2 + 4 + j];
+          }
+          const u32x4 packed = pack8<T>(v);
+          xr[ks] = __builtin_bit_cast(frag_t, packed);
+          if (dst) st16(dst + 16 * ks, packed);
+        }
+      }
+    } else if (code == MOBI_CH_PRODUCT) {
+      const __amdgpu_buffer_rsrc_t r0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(op.p0), 0, CH_NCH * CH_CHUNK, 0x00020000);
+      const bool has_next = op.p1 != nullptr;
+      const __amdgpu_buffer_rsrc_t r1 =
+          __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(has_next ? op.p1 : op.p0), 0, CH_NCH * CH_CHUNK, 0x00020000);
+      if (pend < CH_D) {
+        // not prefetched by a predecessor (the program's first product): every wave must be done with the slots
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        for (int j = pend; j < CH_D; ++j) request(r0, j);
+      }
+#pragma unroll
+      for (int m = 0; m < CH_MT; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+#pragma unroll
+      for (int c = 0; c < CH_NCH; ++c) {
+        wait_vm(pend - 1);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        --pend;
+        if (c + CH_D < CH_NCH) request(r0, c + CH_D);
+        else if (has_next) request(r1, c + CH_D - CH_NCH);
+        const unsigned char* base = ring + slot_c * CH_CHUNK + lane16;
+        slot_c = slot_c + 1 == CH_NSLOT ? 0 : slot_c + 1;
+        frag_t fq[CH_QD];
+#pragma unroll
+        for (int i = 0; i < CH_QD; ++i) fq[i] = __builtin_bit_cast(frag_t, ld16(base + i * 1024));
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int f = 0; f < CH_FR; ++f) {
+          const int kk = f / CH_MT, m = f - kk * CH_MT;
+          acc[m] = mfma32(fq[f % CH_QD], xs[2 * c + kk], acc[m]);
+          if (f + CH_QD < CH_FR) fq[f % CH_QD] = __builtin_bit_cast(frag_t, ld16(base + (f + CH_QD) * 1024));
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      typedef std::true_type Y;
+      typedef std::false_type N;
+      switch (op.flags & 15) {
+        case MOBI_CH_STORE: epilogue(N{}, N{}, N{}, Y{}, op); break;
+        case MOBI_CH_FOLD | MOBI_CH_STORE: epilogue(Y{}, N{}, N{}, Y{}, op); break;
+        case MOBI_CH_RESID | MOBI_CH_TO_R: epilogue(N{}, Y{}, Y{}, N{}, op); break;
+        case MOBI_CH_RESID | MOBI_CH_TO_R | MOBI_CH_STORE: epilogue(N{}, Y{}, Y{}, Y{}, op); break;
+        case MOBI_CH_RESID | MOBI_CH_STORE: epilogue(N{}, Y{}, N{}, Y{}, op); break;
+        case MOBI_CH_TO_R | MOBI_CH_STORE: epilogue(N{}, N{}, Y{}, Y{}, op); break;
+        default: break;                             // (mobi_row_chain rejects every other combination)
+      }
+    }
+  }
+  // the ring may still have requests in flight (a program never ends with a prefetch: p1 of the last product is NULL)
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+}
+
+}  // namespace mobi
+
+extern "C" size_t mobi_row_chain_weight_bytes(int32_t channels) {
+  return channels == mobi::CH_C ? (size_t)mobi::CH_NCH * mobi::CH_CHUNK : 0;
+}
+
+extern "C" int mobi_row_chain_supported(int32_t channels, int32_t rows_per_image) {
+  return channels == mobi::CH_C && rows_per_image > 0 && rows_per_image % 128 == 0;
+}
+
+extern "C" int mobi_row_chain(const mobi_row_chain_params* p, void* stream) {
+  using namespace mobi;
+  if (!p) return MOBI_ERR_ARG;
+  if (p->dtype != MOBI_F16 && p->dtype != MOBI_BF16) return MOBI_ERR_ARG;
+  if (!mobi_row_chain_supported(p->channels, p->rows_per_image)) return MOBI_ERR_UNSUPPORTED;
+  if (p->images <= 0 || (p->nprog != 1 && p->nprog != 2)) return MOBI_ERR_ARG;
+  if (p->nprog == 2 && (p->images & 1)) return MOBI_ERR_ARG;
+  auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+  for (int k = 0; k < p->nprog; ++k) {
+    if (p->nops[k] <= 0 || p->nops[k] > MOBI_CHAIN_MAX_OPS) return MOBI_ERR_ARG;
+    const mobi_chain_op* next_product = nullptr;
+    for (int i = p->nops[k] - 1; i >= 0; --i) {
+      const mobi_chain_op& op = p->prog[k][i];
+      switch (op.code) {
+        case MOBI_CH_LOAD_S: case MOBI_CH_LOAD_R:
+          if (!op.p0) return MOBI_ERR_ARG;
+          if (!al16(op.p0) || (op.img_stride & 7) || (op.row_stride & 7) || op.row_stride < CH_C) return MOBI_ERR_ALIGN;
+          break;
+        case MOBI_CH_AFFINE_S:
+          if (!op.bias || !op.svec) return MOBI_ERR_ARG;
+          if (!al16(op.bias) || !al16(op.svec)) return MOBI_ERR_ALIGN;
+          break;
+        case MOBI_CH_COPY: case MOBI_CH_ROWSTATS: break;
+        case MOBI_CH_STORE_R:
+          if (!op.dst) return MOBI_ERR_ARG;
+          if (!al16(op.dst) || (op.dst_img_stride & 7) || (op.dst_row_stride & 7) || op.dst_row_stride < CH_C) return MOBI_ERR_ALIGN;
+          break;
+        case MOBI_CH_ADAPTER:
+          if (!p->ad_a || !p->ad_a_sum || !p->ad_c || !p->ad_u || !p->ad_b || p->ad_heads <= 0 || p->ad_heads > 8) return MOBI_ERR_ARG;
+          if (!al16(p->ad_a) || !al16(p->ad_b)) return MOBI_ERR_ALIGN;
+          if ((op.flags & MOBI_CH_STORE) && (!op.dst || !al16(op.dst) || (op.dst_img_stride & 7) || (op.dst_row_stride & 7))) return MOBI_ERR_ALIGN;
+          break;
+        case MOBI_CH_PRODUCT: {
+          if (!op.p0 || !al16(op.p0) || !al16(op.p1)) return op.p0 ? MOBI_ERR_ALIGN : MOBI_ERR_ARG;
+          // the prefetch pointer must be the next product's image (or NULL on the last one): the ring is consumed in order
+          if (op.p1 != (next_product ? next_product->p0 : nullptr)) return MOBI_ERR_ARG;
+          const int f = op.flags & 15;
+          if (f != MOBI_CH_STORE && f != (MOBI_CH_FOLD | MOBI_CH_STORE) && f != (MOBI_CH_RESID | MOBI_CH_TO_R) &&
+              f != (MOBI_CH_RESID | MOBI_CH_TO_R | MOBI_CH_STORE) && f != (MOBI_CH_RESID | MOBI_CH_STORE) &&
+              f != (MOBI_CH_TO_R | MOBI_CH_STORE)) return MOBI_ERR_UNSUPPORTED;
+          if ((f & MOBI_CH_FOLD) && (!op.svec || !al16(op.svec))) return MOBI_ERR_ARG;
+          if (!op.bias) return MOBI_ERR_ARG;                      // (a vector of zeros where the layer has none)
+          if (!al16(op.bias) || (op.bias_img_stride & 3)) return MOBI_ERR_ALIGN;
+          if ((f & MOBI_CH_STORE) && (!op.dst || !al16(op.dst) || (op.dst_img_stride & 7) || (op.dst_row_stride & 7) ||
+                                      op.dst_row_stride < CH_C)) return op.dst ? MOBI_ERR_ALIGN : MOBI_ERR_ARG;
+          next_product = &op;
+          break;
+        }
+        default: return MOBI_ERR_ARG;
+      }
+    }
+  }
+  const long long blocks = (long long)p->images * (p->rows_per_image / 128);
+  if (blocks > 0x7fffffffLL) return MOBI_ERR_UNSUPPORTED;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (p->dtype == MOBI_F16) hipLaunchKernelGGL((row_chain_kernel<f16_t>), dim3((unsigned)blocks), dim3(256), 0, st, *p);
+  else hipLaunchKernelGGL((row_chain_kernel<bf16_t>), dim3((unsigned)blocks), dim3(256), 0, st, *p);
+  MOBI_CHECK_LAUNCH();
+  return MOBI_OK;
+}

@@ -230,6 +230,8 @@ extern "C" size_t mobi_struct_size(int id) {
     case 12: return sizeof(mobi_range_prepare_params);
     case 13: return sizeof(mobi_image_prepare_params);
     case 14: return sizeof(mobi_ff_geglu_params);
+    case 15: return sizeof(mobi_row_chain_params);
+    case 16: return sizeof(mobi_chain_op);
     default: return 0;
   }
 }

@@ -34,6 +34,8 @@ from .diffusionmodules.util import Conv2d, GroupNorm32, LayerNorm, Linear, Marke
 FUSED_FF = os.environ.get("MOBI_FUSED_FF", "1") != "0"      # A/B: 0 = GEGLU projection and output projection as two launches
 FUSED_FF_MIN_ROWS = int(os.environ.get("MOBI_FUSED_FF_MIN_ROWS", "24576"))   # 192 workgroups
 FUSED_LN = os.environ.get("MOBI_FUSED_LN", "1") != "0"      # A/B: 0 = the cross-modal LayerNorms as launches of their own
+ROW_CHAIN = os.environ.get("MOBI_ROW_CHAIN", "1") != "0"    # A/B: 0 = the launches between the attention kernels one by one
+ROW_CHAIN_MIN_ROWS = int(os.environ.get("MOBI_ROW_CHAIN_MIN_ROWS", "24576"))   # 128 rows per workgroup: 192 workgroups
 
 
 def _store_in_place(old, new):
@@ -262,6 +264,78 @@ class BasicTransformerBlock(nn.Module):
         g, b = norm.affine()
         return ops.layernorm(x, g, b, norm.eps)
 
+    # -- row-resident chains (C = 320: csrc/chain.hip) ---------------------------------------------------------------
+    def _chain_weights(self):
+        """Chunk images of every [C, C] matrix between the attention kernels (ops.pack_chain_weight), cached per weight
+        version and storage type: attn1.to_out; the cross-modal to_q with its LayerNorm and scale * log2 e folded in; the
+        cross-modal to_k / to_v; connector o to_out of both cross-modal attentions (W = Wc Wo, b = Wc bo + bc, fp64)."""
+        a1, cam, lid = self.attn1, self.cross_modal_attn_camera, self.cross_modal_attn_lidar
+        nc, nl = self.cross_modal_norm_camera, self.cross_modal_norm_lidar
+        cc, cl = self.cross_modal_connector_camera, self.cross_modal_connector_lidar
+        ps = [a1.to_out[0].weight, cam.to_q.weight, cam.to_k.weight, cam.to_v.weight, cam.to_out[0].weight, cam.to_out[0].bias,
+              lid.to_q.weight, lid.to_k.weight, lid.to_v.weight, lid.to_out[0].weight, lid.to_out[0].bias,
+              nc.weight, nc.bias, nl.weight, nl.bias, cc.weight, cc.bias, cl.weight, cl.bias]
+        dtype = engine_dtype()
+        key = tuple(p._version for p in ps) + (ps[0].data_ptr(), ps[0].device, dtype)
+        c = self.__dict__.setdefault("_chain_cache", {})
+        if c.get("key") != key:
+            dev = ps[0].device
+            pk = lambda w, b=None, **kw: ops.pack_chain_weight(w, b, dtype, dev, **kw)
+
+            def fold(attn, con):
+                wc, wo = con.weight.detach().double().cpu(), attn.to_out[0].weight.detach().double().cpu()
+                return pk((wc @ wo).float(), (wc @ attn.to_out[0].bias.detach().double().cpu() + con.bias.detach().double().cpu()).float())
+
+            c["key"] = key
+            c["val"] = {"to_out": pk(a1.to_out[0].weight),            # (its bias rides in the per-image attn2 vector)
+                        "q_cam": pk(cam.to_q.weight, ln=(nc.weight, nc.bias), scale=cam.scale * ops.LOG2E),
+                        "q_lid": pk(lid.to_q.weight, ln=(nl.weight, nl.bias), scale=lid.scale * ops.LOG2E),
+                        "k_cam": pk(cam.to_k.weight), "v_cam": pk(cam.to_v.weight),
+                        "k_lid": pk(lid.to_k.weight), "v_lid": pk(lid.to_v.weight),
+                        "fold_cam": fold(cam, cc), "fold_lid": fold(lid, cl)}
+        return c["val"]
+
+    def _chain_ok(self, x, adapter):
+        return (ROW_CHAIN and self.bbox_cond and adapter is not None and self.multimodal and x.shape[0] % 2 == 0
+                and x.is_contiguous() and x.shape[0] * x.shape[1] >= ROW_CHAIN_MIN_ROWS
+                and ops.row_chain_supported(x.shape[2], x.shape[1]))
+
+    def _forward_chained(self, x, a, ref_vec, adapter):
+        """Everything between attn1's attention kernel and the feed-forward with the token rows resident in registers:
+          chain 1 (all rows)     x = to_out(a) + attn2 vector + x;  x = two-key adapter(x), written back;
+                                 even (camera) images: q = to_q_cam(LN_cam(x));
+                                 odd (lidar) images:   q = to_q_lid(LN_lid(x)),  k | v = to_k | to_v of the CAMERA's attention (x)
+          attention (camera queries, lidar keys)
+          chain 2 (camera rows)  x_cam = x_cam + connector(to_out(a));  k | v of the lidar's attention from the UPDATED rows
+          attention (lidar queries, camera keys), connector o to_out (+ residual) on the lidar rows (mobi_igemm)
+        attention.py:234-261 of the reference.  The unchained sequence is `_forward`'s (MOBI_ROW_CHAIN=0)."""
+        n, t, c = x.shape
+        cw = self._chain_weights()
+        cam, lid = self.cross_modal_attn_camera, self.cross_modal_attn_lidar
+        nc, nl = self.cross_modal_norm_camera, self.cross_modal_norm_lidar
+        new = lambda *shape: torch.empty(shape, device=x.device, dtype=x.dtype)
+        q_cam, q_lid, kv_l, kv_c = new(n // 2, t, c), new(n // 2, t, c), new(n // 2, t, 2 * c), new(n // 2, t, 2 * c)
+        x_in, x = x, new(n, t, c)                  # (the caller's tensor stays as it was, as in the unchained sequence)
+
+        def head(prog):
+            return prog.load(a, "s").load(x_in, "r").product(cw["to_out"], resid=True, to_r=True, bias=ref_vec,
+                                                             bias_img_stride=c).adapter(dst=x)
+        p_cam = head(ops.ChainProgram()).rowstats(nc.eps).copy().product(cw["q_cam"], fold=True, dst=q_cam, dst_img_div=2)
+        p_lid = head(ops.ChainProgram()).rowstats(nl.eps).copy().product(cw["q_lid"], fold=True, dst=q_lid, dst_img_div=2)
+        p_lid.product(cw["k_cam"], dst=kv_l[..., :c], dst_img_div=2).product(cw["v_cam"], dst=kv_l[..., c:], dst_img_div=2)
+        rows = n * t
+        ops.row_chain([p_cam, p_lid], n, t, x.dtype, adapter=(*adapter, self.cond_adapter_norm.eps),
+                      flops=2.0 * rows * c * c * 3.5, nbytes=2.0 * rows * c * 5.0, note=f"post_attn1 rows={rows}")
+        xc, xl = x[::2], x[1::2]
+        ac = ops.attention(q_cam, kv_l[..., :c], kv_l[..., c:], cam.heads, cam.scale, v_rows=True, q_log2_scaled=True)
+        p = ops.ChainProgram().load(ac, "s").load(xc, "r").product(cw["fold_cam"], resid=True, to_r=True, dst=xc).copy()
+        p.product(cw["k_lid"], dst=kv_c[..., :c]).product(cw["v_lid"], dst=kv_c[..., c:])
+        ops.row_chain([p], n // 2, t, x.dtype, flops=2.0 * (rows // 2) * c * c * 3, nbytes=2.0 * (rows // 2) * c * 5.0,
+                      note=f"post_cam rows={rows // 2}")
+        al = ops.attention(q_lid, kv_c[..., :c], kv_c[..., c:], lid.heads, lid.scale, v_rows=True, q_log2_scaled=True)
+        ops.linear(al, self._folded(lid, self.cross_modal_connector_lidar, "lidar"), residual=xl, out=xl)
+        return self.ff(x, residual=x, norm=self.norm3)
+
     def forward(self, x, context=None):
         return self._forward(x, context)
 
@@ -362,6 +436,8 @@ class BasicTransformerBlock(nn.Module):
         ref_vec, ctx_kv, adapter = self._context_terms(ctx)
         # attn1 (self) + attn2 (reference token; norm2 / to_q cancel out of a one-key softmax)
         a = self.attn1.self_attention(self._ln(self.norm1, x))
+        if self._chain_ok(x, adapter):
+            return self._forward_chained(x, a, ref_vec, adapter)
         x = ops.linear(a, self.attn1.to_out[0].packed(), residual=x, rowvec=ref_vec, rowvec_has_bias=True)
 
         ln_cam = ln_lidar = None

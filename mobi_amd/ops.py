@@ -275,6 +275,153 @@ def ff_geglu(x, pf: PackedFf, residual=None, out=None, ln=None):
 
 
 # --------------------------------------------------------------------------------------
+# row-resident chains (mobi_row_chain, csrc/chain.hip)
+# --------------------------------------------------------------------------------------
+class ChainWeight:
+    """One product of a chain: the [320][320] matrix as a 200-KiB chunk image (layout: include/mobi_engine.h), its fp32 bias
+    (zeros where the layer has none) and, for a LayerNorm-folded projection, the row sums of the rounded W diag(gamma)."""
+
+    def __init__(self, image, bias, svec=None):
+        self.image, self.bias, self.svec = image, bias, svec
+
+
+def row_chain_supported(channels, rows_per_image):
+    return bool(_lib.load().mobi_row_chain_supported(int(channels), int(rows_per_image)))
+
+
+def pack_chain_weight(w, bias, dtype, device, ln=None, scale=1.0):
+    """w: [320, 320] (out, in) fp32 master; bias [320] or None; ln = (gamma, beta): the LayerNorm in front of the layer folded
+    in (W' = scale W diag(gamma), svec = row sums of the ROUNDED W', bias' = scale (W beta) + bias -- fp64 on the host,
+    load-time work like the other packs); scale multiplies the layer (to_q's scale * log2 e) -> ChainWeight."""
+    n, k = w.shape
+    assert n == k == 320
+    wd = w.detach().double().cpu() * scale
+    bd = torch.zeros(n, dtype=torch.float64) if bias is None else bias.detach().double().cpu() * scale
+    svec = None
+    if ln is not None:
+        gamma, beta = (t.detach().double().cpu() for t in ln)
+        bd = bd + wd @ beta
+        wd = wd * gamma[None, :]
+    wr = wd.float().to(dtype)                                   # the one rounding to the storage type
+    if ln is not None:
+        svec = wr.double().sum(dim=1).float().contiguous().to(device)
+    ar = torch.arange
+    lane, j = ar(64), ar(8)
+    i = lane & 31
+    tau = (i & 0x13) | ((i & 4) << 1) | ((i & 8) >> 1)
+    # [chunk c][kk][m][lane][j]: row 32 m + tau(lane & 31), column 16 (2 c + kk) + 8 (lane >> 5) + j
+    rows = (ar(10)[None, None, :, None, None] * 32 + tau[None, None, None, :, None]).expand(10, 2, 10, 64, 8)
+    cols = ((2 * ar(10)[:, None, None, None, None] + ar(2)[None, :, None, None, None]) * 16
+            + (lane >> 5)[None, None, None, :, None] * 8 + j[None, None, None, None, :]).expand(10, 2, 10, 64, 8)
+    img = wr[rows, cols].contiguous().view(torch.uint8).reshape(-1).to(device)
+    assert img.numel() == _lib.load().mobi_row_chain_weight_bytes(320)
+    return ChainWeight(img, bd.float().contiguous().to(device), svec)
+
+
+class ChainProgram:
+    """A list of mobi_chain_op; the methods mirror the operation codes (include/mobi_engine.h)."""
+
+    def __init__(self):
+        self.ops, self.keep = [], []
+
+    def _op(self, code, flags=0):
+        o = _lib.ChainOp()
+        o.code, o.flags = code, flags
+        self.ops.append(o)
+        return o
+
+    @staticmethod
+    def _rows(t):
+        """[N, T, >= C] view, channel stride 1 -> (ptr, image stride, row stride)."""
+        assert t.dim() == 3 and t.stride(2) == 1
+        return _ptr(t), t.stride(0), t.stride(1)
+
+    def load(self, t, which="s", img_div=1):
+        o = self._op(_lib.CH_LOAD_S if which == "s" else _lib.CH_LOAD_R)
+        o.p0, o.img_stride, o.row_stride = self._rows(t)
+        o.img_div = img_div
+        self.keep.append(t)
+        return self
+
+    def affine(self, scale, shift):
+        o = self._op(_lib.CH_AFFINE_S)
+        assert scale.dtype == shift.dtype == torch.float32 and scale.is_contiguous() and shift.is_contiguous()
+        o.bias, o.svec = _ptr(scale), _ptr(shift)
+        self.keep += [scale, shift]
+        return self
+
+    def copy(self):
+        self._op(_lib.CH_COPY)
+        return self
+
+    def rowstats(self, eps):
+        self._op(_lib.CH_ROWSTATS).eps = eps
+        return self
+
+    def _dst(self, o, dst, dst_img_div):
+        o.dst, o.dst_img_stride, o.dst_row_stride = self._rows(dst)
+        o.dst_img_div = dst_img_div
+        self.keep.append(dst)
+
+    def product(self, cw: ChainWeight, *, fold=False, resid=False, to_r=False, dst=None, dst_img_div=1, bias=None,
+                bias_img_stride=0, bias_img_div=1):
+        """bias: overrides the packed one (a per-image fp32 [images, 320] vector with bias_img_stride = 320)."""
+        fl = (_lib.CH_FOLD if fold else 0) | (_lib.CH_RESID if resid else 0) | (_lib.CH_TO_R if to_r else 0) | \
+             (_lib.CH_STORE if dst is not None else 0)
+        o = self._op(_lib.CH_PRODUCT, fl)
+        o.p0 = _ptr(cw.image)
+        b = cw.bias if bias is None else bias
+        assert b.dtype == torch.float32 and b.is_contiguous()
+        o.bias, o.bias_img_stride, o.bias_img_div = _ptr(b), bias_img_stride, bias_img_div
+        if fold:
+            assert cw.svec is not None
+            o.svec = _ptr(cw.svec)
+        if dst is not None:
+            self._dst(o, dst, dst_img_div)
+        self.keep += [cw, b]
+        return self
+
+    def adapter(self, dst=None, dst_img_div=1):
+        o = self._op(_lib.CH_ADAPTER, _lib.CH_STORE if dst is not None else 0)
+        if dst is not None:
+            self._dst(o, dst, dst_img_div)
+        return self
+
+    def store(self, dst, dst_img_div=1):
+        self._dst(self._op(_lib.CH_STORE_R), dst, dst_img_div)
+        return self
+
+    def finish(self):
+        """Chain the prefetch pointers: every product names the next product's image."""
+        prods = [o for o in self.ops if o.code == _lib.CH_PRODUCT]
+        for o, nxt in zip(prods, prods[1:] + [None]):
+            o.p1 = None if nxt is None else nxt.p0
+        return self
+
+
+def row_chain(programs, images, rows_per_image, dtype, adapter=None, flops=0.0, nbytes=0.0, note=""):
+    """Run one or two ChainPrograms (two: even images run the first, odd images the second) over `images` x
+    `rows_per_image` token rows of 320 channels.  adapter = (a, a_sum, c, u, b, eps) as for two_key_adapter."""
+    lib = _lib.load()
+    p = _lib.RowChainParams()
+    p.dtype, p.channels, p.images, p.rows_per_image, p.nprog = _dt(dtype), 320, images, rows_per_image, len(programs)
+    for k, prog in enumerate(programs):
+        prog.finish()
+        assert 0 < len(prog.ops) <= _lib.CHAIN_MAX_OPS
+        p.nops[k] = len(prog.ops)
+        for i, o in enumerate(prog.ops):
+            p.prog[k][i] = o
+    if adapter is not None:
+        a, a_sum, c, u, b, eps = adapter
+        for tns in (a, a_sum, c, u, b):
+            assert tns.dtype == torch.float32 and tns.is_contiguous()
+        assert a.shape == u.shape == (images, a.shape[1], 320) and b.shape == (images, 320)
+        p.ad_a, p.ad_a_sum, p.ad_c, p.ad_u, p.ad_b, p.ad_heads, p.ad_eps = _ptr(a), _ptr(a_sum), _ptr(c), _ptr(u), _ptr(b), a.shape[1], eps
+    with _Timed("row_chain", flops, nbytes, note):
+        _lib.check(lib.mobi_row_chain(C.byref(p), _stream()), "mobi_row_chain")
+
+
+# --------------------------------------------------------------------------------------
 # matrix-core ops
 # --------------------------------------------------------------------------------------
 def igemm(x, pw: Packed, *, x2=None, stride=1, pad=None, upsample=False, hout=None, wout=None, rowvec=None,

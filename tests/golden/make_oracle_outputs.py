@@ -25,6 +25,15 @@ def main():
         np.savez_compressed(oc.PATH, **out)
         print(f"wrote {oc.PATH}: {sorted(out)} ({os.path.getsize(oc.PATH) / 1e6:.1f} MB)")
         return
+    if "--add-e2e" in sys.argv:                         # keep what the file holds, add the end-to-end cases only
+        out = dict(np.load(oc.PATH))
+        for side in (32, 64):
+            for k, v in oc.e2e(side, live=True).items():
+                out[f"e2e{side}_{k}"] = v.numpy()
+            print(f"e2e {side}: {time.time() - t0:.0f} s", flush=True)
+        np.savez_compressed(oc.PATH, **out)
+        print(f"wrote {oc.PATH}: {sorted(out)} ({os.path.getsize(oc.PATH) / 1e6:.1f} MB)")
+        return
     out["prod_64_16"] = oc.prod_forward(64, 16, live=True).numpy()
     print(f"prod 64x64 x 16: {time.time() - t0:.0f} s", flush=True)
     out["prod_32_8"] = oc.prod_forward(32, 8, live=True).numpy()
@@ -35,6 +44,9 @@ def main():
         m, d = oc.vae512(lidar, live=True)
         tag = "lidar" if lidar else "camera"
         out[f"vae512_{tag}_moments"], out[f"vae512_{tag}_decode"] = m.numpy(), d.numpy().astype(np.float16)
+    for side in (32, 64):
+        for k, v in oc.e2e(side, live=True).items():
+            out[f"e2e{side}_{k}"] = v.numpy()
     np.savez_compressed(oc.PATH, **out)
     print(f"wrote {oc.PATH}: {sorted(out)} ({os.path.getsize(oc.PATH) / 1e6:.1f} MB, {time.time() - t0:.0f} s)")
 

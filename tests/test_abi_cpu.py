@@ -33,7 +33,7 @@ def test_struct_layouts_match(lib):
     for sid, cls in _lib.STRUCT_IDS.items():
         assert lib.mobi_struct_size(sid) == C.sizeof(cls), cls.__name__
     assert lib.mobi_struct_size(99) == 0
-    assert lib.mobi_abi_version() == 2 == _lib.ABI_VERSION
+    assert lib.mobi_abi_version() == 3 == _lib.ABI_VERSION
     assert lib.mobi_error_string(-2) == b"unsupported shape or mode"
 
 
@@ -55,6 +55,19 @@ def test_argument_validation_without_gpu(lib):
     assert lib.mobi_groupnorm(C.byref(g), None) == -2                  # channels % 32 != 0
     assert lib.mobi_groupnorm_workspace_bytes(2, 4096) == 2 * 64 * 32 * 2 * 4
     assert lib.mobi_groupnorm_workspace_bytes(0, 10) == 0
+    rc = _lib.RowChainParams()                                          # mobi_row_chain: shape, program and pointer checks
+    rc.dtype, rc.channels, rc.images, rc.rows_per_image, rc.nprog = 0, 640, 2, 1024, 1
+    assert lib.mobi_row_chain(C.byref(rc), None) == -2                 # C = 320 only
+    rc.channels, rc.rows_per_image = 320, 100
+    assert lib.mobi_row_chain(C.byref(rc), None) == -2                 # whole 128-row tiles only
+    rc.rows_per_image = 1024
+    assert lib.mobi_row_chain(C.byref(rc), None) == -1                 # empty program
+    rc.nops[0] = 1
+    rc.prog[0][0].code, rc.prog[0][0].flags, rc.prog[0][0].p0, rc.prog[0][0].bias = _lib.CH_PRODUCT, _lib.CH_TO_R, 16, 16
+    assert lib.mobi_row_chain(C.byref(rc), None) == -2                 # a flag combination the kernel has no epilogue for
+    rc.prog[0][0].flags, rc.prog[0][0].p1 = _lib.CH_STORE, 32
+    assert lib.mobi_row_chain(C.byref(rc), None) == -1                 # prefetch pointer without a next product
+    assert lib.mobi_row_chain_weight_bytes(320) == 200 * 1024 and lib.mobi_row_chain_weight_bytes(640) == 0
 
 
 def test_no_cpu_fallback():
