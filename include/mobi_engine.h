@@ -248,24 +248,26 @@ int mobi_ff_geglu(const mobi_ff_geglu_params* p, void* stream);
  *   element j = W[32 m + tau(l & 31)][16 (2 c + kk) + 8 (l >> 5) + j],  tau(i) = i with bits 2 and 3 swapped
  *   (so that the accumulator registers a lane receives are the channels of the fragments it holds).
  *
+ * A wave's registers hold the row state `s` (the operand of every product) and, until it is consumed, a residual `r`.
  * Operations (code):
  *   MOBI_CH_LOAD_S    s <- rows of p0 (T; image index img / img_div, strides in elements)
  *   MOBI_CH_LOAD_R    r <- rows of p0
  *   MOBI_CH_AFFINE_S  s <- s * bias[img][ch] + svec[img][ch]   (f32 [images][C] each: GroupNorm folded to scale / shift)
- *   MOBI_CH_COPY      s <- r
- *   MOBI_CH_ROWSTATS  (rs, cs) <- (rstd, -rstd * mean) of r over the C channels (eps)
+ *   MOBI_CH_ROWSTATS  (rs, cs) <- (rstd, -rstd * mean) of s over the C channels (eps)
  *   MOBI_CH_PRODUCT   v = W s (p0 = weight image, p1 = the NEXT product's image or NULL: prefetched);
  *                     flags FOLD: v = rs * v + cs * svec[ch] (LayerNorm folded into W: W' = W diag(gamma),
  *                                 svec = row sums of the ROUNDED W', bias = W beta);
  *                     v += bias[(img / bias_img_div) * bias_img_stride + ch] (f32, required: zeros where the layer has none);
- *                     RESID: v += r;   TO_R: r <- round(v);   STORE: dst rows <- round(v)
- *   MOBI_CH_ADAPTER   r <- two-key adapter of r (the tables of mobi_two_key_adapter_params, fields ad_*), STORE optional
- *   MOBI_CH_STORE_R   dst rows <- r
+ *                     RESID: v += r (r is consumed);   TO_S: s <- round(v);   STORE: dst rows <- round(v)
+ *   MOBI_CH_ADAPTER   s <- two-key adapter of s (the tables of mobi_two_key_adapter_params as images, ad_image); flags STORE
+ *                     and dst required: the result rows are written
+ *   MOBI_CH_STORE_S   dst rows <- s
+ * At most 4 products per program.
  * nprog = 2: even images run prog[0], odd images prog[1] (camera / lidar rows of the interleaved batch).
  * ------------------------------------------------------------------------- */
-enum { MOBI_CH_LOAD_S = 0, MOBI_CH_LOAD_R = 1, MOBI_CH_AFFINE_S = 2, MOBI_CH_COPY = 3, MOBI_CH_ROWSTATS = 4,
-       MOBI_CH_PRODUCT = 5, MOBI_CH_ADAPTER = 6, MOBI_CH_STORE_R = 7 };
-enum { MOBI_CH_FOLD = 1, MOBI_CH_RESID = 2, MOBI_CH_TO_R = 4, MOBI_CH_STORE = 8 };
+enum { MOBI_CH_LOAD_S = 0, MOBI_CH_LOAD_R = 1, MOBI_CH_AFFINE_S = 2, MOBI_CH_ROWSTATS = 3, MOBI_CH_PRODUCT = 4,
+       MOBI_CH_ADAPTER = 5, MOBI_CH_STORE_S = 6 };
+enum { MOBI_CH_FOLD = 1, MOBI_CH_RESID = 2, MOBI_CH_TO_S = 4, MOBI_CH_STORE = 8 };
 #define MOBI_CHAIN_MAX_OPS 10
 typedef struct mobi_chain_op {
   int32_t code, flags;
@@ -273,7 +275,7 @@ typedef struct mobi_chain_op {
   const void* p1;                 /* PRODUCT: the next product's weight image, or NULL */
   const float* bias;              /* PRODUCT: f32 bias;  AFFINE_S: f32 scale [images][C] */
   const float* svec;              /* PRODUCT + FOLD: f32 [C];  AFFINE_S: f32 shift [images][C] */
-  void* dst;                      /* T rows (PRODUCT + STORE, ADAPTER + STORE, STORE_R) */
+  void* dst;                      /* T rows (PRODUCT + STORE, ADAPTER + STORE, STORE_S) */
   int64_t img_stride, row_stride;           /* of p0 (LOAD_*), elements */
   int64_t dst_img_stride, dst_row_stride;   /* of dst, elements */
   int64_t bias_img_stride;                  /* elements; 0: one vector for all images */
@@ -286,10 +288,16 @@ typedef struct mobi_row_chain_params {
   int32_t nprog;                  /* 1 or 2 */
   int32_t nops[2];
   mobi_chain_op prog[2][MOBI_CHAIN_MAX_OPS];
-  /* MOBI_CH_ADAPTER tables (as mobi_two_key_adapter_params: a, u f32 [image][heads][C]; a_sum, c f32 [image][heads]; b f32 [image][C]) */
-  const float* ad_a; const float* ad_a_sum; const float* ad_c; const float* ad_u; const float* ad_b;
-  int32_t ad_heads; float ad_eps;
+  /* MOBI_CH_ADAPTER: the tables of mobi_two_key_adapter_params as LDS images, mobi_row_chain_adapter_image_bytes() per
+   * image, written once per conditioning by mobi_row_chain_adapter_image (NULL: the programs have no ADAPTER); the
+   * LayerNorm eps of the adapter's statistics. */
+  const void* ad_image; float ad_eps;
 } mobi_row_chain_params;
+/* a, u: f32 [images][heads][C]; c: f32 [images][heads]; b: f32 [images][C] (mobi_two_key_adapter_params' tables; a_sum is
+ * re-derived from the split table) -> out: images x mobi_row_chain_adapter_image_bytes(C) bytes. */
+size_t mobi_row_chain_adapter_image_bytes(int32_t channels);
+int mobi_row_chain_adapter_image(const float* a, const float* c, const float* u, const float* b, int32_t images,
+                                 int32_t heads, int32_t channels, int32_t dtype, void* out, void* stream);
 size_t mobi_row_chain_weight_bytes(int32_t channels);
 int mobi_row_chain_supported(int32_t channels, int32_t rows_per_image);
 int mobi_row_chain(const mobi_row_chain_params* p, void* stream);

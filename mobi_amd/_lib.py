@@ -62,8 +62,8 @@ class FfGegluParams(C.Structure):
                 ("out", vp), ("dtype", i32), ("ln_gamma", vp), ("ln_beta", vp), ("ln_eps", f32)]
 
 
-CH_LOAD_S, CH_LOAD_R, CH_AFFINE_S, CH_COPY, CH_ROWSTATS, CH_PRODUCT, CH_ADAPTER, CH_STORE_R = range(8)
-CH_FOLD, CH_RESID, CH_TO_R, CH_STORE = 1, 2, 4, 8
+CH_LOAD_S, CH_LOAD_R, CH_AFFINE_S, CH_ROWSTATS, CH_PRODUCT, CH_ADAPTER, CH_STORE_S = range(7)
+CH_FOLD, CH_RESID, CH_TO_S, CH_STORE = 1, 2, 4, 8
 CHAIN_MAX_OPS = 10
 
 
@@ -75,8 +75,7 @@ class ChainOp(C.Structure):
 
 class RowChainParams(C.Structure):
     _fields_ = [("dtype", i32), ("channels", i32), ("images", i32), ("rows_per_image", i32), ("nprog", i32),
-                ("nops", i32 * 2), ("prog", (ChainOp * CHAIN_MAX_OPS) * 2), ("ad_a", vp), ("ad_a_sum", vp), ("ad_c", vp),
-                ("ad_u", vp), ("ad_b", vp), ("ad_heads", i32), ("ad_eps", f32)]
+                ("nops", i32 * 2), ("prog", (ChainOp * CHAIN_MAX_OPS) * 2), ("ad_image", vp), ("ad_eps", f32)]
 
 
 class CtxAttentionParams(C.Structure):
@@ -171,6 +170,8 @@ SYMBOLS = {
     "mobi_row_chain": (C.c_int, [C.POINTER(RowChainParams), vp]),
     "mobi_row_chain_weight_bytes": (C.c_size_t, [i32]),
     "mobi_row_chain_supported": (C.c_int, [i32, i32]),
+    "mobi_row_chain_adapter_image_bytes": (C.c_size_t, [i32]),
+    "mobi_row_chain_adapter_image": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, i32, vp, vp]),
     "mobi_quick_gelu": (C.c_int, [vp, vp, i64, i32, vp]),
     "mobi_timestep_embedding": (C.c_int, [vp, vp, vp, i32, i32, vp]),
     "mobi_conv_small_cin": (C.c_int, [C.POINTER(ConvSmallCinParams), vp]),

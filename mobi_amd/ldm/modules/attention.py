@@ -295,12 +295,13 @@ class BasicTransformerBlock(nn.Module):
                         "fold_cam": fold(cam, cc), "fold_lid": fold(lid, cl)}
         return c["val"]
 
-    def _chain_ok(self, x, adapter):
-        return (ROW_CHAIN and self.bbox_cond and adapter is not None and self.multimodal and x.shape[0] % 2 == 0
+    def _chain_ok(self, x, adapter, adapter_image):
+        return (ROW_CHAIN and self.bbox_cond and adapter is not None and adapter_image is not None and self.multimodal
+                and x.shape[0] % 2 == 0
                 and x.is_contiguous() and x.shape[0] * x.shape[1] >= ROW_CHAIN_MIN_ROWS
                 and ops.row_chain_supported(x.shape[2], x.shape[1]))
 
-    def _forward_chained(self, x, a, ref_vec, adapter):
+    def _forward_chained(self, x, a, ref_vec, adapter_image):
         """Everything between attn1's attention kernel and the feed-forward with the token rows resident in registers:
           chain 1 (all rows)     x = to_out(a) + attn2 vector + x;  x = two-key adapter(x), written back;
                                  even (camera) images: q = to_q_cam(LN_cam(x));
@@ -318,17 +319,17 @@ class BasicTransformerBlock(nn.Module):
         x_in, x = x, new(n, t, c)                  # (the caller's tensor stays as it was, as in the unchained sequence)
 
         def head(prog):
-            return prog.load(a, "s").load(x_in, "r").product(cw["to_out"], resid=True, to_r=True, bias=ref_vec,
+            return prog.load(a, "s").load(x_in, "r").product(cw["to_out"], resid=True, to_s=True, bias=ref_vec,
                                                              bias_img_stride=c).adapter(dst=x)
-        p_cam = head(ops.ChainProgram()).rowstats(nc.eps).copy().product(cw["q_cam"], fold=True, dst=q_cam, dst_img_div=2)
-        p_lid = head(ops.ChainProgram()).rowstats(nl.eps).copy().product(cw["q_lid"], fold=True, dst=q_lid, dst_img_div=2)
+        p_cam = head(ops.ChainProgram()).rowstats(nc.eps).product(cw["q_cam"], fold=True, dst=q_cam, dst_img_div=2)
+        p_lid = head(ops.ChainProgram()).rowstats(nl.eps).product(cw["q_lid"], fold=True, dst=q_lid, dst_img_div=2)
         p_lid.product(cw["k_cam"], dst=kv_l[..., :c], dst_img_div=2).product(cw["v_cam"], dst=kv_l[..., c:], dst_img_div=2)
         rows = n * t
-        ops.row_chain([p_cam, p_lid], n, t, x.dtype, adapter=(*adapter, self.cond_adapter_norm.eps),
+        ops.row_chain([p_cam, p_lid], n, t, x.dtype, adapter=(adapter_image, self.cond_adapter_norm.eps),
                       flops=2.0 * rows * c * c * 3.5, nbytes=2.0 * rows * c * 5.0, note=f"post_attn1 rows={rows}")
         xc, xl = x[::2], x[1::2]
         ac = ops.attention(q_cam, kv_l[..., :c], kv_l[..., c:], cam.heads, cam.scale, v_rows=True, q_log2_scaled=True)
-        p = ops.ChainProgram().load(ac, "s").load(xc, "r").product(cw["fold_cam"], resid=True, to_r=True, dst=xc).copy()
+        p = ops.ChainProgram().load(ac, "s").load(xc, "r").product(cw["fold_cam"], resid=True, to_s=True, dst=xc)
         p.product(cw["k_lid"], dst=kv_c[..., :c]).product(cw["v_lid"], dst=kv_c[..., c:])
         ops.row_chain([p], n // 2, t, x.dtype, flops=2.0 * (rows // 2) * c * c * 3, nbytes=2.0 * (rows // 2) * c * 5.0,
                       note=f"post_cam rows={rows // 2}")
@@ -368,11 +369,15 @@ class BasicTransformerBlock(nn.Module):
             ref_vec = self.attn2.single_token_vector(ctx[:, 0], extra_bias=self.attn1.to_out[0].bias)
             kv = self.cond_adapter_attn.context_kv(ctx) if self.bbox_cond else None
             adapter = self._two_key_terms(kv) if self.bbox_cond and ctx.shape[1] == 2 else None
+            # the same tables as the LDS images the row-chain kernel copies in (C = 320 blocks: csrc/chain.hip)
+            image = None
+            if adapter is not None and ROW_CHAIN and ops.row_chain_supported(adapter[0].shape[2], 128):
+                image = ops.chain_adapter_image(adapter[0], adapter[2], adapter[3], adapter[4], engine_dtype())
             # results live in PERSISTENT buffers, refreshed in place while their shapes stay the same (they do for one
             # context tensor): a denoising step captured in a HIP graph (mobi_amd/graph.py) keeps reading these addresses
-            for name, val in (("ref_vec", ref_vec), ("kv", kv), ("adapter", adapter)):
+            for name, val in (("ref_vec", ref_vec), ("kv", kv), ("adapter", adapter), ("adapter_image", image)):
                 c[name] = _store_in_place(c.get(name), val)
-        return c["ref_vec"], c["kv"], c["adapter"]
+        return c["ref_vec"], c["kv"], c["adapter"], c["adapter_image"]
 
     def context_term_addresses(self, ctx):
         """Device addresses of the slot `ctx` owns (None if it has none): what a captured step reads."""
@@ -380,7 +385,7 @@ class BasicTransformerBlock(nn.Module):
         if c is None or c["ref"]() is not ctx or c["key"] is None:
             return None
         flat = []
-        for name in ("ref_vec", "kv", "adapter"):
+        for name in ("ref_vec", "kv", "adapter", "adapter_image"):
             v = c.get(name)
             for t in (v if isinstance(v, tuple) else (v,)):
                 flat.append(None if t is None else t.data_ptr())
@@ -433,11 +438,11 @@ class BasicTransformerBlock(nn.Module):
     def _forward(self, x, context=None):
         """x: engine tokens [N,T,C]; context: fp32 [N, n_ctx, context_dim]."""
         ctx = context.float().contiguous()
-        ref_vec, ctx_kv, adapter = self._context_terms(ctx)
+        ref_vec, ctx_kv, adapter, adapter_image = self._context_terms(ctx)
         # attn1 (self) + attn2 (reference token; norm2 / to_q cancel out of a one-key softmax)
         a = self.attn1.self_attention(self._ln(self.norm1, x))
-        if self._chain_ok(x, adapter):
-            return self._forward_chained(x, a, ref_vec, adapter)
+        if self._chain_ok(x, adapter, adapter_image):
+            return self._forward_chained(x, a, ref_vec, adapter_image)
         x = ops.linear(a, self.attn1.to_out[0].packed(), residual=x, rowvec=ref_vec, rowvec_has_bias=True)
 
         ln_cam = ln_lidar = None

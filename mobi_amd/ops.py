@@ -319,7 +319,8 @@ def pack_chain_weight(w, bias, dtype, device, ln=None, scale=1.0):
 
 
 class ChainProgram:
-    """A list of mobi_chain_op; the methods mirror the operation codes (include/mobi_engine.h)."""
+    """A list of mobi_chain_op; the methods mirror the operation codes (include/mobi_engine.h): the row state `s` (every
+    product's operand; what adapter / rowstats / store work on) and a residual `r` that a `resid` product consumes."""
 
     def __init__(self):
         self.ops, self.keep = [], []
@@ -350,10 +351,6 @@ class ChainProgram:
         self.keep += [scale, shift]
         return self
 
-    def copy(self):
-        self._op(_lib.CH_COPY)
-        return self
-
     def rowstats(self, eps):
         self._op(_lib.CH_ROWSTATS).eps = eps
         return self
@@ -363,10 +360,10 @@ class ChainProgram:
         o.dst_img_div = dst_img_div
         self.keep.append(dst)
 
-    def product(self, cw: ChainWeight, *, fold=False, resid=False, to_r=False, dst=None, dst_img_div=1, bias=None,
+    def product(self, cw: ChainWeight, *, fold=False, resid=False, to_s=False, dst=None, dst_img_div=1, bias=None,
                 bias_img_stride=0, bias_img_div=1):
         """bias: overrides the packed one (a per-image fp32 [images, 320] vector with bias_img_stride = 320)."""
-        fl = (_lib.CH_FOLD if fold else 0) | (_lib.CH_RESID if resid else 0) | (_lib.CH_TO_R if to_r else 0) | \
+        fl = (_lib.CH_FOLD if fold else 0) | (_lib.CH_RESID if resid else 0) | (_lib.CH_TO_S if to_s else 0) | \
              (_lib.CH_STORE if dst is not None else 0)
         o = self._op(_lib.CH_PRODUCT, fl)
         o.p0 = _ptr(cw.image)
@@ -381,14 +378,12 @@ class ChainProgram:
         self.keep += [cw, b]
         return self
 
-    def adapter(self, dst=None, dst_img_div=1):
-        o = self._op(_lib.CH_ADAPTER, _lib.CH_STORE if dst is not None else 0)
-        if dst is not None:
-            self._dst(o, dst, dst_img_div)
+    def adapter(self, dst, dst_img_div=1):
+        self._dst(self._op(_lib.CH_ADAPTER, _lib.CH_STORE), dst, dst_img_div)
         return self
 
     def store(self, dst, dst_img_div=1):
-        self._dst(self._op(_lib.CH_STORE_R), dst, dst_img_div)
+        self._dst(self._op(_lib.CH_STORE_S), dst, dst_img_div)
         return self
 
     def finish(self):
@@ -399,9 +394,26 @@ class ChainProgram:
         return self
 
 
+def chain_adapter_image(a, c, u, b, dtype, out=None):
+    """The two-key adapter's tables (a, u fp32 [N, H, 320]; c [N, H]; b [N, 320]: ops.two_key_adapter's) as the LDS images
+    mobi_row_chain's ADAPTER operation copies in -> uint8 [N, bytes] (mobi_row_chain_adapter_image)."""
+    lib = _lib.load()
+    n, h, ch = a.shape
+    for tns in (a, c, u, b):
+        assert tns.dtype == torch.float32 and tns.is_contiguous()
+    assert u.shape == (n, h, ch) and c.shape == (n, h) and b.shape == (n, ch)
+    nb = lib.mobi_row_chain_adapter_image_bytes(ch)
+    assert nb > 0
+    if out is None:
+        out = torch.empty((n, nb), device=a.device, dtype=torch.uint8)
+    _lib.check(lib.mobi_row_chain_adapter_image(_ptr(a), _ptr(c), _ptr(u), _ptr(b), n, h, ch, _dt(dtype), _ptr(out), _stream()),
+               "mobi_row_chain_adapter_image")
+    return out
+
+
 def row_chain(programs, images, rows_per_image, dtype, adapter=None, flops=0.0, nbytes=0.0, note=""):
     """Run one or two ChainPrograms (two: even images run the first, odd images the second) over `images` x
-    `rows_per_image` token rows of 320 channels.  adapter = (a, a_sum, c, u, b, eps) as for two_key_adapter."""
+    `rows_per_image` token rows of 320 channels.  adapter = (image from chain_adapter_image, eps)."""
     lib = _lib.load()
     p = _lib.RowChainParams()
     p.dtype, p.channels, p.images, p.rows_per_image, p.nprog = _dt(dtype), 320, images, rows_per_image, len(programs)
@@ -412,11 +424,9 @@ def row_chain(programs, images, rows_per_image, dtype, adapter=None, flops=0.0, 
         for i, o in enumerate(prog.ops):
             p.prog[k][i] = o
     if adapter is not None:
-        a, a_sum, c, u, b, eps = adapter
-        for tns in (a, a_sum, c, u, b):
-            assert tns.dtype == torch.float32 and tns.is_contiguous()
-        assert a.shape == u.shape == (images, a.shape[1], 320) and b.shape == (images, 320)
-        p.ad_a, p.ad_a_sum, p.ad_c, p.ad_u, p.ad_b, p.ad_heads, p.ad_eps = _ptr(a), _ptr(a_sum), _ptr(c), _ptr(u), _ptr(b), a.shape[1], eps
+        image, eps = adapter
+        assert image.dtype == torch.uint8 and image.is_contiguous() and image.shape[0] == images
+        p.ad_image, p.ad_eps = _ptr(image), eps
     with _Timed("row_chain", flops, nbytes, note):
         _lib.check(lib.mobi_row_chain(C.byref(p), _stream()), "mobi_row_chain")
 

@@ -63,7 +63,7 @@ def test_argument_validation_without_gpu(lib):
     rc.rows_per_image = 1024
     assert lib.mobi_row_chain(C.byref(rc), None) == -1                 # empty program
     rc.nops[0] = 1
-    rc.prog[0][0].code, rc.prog[0][0].flags, rc.prog[0][0].p0, rc.prog[0][0].bias = _lib.CH_PRODUCT, _lib.CH_TO_R, 16, 16
+    rc.prog[0][0].code, rc.prog[0][0].flags, rc.prog[0][0].p0, rc.prog[0][0].bias = _lib.CH_PRODUCT, _lib.CH_TO_S, 16, 16
     assert lib.mobi_row_chain(C.byref(rc), None) == -2                 # a flag combination the kernel has no epilogue for
     rc.prog[0][0].flags, rc.prog[0][0].p1 = _lib.CH_STORE, 32
     assert lib.mobi_row_chain(C.byref(rc), None) == -1                 # prefetch pointer without a next product

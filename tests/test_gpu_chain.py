@@ -31,7 +31,7 @@ def _rt(t, dtype):
 @pytest.mark.parametrize("dtype", DT)
 @pytest.mark.parametrize("n,t", [(2, 128), (3, 384), (16, 4096)])
 def test_chain_products_residual_store(ops, dtype, n, t):
-    """load, product (+ per-image bias + residual -> row state, stored), copy, two more products of the new row state."""
+    """load, product (+ per-image bias + residual -> row state, stored), two more products of the new row state."""
     name = f"chain.p.{n}.{t}"
     af, ad = rnd(name + ".a", (n, t, C), dtype)
     xf, xd = rnd(name + ".x", (n, t, C), dtype)
@@ -43,8 +43,8 @@ def test_chain_products_residual_store(ops, dtype, n, t):
     x1 = torch.empty_like(xd)
     kv = torch.empty((n, t, 2 * C), device="cuda", dtype=dtype)
     prog = ops.ChainProgram().load(ad, "s").load(xd, "r")
-    prog.product(cw0, resid=True, to_r=True, dst=x1, bias=rv.cuda().contiguous(), bias_img_stride=C)
-    prog.copy().product(cwk, dst=kv[..., :C]).product(cwv, dst=kv[..., C:])
+    prog.product(cw0, resid=True, to_s=True, dst=x1, bias=rv.cuda().contiguous(), bias_img_stride=C)
+    prog.product(cwk, dst=kv[..., :C]).product(cwv, dst=kv[..., C:])
     ops.row_chain([prog], n, t, dtype)
     torch.cuda.synchronize()
     r1 = F.linear(af, _rt(w0, dtype)) + rv[:, None, :] + xf
@@ -69,7 +69,7 @@ def test_chain_layernorm_fold(ops, dtype, n, t):
     bt = torch.from_numpy(W.synth_param(name + ".ln.bias", (C,)))
     cw = ops.pack_chain_weight(w, b, dtype, "cuda", ln=(g, bt), scale=0.25)
     q = torch.empty_like(xd)
-    prog = ops.ChainProgram().load(xd, "r").rowstats(1e-5).copy().product(cw, fold=True, dst=q)
+    prog = ops.ChainProgram().load(xd, "s").rowstats(1e-5).product(cw, fold=True, dst=q)
     ops.row_chain([prog], n, t, dtype)
     ref = F.linear(F.layer_norm(xf, (C,), g, bt, 1e-5), w * 0.25, b * 0.25)
     assert rel(q.float(), ref) < TOL[dtype] * 1.5
@@ -93,7 +93,8 @@ def test_chain_adapter(ops, dtype, n, t, heads):
     ref = xf + b[:, None, :] + torch.einsum("nth,nhc->ntc", torch.sigmoid(z), u)
     out = torch.empty_like(xd)
     tabs = (a.cuda(), a.sum(-1).contiguous().cuda(), cc.cuda(), u.cuda(), b.cuda(), 1e-5)
-    ops.row_chain([ops.ChainProgram().load(xd, "r").adapter(dst=out)], n, t, dtype, adapter=tabs)
+    image = ops.chain_adapter_image(tabs[0], tabs[2], tabs[3], tabs[4], dtype)
+    ops.row_chain([ops.ChainProgram().load(xd, "s").adapter(dst=out)], n, t, dtype, adapter=(image, 1e-5))
     assert rel(out.float(), ref) < TOL[dtype]
     y = ops.two_key_adapter(xd, *tabs)
     assert rel(out.float(), y.float()) < TOL[dtype]
@@ -127,7 +128,7 @@ def test_chain_rejects_what_it_cannot_run(ops):
     assert not ops.row_chain_supported(640, 1024) and not ops.row_chain_supported(320, 100) and ops.row_chain_supported(320, 1024)
     x = torch.zeros((2, 100, C), device="cuda", dtype=torch.float16)
     with pytest.raises(_lib.EngineError):
-        ops.row_chain([ops.ChainProgram().load(x, "r").store(x)], 2, 100, torch.float16)
+        ops.row_chain([ops.ChainProgram().load(x, "s").store(x)], 2, 100, torch.float16)
 
 
 @pytest.mark.parametrize("dtype", DT)
@@ -147,7 +148,7 @@ def test_transformer_block_chained_equals_unchained(dtype, n, side, monkeypatch)
     x0 = x.clone()
     monkeypatch.setattr(A, "ROW_CHAIN", True)
     monkeypatch.setattr(A, "ROW_CHAIN_MIN_ROWS", 1)
-    assert blk._chain_ok(x, (None,))
+    assert blk._chain_ok(x, (None,), object())
     y1 = blk(x, context=ctx)
     assert torch.equal(x, x0)
     monkeypatch.setattr(A, "ROW_CHAIN", False)

@@ -192,3 +192,97 @@ def test_pingpong_race_screen():
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     assert mod.screen(repeats=60) == 0
+
+
+# ---- end to end at production width, pixel space (BASELINE config 1's workload; north star: 1e-3 rel-L2) ---------------
+# measured on the MI355X (profiles/r04_error_table.txt); asserted <= 2x that
+TOL_E2E = {(torch.float16, "latent"): 2.4e-3, (torch.float16, "pixel"): 4e-3,
+           (torch.bfloat16, "latent"): 2.4e-2, (torch.bfloat16, "pixel"): 4e-2}
+
+
+class _TokenStage(torch.nn.Module):
+    """Stands for the conditioning stage (CLIP tower + bbox embedder, pinned on their own in tests/test_gpu_cond_producer.py):
+    hands `get_learned_conditioning` the tokens the oracle case fixes."""
+
+    def __init__(self, toks):
+        super().__init__()
+        self.toks, self.calls = toks, 0
+
+    def encode(self, c):
+        m = ("cam", "lidar")[self.calls % 2]                # get_input encodes the camera's conditioning, then the lidar's
+        self.calls += 1
+        return {"ref_image_token": self.toks[f"tok_{m}"].cuda(), "ref_bbox_token": self.toks[f"bbox_{m}"].cuda()}
+
+
+@functools.lru_cache(maxsize=None)
+def _e2e_vae_sd(lidar):
+    from tests import oracle_cases as oc
+    vcfg = ovae.VAEConfig(in_channels=2 if lidar else 3, out_ch=2 if lidar else 3, ch=128, lidar_adapter=lidar)
+    return W.synth_state_dict(ovae.vae_param_shapes(vcfg), oc.E2E_SEEDS["vae"])
+
+
+@functools.lru_cache(maxsize=None)
+def _e2e_model(side):
+    """LatentDiffusion from the shipped config of that resolution; the 1.04 B-parameter UNet is the cached full-width net of
+    this file (same synthetic parameters, seed 13: generating them takes minutes), built small in the constructor and swapped."""
+    from tests import oracle_cases as oc
+    from mobi_amd.ldm.util import instantiate_from_config, load_config
+    assert oc.E2E_SEEDS["unet"] == 13
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    name = "mobi_nusc-mini_256.yaml" if side == 32 else "mobi_nusc_512.yaml"
+    cfg = load_config(os.path.join(root, "configs", name), ["model.params.lidar_stage_config.params.ckpt_path=null"])
+    cfg["model"]["params"]["cond_stage_config"] = "__is_unconditional__"
+    full_mc = cfg["model"]["params"]["unet_config"]["params"]["model_channels"]
+    cfg["model"]["params"]["unet_config"]["params"]["model_channels"] = 32
+    model = instantiate_from_config(cfg["model"])
+    assert full_mc == ounet.UNetConfig().model_channels and model.image_size == side
+    model.model.diffusion_model = _full_width_net()
+    model.first_stage_model.load_state_dict(_e2e_vae_sd(False))
+    model.lidar_stage_model.load_state_dict(_e2e_vae_sd(True))
+    i = oc.e2e_inputs(side)
+    with torch.no_grad():
+        model.proj_out.weight.copy_(i["proj_w"])
+        model.proj_out.bias.copy_(i["proj_b"])
+    return model.cuda().eval(), i
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("side", [32, 64], ids=["mini256", "nusc512_pair"])
+def test_end_to_end_pixel_space(dtype, side):
+    """scripts/inference_test_bench.py:416-464 on the engine at FULL width for one object -- get_input (four VAE encodes,
+    conditioning projection, lidar alignment, interleave) -> DDIMSampler.sample(S = 10) -> decode_sample -> decode_first_stage
+    + clamp -- against the CPU oracle's run of the same sequence (tests/oracle_cases.py e2e; oracle_outputs.npz): the 9-channel
+    input's index parts bit-exact, the final latent and the decoded camera picture / range view in rel-L2."""
+    from tests import oracle_cases as oc
+    from mobi_amd.ldm.models.diffusion.ddim import DDIMSampler
+    _set(dtype)
+    model, i = _e2e_model(side)
+    ref = oc.e2e(side)
+    model.cond_stage_model = _TokenStage(i)
+    batch = {"image": {"GT": i["img"], "inpaint_image": i["img"] * i["mask"], "inpaint_mask": i["mask"],
+                       "cond": {"ref_image": torch.zeros(1, 3, 224, 224), "ref_bbox": torch.zeros(1, 8, 3)}},
+             "lidar": {"range_data": i["rng"], "range_data_inpaint": i["rng"] * i["mask"], "range_mask": i["mask"],
+                       "cond": {"ref_image": torch.zeros(1, 3, 224, 224), "ref_bbox": torch.zeros(1, 8, 3)}}}
+    to_dev = lambda d: {k: to_dev(v) if isinstance(v, dict) else v.cuda() for k, v in d.items()}
+    noises = {"cam_gt": i["n_cam_gt"].cuda(), "cam_inpaint": i["n_cam_inpaint"].cuda(), "lidar_gt": i["n_lidar_gt"].cuda(),
+              "lidar_inpaint": i["n_lidar_inpaint"].cuda()}
+    data = model.get_input(to_dev(batch), model.first_stage_key, force_c_encode=True, noises=noises)
+    z, cond = data["z"], data["cond"]
+    assert z.shape == ref["z"].shape and cond.shape == ref["cond"].shape
+    assert torch.equal(z[:, 8].cpu(), ref["z"][:, 8])                                   # nearest-resized mask: index-only
+    tag = f"e2e_{side}_{dtype}"
+    check(rel_l2(z[:, :8].cpu(), ref["z"][:, :8]), TOL_VAE[dtype], tag + "_encode")
+    check(rel_l2(cond.cpu(), ref["cond"]), {torch.float16: 5e-4, torch.bfloat16: 2.4e-3}[dtype], tag + "_cond")   # 1.4e-4 / 1.2e-3
+    samples, _ = DDIMSampler(model).sample(S=oc.E2E_STEPS, batch_size=2, shape=[4, side, side], conditioning=cond, verbose=False,
+                                           eta=0.0, x_T=i["x_T"].cuda(),
+                                           test_model_kwargs={"inpaint_image": z[:, 4:8].contiguous(),
+                                                              "inpaint_mask": z[:, 8:9].contiguous()})
+    lat = rel_l2(samples.cpu(), ref["samples"])
+    h_cam, h_lid = model.decode_sample(samples, data["z_lidar"])
+    image = model.decode_first_stage(h_cam.contiguous(), clamp=(-1., 1.))
+    rng = model.decode_first_stage(h_lid.contiguous(), module_name="lidar_stage_model", clamp=(-1., 1.))
+    assert image.shape == ref["image"].shape and rng.shape == ref["range"].shape
+    pix_c, pix_r = rel_l2(image.float().cpu(), ref["image"]), rel_l2(rng.float().cpu(), ref["range"])
+    check(lat, TOL_E2E[(dtype, "latent")], tag + "_latent")
+    check(pix_c, TOL_E2E[(dtype, "pixel")], tag + "_pixel_camera")
+    check(pix_r, TOL_E2E[(dtype, "pixel")], tag + "_pixel_range")
