@@ -323,11 +323,18 @@ def main():
             log = {k: log[k] for k in ("image_sample", "lidar_sample")}
             if backend != "nccl":
                 log = {k: v.cpu() for k, v in log.items()}
-            torch.cuda.synchronize()
-            tg = time.perf_counter()
-            res = mdist.gather_decoded(log, B * world)                  # the one collective of the path
-            torch.cuda.synchronize()
-            gather_stat["s"] = time.perf_counter() - tg
+            # the collective is timed with events on the stream it is issued on (no device sync inside the timed pass; the
+            # gloo form moves host tensors and is timed on the host clock); only the TIMED pass's figure is reported
+            if backend == "nccl":
+                ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                ev[0].record()
+                res = mdist.gather_decoded(log, B * world)              # the one collective of the path
+                ev[1].record()
+                gather_stat["events"] = ev
+            else:
+                tg = time.perf_counter()
+                res = mdist.gather_decoded(log, B * world)
+                gather_stat["s"] = time.perf_counter() - tg
             gather_stat["bytes_per_rank"] = sum(v.numel() * v.element_size() for v in log.values())
             return res
 
@@ -343,6 +350,9 @@ def main():
             out = e2e(batch_t)
             barrier()
             e2e_dt = time.perf_counter() - t0
+            if "events" in gather_stat:                                 # (read after the timed region's closing barrier)
+                ev0, ev1 = gather_stat.pop("events")
+                gather_stat["s"] = ev0.elapsed_time(ev1) * 1e-3
         if world > 1:
             tmax = torch.tensor([e2e_dt], device=red_dev)
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -546,6 +556,19 @@ def main():
             out["plms_cfg5"] = plms_line
         if fp16_line:
             out["fp16"] = fp16_line
+        # end-to-end parity at production width, from the committed measurement of the GPU suite (never re-measured here: the
+        # oracle run behind it takes minutes of CPU): both storage types, the benched one first
+        try:
+            with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r04_parity.json")) as f:
+                pj = json.load(f)
+            key = next(k for k in pj if k.startswith("mobi_nusc_512" if side == 64 else "mobi_nusc-mini_256"))
+            mk = lambda d: {"dtype": d, "latent_rel_l2": pj[key][d]["latent_rel_l2"],
+                            "pixel_rel_l2": max(pj[key][d]["pixel_rel_l2_camera"], pj[key][d]["pixel_rel_l2_range"])}
+            other = "fp16" if args.dtype == "bf16" else "bf16"
+            out["parity"] = {**mk(args.dtype), "other_storage_type": mk(other), "case": key,
+                             "source": "profiles/r04_parity.json (tests/test_gpu_production.py::test_end_to_end_pixel_space)"}
+        except (OSError, KeyError, StopIteration, ValueError):
+            pass
         out["headline_frac_of_peak"] = out["model_frac_of_peak"]     # the model-level fraction; roofline.frac is one kernel's
         if world > 1:
             out["ranks_seen"] = dist.get_world_size()

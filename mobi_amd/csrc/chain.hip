@@ -55,6 +55,9 @@ __device__ __forceinline__ void wait_vm(int groups) {
   }
 }
 
+#ifndef MOBI_CHAIN_DBG
+#define MOBI_CHAIN_DBG 0     // timing-only ablations (WRONG results), lab builds: 1 no epilogue arithmetic / stores, 2 no adapter,
+#endif                       // 4 no row statistics, 8 no MFMAs
 #ifdef MOBI_CHAIN_STAMPS     // lab builds only (tools/chain_stamps.py): shader-clock stamps of one camera and one lidar block
 __device__ unsigned long long g_chain_stamps[2][32];
 #define CH_STAMP(i)                                                                                         \
@@ -165,7 +168,7 @@ __global__ __launch_bounds__(256, 1) void row_chain_kernel(const mobi_row_chain_
 #pragma unroll
     for (int j = 0; j < 8; ++j) { xs[ks][j] = (T)0.0f; xr[ks][j] = (T)0.0f; }
   }
-  int op0 = 0;
+  int op0 = 0, op_r = -1;                           // first operation of the loop below; the LOAD_R among the leading two
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     if (op0 == i && i < nops) {
@@ -176,10 +179,8 @@ __global__ __launch_bounds__(256, 1) void row_chain_kernel(const mobi_row_chain_
         for (int ks = 0; ks < CH_KS; ++ks) xs[ks] = __builtin_bit_cast(frag_t, ld16(p + 16 * ks));
         op0 = i + 1;
       } else if (op.code == MOBI_CH_LOAD_R) {
-        const T* p = row_ptr(op.p0, op.img_stride, op.row_stride, op.img_div);
-#pragma unroll
-        for (int ks = 0; ks < CH_KS; ++ks) xr[ks] = __builtin_bit_cast(frag_t, ld16(p + 16 * ks));
-        op0 = i + 1;
+        op_r = i;                                   // issued LAST (below): only the first epilogue needs these rows, their
+        op0 = i + 1;                                // latency hides behind the first product
       }
     }
   }
@@ -220,19 +221,38 @@ __global__ __launch_bounds__(256, 1) void row_chain_kernel(const mobi_row_chain_
         const __amdgpu_buffer_rsrc_t r0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(op.p0), 0, CH_NCH * CH_CHUNK, 0x00020000);
         for (int j = 0; j < CH_D; ++j) request(r0, j);
       }
-      if (tid < CH_C / 4) {
+      if (wave == (k & 3)) {
+        // product k's bias (and row sums) -> LDS by DMA too, 1280 bytes each: one full request and one of 16 lanes (masked
+        // lanes leave their LDS bytes alone); wave k issues them
         const float* bias = op.bias + (long long)(op.bias_img_div > 1 ? img / op.bias_img_div : img) * op.bias_img_stride;
-        *reinterpret_cast<f32x4*>(s_vec + (2 * k) * CH_C + tid * 4) = *reinterpret_cast<const f32x4*>(bias + tid * 4);
-      } else if (tid < CH_C / 2 && (op.flags & MOBI_CH_FOLD)) {
-        const int t4 = (tid - CH_C / 4) * 4;
-        *reinterpret_cast<f32x4*>(s_vec + (2 * k + 1) * CH_C + t4) = *reinterpret_cast<const f32x4*>(op.svec + t4);
+        const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(bias), 0, CH_C * 4, 0x00020000);
+        float* dstv = s_vec + (2 * k) * CH_C;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_ptr_t)dstv, 16, lane16, 0, 0, 0);
+        if (lane < (CH_C * 4 - 1024) / 16)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_ptr_t)(dstv + 256), 16, lane16, 1024, 0, 0);
+        if (op.flags & MOBI_CH_FOLD) {
+          const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(op.svec), 0, CH_C * 4, 0x00020000);
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, (lds_ptr_t)(dstv + CH_C), 16, lane16, 0, 0, 0);
+          if (lane < (CH_C * 4 - 1024) / 16)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, (lds_ptr_t)(dstv + CH_C + 256), 16, lane16, 1024, 0, 0);
+        }
       }
       ++k;
     }
   }
-  // everything requested so far (rows, tables, vectors, the first chunks) has landed for every wave behind this barrier:
-  // a product starts with ITS chunk 0 in LDS (the invariant of the chunk loop below)
-  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  // Everything requested so far (the operand rows, tables, vectors, the first chunks) has landed for every wave behind
+  // this barrier -- a product starts with ITS chunk 0 in LDS, the invariant of the chunk loop -- except the residual rows,
+  // which are requested last and left in flight (CH_KS loads per lane, the youngest).
+  const bool r_pending = op_r >= 0;
+  if (r_pending) {
+    const mobi_chain_op& op = a.prog[kind][op_r];
+    const T* p = row_ptr(op.p0, op.img_stride, op.row_stride, op.img_div);
+#pragma unroll
+    for (int ks = 0; ks < CH_KS; ++ks) xr[ks] = __builtin_bit_cast(frag_t, ld16(p + 16 * ks));
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(CH_KS) : "memory");
+  } else {
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  }
   __builtin_amdgcn_s_barrier();
   CH_STAMP(1);
 
@@ -245,6 +265,7 @@ __global__ __launch_bounds__(256, 1) void row_chain_kernel(const mobi_row_chain_
                    STORE = decltype(store_)::value;
     const float* bias = s_vec + (2 * pk) * CH_C + ch_lane;
     const float* sv = s_vec + (2 * pk + 1) * CH_C + ch_lane;
+    if (MOBI_CHAIN_DBG & 1) return;
     T* dst = STORE ? const_cast<T*>(row_ptr(op.dst, op.dst_img_stride, op.dst_row_stride, op.dst_img_div)) : nullptr;
     // the vectors of step ks + 1 are read from LDS while step ks is computed: one step of prefetch, no more (left alone the
     // scheduler hoists every read of the loop: 160 registers the kernel does not have)
@@ -292,6 +313,7 @@ __global__ __launch_bounds__(256, 1) void row_chain_kernel(const mobi_row_chain_
   // ---- the two-key adapter on the row state ------------------------------------------------------------------------
   auto adapter = [&](auto store_, const mobi_chain_op& op) {
     constexpr bool STORE = decltype(store_)::value;
+    if (MOBI_CHAIN_DBG & 2) return;
     // x + b + sum_h sigmoid(rstd (x . a_h - mean sum a_h) + c_h) u_h  (mobi_two_key_adapter; tables split hi + lo)
     f32x16 lgh, lgl;
 #pragma unroll
@@ -412,7 +434,11 @@ __global__ __launch_bounds__(256, 1) void row_chain_kernel(const mobi_row_chain_
     for (int c = 0; c < CH_NCH; ++c) {
       // my requests of the next chunk in the stream have landed: in steady state (a product follows) the five chunks
       // c .. c + 4 are out, of which c + 2 .. c + 4 may stay in flight; the last product counts down
-      if (has_next) wait_vm(3);
+      if (FIRST && c < CH_D - 1 && r_pending && has_next) {
+        // (issue order: chunks 0 .. D - 1, the residual rows, then chunk D + c' behind barrier c': until chunk D is the one
+        //  waited for, the CH_KS residual loads are among the youngest and stay in flight)
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * CH_RPW + CH_KS) : "memory");
+      } else if (has_next) wait_vm(3);
       else if (c + 1 < CH_NCH) wait_vm(CH_NCH - c - 2 < 3 ? CH_NCH - c - 2 : 3);
       asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(CH_QD) : "memory");
       __builtin_amdgcn_sched_barrier(0);
@@ -429,7 +455,7 @@ __global__ __launch_bounds__(256, 1) void row_chain_kernel(const mobi_row_chain_
 #pragma unroll
       for (int f = 0; f < CH_FR; ++f) {
         const int kk = f / CH_MT, m = f - kk * CH_MT;
-        acc[m] = mfma32(fq[f % CH_QD], xs[2 * c + kk], acc[m]);
+        if (!(MOBI_CHAIN_DBG & 8)) acc[m] = mfma32(fq[f % CH_QD], xs[2 * c + kk], acc[m]);
         if (f + CH_QD < CH_FR) fq[f % CH_QD] = __builtin_bit_cast(frag_t, ld16(base + (f + CH_QD) * 1024));
         else if (c + 1 < CH_NCH) fq[f % CH_QD] = __builtin_bit_cast(frag_t, ld16(nbase + (f + CH_QD - CH_FR) * 1024));
         if (req && f % 4 == 1 && f / 4 < CH_RPW) {
@@ -498,7 +524,7 @@ __global__ __launch_bounds__(256, 1) void row_chain_kernel(const mobi_row_chain_
       T* dst = const_cast<T*>(row_ptr(op.dst, op.dst_img_stride, op.dst_row_stride, op.dst_img_div));
 #pragma unroll
       for (int ks = 0; ks < CH_KS; ++ks) st16(dst + 16 * ks, __builtin_bit_cast(u32x4, xs[ks]));
-    } else if (code == MOBI_CH_ROWSTATS) {
+    } else if (code == MOBI_CH_ROWSTATS && !(MOBI_CHAIN_DBG & 4)) {
       // mean, then the variance about the mean from the registers (layernorm_kernel's arithmetic); a row's channels lie
       // in lanes ql and ql + 32
       float s1 = 0.f;

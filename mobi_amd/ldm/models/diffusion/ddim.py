@@ -140,6 +140,10 @@ class DDIMSampler(object):
             self._coef_key, self._coef_dev = key, torch.from_numpy(tab).to(self.model.betas.device)
         return self._coef_dev
 
+    def refresh_weights_fingerprint(self):
+        from ...modules.diffusionmodules.util import WEIGHTS_EPOCH
+        self._weights_fp, self._weights_fp_epoch = graph.weights_fingerprint(self.model), WEIGHTS_EPOCH[0]
+
     def _step(self, x, c, t, index, temperature, scale, uncond, noise, kwargs, step_value=None):
         """One denoising step -> (x_prev, pred_x0).  On the GPU the step is ONE graph launch (mobi_amd/graph.py):
         the returned tensors are then the graph's static outputs, valid until the next step."""
@@ -155,7 +159,12 @@ class DDIMSampler(object):
             tv = t.tolist()
             if len(set(tv)) == 1:
                 step_value = int(tv[0])
-                self._weights_fp = graph.weights_fingerprint(self.model)
+                # the fingerprint is a Python walk over every parameter: once per weights epoch here (load_state_dict /
+                # .to() bump it), not per step -- an external loop that edits parameters in place between two steps calls
+                # `refresh_weights_fingerprint()` (the sampling loops of this class refresh it once per run)
+                from ...modules.diffusionmodules.util import WEIGHTS_EPOCH
+                if getattr(self, "_weights_fp_epoch", None) != WEIGHTS_EPOCH[0] or getattr(self, "_weights_fp", None) is None:
+                    self.refresh_weights_fingerprint()
             else:
                 use_graph = False
         if use_graph:

@@ -130,8 +130,8 @@ class CrossAttention(nn.Module):
         type), so the attention kernels exponentiate q.k as a power of two without touching q again
         (mobi_attention_params.q_log2_scaled; `sim = einsum(q, k) * self.scale`, attention.py:178)."""
         mods = [getattr(self, n) for n in names]
-        dtype = mods[0].packed().w.dtype
-        key = (names, fold_q, dtype) + tuple(v for m in mods for v in (m.weight._version, m.weight.data_ptr()))
+        dtype = engine_dtype()
+        key = (names, fold_q, dtype, self.scale) + tuple(v for m in mods for v in (m.weight._version, m.weight.data_ptr()))
         c = self.__dict__.setdefault("_stack_cache", {})
         hit = c.get((names, fold_q))
         if hit is None or hit[0] != key:

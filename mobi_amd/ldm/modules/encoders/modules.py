@@ -284,18 +284,17 @@ class FrozenCLIPImageEmbedder(AbstractEncoder):
         # the same reference image is encoded for the camera and the lidar branch: one tower pass per distinct image
         # (the harness hands the camera branch and the lidar branch two tensors with the same pixels, ddpm.py:788,816).
         # The entry is tied to the weights it was computed with (load_state_dict / .to() bump the epoch, in-place edits
-        # the parameters' version counters) and the storage type; the same tensor object again is a hit without any
-        # device work, another tensor of the same shape costs one device compare + read-back per call (per batch).
+        # the parameters' version counters) and the storage type.
         from ..diffusionmodules.util import WEIGHTS_EPOCH
         wkey = (WEIGHTS_EPOCH[0], sum(p._version for p in self.transformer.parameters()), engine_dtype(), image.device)
-        ident = (id(image), image._version, image.data_ptr(), tuple(image.shape))
         c = self.__dict__.setdefault("_pooled_cache", {})
         hit = c.get("image")
-        same = hit is not None and c.get("wkey") == wkey and (
-            c.get("ident") == ident or (hit.shape == image.shape and hit.device == image.device and torch.equal(hit, image)))
+        # always a pixel compare (one device compare + read-back per call, i.e. per batch): the tensor's identity / version
+        # counter would miss writes that do not bump `_version` -- this repo's own engine ops write through raw pointers
+        same = hit is not None and c.get("wkey") == wkey and hit.shape == image.shape and hit.device == image.device \
+            and torch.equal(hit, image)
         if not same:
             c["image"], c["pooled"], c["wkey"] = image.detach().clone(), self.transformer.pooled(image), wkey
-        c["ident"], c["ident_ref"] = ident, image
         z = self.mapper(c["pooled"])
         return _rows(self.final_ln, z).unsqueeze(1)
 

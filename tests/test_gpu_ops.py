@@ -261,7 +261,7 @@ def test_attention(ops, dtype, heads, dh, tq, tk, v_rows, tune):
 @pytest.mark.parametrize("dh,tq,tk,kind", [(40, 300, 1000, "ramp"), (40, 256, 4096, "ramp"), (80, 130, 700, "ramp"),
                                            (64, 70, 390, "ramp"), (48, 64, 512, "ramp"), (40, 96, 640, "huge"),
                                            (80, 64, 320, "huge"), (32, 64, 256, "huge"), (40, 64, 200, "negative"),
-                                           (8, 40, 130, "ramp"), (24, 33, 257, "spike")])
+                                           (8, 40, 130, "ramp"), (24, 33, 257, "spike"), (40, 128, 4096, "peaky")])
 def test_attention_shift_path(ops, dtype, nw, dh, tq, tk, kind, tune):
     """attention_rows_kernel keeps a shift below the running maximum and raises it only when a probability reaches 2.0
     (the OR test on the packed words); these inputs make that exact path run often or at the extremes: scores that keep
@@ -282,6 +282,12 @@ def test_attention_shift_path(ops, dtype, nw, dh, tq, tk, kind, tune):
         kf = -(kf.abs() + 1.0) * 4.0
     elif kind == "spike":
         kf[:, tk - 3] = qf[:, 0:1].mean(1) * 9.0
+    elif kind == "peaky":
+        # a peaky distribution at the production key count (T = 4,096, dh = 40): every query has a few keys 15 .. 25 nats above
+        # the rest, some of them late in the row (beyond the 32 keys whose maximum fixes the shift on padded head dims; fp16
+        # keeps 13.9 nats of headroom above it: these rows take the block's second, tested pass)
+        for j, pos in enumerate((5, 700, 2049, 4090)):
+            kf[:, pos] = qf[:, j::4].mean(1) * (3.0 + j) + kf[:, pos] * 0.2
     qd, kd = qf.to(dtype).cuda(), kf.to(dtype).cuda()
     qf, kf = qd.float().cpu(), kd.float().cpu()
     sp = lambda t: t.reshape(n, -1, heads, dh).permute(0, 2, 1, 3)
@@ -291,9 +297,22 @@ def test_attention_shift_path(ops, dtype, nw, dh, tq, tk, kind, tune):
     y = ops.attention(qd, kd, vd, heads, dh ** -0.5, v_rows=True)
     assert torch.isfinite(y.float()).all()
     # the kernel rounds Q' = Q * scale * log2(e) to the storage type once more (callers that fold the factor into to_q do
-    # not pay this: q_log2_scaled): 1.5 x the one-kernel bound; scores of ~1e3 ('huge') move by several units with it
-    tol = TOL[dtype] * (40 if kind == "huge" else 2.5 if kind in ("ramp", "spike") else 1.5)
+    # not pay this: q_log2_scaled): 1.5 x the one-kernel bound; scores of ~1e3 ('huge') move by several units with that
+    # rounding -- measured on the MI355X 7.4e-3 (fp16) / 5.9e-2 (bf16), asserted at 2x
+    tol = {"huge": {torch.float16: 1.5e-2, torch.bfloat16: 1.2e-1}[dtype]}.get(
+        kind, TOL[dtype] * (2.5 if kind in ("ramp", "spike", "peaky") else 1.5))
     assert rel(y.float(), ref) < tol
+    if kind in ("huge", "peaky"):
+        # the form the transformer blocks use -- Q' handed over already scaled (q_log2_scaled), so the kernel adds no
+        # rounding of its own -- against a reference built from the SAME rounded Q': the one-kernel bound holds on the very
+        # inputs that overflow the speculative exponentials
+        log2e = 1.4426950408889634
+        qs = (qf * (dh ** -0.5 * log2e)).to(dtype)
+        sim2 = torch.einsum("bhid,bhjd->bhij", sp(qs.float()).double(), sp(kf).double()) / log2e
+        ref2 = torch.einsum("bhij,bhjd->bhid", sim2.softmax(-1), sp(vf).double()).permute(0, 2, 1, 3).reshape(n, tq, c)
+        y2 = ops.attention(qs.cuda(), kd, vd, heads, 1.0, v_rows=True, q_log2_scaled=True)
+        assert torch.isfinite(y2.float()).all()
+        assert rel(y2.float(), ref2) < TOL[dtype] * 1.5
 
 
 @pytest.mark.parametrize("dtype", DT)

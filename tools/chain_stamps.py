@@ -62,6 +62,13 @@ def main():
     for _ in range(3):
         assert lab.mobi_row_chain(captured["p"], st) == 0
     torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(20):
+        lab.mobi_row_chain(captured["p"], st)
+    e1.record()
+    torch.cuda.synchronize()
+    print(f"launch (post-attn1 program, [16, 4096, 320] bf16, flags {sys.argv[1:]}): {e0.elapsed_time(e1) * 50:.1f} us")
     buf = (C.c_ulonglong * 64)()
     assert lab.mobi_chain_debug_stamps(buf) == 0
     names = {0: ["(LOAD_S: hoisted)", "(LOAD_R: hoisted)", "PRODUCT to_out", "ADAPTER", "ROWSTATS", "PRODUCT q"],
