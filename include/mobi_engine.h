@@ -36,7 +36,8 @@ extern "C" {
  *   1  first layout (later also mobi_igemm_params.weight_tiled, mobi_ddim_step_params.coef_dev)
  *   2  mobi_attention_params.q_log2_scaled; mobi_two_key_adapter_params.ln_out / ln_gamma / ln_beta / ln_eps;
  *      mobi_ff_geglu_params (struct id 14); mobi_two_key_adapter_fuses_ln(channels, total_rows)
- *   3  mobi_row_chain_params / mobi_chain_op (struct ids 15, 16), mobi_row_chain* */
+ *   3  mobi_row_chain_params / mobi_chain_op (struct ids 15, 16), mobi_row_chain*; the backward entry points
+ *      (mobi_layernorm_bwd_params 17, mobi_attention_bwd_params 18) */
 #define MOBI_ABI_VERSION 3
 
 enum { MOBI_OK = 0, MOBI_ERR_ARG = -1, MOBI_ERR_UNSUPPORTED = -2, MOBI_ERR_LAUNCH = -3, MOBI_ERR_ALIGN = -4 };
@@ -48,7 +49,7 @@ const char* mobi_error_string(int code);
  * their own layout before the first call.  id: 0 igemm, 1 groupnorm, 2 layernorm,
  * 3 attention, 4 ctx_attention, 5 skinny_linear, 6 conv_small_cin, 7 conv_small_cout,
  * 8 ddim_step, 9 two_key_adapter, 10 range_paste, 11 lidar_metrics, 12 range_prepare, 13 image_prepare, 14 ff_geglu,
- * 15 row_chain, 16 chain_op.  Returns 0 for an unknown id. */
+ * 15 row_chain, 16 chain_op, 17 layernorm_bwd, 18 attention_bwd.  Returns 0 for an unknown id. */
 size_t mobi_struct_size(int id);
 /* Development hook: the library reads its MOBI_* A/B environment variables once, at the first launch
  * (mobi_amd/csrc/tuning.h lists them); this re-reads them.  Not needed by a product caller. */
@@ -301,6 +302,50 @@ int mobi_row_chain_adapter_image(const float* a, const float* c, const float* u,
 size_t mobi_row_chain_weight_bytes(int32_t channels);
 int mobi_row_chain_supported(int32_t channels, int32_t rows_per_image);
 int mobi_row_chain(const mobi_row_chain_params* p, void* stream);
+
+/* ---------------------------------------------------------------------------
+ * Backward pass of the transformer block (FIRST SLICE: the training step of the adapter
+ * parameters, ldm/models/diffusion/ddpm.py:356-370, 1616-1669 of the reference: `cond_adapter*` / `cross_modal*` of
+ * every BasicTransformerBlock, ldm/modules/attention.py:197-266).  What torch.autograd does for the reference:
+ *   linear layers     dx = dy W  and  dW = dy^T x  are mobi_igemm launches (the weight read as [in][out]; both operands of
+ *                     the weight gradient transposed by mobi_transpose, the token axis as k, MOBI_OUT_ROWS_F32), the bias
+ *                     gradient is mobi_colsum;
+ *   nn.LayerNorm      mobi_layernorm_bwd;   GEGLU (attention.py:38-46)  mobi_geglu_fwd on the un-fused projection / _bwd;
+ *   attention         mobi_attention_bwd (softmax(q k^T scale) v per head, attention.py:171-194).
+ * Correct and bit-reproducible (fixed-order reductions), not tuned: fp32 vector arithmetic on LDS tiles.
+ * ------------------------------------------------------------------------- */
+int mobi_transpose(const void* src, int64_t src_row_stride, void* out, int32_t rows, int32_t cols, int32_t dtype,
+                   void* stream);                          /* T [rows][cols] (row stride in elements) -> T [cols][rows] */
+int32_t mobi_backward_partial_blocks(int64_t rows);        /* blocks of per-block partial sums the two calls below use */
+/* out[c] = sum_rows dy[row][c]; partial: f32 [mobi_backward_partial_blocks(rows)][cols] scratch. */
+int mobi_colsum(const void* dy, int64_t row_stride, int64_t rows, int32_t cols, int32_t dtype, float* partial, float* out,
+                void* stream);
+typedef struct mobi_layernorm_bwd_params {
+  const void* x; const void* dy;            /* T [rows][channels]; row strides in elements (0 = dense) */
+  int64_t x_row_stride, dy_row_stride;
+  const float* gamma; float eps;
+  const void* dx_add;                       /* T [rows][channels] dense or NULL: added to dx (the residual branch's gradient) */
+  void* dx;                                 /* T [rows][channels] dense */
+  float* partial;                           /* f32 [mobi_backward_partial_blocks(rows)][2][channels] scratch */
+  float* dgamma_dbeta;                      /* f32 [2][channels]: d gamma, then d beta */
+  int64_t rows; int32_t channels; int32_t dtype;
+} mobi_layernorm_bwd_params;
+int mobi_layernorm_bwd(const mobi_layernorm_bwd_params* p, void* stream);
+/* pre: T [rows][2 inner] = [value | gate] (GEGLU.proj's output, un-fused); h = value * gelu_erf(gate): T [rows][inner]. */
+int mobi_geglu_fwd(const void* pre, void* h, int64_t rows, int32_t inner, int32_t dtype, void* stream);
+int mobi_geglu_bwd(const void* pre, const void* dh, void* dpre, int64_t rows, int32_t inner, int32_t dtype, void* stream);
+typedef struct mobi_attention_bwd_params {
+  const void* q; int64_t q_img_stride, q_row_stride;       /* T [image][tq][>= heads*dh], strides in elements */
+  const void* k; int64_t k_img_stride, k_row_stride;       /* T [image][tk][..] */
+  const void* v; int64_t v_img_stride, v_row_stride;
+  const void* o; int64_t o_img_stride, o_row_stride;       /* the forward result */
+  const void* dout; int64_t dout_img_stride, dout_row_stride;
+  void* dq; void* dk; void* dv;                            /* T [image][t][heads*dh] dense */
+  float* lse; float* dvec;                                 /* f32 [image][heads][tq] scratch each */
+  int32_t images, heads, dh, tq, tk;                       /* dh <= 160 */
+  float scale; int32_t dtype;
+} mobi_attention_bwd_params;
+int mobi_attention_bwd(const mobi_attention_bwd_params* p, void* stream);
 
 /* Attention against a handful of context tokens (tk <= 8): the bbox adapter
  * (attention.py:237-243, tk = 2).  k, v are fp32 [image][tk][heads*dh]. */

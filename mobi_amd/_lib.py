@@ -78,6 +78,20 @@ class RowChainParams(C.Structure):
                 ("nops", i32 * 2), ("prog", (ChainOp * CHAIN_MAX_OPS) * 2), ("ad_image", vp), ("ad_eps", f32)]
 
 
+class LayerNormBwdParams(C.Structure):
+    _fields_ = [("x", vp), ("dy", vp), ("x_row_stride", i64), ("dy_row_stride", i64), ("gamma", vp), ("eps", f32),
+                ("dx_add", vp), ("dx", vp), ("partial", vp), ("dgamma_dbeta", vp), ("rows", i64), ("channels", i32),
+                ("dtype", i32)]
+
+
+class AttentionBwdParams(C.Structure):
+    _fields_ = [("q", vp), ("q_img_stride", i64), ("q_row_stride", i64), ("k", vp), ("k_img_stride", i64), ("k_row_stride", i64),
+                ("v", vp), ("v_img_stride", i64), ("v_row_stride", i64), ("o", vp), ("o_img_stride", i64), ("o_row_stride", i64),
+                ("dout", vp), ("dout_img_stride", i64), ("dout_row_stride", i64), ("dq", vp), ("dk", vp), ("dv", vp),
+                ("lse", vp), ("dvec", vp), ("images", i32), ("heads", i32), ("dh", i32), ("tq", i32), ("tk", i32),
+                ("scale", f32), ("dtype", i32)]
+
+
 class CtxAttentionParams(C.Structure):
     _fields_ = [("q", vp), ("out", vp), ("k", vp), ("v", vp), ("images", i32), ("heads", i32), ("dh", i32),
                 ("tq", i32), ("tk", i32), ("scale", f32), ("dtype", i32)]
@@ -141,7 +155,8 @@ class ImagePrepareParams(C.Structure):
 STRUCT_IDS = {0: IgemmParams, 1: GroupNormParams, 2: LayerNormParams, 3: AttentionParams, 4: CtxAttentionParams,
               5: SkinnyLinearParams, 6: ConvSmallCinParams, 7: ConvSmallCoutParams, 8: DdimStepParams, 9: TwoKeyAdapterParams,
               10: RangePasteParams, 11: LidarMetricsParams, 12: RangePrepareParams, 13: ImagePrepareParams,
-              14: FfGegluParams, 15: RowChainParams, 16: ChainOp}
+              14: FfGegluParams, 15: RowChainParams, 16: ChainOp,
+              17: LayerNormBwdParams, 18: AttentionBwdParams}
 
 # every symbol include/mobi_engine.h declares: name -> (restype, argtypes)
 SYMBOLS = {
@@ -172,6 +187,13 @@ SYMBOLS = {
     "mobi_row_chain_supported": (C.c_int, [i32, i32]),
     "mobi_row_chain_adapter_image_bytes": (C.c_size_t, [i32]),
     "mobi_row_chain_adapter_image": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, i32, vp, vp]),
+    "mobi_transpose": (C.c_int, [vp, i64, vp, i32, i32, i32, vp]),
+    "mobi_backward_partial_blocks": (i32, [i64]),
+    "mobi_colsum": (C.c_int, [vp, i64, i64, i32, i32, vp, vp, vp]),
+    "mobi_layernorm_bwd": (C.c_int, [C.POINTER(LayerNormBwdParams), vp]),
+    "mobi_geglu_fwd": (C.c_int, [vp, vp, i64, i32, i32, vp]),
+    "mobi_geglu_bwd": (C.c_int, [vp, vp, vp, i64, i32, i32, vp]),
+    "mobi_attention_bwd": (C.c_int, [C.POINTER(AttentionBwdParams), vp]),
     "mobi_quick_gelu": (C.c_int, [vp, vp, i64, i32, vp]),
     "mobi_timestep_embedding": (C.c_int, [vp, vp, vp, i32, i32, vp]),
     "mobi_conv_small_cin": (C.c_int, [C.POINTER(ConvSmallCinParams), vp]),

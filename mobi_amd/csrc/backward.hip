@@ -1,0 +1,473 @@
+// Backward-pass kernels of the transformer block (the training step of the adapter parameters,
+// ldm/models/diffusion/ddpm.py:356-370, 1616-1669 of the reference -- `cond_adapter*`, `cross_modal*` of every
+// BasicTransformerBlock, ldm/modules/attention.py:197-266).  FIRST SLICE: correct and deterministic, not tuned -- fp32
+// vector arithmetic on LDS tiles; the data-gradient and weight-gradient PRODUCTS of the linear layers run on mobi_igemm
+// (dx = dy W: the layer's weight read as [in][out]; dW = dy^T x: both operands transposed by transpose_kernel, the token
+// axis as k).  What is here: LayerNorm backward (dx, per-block partial d gamma / d beta), GEGLU forward / backward on the
+// un-fused projection, attention backward (log-sum-exp and row dots, dQ, dK | dV) for any head dim <= 160 and any token
+// counts (self / cross-modal attention; two context tokens for the bbox adapter), column sums (bias gradients), a 16-bit
+// transpose, the reduction of per-block partials (fixed order: bit-reproducible).
+#include "common.h"
+
+namespace mobi {
+namespace {
+
+constexpr int BW_TILE = 32;          // attention backward: queries / keys per tile
+constexpr int BW_DH = 160;           // largest head dim
+constexpr int BW_LD = BW_DH + 1;     // LDS row pitch in floats (odd: conflict-free column walks)
+
+template <typename T>
+__device__ __forceinline__ void load_tile(float* dst, const T* src, long long row_stride, int rows_valid, int dh, int tid) {
+  // dst [BW_TILE][BW_LD] <- src [rows][dh] (zero rows beyond rows_valid)
+  for (int i = tid; i < BW_TILE * dh; i += 256) {
+    const int r = i / dh, d = i - r * dh;
+    dst[r * BW_LD + d] = r < rows_valid ? (float)src[(long long)r * row_stride + d] : 0.f;
+  }
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------------------------------
+// 16-bit transpose: src [rows][cols] (row stride in elements) -> out [cols][rows] dense
+template <typename T>
+__global__ __launch_bounds__(256) void transpose_kernel(const T* __restrict__ src, long long src_stride, T* __restrict__ out,
+                                                        int rows, int cols) {
+  __shared__ T tile[64][66];
+  const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64, tid = threadIdx.x;
+  for (int i = tid; i < 64 * 64; i += 256) {
+    const int r = i >> 6, c = i & 63;
+    if (r0 + r < rows && c0 + c < cols) tile[r][c] = src[(long long)(r0 + r) * src_stride + c0 + c];
+  }
+  __syncthreads();
+  for (int i = tid; i < 64 * 64; i += 256) {
+    const int c = i >> 6, r = i & 63;
+    if (r0 + r < rows && c0 + c < cols) out[(long long)(c0 + c) * rows + r0 + r] = tile[r][c];
+  }
+}
+
+// column sums of dy [rows][cols] (T) -> partial [gridDim.x][cols] fp32 (fixed order within a block)
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ dy, long long stride, float* __restrict__ partial,
+                                                     long long rows, int cols, int rows_per_block) {
+  const long long r0 = (long long)blockIdx.x * rows_per_block;
+  const long long r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
+  for (int c = threadIdx.x; c < cols; c += 256) {
+    float s = 0.f;
+    for (long long r = r0; r < r1; ++r) s += (float)dy[r * stride + c];
+    partial[(long long)blockIdx.x * cols + c] = s;
+  }
+}
+
+// out[i] = sum_b partial[b][i] (ascending b)
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ partial, float* __restrict__ out, int nblk,
+                                                              long long len) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= len) return;
+  float s = 0.f;
+  for (int b = 0; b < nblk; ++b) s += partial[(long long)b * len + i];
+  out[i] = s;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// LayerNorm backward over the last axis (nn.LayerNorm, attention.py:213-223): one wave per row
+//   xh = (x - mean) rstd,  g = dy gamma,  dx = rstd (g - mean(g) - xh mean(g xh)) (+ dx_add)
+//   partial[block][0][c] = sum_rows dy xh,  partial[block][1][c] = sum_rows dy   (the block's rows, fixed order)
+template <typename T>
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict__ x, long long x_stride, const T* __restrict__ dy,
+                                                            long long dy_stride, const float* __restrict__ gamma, float eps,
+                                                            const T* __restrict__ dx_add, T* __restrict__ dx, float* __restrict__ partial,
+                                                            long long rows, int C, int rows_per_block) {
+  constexpr int MAXV = 24;                         // channels per lane: C <= 1536
+  __shared__ float red[4][2][1536];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float ag[MAXV], ab[MAXV];
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) { ag[i] = 0.f; ab[i] = 0.f; }
+  const long long r0 = (long long)blockIdx.x * rows_per_block;
+  const long long r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
+  const float inv_c = 1.0f / (float)C;
+  for (long long r = r0 + wave; r < r1; r += 4) {
+    float xv[MAXV], gv[MAXV], dv[MAXV];
+    float s1 = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+      const int c = lane + 64 * i;
+      xv[i] = c < C ? (float)x[r * x_stride + c] : 0.f;
+      dv[i] = c < C ? (float)dy[r * dy_stride + c] : 0.f;
+      s1 += xv[i];
+    }
+    const float mean = wave_sum(s1) * inv_c;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+      const int c = lane + 64 * i;
+      const float d = c < C ? xv[i] - mean : 0.f;
+      q += d * d;
+    }
+    const float rstd = rsqrtf(wave_sum(q) * inv_c + eps);
+    float sg = 0.f, sgx = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+      const int c = lane + 64 * i;
+      const float xh = c < C ? (xv[i] - mean) * rstd : 0.f;
+      gv[i] = c < C ? dv[i] * gamma[c] : 0.f;
+      sg += gv[i];
+      sgx += gv[i] * xh;
+      ag[i] += dv[i] * xh;
+      ab[i] += dv[i];
+      xv[i] = xh;
+    }
+    const float mg = wave_sum(sg) * inv_c, mgx = wave_sum(sgx) * inv_c;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+      const int c = lane + 64 * i;
+      if (c < C) {
+        float v = rstd * (gv[i] - mg - xv[i] * mgx);
+        if (dx_add) v += (float)dx_add[r * (long long)C + c];
+        dx[r * (long long)C + c] = (T)v;
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int c = lane + 64 * i;
+    if (c < C) { red[wave][0][c] = ag[i]; red[wave][1][c] = ab[i]; }
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += 256) {
+    partial[((long long)blockIdx.x * 2 + 0) * C + c] = (red[0][0][c] + red[1][0][c]) + (red[2][0][c] + red[3][0][c]);
+    partial[((long long)blockIdx.x * 2 + 1) * C + c] = (red[0][1][c] + red[1][1][c]) + (red[2][1][c] + red[3][1][c]);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// GEGLU on the UN-fused projection (attention.py:38-46): pre [rows][2 inner] = [value | gate];  h = value gelu_erf(gate)
+template <typename T>
+__global__ __launch_bounds__(256) void geglu_fwd_kernel(const T* __restrict__ pre, T* __restrict__ h, long long rows, int inner) {
+  const long long n = rows * inner;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    const long long r = i / inner;
+    const int c = (int)(i - r * inner);
+    const float v = (float)pre[r * 2 * inner + c], g = (float)pre[r * 2 * inner + inner + c];
+    h[i] = (T)(v * gelu_erf_f(g));
+  }
+}
+// d value = dh gelu(g);  d gate = dh value gelu'(g),  gelu'(g) = Phi(g) + g phi(g)
+template <typename T>
+__global__ __launch_bounds__(256) void geglu_bwd_kernel(const T* __restrict__ pre, const T* __restrict__ dh, T* __restrict__ dpre,
+                                                        long long rows, int inner) {
+  const long long n = rows * inner;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    const long long r = i / inner;
+    const int c = (int)(i - r * inner);
+    const float v = (float)pre[r * 2 * inner + c], g = (float)pre[r * 2 * inner + inner + c], d = (float)dh[i];
+    const float cdf = 0.5f * (1.0f + erf_as_f(g * 0.70710678118654752440f));
+    const float pdf = 0.3989422804014327f * __expf(-0.5f * g * g);
+    dpre[r * 2 * inner + c] = (T)(d * g * cdf);
+    dpre[r * 2 * inner + inner + c] = (T)(d * v * (cdf + g * pdf));
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Attention backward (CrossAttention.forward, attention.py:171-194: softmax(q k^T scale) v per head).
+//   pass 1 (per query tile): L = log-sum-exp of the scaled scores, D = do . o           -> fp32 [image][head][tq] each
+//   pass 2 (per query tile): P = exp(s - L), dS = P (dO V^T - D) scale, dQ = dS K
+//   pass 3 (per key tile):   dV = P^T dO,  dK = dS^T Q
+// Tiles of 32 x 32 scores, operands as fp32 in LDS, a thread owns row t / 8, columns 4 (t % 8) .. + 3 of the score tile
+// and rows t / 8, channels t % 8 + 8 i of the [32][dh] results.
+struct AttnBwdArgs {
+  const void *q, *k, *v, *o, *dout;
+  long long q_is, q_rs, k_is, k_rs, v_is, v_rs, o_is, o_rs, do_is, do_rs;   // image / row strides, elements
+  void *dq, *dk, *dv;                                                         // T [image][t][heads * dh] dense
+  float *lse, *dvec;                                                          // fp32 [image][head][tq]
+  int heads, dh, tq, tk;
+  float scale;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void attn_bwd_stats_kernel(const AttnBwdArgs a) {
+  __shared__ float sQ[BW_TILE * BW_LD], sK[BW_TILE * BW_LD];
+  const int tid = threadIdx.x, r = tid >> 3, cg = tid & 7;
+  const int q0 = blockIdx.x * BW_TILE, h = blockIdx.y, img = blockIdx.z;
+  const int qv = min(BW_TILE, a.tq - q0);
+  const T* qp = reinterpret_cast<const T*>(a.q) + img * a.q_is + (long long)q0 * a.q_rs + h * a.dh;
+  load_tile(sQ, qp, a.q_rs, qv, a.dh, tid);
+  float m = -3.0e38f, l = 0.f;
+  for (int k0 = 0; k0 < a.tk; k0 += BW_TILE) {
+    const int kv = min(BW_TILE, a.tk - k0);
+    __syncthreads();
+    load_tile(sK, reinterpret_cast<const T*>(a.k) + img * a.k_is + (long long)k0 * a.k_rs + h * a.dh, a.k_rs, kv, a.dh, tid);
+    __syncthreads();
+    float s[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int d = 0; d < a.dh; ++d) {
+      const float qd = sQ[r * BW_LD + d];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) s[j] += qd * sK[(4 * cg + j) * BW_LD + d];
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (4 * cg + j < kv) {
+        const float sv = s[j] * a.scale;
+        const float mn = fmaxf(m, sv);
+        l = l * __expf(m - mn) + __expf(sv - mn);
+        m = mn;
+      }
+    }
+  }
+  // the eight threads of a row (consecutive lanes) combine their (m, l)
+#pragma unroll
+  for (int o = 1; o < 8; o <<= 1) {
+    const float m2 = __shfl_xor(m, o, 64), l2 = __shfl_xor(l, o, 64);
+    const float mn = fmaxf(m, m2);
+    l = l * __expf(m - mn) + l2 * __expf(m2 - mn);
+    m = mn;
+  }
+  // D = do . o over the head's channels
+  const T* op = reinterpret_cast<const T*>(a.o) + img * a.o_is + (long long)(q0 + r) * a.o_rs + h * a.dh;
+  const T* dp = reinterpret_cast<const T*>(a.dout) + img * a.do_is + (long long)(q0 + r) * a.do_rs + h * a.dh;
+  float dd = 0.f;
+  if (r < qv)
+    for (int d = cg; d < a.dh; d += 8) dd += (float)op[d] * (float)dp[d];
+#pragma unroll
+  for (int o = 1; o < 8; o <<= 1) dd += __shfl_xor(dd, o, 64);
+  if (cg == 0 && r < qv) {
+    const long long idx = ((long long)img * a.heads + h) * a.tq + q0 + r;
+    a.lse[idx] = m + __logf(l);
+    a.dvec[idx] = dd;
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnBwdArgs a) {
+  __shared__ float sQ[BW_TILE * BW_LD], sO[BW_TILE * BW_LD], sK[BW_TILE * BW_LD], sV[BW_TILE * BW_LD], sS[BW_TILE * 33];
+  const int tid = threadIdx.x, r = tid >> 3, cg = tid & 7;
+  const int q0 = blockIdx.x * BW_TILE, h = blockIdx.y, img = blockIdx.z;
+  const int qv = min(BW_TILE, a.tq - q0);
+  load_tile(sQ, reinterpret_cast<const T*>(a.q) + img * a.q_is + (long long)q0 * a.q_rs + h * a.dh, a.q_rs, qv, a.dh, tid);
+  load_tile(sO, reinterpret_cast<const T*>(a.dout) + img * a.do_is + (long long)q0 * a.do_rs + h * a.dh, a.do_rs, qv, a.dh, tid);
+  const long long sidx = ((long long)img * a.heads + h) * a.tq + q0 + r;
+  const float L = r < qv ? a.lse[sidx] : 0.f, D = r < qv ? a.dvec[sidx] : 0.f;
+  float acc[BW_DH / 8];
+#pragma unroll
+  for (int i = 0; i < BW_DH / 8; ++i) acc[i] = 0.f;
+  for (int k0 = 0; k0 < a.tk; k0 += BW_TILE) {
+    const int kv = min(BW_TILE, a.tk - k0);
+    __syncthreads();
+    load_tile(sK, reinterpret_cast<const T*>(a.k) + img * a.k_is + (long long)k0 * a.k_rs + h * a.dh, a.k_rs, kv, a.dh, tid);
+    load_tile(sV, reinterpret_cast<const T*>(a.v) + img * a.v_is + (long long)k0 * a.v_rs + h * a.dh, a.v_rs, kv, a.dh, tid);
+    __syncthreads();
+    float s[4] = {0.f, 0.f, 0.f, 0.f}, dp[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int d = 0; d < a.dh; ++d) {
+      const float qd = sQ[r * BW_LD + d], od = sO[r * BW_LD + d];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        s[j] += qd * sK[(4 * cg + j) * BW_LD + d];
+        dp[j] += od * sV[(4 * cg + j) * BW_LD + d];
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float p = (4 * cg + j < kv && r < qv) ? __expf(s[j] * a.scale - L) : 0.f;
+      sS[r * 33 + 4 * cg + j] = p * (dp[j] - D) * a.scale;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < BW_DH / 8; ++i) {
+      const int d = cg + 8 * i;
+      if (d < a.dh) {
+        float v = acc[i];
+        for (int c = 0; c < BW_TILE; ++c) v += sS[r * 33 + c] * sK[c * BW_LD + d];
+        acc[i] = v;
+      }
+    }
+  }
+  if (r < qv) {
+    T* out = reinterpret_cast<T*>(a.dq) + ((long long)img * a.tq + q0 + r) * (a.heads * a.dh) + h * a.dh;
+#pragma unroll
+    for (int i = 0; i < BW_DH / 8; ++i) {
+      const int d = cg + 8 * i;
+      if (d < a.dh) out[d] = (T)acc[i];
+    }
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnBwdArgs a) {
+  __shared__ float sQ[BW_TILE * BW_LD], sO[BW_TILE * BW_LD], sK[BW_TILE * BW_LD], sV[BW_TILE * BW_LD], sP[BW_TILE * 33], sS[BW_TILE * 33];
+  __shared__ float sL[BW_TILE], sD[BW_TILE];
+  const int tid = threadIdx.x, r = tid >> 3, cg = tid & 7;
+  const int k0 = blockIdx.x * BW_TILE, h = blockIdx.y, img = blockIdx.z;
+  const int kv = min(BW_TILE, a.tk - k0);
+  load_tile(sK, reinterpret_cast<const T*>(a.k) + img * a.k_is + (long long)k0 * a.k_rs + h * a.dh, a.k_rs, kv, a.dh, tid);
+  load_tile(sV, reinterpret_cast<const T*>(a.v) + img * a.v_is + (long long)k0 * a.v_rs + h * a.dh, a.v_rs, kv, a.dh, tid);
+  float ak[BW_DH / 8], av[BW_DH / 8];              // this thread: key row r, channels cg + 8 i
+#pragma unroll
+  for (int i = 0; i < BW_DH / 8; ++i) { ak[i] = 0.f; av[i] = 0.f; }
+  for (int q0 = 0; q0 < a.tq; q0 += BW_TILE) {
+    const int qv = min(BW_TILE, a.tq - q0);
+    __syncthreads();
+    load_tile(sQ, reinterpret_cast<const T*>(a.q) + img * a.q_is + (long long)q0 * a.q_rs + h * a.dh, a.q_rs, qv, a.dh, tid);
+    load_tile(sO, reinterpret_cast<const T*>(a.dout) + img * a.do_is + (long long)q0 * a.do_rs + h * a.dh, a.do_rs, qv, a.dh, tid);
+    if (tid < BW_TILE) {
+      const long long sidx = ((long long)img * a.heads + h) * a.tq + q0 + tid;
+      sL[tid] = tid < qv ? a.lse[sidx] : 0.f;
+      sD[tid] = tid < qv ? a.dvec[sidx] : 0.f;
+    }
+    __syncthreads();
+    // score tile: this thread owns query row r, keys 4 cg .. + 3
+    float s[4] = {0.f, 0.f, 0.f, 0.f}, dp[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int d = 0; d < a.dh; ++d) {
+      const float qd = sQ[r * BW_LD + d], od = sO[r * BW_LD + d];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        s[j] += qd * sK[(4 * cg + j) * BW_LD + d];
+        dp[j] += od * sV[(4 * cg + j) * BW_LD + d];
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float p = (4 * cg + j < kv && r < qv) ? __expf(s[j] * a.scale - sL[r]) : 0.f;
+      sP[r * 33 + 4 * cg + j] = p;
+      sS[r * 33 + 4 * cg + j] = p * (dp[j] - sD[r]) * a.scale;
+    }
+    __syncthreads();
+    // accumulate: key row r (of this tile), channels cg + 8 i, over the 32 queries
+#pragma unroll
+    for (int i = 0; i < BW_DH / 8; ++i) {
+      const int d = cg + 8 * i;
+      if (d < a.dh) {
+        float vk = ak[i], vv = av[i];
+        for (int qq = 0; qq < BW_TILE; ++qq) {
+          vv += sP[qq * 33 + r] * sO[qq * BW_LD + d];
+          vk += sS[qq * 33 + r] * sQ[qq * BW_LD + d];
+        }
+        ak[i] = vk;
+        av[i] = vv;
+      }
+    }
+  }
+  if (r < kv) {
+    const long long off = ((long long)img * a.tk + k0 + r) * (a.heads * a.dh) + h * a.dh;
+    T* outk = reinterpret_cast<T*>(a.dk) + off;
+    T* outv = reinterpret_cast<T*>(a.dv) + off;
+#pragma unroll
+    for (int i = 0; i < BW_DH / 8; ++i) {
+      const int d = cg + 8 * i;
+      if (d < a.dh) { outk[d] = (T)ak[i]; outv[d] = (T)av[i]; }
+    }
+  }
+}
+
+}  // namespace mobi
+
+#define ST(s) reinterpret_cast<hipStream_t>(s)
+#define BW_DISPATCH(dtype, KERNEL, grid, ...)                                                                      \
+  do {                                                                                                             \
+    if ((dtype) == MOBI_F16) hipLaunchKernelGGL((KERNEL<mobi::f16_t>), grid, dim3(256), 0, ST(stream), __VA_ARGS__); \
+    else hipLaunchKernelGGL((KERNEL<mobi::bf16_t>), grid, dim3(256), 0, ST(stream), __VA_ARGS__);                  \
+  } while (0)
+
+extern "C" int mobi_transpose(const void* src, int64_t src_row_stride, void* out, int32_t rows, int32_t cols, int32_t dtype,
+                              void* stream) {
+  using namespace mobi;
+  if (!src || !out || rows <= 0 || cols <= 0 || src_row_stride < cols) return MOBI_ERR_ARG;
+  if (dtype != MOBI_F16 && dtype != MOBI_BF16) return MOBI_ERR_ARG;
+  const dim3 grid((cols + 63) / 64, (rows + 63) / 64);
+  if (dtype == MOBI_F16)
+    hipLaunchKernelGGL((transpose_kernel<f16_t>), grid, dim3(256), 0, ST(stream), reinterpret_cast<const f16_t*>(src), src_row_stride,
+                       reinterpret_cast<f16_t*>(out), rows, cols);
+  else
+    hipLaunchKernelGGL((transpose_kernel<bf16_t>), grid, dim3(256), 0, ST(stream), reinterpret_cast<const bf16_t*>(src), src_row_stride,
+                       reinterpret_cast<bf16_t*>(out), rows, cols);
+  MOBI_CHECK_LAUNCH();
+  return MOBI_OK;
+}
+
+extern "C" int32_t mobi_backward_partial_blocks(int64_t rows) {
+  const int64_t b = (rows + 255) / 256;
+  return (int32_t)(b < 1 ? 1 : (b > 256 ? 256 : b));
+}
+
+extern "C" int mobi_colsum(const void* dy, int64_t row_stride, int64_t rows, int32_t cols, int32_t dtype, float* partial,
+                           float* out, void* stream) {
+  using namespace mobi;
+  if (!dy || !partial || !out || rows <= 0 || cols <= 0) return MOBI_ERR_ARG;
+  if (dtype != MOBI_F16 && dtype != MOBI_BF16) return MOBI_ERR_ARG;
+  const int nblk = mobi_backward_partial_blocks(rows);
+  const int rpb = (int)((rows + nblk - 1) / nblk);
+  if (dtype == MOBI_F16)
+    hipLaunchKernelGGL((colsum_kernel<f16_t>), dim3(nblk), dim3(256), 0, ST(stream), reinterpret_cast<const f16_t*>(dy), row_stride, partial, rows, cols, rpb);
+  else
+    hipLaunchKernelGGL((colsum_kernel<bf16_t>), dim3(nblk), dim3(256), 0, ST(stream), reinterpret_cast<const bf16_t*>(dy), row_stride, partial, rows, cols, rpb);
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3((cols + 255) / 256), dim3(256), 0, ST(stream), partial, out, nblk, (long long)cols);
+  MOBI_CHECK_LAUNCH();
+  return MOBI_OK;
+}
+
+extern "C" int mobi_layernorm_bwd(const mobi_layernorm_bwd_params* p, void* stream) {
+  using namespace mobi;
+  if (!p || !p->x || !p->dy || !p->gamma || !p->dx || !p->partial || !p->dgamma_dbeta) return MOBI_ERR_ARG;
+  if (p->dtype != MOBI_F16 && p->dtype != MOBI_BF16) return MOBI_ERR_ARG;
+  if (p->rows <= 0 || p->channels <= 0 || p->channels > 1536) return MOBI_ERR_UNSUPPORTED;
+  const int nblk = mobi_backward_partial_blocks(p->rows);
+  const int rpb = (int)((p->rows + nblk - 1) / nblk);
+  const long long xs = p->x_row_stride ? p->x_row_stride : p->channels, ds = p->dy_row_stride ? p->dy_row_stride : p->channels;
+  if (p->dtype == MOBI_F16)
+    hipLaunchKernelGGL((layernorm_bwd_kernel<f16_t>), dim3(nblk), dim3(256), 0, ST(stream), reinterpret_cast<const f16_t*>(p->x), xs,
+                       reinterpret_cast<const f16_t*>(p->dy), ds, p->gamma, p->eps, reinterpret_cast<const f16_t*>(p->dx_add),
+                       reinterpret_cast<f16_t*>(p->dx), p->partial, (long long)p->rows, p->channels, rpb);
+  else
+    hipLaunchKernelGGL((layernorm_bwd_kernel<bf16_t>), dim3(nblk), dim3(256), 0, ST(stream), reinterpret_cast<const bf16_t*>(p->x), xs,
+                       reinterpret_cast<const bf16_t*>(p->dy), ds, p->gamma, p->eps, reinterpret_cast<const bf16_t*>(p->dx_add),
+                       reinterpret_cast<bf16_t*>(p->dx), p->partial, (long long)p->rows, p->channels, rpb);
+  // partial is [nblk][2][C]: d gamma = sum of the [.][0][.] planes, d beta of the [.][1][.] planes
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3((2 * p->channels + 255) / 256), dim3(256), 0, ST(stream), p->partial, p->dgamma_dbeta, nblk,
+                     (long long)2 * p->channels);
+  MOBI_CHECK_LAUNCH();
+  return MOBI_OK;
+}
+
+extern "C" int mobi_geglu_fwd(const void* pre, void* h, int64_t rows, int32_t inner, int32_t dtype, void* stream) {
+  using namespace mobi;
+  if (!pre || !h || rows <= 0 || inner <= 0) return MOBI_ERR_ARG;
+  if (dtype != MOBI_F16 && dtype != MOBI_BF16) return MOBI_ERR_ARG;
+  const long long n = rows * inner;
+  const dim3 grid((unsigned)((n + 255) / 256 > 65536 ? 65536 : (n + 255) / 256));
+  if (dtype == MOBI_F16) hipLaunchKernelGGL((geglu_fwd_kernel<f16_t>), grid, dim3(256), 0, ST(stream), reinterpret_cast<const f16_t*>(pre), reinterpret_cast<f16_t*>(h), (long long)rows, inner);
+  else hipLaunchKernelGGL((geglu_fwd_kernel<bf16_t>), grid, dim3(256), 0, ST(stream), reinterpret_cast<const bf16_t*>(pre), reinterpret_cast<bf16_t*>(h), (long long)rows, inner);
+  MOBI_CHECK_LAUNCH();
+  return MOBI_OK;
+}
+
+extern "C" int mobi_geglu_bwd(const void* pre, const void* dh, void* dpre, int64_t rows, int32_t inner, int32_t dtype, void* stream) {
+  using namespace mobi;
+  if (!pre || !dh || !dpre || rows <= 0 || inner <= 0) return MOBI_ERR_ARG;
+  if (dtype != MOBI_F16 && dtype != MOBI_BF16) return MOBI_ERR_ARG;
+  const long long n = rows * inner;
+  const dim3 grid((unsigned)((n + 255) / 256 > 65536 ? 65536 : (n + 255) / 256));
+  if (dtype == MOBI_F16) hipLaunchKernelGGL((geglu_bwd_kernel<f16_t>), grid, dim3(256), 0, ST(stream), reinterpret_cast<const f16_t*>(pre), reinterpret_cast<const f16_t*>(dh), reinterpret_cast<f16_t*>(dpre), (long long)rows, inner);
+  else hipLaunchKernelGGL((geglu_bwd_kernel<bf16_t>), grid, dim3(256), 0, ST(stream), reinterpret_cast<const bf16_t*>(pre), reinterpret_cast<const bf16_t*>(dh), reinterpret_cast<bf16_t*>(dpre), (long long)rows, inner);
+  MOBI_CHECK_LAUNCH();
+  return MOBI_OK;
+}
+
+extern "C" int mobi_attention_bwd(const mobi_attention_bwd_params* p, void* stream) {
+  using namespace mobi;
+  if (!p || !p->q || !p->k || !p->v || !p->o || !p->dout || !p->dq || !p->dk || !p->dv || !p->lse || !p->dvec) return MOBI_ERR_ARG;
+  if (p->dtype != MOBI_F16 && p->dtype != MOBI_BF16) return MOBI_ERR_ARG;
+  if (p->images <= 0 || p->heads <= 0 || p->dh <= 0 || p->tq <= 0 || p->tk <= 0) return MOBI_ERR_ARG;
+  if (p->dh > BW_DH) return MOBI_ERR_UNSUPPORTED;
+  AttnBwdArgs a;
+  a.q = p->q; a.k = p->k; a.v = p->v; a.o = p->o; a.dout = p->dout;
+  a.q_is = p->q_img_stride; a.q_rs = p->q_row_stride; a.k_is = p->k_img_stride; a.k_rs = p->k_row_stride;
+  a.v_is = p->v_img_stride; a.v_rs = p->v_row_stride; a.o_is = p->o_img_stride; a.o_rs = p->o_row_stride;
+  a.do_is = p->dout_img_stride; a.do_rs = p->dout_row_stride;
+  a.dq = p->dq; a.dk = p->dk; a.dv = p->dv; a.lse = p->lse; a.dvec = p->dvec;
+  a.heads = p->heads; a.dh = p->dh; a.tq = p->tq; a.tk = p->tk; a.scale = p->scale;
+  const dim3 gq((p->tq + BW_TILE - 1) / BW_TILE, p->heads, p->images), gk((p->tk + BW_TILE - 1) / BW_TILE, p->heads, p->images);
+  BW_DISPATCH(p->dtype, attn_bwd_stats_kernel, gq, a);
+  BW_DISPATCH(p->dtype, attn_bwd_dq_kernel, gq, a);
+  BW_DISPATCH(p->dtype, attn_bwd_dkv_kernel, gk, a);
+  MOBI_CHECK_LAUNCH();
+  return MOBI_OK;
+}

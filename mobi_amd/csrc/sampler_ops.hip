@@ -232,6 +232,8 @@ extern "C" size_t mobi_struct_size(int id) {
     case 14: return sizeof(mobi_ff_geglu_params);
     case 15: return sizeof(mobi_row_chain_params);
     case 16: return sizeof(mobi_chain_op);
+    case 17: return sizeof(mobi_layernorm_bwd_params);
+    case 18: return sizeof(mobi_attention_bwd_params);
     default: return 0;
   }
 }

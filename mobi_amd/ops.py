@@ -432,6 +432,102 @@ def row_chain(programs, images, rows_per_image, dtype, adapter=None, flops=0.0, 
 
 
 # --------------------------------------------------------------------------------------
+# backward pass (first slice of the training step: csrc/backward.hip)
+# --------------------------------------------------------------------------------------
+def transpose(x):
+    """T [rows, cols] (row stride free) -> T [cols, rows] dense."""
+    lib = _lib.load()
+    assert x.dim() == 2 and x.stride(1) == 1
+    rows, cols = x.shape
+    out = torch.empty((cols, rows), device=x.device, dtype=x.dtype)
+    _lib.check(lib.mobi_transpose(_ptr(x), x.stride(0), _ptr(out), rows, cols, _dt(x.dtype), _stream()), "mobi_transpose")
+    return out
+
+
+def colsum(dy):
+    """T [rows, cols] (row stride free) -> fp32 [cols] (a bias gradient; fixed summation order)."""
+    lib = _lib.load()
+    assert dy.dim() == 2 and dy.stride(1) == 1
+    rows, cols = dy.shape
+    part = torch.empty((lib.mobi_backward_partial_blocks(rows), cols), device=dy.device, dtype=torch.float32)
+    out = torch.empty(cols, device=dy.device, dtype=torch.float32)
+    _lib.check(lib.mobi_colsum(_ptr(dy), dy.stride(0), rows, cols, _dt(dy.dtype), _ptr(part), _ptr(out), _stream()), "mobi_colsum")
+    return out
+
+
+def linear_wgrad(dy, x):
+    """dW = dy^T x for y = x W^T: dy T [rows, n], x T [rows, k] (row strides free; rows % 32 == 0) -> fp32 [n, k].
+    Both operands are transposed (mobi_transpose) and multiplied on mobi_igemm with the token axis as k."""
+    rows, n = dy.shape
+    k = x.shape[1]
+    assert x.shape[0] == rows and rows % 32 == 0
+    dyt, xt = transpose(dy), transpose(x)                                    # [n, rows], [k, rows]
+    pw = Packed(xt, None, 1, 1, rows, k, k)
+    return igemm(dyt.view(1, 1, n, rows), pw, out_mode=OUT_ROWS_F32).view(n, k)
+
+
+def layernorm_bwd(x, dy, gamma, eps, dx_add=None):
+    """x, dy: T [N, T, C] (x may be a batch-strided view with dense rows) -> (dx T [N, T, C], d gamma fp32 [C], d beta fp32 [C]);
+    dx_add: T [N, T, C] dense, added to dx (the gradient arriving over the residual branch)."""
+    lib = _lib.load()
+    n, t, c = x.shape
+    x2, dy2 = x.reshape(n * t, c), dy.reshape(n * t, c)                       # (views when dense, copies when strided)
+    dx = torch.empty((n, t, c), device=x.device, dtype=x.dtype)
+    nb = lib.mobi_backward_partial_blocks(n * t)
+    part = torch.empty((nb, 2, c), device=x.device, dtype=torch.float32)
+    dgb = torch.empty((2, c), device=x.device, dtype=torch.float32)
+    p = _lib.LayerNormBwdParams()
+    p.x, p.dy, p.x_row_stride, p.dy_row_stride = _ptr(x2), _ptr(dy2), x2.stride(0), dy2.stride(0)
+    p.gamma, p.eps = _ptr(gamma), eps
+    if dx_add is not None:
+        assert dx_add.is_contiguous() and dx_add.shape == (n, t, c)
+        p.dx_add = _ptr(dx_add)
+    p.dx, p.partial, p.dgamma_dbeta, p.rows, p.channels, p.dtype = _ptr(dx), _ptr(part), _ptr(dgb), n * t, c, _dt(x.dtype)
+    _lib.check(lib.mobi_layernorm_bwd(C.byref(p), _stream()), "mobi_layernorm_bwd")
+    return dx, dgb[0], dgb[1]
+
+
+def geglu_fwd(pre):
+    """pre: T [..., 2 inner] = [value | gate] dense -> value * gelu_erf(gate): T [..., inner]."""
+    lib = _lib.load()
+    assert pre.is_contiguous()
+    inner = pre.shape[-1] // 2
+    h = torch.empty(pre.shape[:-1] + (inner,), device=pre.device, dtype=pre.dtype)
+    _lib.check(lib.mobi_geglu_fwd(_ptr(pre), _ptr(h), pre.numel() // (2 * inner), inner, _dt(pre.dtype), _stream()), "mobi_geglu_fwd")
+    return h
+
+
+def geglu_bwd(pre, dh):
+    lib = _lib.load()
+    assert pre.is_contiguous() and dh.is_contiguous()
+    inner = pre.shape[-1] // 2
+    dpre = torch.empty_like(pre)
+    _lib.check(lib.mobi_geglu_bwd(_ptr(pre), _ptr(dh), _ptr(dpre), pre.numel() // (2 * inner), inner, _dt(pre.dtype), _stream()),
+               "mobi_geglu_bwd")
+    return dpre
+
+
+def attention_bwd(q, k, v, o, dout, heads, scale):
+    """q: T [N, Tq, >= C] view, k / v: T [N, Tk, >= C] views (channel stride 1), o / dout: [N, Tq, C] -> (dq, dk, dv) dense T."""
+    lib = _lib.load()
+    n, tq, tk = q.shape[0], q.shape[1], k.shape[1]
+    c = o.shape[2]
+    new = lambda t_: torch.empty((n, t_, c), device=q.device, dtype=q.dtype)
+    dq, dk, dv = new(tq), new(tk), new(tk)
+    lse = torch.empty((2, n, heads, tq), device=q.device, dtype=torch.float32)
+    p = _lib.AttentionBwdParams()
+    for name, t_ in (("q", q), ("k", k), ("v", v), ("o", o), ("dout", dout)):
+        assert t_.shape[2] == 1 or t_.stride(2) == 1
+        setattr(p, name, _ptr(t_))
+        setattr(p, name + "_img_stride", t_.stride(0))
+        setattr(p, name + "_row_stride", t_.stride(1))
+    p.dq, p.dk, p.dv, p.lse, p.dvec = _ptr(dq), _ptr(dk), _ptr(dv), _ptr(lse[0]), _ptr(lse[1])
+    p.images, p.heads, p.dh, p.tq, p.tk, p.scale, p.dtype = n, heads, c // heads, tq, tk, scale, _dt(q.dtype)
+    _lib.check(lib.mobi_attention_bwd(C.byref(p), _stream()), "mobi_attention_bwd")
+    return dq, dk, dv
+
+
+# --------------------------------------------------------------------------------------
 # matrix-core ops
 # --------------------------------------------------------------------------------------
 def igemm(x, pw: Packed, *, x2=None, stride=1, pad=None, upsample=False, hout=None, wout=None, rowvec=None,

@@ -58,3 +58,39 @@ def test_shard_ranges_cover_exactly():
             assert spans[0][0] == 0 and spans[-1][1] == n
             assert all(spans[i][1] == spans[i + 1][0] for i in range(w - 1))
             assert max(h - l for l, h in spans) - min(h - l for l, h in spans) <= 1
+
+
+def _grad_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from mobi_amd import dist as md
+    g = torch.Generator().manual_seed(100 + rank)
+    shapes = {"a.to_q.weight": (64, 64), "a.to_out.0.bias": (64,), "b.norm.weight": (64,), "c.connector.weight": (64, 64),
+              "d.to_k.weight": (64, 768)}
+    mine = {k: torch.randn(s, generator=g) for k, s in shapes.items()}
+    every = []
+    for r in range(world):
+        gr = torch.Generator().manual_seed(100 + r)
+        every.append({k: torch.randn(s, generator=gr) for k, s in shapes.items()})
+    want = {k: sum(e[k] for e in every) / world for k in shapes}
+    got = md.allreduce_gradients({k: v.clone() for k, v in mine.items()}, bucket_bytes=20000)      # several buckets, one ragged
+    ok = all(torch.allclose(got[k], want[k], atol=1e-6) and got[k].shape == want[k].shape for k in shapes)
+    tot = md.allreduce_gradients({k: v.clone() for k, v in mine.items()}, average=False)
+    ok = ok and all(torch.allclose(tot[k], want[k] * world, atol=1e-5) for k in shapes)
+    q.put((rank, bool(ok)))
+    dist.destroy_process_group()
+
+
+def test_gradient_allreduce_gloo_world2():
+    """The training step's collective (mobi_amd.dist.allreduce_gradients): bucketed, in name order, sum and mean."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_grad_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok in res), res

@@ -1,0 +1,127 @@
+"""GPU parity of the training step's first slice: the backward kernels of csrc/backward.hip one by one
+against torch autograd in fp32 on inputs pre-rounded to the storage type, then the backward pass of a whole
+BasicTransformerBlock (mobi_amd/train.py) against torch.autograd through the CPU oracle's block (oracle/unet.py
+transformer_block = ldm/modules/attention.py:230-266 of the reference): the data gradient and the gradient of every tensor
+the reference's optimizer filter selects (ddpm.py:1616-1629)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import unet as ounet, weights as W
+from tests.golden_cases import record
+from tests.test_gpu_ops import DT, rnd
+
+pytestmark = pytest.mark.gpu
+# gradients are 16-bit tensors between the kernels (as the activations are): 2x the values measured on the MI355X
+# (profiles/r04_error_table.txt) -- one kernel; the block's data gradient; its worst parameter gradient
+# measured: one kernel 4.0e-4 / 3.3e-3 (fp16 / bf16, attention dK); the block's forward 6.8e-4 / 5.5e-3, its data gradient
+# 9.2e-4 / 7.5e-3, its worst parameter gradient 5.5e-3 / 3.4e-2
+TOL1 = {torch.float16: 8e-4, torch.bfloat16: 6.6e-3}
+TOL_DX = {torch.float16: 1.9e-3, torch.bfloat16: 1.5e-2}
+TOL_DW = {torch.float16: 1.1e-2, torch.bfloat16: 6.8e-2}
+
+
+def rel(a, b, name="rel"):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    err = float((a - b).norm() / b.norm().clamp_min(1e-30))
+    record(name, err)
+    return err
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from mobi_amd import ops as o
+    return o
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_transpose_colsum_wgrad(ops, dtype):
+    xf, xd = rnd("bw.x", (1024, 320), dtype)
+    dyf, dyd = rnd("bw.dy", (1024, 96), dtype)
+    assert torch.equal(ops.transpose(xd).cpu(), xd.cpu().t())
+    assert torch.equal(ops.transpose(xd[:, :77]).cpu(), xd.cpu()[:, :77].t())            # strided rows, ragged tiles
+    assert rel(ops.colsum(dyd), dyf.sum(0)) < 1e-5
+    assert rel(ops.linear_wgrad(dyd, xd), dyf.t() @ xf) < 1e-5                           # exact products, fp32 sums
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("n,t,c", [(2, 64, 320), (3, 50, 64), (2, 256, 1280)])
+def test_layernorm_backward(ops, dtype, n, t, c):
+    xf, xd = rnd(f"bw.ln.x{c}", (n, t, c), dtype, 2.0)
+    dyf, dyd = rnd(f"bw.ln.dy{c}", (n, t, c), dtype)
+    addf, addd = rnd(f"bw.ln.add{c}", (n, t, c), dtype)
+    g = torch.from_numpy(W.synth_param(f"bw.ln{c}.weight", (c,)))
+    b = torch.from_numpy(W.synth_param(f"bw.ln{c}.bias", (c,)))
+    x = xf.clone().requires_grad_(True)
+    gp, bp = g.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    F.layer_norm(x, (c,), gp, bp, 1e-5).backward(dyf)
+    dx, dg, db = ops.layernorm_bwd(xd, dyd, g.cuda(), 1e-5, dx_add=addd)
+    assert rel(dx.float(), x.grad + addf) < TOL1[dtype]
+    assert rel(dg, gp.grad) < 1e-4 and rel(db, bp.grad) < 1e-4
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_geglu_forward_backward(ops, dtype):
+    pf, pd = rnd("bw.geglu.pre", (2, 100, 2 * 160), dtype, 1.5)
+    dhf, dhd = rnd("bw.geglu.dh", (2, 100, 160), dtype)
+    p = pf.clone().requires_grad_(True)
+    v, g = p.chunk(2, dim=-1)
+    h = v * F.gelu(g)
+    h.backward(dhf)
+    assert rel(ops.geglu_fwd(pd).float(), h) < TOL1[dtype]
+    assert rel(ops.geglu_bwd(pd, dhd).float(), p.grad) < TOL1[dtype]
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("heads,dh,tq,tk", [(8, 40, 256, 256), (2, 160, 64, 64), (8, 8, 100, 70), (8, 40, 64, 2), (4, 80, 33, 129)])
+def test_attention_backward(ops, dtype, heads, dh, tq, tk):
+    n, c = 2, heads * dh
+    qf, qd = rnd(f"bw.at.q{dh}.{tq}", (n, tq, c), dtype)
+    kf, kd = rnd(f"bw.at.k{dh}.{tk}", (n, tk, c), dtype)
+    vf, vd = rnd(f"bw.at.v{dh}.{tk}", (n, tk, c), dtype)
+    dof, dod = rnd(f"bw.at.do{dh}.{tq}", (n, tq, c), dtype)
+    scale = dh ** -0.5
+    q, k, v = (t.clone().requires_grad_(True) for t in (qf, kf, vf))
+    sp = lambda t: t.reshape(n, -1, heads, dh).permute(0, 2, 1, 3)
+    o = torch.einsum("bhij,bhjd->bhid", (torch.einsum("bhid,bhjd->bhij", sp(q), sp(k)) * scale).softmax(-1), sp(v))
+    o = o.permute(0, 2, 1, 3).reshape(n, tq, c)
+    o.backward(dof)
+    od = o.detach().to(dtype).cuda()
+    dq, dk, dv = ops.attention_bwd(qd, kd, vd, od, dod, heads, scale)
+    for got, want, nm in ((dq, q.grad, "dq"), (dk, k.grad, "dk"), (dv, v.grad, "dv")):
+        assert rel(got.float(), want, nm) < TOL1[dtype], nm
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("c,heads,n,side", [(64, 8, 4, 8), (320, 8, 2, 16)])
+def test_transformer_block_backward_vs_autograd(dtype, c, heads, n, side):
+    import mobi_amd
+    from mobi_amd import train
+    from mobi_amd.ldm.modules import attention as A
+    mobi_amd.set_engine_dtype(dtype)
+    blk = A.BasicTransformerBlock(c, heads, c // heads, context_dim=768, bbox_cond=True, multimodal=True)
+    W.fill_module_(blk, seed=53)
+    sd = {"b." + k: v.detach().clone() for k, v in blk.state_dict().items()}
+    blk = blk.cuda()
+    t = side * side
+    xf, xd = rnd(f"bw.blk.x{c}", (n, t, c), dtype)
+    ctx = W.synth_input(f"bw.blk.ctx{c}", (n, 2, 768))
+    rf, rd = rnd(f"bw.blk.dout{c}", (n, t, c), dtype)
+    # reference: autograd through the oracle's block, fp32 CPU
+    cfg = ounet.UNetConfig(num_heads=heads)
+    ps = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    x = xf.clone().requires_grad_(True)
+    ref_out = ounet.transformer_block(ps, "b", x, ctx, cfg)
+    ref_out.backward(rf)
+    names = train.trainable_names(blk)
+    assert len(names) == 27 and all(ps["b." + k].grad is not None for k in names)
+    out, tape = train.block_forward(blk, xd, ctx.cuda())
+    assert rel(out.float(), ref_out.detach(), "fwd") < TOL_DX[dtype]
+    dx, grads = train.block_backward(blk, tape, rd)
+    assert sorted(grads) == sorted(names)
+    assert rel(dx.float(), x.grad, "dx") < TOL_DX[dtype]
+    worst = max(rel(grads[k], ps["b." + k].grad, "dw") for k in names)
+    assert worst < TOL_DW[dtype], worst
+    # frozen tensors get no gradient, and the result does not depend on the order of calls (fixed-order reductions)
+    dx2, grads2 = train.block_backward(blk, tape, rd)
+    assert torch.equal(dx, dx2) and all(torch.equal(grads[k], grads2[k]) for k in names)
