@@ -334,6 +334,16 @@ int mobi_layernorm_bwd(const mobi_layernorm_bwd_params* p, void* stream);
 /* pre: T [rows][2 inner] = [value | gate] (GEGLU.proj's output, un-fused); h = value * gelu_erf(gate): T [rows][inner]. */
 int mobi_geglu_fwd(const void* pre, void* h, int64_t rows, int32_t inner, int32_t dtype, void* stream);
 int mobi_geglu_bwd(const void* pre, const void* dh, void* dpre, int64_t rows, int32_t inner, int32_t dtype, void* stream);
+/* GroupNorm (32 groups) (+ SiLU) backward, data gradient only (the UNet's GroupNorm parameters are frozen):
+ * x, dy, dx (and dx_add, or NULL): T [image][hw][channels] dense.  Replaces autograd through GroupNorm32 + SiLU
+ * (util.py:199-216, openaimodel.py:211-236) and Normalize (attention.py:77-78). */
+int mobi_groupnorm_bwd(const void* x, const void* dy, const float* gamma, const float* beta, float eps, int32_t silu,
+                       const void* dx_add, void* dx, int32_t images, int32_t hw, int32_t channels, int32_t dtype, void* stream);
+/* out[image][y][x][c] = sum of the 2 x 2 pixels src[image][2y..][2x..][c]: the backward of F.interpolate(nearest, x2)
+ * (openaimodel.py:116).  src: T [image][2h][2w][channels]. */
+int mobi_sumpool2(const void* src, void* out, int32_t images, int32_t h, int32_t w, int32_t channels, int32_t dtype, void* stream);
+/* out = a + b over n elements of T (two gradients meeting at a fork: a skip connection's consumers). */
+int mobi_add(const void* a, const void* b, void* out, int64_t n, int32_t dtype, void* stream);
 typedef struct mobi_attention_bwd_params {
   const void* q; int64_t q_img_stride, q_row_stride;       /* T [image][tq][>= heads*dh], strides in elements */
   const void* k; int64_t k_img_stride, k_row_stride;       /* T [image][tk][..] */

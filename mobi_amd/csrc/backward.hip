@@ -358,6 +358,89 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnBwdArgs a) 
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// GroupNorm (32 groups) (+ SiLU) backward, data gradient only (the affine parameters of the UNet's GroupNorms are frozen):
+//   z = xh gamma + beta, y = act(z);  dxh = dy act'(z) gamma;  dx = rstd (dxh - mean_g(dxh) - xh mean_g(dxh xh)) (+ dx_add)
+// One block per (image, group); statistics re-derived from x (mean, then variance about the mean), four passes over the
+// group's [hw][C / 32] slab.  x, dy, dx: T [image][hw][C] dense.
+template <typename T>
+__global__ __launch_bounds__(256) void groupnorm_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, float eps, int silu,
+                                                            const T* __restrict__ dx_add, T* __restrict__ dx, int hw, int C) {
+  __shared__ float red[8];
+  const int G = C / 32, g = blockIdx.x, img = blockIdx.y, tid = threadIdx.x;
+  const long long base = (long long)img * hw * C + g * G;
+  auto block_sum = [&](float v) {
+    v = wave_sum(v);
+    __syncthreads();
+    if ((tid & 63) == 0) red[tid >> 6] = v;
+    __syncthreads();
+    return (red[0] + red[1]) + (red[2] + red[3]);
+  };
+  const float inv_m = 1.0f / ((float)G * (float)hw);
+  float s = 0.f;
+  for (int p = tid; p < hw; p += 256)
+    for (int c = 0; c < G; ++c) s += (float)x[base + (long long)p * C + c];
+  const float mean = block_sum(s) * inv_m;
+  s = 0.f;
+  for (int p = tid; p < hw; p += 256)
+    for (int c = 0; c < G; ++c) { const float d = (float)x[base + (long long)p * C + c] - mean; s += d * d; }
+  const float rstd = rsqrtf(block_sum(s) * inv_m + eps);
+  auto dxh_of = [&](long long off, int c, float& xh) {
+    xh = ((float)x[off] - mean) * rstd;
+    const float ga = gamma[g * G + c];
+    float d = (float)dy[off];
+    if (silu) {
+      const float z = xh * ga + beta[g * G + c];
+      const float sg = 1.0f / (1.0f + __expf(-z));
+      d *= sg * (1.0f + z * (1.0f - sg));
+    }
+    return d * ga;
+  };
+  float s1 = 0.f, s2 = 0.f;
+  for (int p = tid; p < hw; p += 256)
+    for (int c = 0; c < G; ++c) {
+      float xh;
+      const float d = dxh_of(base + (long long)p * C + c, c, xh);
+      s1 += d;
+      s2 += d * xh;
+    }
+  const float m1 = block_sum(s1) * inv_m;
+  const float m2 = block_sum(s2) * inv_m;
+  for (int p = tid; p < hw; p += 256)
+    for (int c = 0; c < G; ++c) {
+      const long long off = base + (long long)p * C + c;
+      float xh;
+      const float d = dxh_of(off, c, xh);
+      float v = rstd * (d - m1 - xh * m2);
+      if (dx_add) v += (float)dx_add[off];
+      dx[off] = (T)v;
+    }
+}
+
+// out = a + b (gradients meeting at a fork of the graph: a skip connection's two consumers)
+template <typename T>
+__global__ __launch_bounds__(256) void add_kernel(const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ out, long long n) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256)
+    out[i] = (T)((float)a[i] + (float)b[i]);
+}
+
+// sum of every 2 x 2 block of pixels: src T [image][2h][2w][C] -> out T [image][h][w][C] (the backward of nearest x2)
+template <typename T>
+__global__ __launch_bounds__(256) void sumpool2_kernel(const T* __restrict__ src, T* __restrict__ out, int n, int h, int w, int C) {
+  const long long total = (long long)n * h * w * C;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int c = (int)(i % C);
+    long long r = i / C;
+    const int xo = (int)(r % w);
+    r /= w;
+    const int yo = (int)(r % h), im = (int)(r / h);
+    const long long b = (((long long)im * 2 * h + 2 * yo) * 2 * w + 2 * xo) * C + c;
+    const float v = ((float)src[b] + (float)src[b + C]) + ((float)src[b + (long long)2 * w * C] + (float)src[b + (long long)2 * w * C + C]);
+    out[i] = (T)v;
+  }
+}
+
 }  // namespace mobi
 
 #define ST(s) reinterpret_cast<hipStream_t>(s)
@@ -468,6 +551,48 @@ extern "C" int mobi_attention_bwd(const mobi_attention_bwd_params* p, void* stre
   BW_DISPATCH(p->dtype, attn_bwd_stats_kernel, gq, a);
   BW_DISPATCH(p->dtype, attn_bwd_dq_kernel, gq, a);
   BW_DISPATCH(p->dtype, attn_bwd_dkv_kernel, gk, a);
+  MOBI_CHECK_LAUNCH();
+  return MOBI_OK;
+}
+
+extern "C" int mobi_groupnorm_bwd(const void* x, const void* dy, const float* gamma, const float* beta, float eps, int32_t silu,
+                                  const void* dx_add, void* dx, int32_t images, int32_t hw, int32_t channels, int32_t dtype,
+                                  void* stream) {
+  using namespace mobi;
+  if (!x || !dy || !gamma || !beta || !dx || images <= 0 || hw <= 0) return MOBI_ERR_ARG;
+  if (dtype != MOBI_F16 && dtype != MOBI_BF16) return MOBI_ERR_ARG;
+  if (channels <= 0 || channels % 32) return MOBI_ERR_UNSUPPORTED;
+  const dim3 grid(32, images);
+  if (dtype == MOBI_F16)
+    hipLaunchKernelGGL((groupnorm_bwd_kernel<f16_t>), grid, dim3(256), 0, ST(stream), reinterpret_cast<const f16_t*>(x), reinterpret_cast<const f16_t*>(dy),
+                       gamma, beta, eps, silu, reinterpret_cast<const f16_t*>(dx_add), reinterpret_cast<f16_t*>(dx), hw, channels);
+  else
+    hipLaunchKernelGGL((groupnorm_bwd_kernel<bf16_t>), grid, dim3(256), 0, ST(stream), reinterpret_cast<const bf16_t*>(x), reinterpret_cast<const bf16_t*>(dy),
+                       gamma, beta, eps, silu, reinterpret_cast<const bf16_t*>(dx_add), reinterpret_cast<bf16_t*>(dx), hw, channels);
+  MOBI_CHECK_LAUNCH();
+  return MOBI_OK;
+}
+
+extern "C" int mobi_sumpool2(const void* src, void* out, int32_t images, int32_t h, int32_t w, int32_t channels, int32_t dtype,
+                             void* stream) {
+  using namespace mobi;
+  if (!src || !out || images <= 0 || h <= 0 || w <= 0 || channels <= 0) return MOBI_ERR_ARG;
+  if (dtype != MOBI_F16 && dtype != MOBI_BF16) return MOBI_ERR_ARG;
+  const long long total = (long long)images * h * w * channels;
+  const dim3 grid((unsigned)((total + 255) / 256 > 65536 ? 65536 : (total + 255) / 256));
+  if (dtype == MOBI_F16) hipLaunchKernelGGL((sumpool2_kernel<f16_t>), grid, dim3(256), 0, ST(stream), reinterpret_cast<const f16_t*>(src), reinterpret_cast<f16_t*>(out), images, h, w, channels);
+  else hipLaunchKernelGGL((sumpool2_kernel<bf16_t>), grid, dim3(256), 0, ST(stream), reinterpret_cast<const bf16_t*>(src), reinterpret_cast<bf16_t*>(out), images, h, w, channels);
+  MOBI_CHECK_LAUNCH();
+  return MOBI_OK;
+}
+
+extern "C" int mobi_add(const void* a, const void* b, void* out, int64_t n, int32_t dtype, void* stream) {
+  using namespace mobi;
+  if (!a || !b || !out || n <= 0) return MOBI_ERR_ARG;
+  if (dtype != MOBI_F16 && dtype != MOBI_BF16) return MOBI_ERR_ARG;
+  const dim3 grid((unsigned)((n + 255) / 256 > 65536 ? 65536 : (n + 255) / 256));
+  if (dtype == MOBI_F16) hipLaunchKernelGGL((add_kernel<f16_t>), grid, dim3(256), 0, ST(stream), reinterpret_cast<const f16_t*>(a), reinterpret_cast<const f16_t*>(b), reinterpret_cast<f16_t*>(out), (long long)n);
+  else hipLaunchKernelGGL((add_kernel<bf16_t>), grid, dim3(256), 0, ST(stream), reinterpret_cast<const bf16_t*>(a), reinterpret_cast<const bf16_t*>(b), reinterpret_cast<bf16_t*>(out), (long long)n);
   MOBI_CHECK_LAUNCH();
   return MOBI_OK;
 }

@@ -61,7 +61,7 @@ class DDPM(nn.Module):
         self.v_posterior = v_posterior
         self.loss_type, self.l_simple_weight, self.original_elbo_weight = loss_type, l_simple_weight, original_elbo_weight
         if learn_logvar:
-            raise NotImplementedError("learn_logvar needs the backward pass (training row, not built)")
+            raise NotImplementedError("learn_logvar: the engine's backward pass covers the UNet's adapter tensors, not logvar")
         self.learn_logvar = learn_logvar
         if monitor is not None:
             self.monitor = monitor
@@ -326,58 +326,57 @@ class LatentDiffusion(DDPM):
             out["cond"] = {kk: cat_interleave([d[kk] for d in out["cond"]]) for kk in self.cond_stage_key}
         return out
 
-    # ---- loss side of the training / validation step (forward only) --------------------------------------------------
+    # ---- training / validation step: the loss, and (training_step) the adapter gradients on the engine ------------------
     def shared_step(self, batch, **kwargs):
         """ddpm.py:1036-1038: batch -> (loss, loss dict)."""
         data = self.get_input(batch, self.first_stage_key)
         return self(data["z"], data["cond"])
 
-    def forward(self, x, c, *args, **kwargs):
-        """ddpm.py:1040-1058: a random timestep per element, the conditioning (encoded here when the conditioning stage is
-        trainable), with probability `u_cond_percent` replaced by the learnt unconditional vectors; then `p_losses`."""
+    def _draw_step(self, x, c):
+        """What ddpm.py:1040-1058 decides per call: a timestep per element, and -- with probability `u_cond_percent` -- the
+        learnt unconditional tokens in place of the conditioning (the draw is kept in `self.u_cond_prop` as there)."""
         import random
         t = torch.randint(0, self.num_timesteps, (x.shape[0],), device=self.device).long()
-        self.u_cond_prop = random.uniform(0, 1)
         if self.model.conditioning_key is not None:
             assert c is not None
             if self.cond_stage_trainable:
                 c = self.get_learned_conditioning(c)
+        self.u_cond_prop = random.uniform(0, 1)
         if self.u_cond_prop < self.u_cond_percent:
-            c = [self.learnable_vector.repeat(x.shape[0], 1, 1)]
-            if "ref_bbox" in self.cond_stage_key:
-                c.append(self.bbox_uncond_vector.repeat(x.shape[0], 1, 1))
-            c = torch.cat(c, dim=1)
+            toks = [self.learnable_vector] + ([self.bbox_uncond_vector] if "ref_bbox" in self.cond_stage_key else [])
+            c = torch.cat([v.repeat(x.shape[0], 1, 1) for v in toks], dim=1)
+        return t, c
+
+    def forward(self, x, c, *args, **kwargs):
+        t, c = self._draw_step(x, c)
         return self.p_losses(x, c, t, *args, **kwargs)
+
+    def _noised_input(self, x_start, t, noise):
+        """The UNet's input of a training step (ddpm.py:1179-1187): the 4 latent channels noised to level t on the engine
+        (`mobi_q_sample`), the inpainting channels (masked latent, mask) passed through -> (x_noisy, target = the noise)."""
+        inpaint = self.first_stage_key == "inpaint"
+        clean = x_start[:, :4] if inpaint else x_start
+        noise = default(noise, lambda: torch.randn_like(clean))
+        x_noisy = self.q_sample(x_start=clean, t=t, noise=noise)
+        if inpaint:
+            x_noisy = torch.cat((x_noisy, x_start[:, 4:].float()), dim=1)
+        return x_noisy, noise.float()
+
+    def _loss_terms(self, loss_simple, t):
+        """loss_simple [N] -> (loss, dict) with the weights of ddpm.py:1196-1216: l_simple_weight * mean(loss_simple /
+        exp(logvar_t) + logvar_t) + original_elbo_weight * mean(lvlb_weights_t * loss_simple)."""
+        prefix = "train" if self.training else "val"
+        logvar_t = self.logvar[t].to(self.device)
+        loss_vlb = (self.lvlb_weights[t] * loss_simple).mean()
+        loss = self.l_simple_weight * (loss_simple / torch.exp(logvar_t) + logvar_t).mean() + self.original_elbo_weight * loss_vlb
+        return loss, {f"{prefix}/loss_simple": loss_simple.mean(), f"{prefix}/loss_vlb": loss_vlb, f"{prefix}/loss": loss}
 
     @torch.no_grad()
     def p_losses(self, x_start, cond, t, noise=None):
-        """ddpm.py:1177-1217 (eps-parameterisation): noise the 4 latent channels (`mobi_q_sample`), keep the inpainting
-        channels, one UNet evaluation on the engine, then
-          loss_simple = mean over (C, H, W) of get_loss(eps_hat, noise);   loss = l_simple_weight * mean(loss_simple /
-          exp(logvar[t]) + logvar[t]) + original_elbo_weight * mean(lvlb_weights[t] * loss_simple).
-        Forward only: the engine has no backward pass, hence no_grad."""
-        if self.first_stage_key == "inpaint":
-            noise = default(noise, lambda: torch.randn_like(x_start[:, :4, :, :]))
-            x_noisy = self.q_sample(x_start=x_start[:, :4, :, :], t=t, noise=noise)
-            x_noisy = torch.cat((x_noisy, x_start[:, 4:, :, :].float()), dim=1)
-        else:
-            noise = default(noise, lambda: torch.randn_like(x_start))
-            x_noisy = self.q_sample(x_start=x_start, t=t, noise=noise)
+        """ddpm.py:1177-1217 (eps-parameterisation), forward only: one UNet evaluation on the engine."""
+        x_noisy, target = self._noised_input(x_start, t, noise)
         model_output = self.apply_model(x_noisy, t, cond)
-        prefix = "train" if self.training else "val"
-        target = noise.float()
-        loss_dict = {}
-        loss_simple = self.get_loss(model_output, target, mean=False).mean([1, 2, 3])
-        loss_dict.update({f"{prefix}/loss_simple": loss_simple.mean()})
-        logvar_t = self.logvar[t].to(self.device)
-        loss = loss_simple / torch.exp(logvar_t) + logvar_t
-        loss = self.l_simple_weight * loss.mean()
-        loss_vlb = self.get_loss(model_output, target, mean=False).mean(dim=(1, 2, 3))
-        loss_vlb = (self.lvlb_weights[t] * loss_vlb).mean()
-        loss_dict.update({f"{prefix}/loss_vlb": loss_vlb})
-        loss += (self.original_elbo_weight * loss_vlb)
-        loss_dict.update({f"{prefix}/loss": loss})
-        return loss, loss_dict
+        return self._loss_terms(self.get_loss(model_output, target, mean=False).mean([1, 2, 3]), t)
 
     def validation_step(self, batch, batch_idx=0):
         """ddpm.py:372-378 without the Lightning logger: the loss dict (and its `_ema` twin: use_ema is False)."""
@@ -386,9 +385,35 @@ class LatentDiffusion(DDPM):
             _, loss_dict_ema = self.shared_step(batch)
         return {**loss_dict, **{k + "_ema": v for k, v in loss_dict_ema.items()}}
 
-    def training_step(self, batch, batch_idx=0):
-        raise NotImplementedError("the engine evaluates the training loss (shared_step) but has no backward pass: "
-                                  "SURVEY.md section 8(f) row 4 is not built")
+    @torch.no_grad()
+    def training_step(self, batch, batch_idx=0, t=None, noise=None, loss_scale=None, allreduce=True):
+        """ddpm.py:356-370 of the reference + what Lightning does around it (autograd backward, DDP's gradient all-reduce,
+        main.py:510): returns the loss and leaves `self.adapter_grads` = {`model.diffusion_model.<name>`: fp32 gradient} for
+        every UNet tensor the reference's optimizer filter selects (ddpm.py:1616-1629: `cond_adapter*`, `cross_modal*` --
+        432 tensors, 180 M parameters), computed by the engine's backward pass (mobi_amd/train.py) and summed over the ranks
+        (mobi_amd.dist.allreduce_gradients).  FIRST SLICE of SURVEY 8(f) row 4: l2 loss with the default weights
+        (`learn_logvar=False`, `original_elbo_weight=0`: the gradient of mean(loss_simple)); the conditioning stage's
+        trainable tensors (bbox embedder, `bbox_uncond_vector`) and the optimizer step are not built."""
+        from .... import dist as mdist, engine_dtype, train
+        if self.loss_type != "l2" or self.parameterization != "eps" or self.learn_logvar or self.original_elbo_weight != 0:
+            raise NotImplementedError("the engine's training step covers the eps / l2 simple loss MObI trains with")
+        data = self.get_input(batch, self.first_stage_key)
+        x, c = data["z"], data["cond"]
+        t_draw, c = self._draw_step(x, c)
+        t = t_draw if t is None else t
+        x_noisy, target = self._noised_input(x, t, noise)
+        if loss_scale is None:                   # fp16 gradients underflow at production sizes without it; bf16 has the range
+            loss_scale = 1024.0 if engine_dtype() == torch.float16 else 1.0
+        logvar_t = self.logvar[t].to(self.device)                      # (zeros unless a checkpoint says otherwise)
+        if bool((logvar_t != 0).any()):
+            raise NotImplementedError("per-timestep logvar weights in the backward pass")
+        mse, grads = train.loss_and_gradients(self.model.diffusion_model, x_noisy, t, c, target, loss_scale=loss_scale)
+        if self.l_simple_weight != 1.0:
+            grads = {k: ops.lincomb4([g.contiguous()], [float(self.l_simple_weight)]) for k, g in grads.items()}
+        if allreduce:
+            mdist.allreduce_gradients(grads)
+        self.adapter_grads = {"model.diffusion_model." + k: v for k, v in grads.items()}
+        return self.l_simple_weight * mse
 
     def apply_model(self, x_noisy, t, cond, return_ids=False):
         """x_noisy: fp32 [N, 9, h, w] or the un-concatenated list [x, inpaint_image, inpaint_mask]."""

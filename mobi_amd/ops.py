@@ -460,7 +460,10 @@ def linear_wgrad(dy, x):
     Both operands are transposed (mobi_transpose) and multiplied on mobi_igemm with the token axis as k."""
     rows, n = dy.shape
     k = x.shape[1]
-    assert x.shape[0] == rows and rows % 32 == 0
+    assert x.shape[0] == rows
+    if rows % 32:
+        # a handful of token rows (the 1 x 1 ... 4 x 4 levels of a small latent): fp32 FMA chains instead of the matrix cores
+        return linear_f32(dy.float().t().contiguous(), x.float().t().contiguous())
     dyt, xt = transpose(dy), transpose(x)                                    # [n, rows], [k, rows]
     pw = Packed(xt, None, 1, 1, rows, k, k)
     return igemm(dyt.view(1, 1, n, rows), pw, out_mode=OUT_ROWS_F32).view(n, k)
@@ -485,6 +488,36 @@ def layernorm_bwd(x, dy, gamma, eps, dx_add=None):
     p.dx, p.partial, p.dgamma_dbeta, p.rows, p.channels, p.dtype = _ptr(dx), _ptr(part), _ptr(dgb), n * t, c, _dt(x.dtype)
     _lib.check(lib.mobi_layernorm_bwd(C.byref(p), _stream()), "mobi_layernorm_bwd")
     return dx, dgb[0], dgb[1]
+
+
+def groupnorm_bwd(x, dy, gamma, beta, eps, silu, dx_add=None):
+    """x, dy: T [N, H, W, C] dense -> dx (+ dx_add) of GroupNorm(32 groups)(+ SiLU); the affine parameters are frozen."""
+    lib = _lib.load()
+    n, h, w, c = x.shape
+    assert x.is_contiguous() and dy.is_contiguous() and dy.shape == x.shape and (dx_add is None or dx_add.is_contiguous())
+    dx = torch.empty_like(x)
+    _lib.check(lib.mobi_groupnorm_bwd(_ptr(x), _ptr(dy), _ptr(gamma), _ptr(beta), eps, int(silu), _ptr(dx_add), _ptr(dx), n, h * w, c,
+                                      _dt(x.dtype), _stream()), "mobi_groupnorm_bwd")
+    return dx
+
+
+def sumpool2(src):
+    """T [N, 2h, 2w, C] -> T [N, h, w, C]: sums of the 2 x 2 pixel blocks (backward of nearest x2 upsampling)."""
+    lib = _lib.load()
+    n, h2, w2, c = src.shape
+    assert src.is_contiguous() and h2 % 2 == 0 and w2 % 2 == 0
+    out = torch.empty((n, h2 // 2, w2 // 2, c), device=src.device, dtype=src.dtype)
+    _lib.check(lib.mobi_sumpool2(_ptr(src), _ptr(out), n, h2 // 2, w2 // 2, c, _dt(src.dtype), _stream()), "mobi_sumpool2")
+    return out
+
+
+def add(a, b):
+    """T + T -> T (dense, same shape)."""
+    lib = _lib.load()
+    assert a.is_contiguous() and b.is_contiguous() and a.shape == b.shape and a.dtype == b.dtype
+    out = torch.empty_like(a)
+    _lib.check(lib.mobi_add(_ptr(a), _ptr(b), _ptr(out), a.numel(), _dt(a.dtype), _stream()), "mobi_add")
+    return out
 
 
 def geglu_fwd(pre):

@@ -1,19 +1,22 @@
-"""First slice of the training step: forward WITH a tape and the backward pass of one
-`BasicTransformerBlock` on the engine -- every trainable tensor of the reference's optimizer filter that lives in a block
-(`cond_adapter*`, `cross_modal*`: ldm/models/diffusion/ddpm.py:1616-1629 of the reference; 27 tensors per block) gets its
-gradient, and the data gradient is handed on to the block's input (ldm/modules/attention.py:230-266 is what is
-differentiated; torch.autograd does this for the reference).
+"""The training step of the adapter parameters on the engine: forward WITH a tape and the backward
+pass through the WHOLE UNet -- every tensor the reference's optimizer filter selects (`cond_adapter*`, `cross_modal*`:
+ldm/models/diffusion/ddpm.py:1616-1629 of the reference; 27 tensors in each of the 16 transformer blocks = 432 tensors,
+180 M parameters at full width) gets its gradient.  ldm/modules/attention.py:230-266 and
+ldm/modules/diffusionmodules/openaimodel.py:255-275, 861-898 are what is differentiated; torch.autograd does this for the
+reference, Lightning's DDP all-reduces the result (main.py:510).
 
-What runs where: the products -- y = x W^T, dx = dy W, dW = dy^T x -- are mobi_igemm launches (the last on operands
-transposed by mobi_transpose, token axis as k, fp32 result); LayerNorm, GEGLU and attention have backward kernels of their
-own (csrc/backward.hip: correct and bit-reproducible, not tuned).  The training forward is the UN-folded sequence: the
-sampling path's algebra (two-key adapter tables, connector o to_out, LayerNorm folded into to_q, the row chains) bakes
-trainable weights into per-run constants and has no place here.  Frozen layers (attn1, attn2, the feed-forward, norm1 /
-norm3) only pass the data gradient on.
+What runs where: the products -- y = x W^T, dx = dy W, dW = dy^T x, and the data gradients of the 3 x 3 / strided /
+upsampling convolutions (the kernel rotated by 180 degrees with its in / out axes swapped; stride 2: dy spread onto the even
+pixels first; nearest x2: 2 x 2 sums after) -- are mobi_igemm launches; LayerNorm, GroupNorm (+ SiLU), GEGLU and attention
+have backward kernels of their own (csrc/backward.hip: correct and bit-reproducible, NOT tuned: fp32 vector arithmetic).
+The training forward is the UN-folded sequence: the sampling path's algebra (two-key adapter tables, connector o to_out,
+LayerNorm folded into to_q, the row chains, the un-materialised skip concat) bakes trainable weights into per-run constants
+or hides tensors the backward pass needs, and has no place here.  Frozen layers only pass the data gradient on.
 
-Not built yet (the rest of row 4): the same for ResBlock / GroupNorm / the convolutions' data gradients, i.e. the chain
-through the whole UNet, the loss scaling an fp16 run needs, the optimizer step.  `mobi_amd.dist.allreduce_gradients` is the
-gradient collective (bucketed, RCCL; gloo on CPU in the tests).
+Pinned to torch.autograd through the CPU oracle (tests/test_gpu_backward.py): one block, and the reduced UNet end to end.
+Not built: the conditioning stage's trainable tensors (bbox embedder, `bbox_uncond_vector`: ddpm.py:1635-1647), `logvar`,
+the optimizer step, activation checkpointing (the tape of a full-width step at 64 x 64 x 16 is tens of GB: fine in 288 GB).
+`mobi_amd.dist.allreduce_gradients` is the gradient collective (bucketed, RCCL; gloo on CPU in the tests).
 """
 import torch
 
@@ -165,3 +168,177 @@ def block_backward(blk, tape, dout):
     dxn1 = _dgrad(dv, a1m.to_v, residual=_dgrad(dk, a1m.to_k, residual=_dgrad(dq, a1m.to_q)))
     dx, _, _ = ops.layernorm_bwd(t.x, dxn1, blk.norm1.affine()[0], blk.norm1.eps, dx_add=dx2)
     return dx, g
+
+
+# ======================================================================================================================
+# The whole UNet (openaimodel.py:861-898 of the reference): forward with a tape, backward to every adapter tensor
+# ======================================================================================================================
+def _conv_dgrad_pack(conv):
+    """Data gradient of a stride-1 convolution = the convolution of dy with the kernel rotated by 180 degrees and its
+    in / out axes swapped (the same padding for the odd kernels used here): packed once like any other weight."""
+    key = (conv.weight._version, conv.weight.data_ptr(), engine_dtype())
+    c = conv.__dict__.setdefault("_dgrad_pack", {})
+    if c.get("key") != key:
+        w = conv.weight.detach().flip(2, 3).transpose(0, 1).contiguous()
+        c["key"], c["val"] = key, ops.pack_conv(w, None, engine_dtype(), conv.weight.device)
+    return c["val"]
+
+
+def _res_forward(rb, x, embd, skip):
+    lo, hi = rb._emb_slice
+    emb_out = embd["proj"][:, lo:hi]                           # (carries conv1's bias: UNetModel._emb_projection)
+    xin = x if skip is None else torch.cat([x, skip], dim=3)  # the concat IS materialised here: its gradient is split below
+    n1, n2 = rb.in_layers[0], rb.out_layers[0]
+    a1 = ops.groupnorm(xin, *n1.affine(), n1.eps, silu=True)
+    h1 = ops.igemm(a1, rb.in_layers[2].packed(), rowvec=emb_out, rowvec_has_bias=True)
+    a2 = ops.groupnorm(h1, *n2.affine(), n2.eps, silu=True)
+    has_conv = not isinstance(rb.skip_connection, torch.nn.Identity) and hasattr(rb.skip_connection, "weight")
+    xs = ops.igemm(xin, rb.skip_connection.packed()) if has_conv else xin
+    out = ops.igemm(a2, rb.out_layers[3].packed(), residual=xs)
+    return out, (xin, h1, x.shape[3], has_conv)
+
+
+def _res_backward(rb, tape, dout):
+    xin, h1, c0, has_conv = tape
+    n1, n2 = rb.in_layers[0], rb.out_layers[0]
+    da2 = ops.igemm(dout, _conv_dgrad_pack(rb.out_layers[3]))
+    dh1 = ops.groupnorm_bwd(h1, da2, *n2.affine(), n2.eps, True)
+    da1 = ops.igemm(dh1, _conv_dgrad_pack(rb.in_layers[2]))
+    dside = ops.igemm(dout, _conv_dgrad_pack(rb.skip_connection)) if has_conv else dout
+    dxin = ops.groupnorm_bwd(xin, da1, *n1.affine(), n1.eps, True, dx_add=dside)
+    if c0 < xin.shape[3]:
+        return dxin[..., :c0].contiguous(), dxin[..., c0:].contiguous()
+    return dxin, None
+
+
+def _st_forward(st, x, context):
+    n, h, w, c = x.shape
+    g, b = st.norm.affine()
+    t = ops.igemm(ops.groupnorm(x, g, b, st.norm.eps, silu=False), st.proj_in.packed())
+    t = t.view(n, h * w, t.shape[3])
+    tapes = []
+    for blk in st.transformer_blocks:
+        t, tp = block_forward(blk, t, context)
+        tapes.append(tp)
+    return ops.igemm(t.view(n, h, w, t.shape[2]), st.proj_out.packed(), residual=x), (x, tapes)
+
+
+def _st_backward(st, tape, dout, grads, prefix):
+    x, tapes = tape
+    n, h, w, c = x.shape
+    dt = ops.igemm(dout, _conv_dgrad_pack(st.proj_out))
+    dt = dt.view(n, h * w, dt.shape[3])
+    for i in reversed(range(len(tapes))):
+        dt, g = block_backward(st.transformer_blocks[i], tapes[i], dt)
+        grads.update({f"{prefix}.transformer_blocks.{i}.{k}": v for k, v in g.items()})
+    dxn = ops.igemm(dt.view(n, h, w, dt.shape[2]), _conv_dgrad_pack(st.proj_in))
+    g, b = st.norm.affine()
+    return ops.groupnorm_bwd(x, dxn, g, b, st.norm.eps, False, dx_add=dout)
+
+
+def _seq_forward(seq, h, embd, context, skip=None):
+    from .ldm.modules.attention import SpatialTransformer
+    from .ldm.modules.diffusionmodules.openaimodel import Downsample, ResBlock, Upsample, _plain_conv
+    tapes = []
+    for layer in seq:
+        if isinstance(layer, ResBlock):
+            h, tp = _res_forward(layer, h, embd, skip)
+            skip = None
+        elif isinstance(layer, SpatialTransformer):
+            h, tp = _st_forward(layer, h, context)
+        elif isinstance(layer, (Downsample, Upsample)):
+            tp, h = tuple(h.shape), layer(h)
+        else:
+            h, tp = _plain_conv(layer, h), None          # input_blocks.0: nothing trainable in front of it, the gradient stops
+        tapes.append(tp)
+    return h, tapes
+
+
+def _seq_backward(seq, tapes, dh, grads, prefix):
+    from .ldm.modules.attention import SpatialTransformer
+    from .ldm.modules.diffusionmodules.openaimodel import Downsample, ResBlock, Upsample
+    dskip = None
+    for i in reversed(range(len(seq))):
+        layer, tp = seq[i], tapes[i]
+        if isinstance(layer, ResBlock):
+            dh, dskip = _res_backward(layer, tp, dh)
+        elif isinstance(layer, SpatialTransformer):
+            dh = _st_backward(layer, tp, dh, grads, f"{prefix}.{i}")
+        elif isinstance(layer, Upsample):
+            dh = ops.sumpool2(ops.igemm(dh, _conv_dgrad_pack(layer.conv)))       # nearest x2, then the convolution
+        elif isinstance(layer, Downsample):
+            # stride 2: dy spread onto the even pixels of the input grid (placement), then the stride-1 data gradient
+            n, ho, wo, c = dh.shape
+            dz = torch.zeros((n, tp[1], tp[2], c), device=dh.device, dtype=dh.dtype)
+            dz[:, : 2 * ho: 2, : 2 * wo: 2] = dh
+            dh = ops.igemm(dz, _conv_dgrad_pack(layer.op))
+        else:
+            dh = None
+    return dh, dskip
+
+
+def unet_forward(net, x, timesteps, context):
+    """UNetModel.forward for training: x fp32 [N, in_channels, h, w] -> (eps fp32 [N, out_channels, h, w], tape)."""
+    from ._lib import ACT_SILU
+    from .ldm.modules.diffusionmodules.util import timestep_embedding
+    t_emb = timestep_embedding(timesteps, net.model_channels)
+    w0, b0 = net.time_embed[0].skinny()
+    w2, b2 = net.time_embed[2].skinny()
+    emb = ops.skinny_linear(ops.skinny_linear(t_emb, w0, b0, post_act=ACT_SILU), w2, b2)
+    we, be = net._emb_projection()
+    embd = {"emb": emb, "proj": ops.skinny_linear(emb, we, be, pre_act=ACT_SILU)}
+    context = context.float().contiguous()
+    tape = {"in": [], "out": []}
+    hs, h = [], x
+    for module in net.input_blocks:
+        h, tp = _seq_forward(module, h, embd, context)
+        hs.append(h)
+        tape["in"].append(tp)
+    h, tape["mid"] = _seq_forward(net.middle_block, h, embd, context)
+    for module in net.output_blocks:
+        h, tp = _seq_forward(module, h, embd, context, skip=hs.pop())
+        tape["out"].append(tp)
+    n0 = net.out[0]
+    tape["head"] = h
+    a = ops.groupnorm(h, *n0.affine(), n0.eps, silu=True)
+    return ops.conv_small_cout(a, net.out[2].packed_tap_major(), pad=net.out[2].padding), tape
+
+
+def unet_backward(net, tape, deps):
+    """deps: fp32 [N, out_channels, h, w], the gradient of the loss w.r.t. `unet_forward`'s result -> {parameter name relative
+    to the UNet: fp32 gradient} for every tensor of `trainable_names(net)` (ddpm.py:1616-1629 of the reference)."""
+    grads = {}
+    conv = net.out[2]
+    key = (conv.weight._version, conv.weight.data_ptr(), engine_dtype())
+    c = conv.__dict__.setdefault("_dgrad_thin", {})
+    if c.get("key") != key:                       # 4 -> 320 channels: the thin side zero-padded to 32 like the input convolution's
+        w = conv.weight.detach().flip(2, 3).transpose(0, 1).contiguous()
+        c["key"], c["val"] = key, ops.pack_conv_padded_cin(w, None, engine_dtype(), conv.weight.device)
+    dy = ops.pack_sources([deps.float().contiguous()], engine_dtype())
+    n0 = net.out[0]
+    dh = ops.groupnorm_bwd(tape["head"], ops.igemm(dy, c["val"]), *n0.affine(), n0.eps, True)
+    nin = len(net.input_blocks)
+    dhs = {}
+    for i in reversed(range(len(net.output_blocks))):
+        dh, dskip = _seq_backward(net.output_blocks[i], tape["out"][i], dh, grads, f"output_blocks.{i}")
+        dhs[nin - 1 - i] = dskip                   # output block i consumed hs.pop() = the result of input block nin - 1 - i
+    dh, _ = _seq_backward(net.middle_block, tape["mid"], dh, grads, "middle_block")
+    for j in reversed(range(1, nin)):              # input_blocks.0 is the bare input convolution: nothing trainable before it
+        dh = ops.add(dh, dhs[j])
+        dh, _ = _seq_backward(net.input_blocks[j], tape["in"][j], dh, grads, f"input_blocks.{j}")
+    return grads
+
+
+def loss_and_gradients(net, x_noisy, timesteps, context, target, loss_scale=1.0):
+    """The eps-parameterised simple loss of `p_losses` (ddpm.py:1177-1217: mean squared error of the UNet's output against
+    the noise) and its gradient w.r.t. every adapter tensor.  loss_scale multiplies the gradient that enters the backward
+    pass and is divided out of the fp32 results (fp16 storage underflows without it at production sizes)."""
+    eps, tape = unet_forward(net, x_noisy, timesteps, context)
+    target = target.float().contiguous()
+    loss = torch.mean((eps - target) ** 2)
+    k = 2.0 * loss_scale / eps.numel()
+    deps = ops.lincomb4([eps.contiguous(), target], [k, -k])
+    grads = unet_backward(net, tape, deps)
+    if loss_scale != 1.0:
+        grads = {name: ops.lincomb4([g.contiguous()], [1.0 / loss_scale]) for name, g in grads.items()}
+    return loss, grads

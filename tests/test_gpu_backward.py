@@ -19,6 +19,9 @@ pytestmark = pytest.mark.gpu
 TOL1 = {torch.float16: 8e-4, torch.bfloat16: 6.6e-3}
 TOL_DX = {torch.float16: 1.9e-3, torch.bfloat16: 1.5e-2}
 TOL_DW = {torch.float16: 1.1e-2, torch.bfloat16: 6.8e-2}
+# the reduced UNet's training step: (all 432 adapter gradients as one vector, the worst single tensor); measured
+# 2.9e-3 / 1.1e-2 (fp16), 1.6e-2 / 8.3e-2 (bf16)
+TOL_UNET = {torch.float16: (6e-3, 2.3e-2), torch.bfloat16: (3.3e-2, 1.7e-1)}
 
 
 def rel(a, b, name="rel"):
@@ -125,3 +128,65 @@ def test_transformer_block_backward_vs_autograd(dtype, c, heads, n, side):
     # frozen tensors get no gradient, and the result does not depend on the order of calls (fixed-order reductions)
     dx2, grads2 = train.block_backward(blk, tape, rd)
     assert torch.equal(dx, dx2) and all(torch.equal(grads[k], grads2[k]) for k in names)
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_groupnorm_backward_and_sumpool(ops, dtype):
+    for c, hw, silu in ((64, 64, True), (320, 256, True), (128, 100, False)):
+        n, side = 2, int(hw ** 0.5)
+        xf, xd = rnd(f"bw.gn.x{c}", (n, side, side, c), dtype, 1.5)
+        dyf, dyd = rnd(f"bw.gn.dy{c}", (n, side, side, c), dtype)
+        addf, addd = rnd(f"bw.gn.add{c}", (n, side, side, c), dtype)
+        g = torch.from_numpy(W.synth_param(f"bw.gn{c}.weight", (c,)))
+        b = torch.from_numpy(W.synth_param(f"bw.gn{c}.bias", (c,)))
+        x = xf.clone().requires_grad_(True)
+        y = F.group_norm(x.permute(0, 3, 1, 2), 32, g, b, 1e-5)
+        y = F.silu(y) if silu else y
+        y.backward(dyf.permute(0, 3, 1, 2))
+        dx = ops.groupnorm_bwd(xd, dyd, g.cuda(), b.cuda(), 1e-5, silu, dx_add=addd)
+        assert rel(dx.float(), x.grad + addf) < TOL1[dtype], (c, silu)
+    sf, sd_ = rnd("bw.pool", (2, 8, 12, 64), dtype)
+    want = sf.view(2, 4, 2, 6, 2, 64).sum((2, 4))
+    assert rel(ops.sumpool2(sd_).float(), want) < TOL1[dtype]
+    af, ad = rnd("bw.add.a", (3, 50, 64), dtype)
+    bf, bd = rnd("bw.add.b", (3, 50, 64), dtype)
+    assert torch.equal(ops.add(ad, bd).cpu(), (af + bf).to(dtype))
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_unet_training_step_gradients_vs_autograd(dtype):
+    """The reduced UNet (model_channels 64, latent 16 x 16, two camera / lidar pairs): loss and the gradient of EVERY tensor
+    the reference's optimizer filter selects (432 = 16 blocks x 27, ddpm.py:1616-1629) against torch.autograd through the CPU
+    oracle's UNet -- the backward pass crosses every operator of the network (ResBlocks, GroupNorm + SiLU, the 3 x 3 / strided /
+    upsampling convolutions' data gradients, skip connections, all attention forms, GEGLU)."""
+    import mobi_amd
+    from mobi_amd import train
+    from tests.test_gpu_models import _unet
+    mobi_amd.set_engine_dtype(dtype)
+    cfg = ounet.UNetConfig(model_channels=64)
+    sd = W.synth_state_dict(ounet.unet_param_shapes(cfg), 9)
+    net = _unet(cfg, 16)
+    net.load_state_dict(sd)
+    net = net.cuda()
+    n, side = 4, 16
+    x = W.synth_input("bw.unet.x", (n, 9, side, side))
+    ctx = W.synth_input("bw.unet.ctx", (n, 2, 768))
+    noise = W.synth_input("bw.unet.noise", (n, 4, side, side))
+    t = torch.tensor([741, 741, 21, 21], dtype=torch.long)
+    names = train.trainable_names(net)
+    assert len(names) == 432
+    ps = {k: (v.clone().requires_grad_(True) if k in set(names) else v) for k, v in sd.items()}
+    ref = ounet.unet_forward(ps, cfg, x, t, ctx)
+    ref_loss = torch.mean((ref - noise) ** 2)
+    ref_loss.backward()
+    loss, grads = train.loss_and_gradients(net, x.cuda(), t.cuda(), ctx.cuda(), noise.cuda(), loss_scale=256.0)
+    assert sorted(grads) == sorted(names)
+    assert abs(float(loss) - float(ref_loss.detach())) / float(ref_loss.detach()) < TOL_DX[dtype]
+    # every tensor on its own, and all of them as one vector
+    errs = {k: rel(grads[k], ps[k].grad, "dw") for k in names}
+    flat_g = torch.cat([grads[k].reshape(-1).double().cpu() for k in names])
+    flat_r = torch.cat([ps[k].grad.reshape(-1).double() for k in names])
+    whole = float((flat_g - flat_r).norm() / flat_r.norm())
+    record("all_adapter_gradients", whole)
+    assert whole < TOL_UNET[dtype][0], whole
+    assert max(errs.values()) < TOL_UNET[dtype][1], max(errs.items(), key=lambda kv: kv[1])

@@ -522,8 +522,19 @@ def test_loss_side_of_the_training_step():
     z = c(x0)
     out, dd = ld(z, c(ctx))
     assert torch.isfinite(out) and set(dd) == {"val/loss_simple", "val/loss_vlb", "val/loss"} and 0.0 <= ld.u_cond_prop <= 1.0
-    with pytest.raises(NotImplementedError):
-        ld.training_step({}, 0)
+    # training_step (ddpm.py:356-370 + the backward pass Lightning runs around it): the same loss as p_losses on the same
+    # draw, and a gradient for every tensor of the reference's optimizer filter (tests/test_gpu_backward.py pins the
+    # gradients themselves to torch.autograd through the oracle)
+    from mobi_amd import train
+    ld.u_cond_percent = 0.0
+    ld.get_input = lambda batch, k, **kw: {"z": z, "cond": c(ctx)}
+    tl = ld.training_step({"any": "batch"}, 0, t=c(t), noise=c(noise))
+    assert abs(float(tl) - float(d["val/loss_simple"])) <= 2 * TOL_NET[torch.float16] * float(d["val/loss_simple"])
+    names = ["model.diffusion_model." + k for k in train.trainable_names(ld.model.diffusion_model)]
+    assert sorted(ld.adapter_grads) == sorted(names) and len(names) == 432
+    assert all(bool(torch.isfinite(v).all()) and v.dtype == torch.float32 for v in ld.adapter_grads.values())
+    assert all(ld.adapter_grads[k].shape == dict(ld.named_parameters())[k].shape for k in names)
+    assert sum(float(v.abs().sum()) for v in ld.adapter_grads.values()) > 0
     with pytest.raises(NotImplementedError):
         LatentDiffusion(cond_stage_config="__is_unconditional__", unet_config=unet_cfg, use_ema=False, learn_logvar=True,
                         first_stage_key="inpaint", conditioning_key="crossattn", use_camera=True, use_lidar=True)
