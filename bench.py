@@ -43,7 +43,7 @@ WORKLOADS = {  # BASELINE.json configs[2] / configs[1]
     "mobi_nusc_512": dict(latent=64, objects=8, gflop_per_element=1021.9, gflop_skippable=78.0),
     "mobi_nusc_256": dict(latent=32, objects=4, gflop_per_element=209.7, gflop_skippable=19.5),
 }
-PMC_TRAFFIC = "r03_pmc_traffic.json"   # written by tools/pmc_summary.py from the --pmc passes of this round's build
+PMC_TRAFFIC = "r04_pmc_traffic.json"   # written by tools/pmc_summary.py from the --pmc passes of this round's build
 PEAK_TFLOPS = 2500.0          # dense bf16/fp16 MFMA, /opt/skills/guides/MI355X_MICROARCH.md
 
 
@@ -466,7 +466,7 @@ def main():
         if os.path.exists(pmc):
             traffic = {}
             for fam_k in ("igemm_ring_kernel", "igemm_pp_kernel", "attention_rows_kernel", "attention_kernel", "ff_geglu_kernel",
-                          "gn_regs_kernel", "gn_stats_kernel", "gn_apply_kernel", "layernorm_kernel"):
+                          "gn_regs_kernel", "gn_stats_kernel", "gn_apply_kernel", "layernorm_kernel", "row_chain_kernel"):
                 rec = doc.get(fam_k)
                 if rec and doc.get("config") == run_cfg:
                     traffic[fam_k] = round(rec["hbm_bytes_per_launch_corrected"])

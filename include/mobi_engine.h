@@ -303,6 +303,11 @@ size_t mobi_row_chain_weight_bytes(int32_t channels);
 int mobi_row_chain_supported(int32_t channels, int32_t rows_per_image);
 int mobi_row_chain(const mobi_row_chain_params* p, void* stream);
 
+/* The VAE decoder's fp32 residual trunk (Decoder.forward / ResnetBlock / AttnBlock, model.py:121-141, 178-202, 587-630 of the
+ * reference run in fp32): trunk (f32, n elements, updated in place) += inc (T), x16 = T(trunk) -- the 16-bit copy the next
+ * GroupNorm / convolution reads.  inc == NULL: only the conversion.  n % 8 == 0. */
+int mobi_trunk_add(float* trunk, const void* inc, void* x16, int64_t n, int32_t dtype, void* stream);
+
 /* ---------------------------------------------------------------------------
  * Backward pass of the transformer block (FIRST SLICE: the training step of the adapter
  * parameters, ldm/models/diffusion/ddpm.py:356-370, 1616-1669 of the reference: `cond_adapter*` / `cross_modal*` of

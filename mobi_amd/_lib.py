@@ -187,6 +187,7 @@ SYMBOLS = {
     "mobi_row_chain_supported": (C.c_int, [i32, i32]),
     "mobi_row_chain_adapter_image_bytes": (C.c_size_t, [i32]),
     "mobi_row_chain_adapter_image": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, i32, vp, vp]),
+    "mobi_trunk_add": (C.c_int, [vp, vp, vp, i64, i32, vp]),
     "mobi_transpose": (C.c_int, [vp, i64, vp, i32, i32, i32, vp]),
     "mobi_backward_partial_blocks": (i32, [i64]),
     "mobi_colsum": (C.c_int, [vp, i64, i64, i32, i32, vp, vp, vp]),

@@ -1433,3 +1433,37 @@ extern "C" int mobi_nhwc_to_nchw_f32(const void* src, float* out, int32_t batch,
   MOBI_CHECK_LAUNCH();
   return MOBI_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------
+// fp32 residual trunk (the VAE decoder's precise mode): trunk (f32, in place) += inc (T); x16 = T(trunk).  With inc == NULL
+// only the conversion.  8 elements per thread, 16-byte accesses.
+// ---------------------------------------------------------------------------------------------------------
+namespace mobi {
+template <typename T>
+__global__ __launch_bounds__(256) void trunk_add_kernel(float* __restrict__ trunk, const T* __restrict__ inc, T* __restrict__ x16, long long vecs) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < vecs; i += (long long)gridDim.x * 256) {
+    f32x4 a = *reinterpret_cast<const f32x4*>(trunk + 8 * i), b = *reinterpret_cast<const f32x4*>(trunk + 8 * i + 4);
+    float f[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+    if (inc) {
+      float g[8];
+      unpack8<T>(ld16(inc + 8 * i), g);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) f[j] += g[j];
+      *reinterpret_cast<f32x4*>(trunk + 8 * i) = f32x4{f[0], f[1], f[2], f[3]};
+      *reinterpret_cast<f32x4*>(trunk + 8 * i + 4) = f32x4{f[4], f[5], f[6], f[7]};
+    }
+    st16(x16 + 8 * i, pack8<T>(f));
+  }
+}
+}  // namespace mobi
+
+extern "C" int mobi_trunk_add(float* trunk, const void* inc, void* x16, int64_t n, int32_t dtype, void* stream) {
+  using namespace mobi;
+  if (!trunk || !x16 || n <= 0 || (n & 7) || !DT_OK(dtype)) return MOBI_ERR_ARG;
+  if ((reinterpret_cast<uintptr_t>(trunk) | reinterpret_cast<uintptr_t>(inc) | reinterpret_cast<uintptr_t>(x16)) & 15) return MOBI_ERR_ALIGN;
+  const unsigned g = grid_for(n / 8, 256, 16384);
+  if (dtype == MOBI_F16) hipLaunchKernelGGL((trunk_add_kernel<f16_t>), dim3(g), dim3(256), 0, ST(stream), trunk, (const f16_t*)inc, (f16_t*)x16, (long long)(n / 8));
+  else hipLaunchKernelGGL((trunk_add_kernel<bf16_t>), dim3(g), dim3(256), 0, ST(stream), trunk, (const bf16_t*)inc, (bf16_t*)x16, (long long)(n / 8));
+  MOBI_CHECK_LAUNCH();
+  return MOBI_OK;
+}

@@ -6,12 +6,30 @@ ldm/modules/diffusionmodules/model.py: Normalize :38, Upsample :42-57, Downsampl
 Only what MObI's configs instantiate is built (attn_resolutions [], vanilla
 mid attention, conv resampling, temb_channels 0).
 """
+import os
+
 import torch
 import torch.nn as nn
 
 from .... import engine_dtype, ops
 from ...._lib import OUT_ROWS_F32, OUT_TRANSPOSED
 from .util import Conv2d, GroupNorm32, enter, leave
+
+
+# The decoder's residual trunk in fp32: every `x + h` of Decoder.forward accumulates in an fp32 tensor and the 16-bit copy the
+# next GroupNorm / convolution reads is made from it, so the trunk is rounded once per consumer instead of re-rounded at
+# every block.  End to end at production width (tests/test_gpu_production.py::test_end_to_end_pixel_space, fp16): camera
+# picture 1.26-1.37e-3 -> 0.91-0.98e-3 rel-L2 (inside the north star's 1e-3), range view 1.69-1.82e-3 -> 1.24-1.37e-3; bf16
+# 1.0-1.4e-2 -> 0.7-1.0e-2.  Costs one elementwise pass per block (mobi_trunk_add; profiles/r04_vae_trunk.txt).
+# Default: on with fp16 storage (the storage type chosen for parity), off with bf16 (the throughput configuration);
+# MOBI_VAE_FP32_TRUNK=1 / 0 forces it.
+_TRUNK_ENV = os.environ.get("MOBI_VAE_FP32_TRUNK", "")
+
+
+def fp32_trunk():
+    if _TRUNK_ENV in ("0", "1"):
+        return _TRUNK_ENV == "1"
+    return engine_dtype() == torch.float16
 
 
 def Normalize(in_channels, num_groups=32):
@@ -68,6 +86,14 @@ class ResnetBlock(nn.Module):
         xs = ops.igemm(x, self.nin_shortcut.packed()) if self.in_channels != self.out_channels else x
         return leave(ops.igemm(h, self.conv2.packed(), pad=self.conv2.padding, residual=xs), ext)
 
+    def forward_trunk(self, x, trunk):
+        """The same block on an fp32 trunk: x = the trunk's 16-bit copy -> (x', trunk')."""
+        h = ops.igemm(_gn_swish(self.norm1, x), self.conv1.packed(), pad=self.conv1.padding)
+        h = ops.igemm(_gn_swish(self.norm2, h), self.conv2.packed(), pad=self.conv2.padding)
+        if self.in_channels != self.out_channels:
+            trunk = ops.igemm(x, self.nin_shortcut.packed(), out_mode=OUT_ROWS_F32)
+        return ops.trunk_add(trunk, h, x.dtype), trunk
+
 
 class AttnBlock(nn.Module):
     """Single-head attention over all h*w positions (model.py:178-202).  c = 512 does not fit the
@@ -83,7 +109,7 @@ class AttnBlock(nn.Module):
         self.v = Conv2d(in_channels, in_channels, kernel_size=1)
         self.proj_out = Conv2d(in_channels, in_channels, kernel_size=1)
 
-    def forward(self, x):
+    def forward(self, x, trunk=None):
         x, ext = enter(x)
         n, h, w, c = x.shape
         t = h * w
@@ -97,6 +123,8 @@ class AttnBlock(nn.Module):
         p = ops.softmax_rows(s.view(n * t, t), x.dtype).view(n, t, 1, t)
         vw = ops.Packed(vt, None, 1, 1, t, c, c)
         o = ops.igemm(p, vw, weight_per_image=True, w_group_stride=c * t).view(n, h, w, c)
+        if trunk is not None:
+            return ops.trunk_add(trunk, ops.igemm(o, self.proj_out.packed()), x.dtype), trunk
         return leave(ops.igemm(o, self.proj_out.packed(), residual=x), ext)
 
 
@@ -206,7 +234,32 @@ class Decoder(nn.Module):
     def forward(self, z, clamp=None):
         """z: fp32 NCHW latent -> fp32 NCHW image; `clamp=(lo, hi)` fuses the torch.clamp the
         harness applies to every decode (ddpm.py:1476,1504)."""
-        h = ops.igemm(ops.pack_sources([z.float().contiguous()], engine_dtype()), self.conv_in.packed_thin(), pad=(1, 1))
+        zin = ops.pack_sources([z.float().contiguous()], engine_dtype())
+        if fp32_trunk():
+            dt = engine_dtype()
+            t32 = ops.igemm(zin, self.conv_in.packed_thin(), pad=(1, 1), out_mode=OUT_ROWS_F32)
+            h = ops.trunk_add(t32, None, dt)
+            h, t32 = self.mid.block_1.forward_trunk(h, t32)
+            h, t32 = self.mid.attn_1(h, trunk=t32)
+            h, t32 = self.mid.block_2.forward_trunk(h, t32)
+            for i_level in reversed(range(self.num_resolutions)):
+                for i_block in range(self.num_res_blocks + 1):
+                    h, t32 = self.up[i_level].block[i_block].forward_trunk(h, t32)
+                if i_level != 0:
+                    up = self.up[i_level].upsample
+                    t32 = ops.igemm(h, up.conv.packed(), upsample=True, pad=(1, 1), out_mode=OUT_ROWS_F32)
+                    h = ops.trunk_add(t32, None, dt)
+            if self.lidar_adapter:
+                h, t32 = self.res_block_lidar1.forward_trunk(h, t32)
+                # (GroupNorm + swish of the adapter: a new stream, not a residual update -- model.py:617-618)
+                h = _gn_swish(self.norm_out_lidar1, h)
+                h = _gn_swish(self.norm_out_lidar2, self.res_block_lidar2(h))
+                cout = self.conv_out_lidar
+            else:
+                h = _gn_swish(self.norm_out, h)
+                cout = self.conv_out
+            return ops.conv_small_cout(h, cout.packed_tap_major(), pad=cout.padding, clamp=clamp)
+        h = ops.igemm(zin, self.conv_in.packed_thin(), pad=(1, 1))
         h = self.mid.block_2(self.mid.attn_1(self.mid.block_1(h)))
         for i_level in reversed(range(self.num_resolutions)):
             for i_block in range(self.num_res_blocks + 1):

@@ -434,6 +434,15 @@ def row_chain(programs, images, rows_per_image, dtype, adapter=None, flops=0.0, 
 # --------------------------------------------------------------------------------------
 # backward pass (first slice of the training step: csrc/backward.hip)
 # --------------------------------------------------------------------------------------
+def trunk_add(trunk, inc, dtype):
+    """trunk: fp32 dense tensor, updated in place: trunk += inc (T, same shape; None: no update) -> its 16-bit copy."""
+    lib = _lib.load()
+    assert trunk.dtype == torch.float32 and trunk.is_contiguous() and (inc is None or (inc.is_contiguous() and inc.shape == trunk.shape))
+    x16 = torch.empty(trunk.shape, device=trunk.device, dtype=dtype)
+    _lib.check(lib.mobi_trunk_add(_ptr(trunk), _ptr(inc), _ptr(x16), trunk.numel(), _dt(dtype), _stream()), "mobi_trunk_add")
+    return x16
+
+
 def transpose(x):
     """T [rows, cols] (row stride free) -> T [cols, rows] dense."""
     lib = _lib.load()

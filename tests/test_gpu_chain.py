@@ -155,3 +155,36 @@ def test_transformer_block_chained_equals_unchained(dtype, n, side, monkeypatch)
     y0 = blk(x, context=ctx)
     assert bool(torch.isfinite(y1).all())
     assert rel(y1.float(), y0.float()) < 2 * TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_routing_thresholds_at_their_boundary_rows(dtype, monkeypatch):
+    """The row-count switches of the transformer block (`FUSED_FF_MIN_ROWS`, `ROW_CHAIN_MIN_ROWS`, the two-key adapter's
+    register kernel) at the boundary: 24,576 token rows (6 images of 64 x 64 -- the first count that takes the one-launch
+    feed-forward and the row chains) and one 128-row tile below it must give the same function on either side of the switch."""
+    import mobi_amd
+    from mobi_amd import ops as O
+    from mobi_amd.ldm.modules import attention as A
+    mobi_amd.set_engine_dtype(dtype)
+    assert A.FUSED_FF_MIN_ROWS == 24576 and A.ROW_CHAIN_MIN_ROWS == 24576
+    blk = A.BasicTransformerBlock(C, 8, 40, context_dim=768, bbox_cond=True, multimodal=True)
+    W.fill_module_(blk, seed=43)
+    blk = blk.cuda()
+    ff = blk.ff
+    for rows in (24576, 24576 - 128):
+        _, x = rnd(f"thr.ff.{rows}", (1, rows, C), dtype)
+        fused = rows >= A.FUSED_FF_MIN_ROWS
+        y = ff(x, residual=x, norm=blk.norm3)
+        monkeypatch.setattr(A, "FUSED_FF_MIN_ROWS", 1 if not fused else 1 << 30)          # the other side of the switch
+        y2 = ff(x, residual=x, norm=blk.norm3)
+        monkeypatch.setattr(A, "FUSED_FF_MIN_ROWS", 24576)
+        assert rel(y.float(), y2.float()) < 2 * TOL[dtype], rows
+    for n, t in ((6, 4096), (2, 4096)):                                                  # 24,576 rows: chained; 8,192: one by one
+        _, x = rnd(f"thr.blk.{n}", (n, t, C), dtype)
+        ctx = W.synth_input(f"thr.ctx.{n}", (n, 2, 768)).cuda()
+        assert O.two_key_adapter_fuses_ln(C, n * t)
+        y = blk(x, context=ctx)
+        monkeypatch.setattr(A, "ROW_CHAIN_MIN_ROWS", 1 if n * t < 24576 else 1 << 30)
+        y2 = blk(x, context=ctx)
+        monkeypatch.setattr(A, "ROW_CHAIN_MIN_ROWS", 24576)
+        assert rel(y.float(), y2.float()) < 2 * TOL[dtype], n

@@ -195,12 +195,12 @@ def test_pingpong_race_screen():
 
 
 # ---- end to end at production width, pixel space (BASELINE config 1's workload; north star: 1e-3 rel-L2) ---------------
-# measured on the MI355X (profiles/r04_error_table.txt): fp16 latent 4.1e-4 / 5.2e-4 (64 x 64 / 32 x 32), camera picture
-# 1.26e-3 / 1.37e-3, range view 1.69e-3 / 1.82e-3; bf16 latent 3.5e-3 / 4.0e-3, pictures 0.97 - 1.40e-2.  The latent bound of
-# fp16 IS the north star's 1e-3; the decoded pictures are asserted at 2x the measured values (the VAE decode alone is
-# 1.45 - 1.75e-3 in fp16: DESIGN section 3).
-TOL_E2E = {(torch.float16, "latent"): 1e-3, (torch.float16, "pixel"): 3.6e-3,
-           (torch.bfloat16, "latent"): 8e-3, (torch.bfloat16, "pixel"): 2.8e-2}
+# measured on the MI355X (profiles/r04_error_table.txt, profiles/r04_parity.json): fp16 (decoder trunk in fp32, the default of that
+# storage type) latent 4.1e-4 / 5.2e-4 (64 x 64 / 32 x 32), camera picture 9.1e-4 / 9.8e-4, range view 1.24e-3 / 1.37e-3;
+# bf16 latent 3.5e-3 / 4.0e-3, pictures 0.97 - 1.40e-2.  The fp16 bounds of the latent AND of the camera picture are the north
+# star's 1e-3 itself (the arithmetic is bit-reproducible: fixed-order reductions); the rest is asserted at 2x the measurement.
+TOL_E2E = {(torch.float16, "latent"): 1e-3, (torch.float16, "pixel_camera"): 1e-3, (torch.float16, "pixel_range"): 2.8e-3,
+           (torch.bfloat16, "latent"): 8e-3, (torch.bfloat16, "pixel_camera"): 2.8e-2, (torch.bfloat16, "pixel_range"): 2.8e-2}
 
 
 class _TokenStage(torch.nn.Module):
@@ -287,5 +287,5 @@ def test_end_to_end_pixel_space(dtype, side):
     assert image.shape == ref["image"].shape and rng.shape == ref["range"].shape
     pix_c, pix_r = rel_l2(image.float().cpu(), ref["image"]), rel_l2(rng.float().cpu(), ref["range"])
     check(lat, TOL_E2E[(dtype, "latent")], tag + "_latent")
-    check(pix_c, TOL_E2E[(dtype, "pixel")], tag + "_pixel_camera")
-    check(pix_r, TOL_E2E[(dtype, "pixel")], tag + "_pixel_range")
+    check(pix_c, TOL_E2E[(dtype, "pixel_camera")], tag + "_pixel_camera")
+    check(pix_r, TOL_E2E[(dtype, "pixel_range")], tag + "_pixel_range")

@@ -36,9 +36,23 @@ def main():
     cp("launches.tsv", "launches_one_step.tsv")
     cp("launches256.tsv", "launches_one_step_nusc256.tsv")
     cp("pmc_traffic.json", "pmc_traffic.json")
+    cp("vae_prof.txt", "vae_encode_decode.txt")
+    cp("chain_lab.txt", "chain_lab.txt")
+    cp("chain_stamps.txt", "chain_stamps.txt")
     bench = line_of(os.path.join(src, "bench.json"))
     pmc = json.load(open(os.path.join(src, "pmc_traffic.json")))
     rows = list(csv.DictReader(open(os.path.join(src, "kernel_stats.csv"))))
+    # fully demangled kernel names (rocprofv3 leaves some instances mangled, some half-demangled)
+    import subprocess
+    filt = "/opt/rocm/lib/llvm/bin/llvm-cxxfilt"
+    if os.path.exists(filt):
+        names = subprocess.run([filt], input="\n".join(r["Name"] for r in rows), capture_output=True, text=True).stdout.split("\n")
+        for r, nm in zip(rows, names):
+            r["Name"] = nm.replace("__bf16", "bf16").replace("_Float16", "f16")
+        with open(os.path.join(dst, f"{tag}_unet512_b16_bf16_kernel_stats.csv"), "w", newline="") as f:
+            w = csv.DictWriter(f, fieldnames=list(rows[0].keys()))
+            w.writeheader()
+            w.writerows(rows)
     roof = bench["roofline"]
     kname = roof["kernel"]
     dom = [r for r in rows if kname in r["Name"]]
@@ -81,7 +95,8 @@ def main():
               f"HIP-event brackets on the same box.  `roofline.achieved` = {roof['achieved']} TFLOP/s = {roof['gflop_per_launch']} GFLOP "
               f"(algorithmic 2*M*N*K) / that launch time; frac {roof['frac']}.  igemm time per step by main loop: "
               f"{roof['igemm_ms_by_variant']}.", "`__amd_rocclr_copyBuffer` rows are the one-off weight upload / packing, not per-step work.", ""]
-    for fam in ("igemm_pp_kernel", "igemm_ring_kernel", "attention_rows_kernel", "attention_kernel", "gn_regs_kernel"):
+    for fam in ("igemm_pp_kernel", "igemm_ring_kernel", "attention_rows_kernel", "attention_kernel", "gn_regs_kernel", "row_chain_kernel",
+                "ff_geglu_kernel"):
         rec = pmc.get(fam)
         if rec:
             lines.append(f"HBM traffic of `{fam}` (`{tag}_pmc_traffic.json`, FETCH_SIZE x 2 + WRITE_SIZE, separate `--pmc` passes): "
@@ -93,6 +108,8 @@ def main():
               f"* `{tag}_unet512_b16_bf16_kernel_stats.csv` rocprofv3 stats; `{tag}_bench_unet512_b16_bf16.json` bench line of the same box",
               f"* `{tag}_launches_one_step.tsv` (`..._nusc256.tsv`) kind, GFLOP, us, algorithmic MB, kernel variant and shape of every launch of one step",
               f"* `{tag}_pmc_traffic.json` per-kernel-family FETCH_SIZE / WRITE_SIZE (tools/pmc_summary.py)",
+              f"* `{tag}_vae_encode_decode.txt` per-launch times of the VAEs (8 images, 512 x 512, both autoencoders; tools/vae_prof.py)",
+              f"* `{tag}_chain_lab.txt`, `{tag}_chain_stamps.txt` the row-chain kernel against the launches it replaces, its phase stamps and ablations",
               f"* `{tag}_error_table.txt` measured rel-L2 of every parity assertion of `pytest -m gpu` (MOBI_RECORD_ERRORS)",
               f"* `{tag}_graph_breakdown.txt` per-kernel time INSIDE the replayed step graph, both workloads (tools/graph_gaps.py)",
               f"* `{tag}_attention_*.txt` attention lab: ablations, variants, SQ counters; `{tag}_mfma_fill_probe.txt`",

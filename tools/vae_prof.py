@@ -3,7 +3,9 @@ sys.path.insert(0, os.getcwd())
 import mobi_amd
 from mobi_amd import ops
 from bench import build_model
-mobi_amd.set_engine_dtype(torch.bfloat16)
+DT = torch.float16 if 'fp16' in sys.argv else torch.bfloat16
+mobi_amd.set_engine_dtype(DT)
+print(f'storage type {DT}, MOBI_VAE_FP32_TRUNK={os.environ.get("MOBI_VAE_FP32_TRUNK", "(unset: on for fp16)")}')
 model = build_model("mobi_nusc_512").cuda()
 B = 8
 z = torch.randn(B, 4, 64, 64, device="cuda")
