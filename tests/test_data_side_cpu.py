@@ -181,3 +181,37 @@ def test_dataset_options(mini):
     assert len(one) == 1 and one[one.objects_meta.index[0]]["id_name"] == name
     with pytest.raises(NotImplementedError):
         _dataset(mini, ref_aug=True)
+
+
+def test_whole_lidar_item_against_the_reference(mini):
+    """tests/golden/data_item.npz: `NuScenesDataset.get_range_data` of the REFERENCE (ldm/data/nuscenes.py:396-493) on this
+    miniature database, every field that does not go through cv2 / torchvision (make_golden_data_item.py says which): the
+    untouched sweep, the crop window, the object's depth range and the 8-corner box token -- bit for bit."""
+    import ast
+    from mobi_amd.ldm.data.nuscenes import NuScenesDataset
+    csv, pkl = mini
+    g = dict(np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "data_item.npz")))
+    st = dict(ast.literal_eval(str(g["settings"])))
+    ds = NuScenesDataset("test", csv, pkl, ["car", "pedestrian"], ref_aug=False, use_lidar=True, use_camera=False,
+                         range_height=st["range_height"], range_width=st["range_width"], random_range_crop=st["random_range_crop"],
+                         range_object_norm=st["range_object_norm"], range_object_norm_scale=st["range_object_norm_scale"],
+                         range_int_norm=st["range_int_norm"], expand_mask_ratio=st["expand_mask_ratio"],
+                         prob_drop_context=st["prob_drop_context"], min_lidar_points=0, reference_image_min_h=0, reference_image_min_w=0)
+    import pickle
+    with open(pkl, "rb") as f:
+        scenes = pickle.load(f)
+    n = 0
+    for token, scene in sorted(scenes.items()):
+        for k in range(len(scene["gt_bboxes_3d_corners"])):
+            item = ds.get_range_data(scene, scene["gt_bboxes_3d_corners"][k], k)
+            tag = f"{token}.{k}"
+            for key in ("range_depth_orig", "range_int_orig", "range_instance_mask_orig", "range_pitch", "range_yaw"):
+                v = np.asarray(item[key])
+                assert tuple(g[f"{tag}.{key}.shape"]) == v.shape and float(g[f"{tag}.{key}.sum"]) == float(v.astype(np.float64).sum())
+                assert np.array_equal(g[f"{tag}.{key}.sample"], v.reshape(-1)[::97])
+            for key in ("min_depth_obj", "max_depth_obj"):
+                assert np.array_equal(np.asarray(item[key]), g[f"{tag}.{key}"]), (tag, key)
+            assert int(item["range_shift_left"]) == int(g[f"{tag}.range_shift_left"]) and int(item["width_crop"]) == int(g[f"{tag}.width_crop"])
+            assert np.array_equal(item["cond"]["ref_bbox"].numpy(), g[f"{tag}.ref_bbox"]), tag
+            n += 1
+    assert n == 6
