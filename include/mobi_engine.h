@@ -349,6 +349,12 @@ int mobi_groupnorm_bwd(const void* x, const void* dy, const float* gamma, const 
 int mobi_sumpool2(const void* src, void* out, int32_t images, int32_t h, int32_t w, int32_t channels, int32_t dtype, void* stream);
 /* out = a + b over n elements of T (two gradients meeting at a fork: a skip connection's consumers). */
 int mobi_add(const void* a, const void* b, void* out, int64_t n, int32_t dtype, void* stream);
+/* dx = dy * silu'(z), fp32 (the bbox embedder's MLP, ldm/modules/encoders/modules.py:77-83 of the reference). */
+int mobi_silu_bwd_f32(const float* z, const float* dy, float* dx, int64_t n, void* stream);
+/* One AdamW update of fp32 master parameters in place (torch.optim.AdamW, ddpm.py:1649 of the reference): decoupled weight
+ * decay, bias-corrected moments; step counts from 1. */
+int mobi_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
+                    float beta2, float eps, float weight_decay, int32_t step, void* stream);
 typedef struct mobi_attention_bwd_params {
   const void* q; int64_t q_img_stride, q_row_stride;       /* T [image][tq][>= heads*dh], strides in elements */
   const void* k; int64_t k_img_stride, k_row_stride;       /* T [image][tk][..] */

@@ -198,6 +198,8 @@ SYMBOLS = {
     "mobi_groupnorm_bwd": (C.c_int, [vp, vp, vp, vp, f32, i32, vp, vp, i32, i32, i32, i32, vp]),
     "mobi_sumpool2": (C.c_int, [vp, vp, i32, i32, i32, i32, i32, vp]),
     "mobi_add": (C.c_int, [vp, vp, vp, i64, i32, vp]),
+    "mobi_silu_bwd_f32": (C.c_int, [vp, vp, vp, i64, vp]),
+    "mobi_adamw_step": (C.c_int, [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i32, vp]),
     "mobi_quick_gelu": (C.c_int, [vp, vp, i64, i32, vp]),
     "mobi_timestep_embedding": (C.c_int, [vp, vp, vp, i32, i32, vp]),
     "mobi_conv_small_cin": (C.c_int, [C.POINTER(ConvSmallCinParams), vp]),

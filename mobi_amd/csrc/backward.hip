@@ -425,6 +425,30 @@ __global__ __launch_bounds__(256) void add_kernel(const T* __restrict__ a, const
     out[i] = (T)((float)a[i] + (float)b[i]);
 }
 
+// dx = dy * silu'(z), fp32 (the bbox embedder's MLP, modules.py:77-83 of the reference: a handful of rows)
+__global__ __launch_bounds__(256) void silu_bwd_f32_kernel(const float* __restrict__ z, const float* __restrict__ dy, float* __restrict__ dx, long long n) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    const float v = z[i], sg = 1.0f / (1.0f + __expf(-v));
+    dx[i] = dy[i] * sg * (1.0f + v * (1.0f - sg));
+  }
+}
+
+// AdamW (torch.optim.AdamW's update, ddpm.py:1649 of the reference), fp32 master parameters updated in place:
+//   p *= 1 - lr wd;  m = b1 m + (1 - b1) g;  v = b2 v + (1 - b2) g^2;  p -= lr / bc1 * m / (sqrt(v) / sqrt(bc2) + eps)
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                                                    long long n, float lr, float b1, float b2, float eps, float wd, float bc1, float bc2_sqrt) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    const float gi = g[i];
+    float pi = p[i] * (1.0f - lr * wd);
+    const float mi = b1 * m[i] + (1.0f - b1) * gi;
+    const float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    pi -= (lr / bc1) * mi / (sqrtf(vi) / bc2_sqrt + eps);
+    p[i] = pi;
+  }
+}
+
 // sum of every 2 x 2 block of pixels: src T [image][2h][2w][C] -> out T [image][h][w][C] (the backward of nearest x2)
 template <typename T>
 __global__ __launch_bounds__(256) void sumpool2_kernel(const T* __restrict__ src, T* __restrict__ out, int n, int h, int w, int C) {
@@ -593,6 +617,27 @@ extern "C" int mobi_add(const void* a, const void* b, void* out, int64_t n, int3
   const dim3 grid((unsigned)((n + 255) / 256 > 65536 ? 65536 : (n + 255) / 256));
   if (dtype == MOBI_F16) hipLaunchKernelGGL((add_kernel<f16_t>), grid, dim3(256), 0, ST(stream), reinterpret_cast<const f16_t*>(a), reinterpret_cast<const f16_t*>(b), reinterpret_cast<f16_t*>(out), (long long)n);
   else hipLaunchKernelGGL((add_kernel<bf16_t>), grid, dim3(256), 0, ST(stream), reinterpret_cast<const bf16_t*>(a), reinterpret_cast<const bf16_t*>(b), reinterpret_cast<bf16_t*>(out), (long long)n);
+  MOBI_CHECK_LAUNCH();
+  return MOBI_OK;
+}
+
+extern "C" int mobi_silu_bwd_f32(const float* z, const float* dy, float* dx, int64_t n, void* stream) {
+  using namespace mobi;
+  if (!z || !dy || !dx || n <= 0) return MOBI_ERR_ARG;
+  const dim3 grid((unsigned)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256));
+  hipLaunchKernelGGL(silu_bwd_f32_kernel, grid, dim3(256), 0, ST(stream), z, dy, dx, (long long)n);
+  MOBI_CHECK_LAUNCH();
+  return MOBI_OK;
+}
+
+extern "C" int mobi_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
+                               float beta2, float eps, float weight_decay, int32_t step, void* stream) {
+  using namespace mobi;
+  if (!param || !grad || !exp_avg || !exp_avg_sq || n <= 0 || step <= 0) return MOBI_ERR_ARG;
+  const float bc1 = 1.0f - powf(beta1, (float)step), bc2 = 1.0f - powf(beta2, (float)step);
+  const dim3 grid((unsigned)((n + 255) / 256 > 16384 ? 16384 : (n + 255) / 256));
+  hipLaunchKernelGGL(adamw_kernel, grid, dim3(256), 0, ST(stream), param, grad, exp_avg, exp_avg_sq, (long long)n, lr, beta1, beta2, eps,
+                     weight_decay, bc1, sqrtf(bc2));
   MOBI_CHECK_LAUNCH();
   return MOBI_OK;
 }

@@ -339,7 +339,7 @@ class LatentDiffusion(DDPM):
         t = torch.randint(0, self.num_timesteps, (x.shape[0],), device=self.device).long()
         if self.model.conditioning_key is not None:
             assert c is not None
-            if self.cond_stage_trainable:
+            if self.cond_stage_trainable and isinstance(c, dict):    # (raw conditioning inputs; tokens pass through)
                 c = self.get_learned_conditioning(c)
         self.u_cond_prop = random.uniform(0, 1)
         if self.u_cond_prop < self.u_cond_percent:
@@ -393,13 +393,27 @@ class LatentDiffusion(DDPM):
         432 tensors, 180 M parameters), computed by the engine's backward pass (mobi_amd/train.py) and summed over the ranks
         (mobi_amd.dist.allreduce_gradients).  FIRST SLICE of SURVEY 8(f) row 4: l2 loss with the default weights
         (`learn_logvar=False`, `original_elbo_weight=0`: the gradient of mean(loss_simple)); the conditioning stage's
-        trainable tensors (bbox embedder, `bbox_uncond_vector`) and the optimizer step are not built."""
+        trainable tensors (the 3-D box embedder's four Linear layers, or `bbox_uncond_vector` on an unconditional draw) get
+        theirs too when `cond_stage_trainable`; `configure_optimizers()` returns the engine's AdamW to step with them."""
         from .... import dist as mdist, engine_dtype, train
         if self.loss_type != "l2" or self.parameterization != "eps" or self.learn_logvar or self.original_elbo_weight != 0:
             raise NotImplementedError("the engine's training step covers the eps / l2 simple loss MObI trains with")
         data = self.get_input(batch, self.first_stage_key)
         x, c = data["z"], data["cond"]
+        # the conditioning stage's trainable part (ddpm.py:1635-1647): the 3-D box embedder runs with a tape, so that the
+        # gradient the UNet hands back for the box token reaches its four Linear layers (or `bbox_uncond_vector`)
+        bbox_tape = None
+        if self.cond_stage_trainable and isinstance(c, dict) and "ref_bbox" in self.cond_stage_key \
+                and hasattr(self.cond_stage_model, "bbox_embedder"):
+            tok = self.cond_stage_model.encode({"ref_image": c["ref_image"]})["ref_image_token"].float()
+            w, b = self.proj_out.skinny()
+            nn_, one, d = tok.shape
+            ref_tok = ops.skinny_linear(tok.reshape(nn_ * one, d).contiguous(), w, b).reshape(nn_, one, -1)
+            box_tok, bbox_tape = train.bbox_embedder_forward(self.cond_stage_model.bbox_embedder, c["ref_bbox"])
+            c = torch.cat([ref_tok, box_tok.float()], dim=1)
+        cond_was_given = c
         t_draw, c = self._draw_step(x, c)
+        uncond = c is not cond_was_given and self.u_cond_prop < self.u_cond_percent
         t = t_draw if t is None else t
         x_noisy, target = self._noised_input(x, t, noise)
         if loss_scale is None:                   # fp16 gradients underflow at production sizes without it; bf16 has the range
@@ -410,10 +424,34 @@ class LatentDiffusion(DDPM):
         mse, grads = train.loss_and_gradients(self.model.diffusion_model, x_noisy, t, c, target, loss_scale=loss_scale)
         if self.l_simple_weight != 1.0:
             grads = {k: ops.lincomb4([g.contiguous()], [float(self.l_simple_weight)]) for k, g in grads.items()}
+        dctx = grads.pop("__dcontext__", None)                         # fp32 [N, 2, ctx_dim]
+        named = {"model.diffusion_model." + k: v for k, v in grads.items()}
+        if self.cond_stage_trainable and dctx is not None and "ref_bbox" in self.cond_stage_key:
+            dbox = dctx[:, 1].contiguous()
+            if uncond:                                                 # the learnt unconditional box token stood in for every element
+                ones = torch.ones((1, dbox.shape[0]), device=dbox.device, dtype=torch.float32)
+                named["bbox_uncond_vector"] = ops.linear_f32(dbox.t().contiguous(), ones).reshape(1, 1, -1)
+            elif bbox_tape is not None:
+                eg = train.bbox_embedder_backward(self.cond_stage_model.bbox_embedder, bbox_tape, dbox.unsqueeze(1))
+                named.update({"cond_stage_model.bbox_embedder." + k: v for k, v in eg.items()})
         if allreduce:
-            mdist.allreduce_gradients(grads)
-        self.adapter_grads = {"model.diffusion_model." + k: v for k, v in grads.items()}
+            mdist.allreduce_gradients(named)
+        self.adapter_grads = named
         return self.l_simple_weight * mse
+
+    def configure_optimizers(self):
+        """ddpm.py:1616-1669 of the reference: AdamW (lr = `self.learning_rate`) over the UNet tensors whose names contain
+        `cond_adapter`, `lidar` or `cross_modal`, plus -- with a trainable conditioning stage -- the box embedder and
+        `bbox_uncond_vector`; here the engine's AdamW (mobi_amd.train.AdamW, `mobi_adamw_step`), stepped with
+        `self.adapter_grads` after `training_step`.  LR schedulers (`use_scheduler`) are the training harness's: not built."""
+        from .... import train
+        params = {"model.diffusion_model." + n: p for n, p in self.model.diffusion_model.named_parameters()
+                  if any(m in n for m in train.TRAINABLE_MARKERS)}
+        if self.cond_stage_trainable and "ref_bbox" in self.cond_stage_key and hasattr(self.cond_stage_model, "bbox_embedder"):
+            params.update({"cond_stage_model.bbox_embedder." + n: p for n, p in self.cond_stage_model.bbox_embedder.named_parameters()
+                           if "class_embedder" not in n})
+            params["bbox_uncond_vector"] = self.bbox_uncond_vector
+        return train.AdamW(params, lr=getattr(self, "learning_rate", 1e-4))
 
     def apply_model(self, x_noisy, t, cond, return_ids=False):
         """x_noisy: fp32 [N, 9, h, w] or the un-concatenated list [x, inpaint_image, inpaint_mask]."""

@@ -529,6 +529,23 @@ def add(a, b):
     return out
 
 
+def silu_bwd_f32(z, dy):
+    lib = _lib.load()
+    assert z.dtype == dy.dtype == torch.float32 and z.is_contiguous() and dy.is_contiguous() and z.shape == dy.shape
+    dx = torch.empty_like(z)
+    _lib.check(lib.mobi_silu_bwd_f32(_ptr(z), _ptr(dy), _ptr(dx), z.numel(), _stream()), "mobi_silu_bwd_f32")
+    return dx
+
+
+def adamw_step(param, grad, exp_avg, exp_avg_sq, step, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
+    """One AdamW update of an fp32 parameter tensor IN PLACE (raw-pointer write: the caller bumps the tensor's version)."""
+    lib = _lib.load()
+    for t_ in (param, grad, exp_avg, exp_avg_sq):
+        assert t_.dtype == torch.float32 and t_.is_contiguous() and t_.numel() == param.numel()
+    _lib.check(lib.mobi_adamw_step(_ptr(param), _ptr(grad), _ptr(exp_avg), _ptr(exp_avg_sq), param.numel(), lr, betas[0], betas[1], eps,
+                                   weight_decay, step, _stream()), "mobi_adamw_step")
+
+
 def geglu_fwd(pre):
     """pre: T [..., 2 inner] = [value | gate] dense -> value * gelu_erf(gate): T [..., inner]."""
     lib = _lib.load()

@@ -14,8 +14,8 @@ LayerNorm folded into to_q, the row chains, the un-materialised skip concat) bak
 or hides tensors the backward pass needs, and has no place here.  Frozen layers only pass the data gradient on.
 
 Pinned to torch.autograd through the CPU oracle (tests/test_gpu_backward.py): one block, and the reduced UNet end to end.
-Not built: the conditioning stage's trainable tensors (bbox embedder, `bbox_uncond_vector`: ddpm.py:1635-1647), `logvar`,
-the optimizer step, activation checkpointing (the tape of a full-width step at 64 x 64 x 16 is tens of GB: fine in 288 GB).
+Also here: the conditioning stage's trainable part (the 3-D box embedder, `bbox_uncond_vector`: ddpm.py:1635-1647) and AdamW.
+Not built: `logvar`, LR schedulers, activation checkpointing (the tape of a full-width step at 64 x 64 x 4 is 17 GB: fine in 288 GB).
 `mobi_amd.dist.allreduce_gradients` is the gradient collective (bucketed, RCCL; gloo on CPU in the tests).
 """
 import torch
@@ -121,7 +121,9 @@ def _attn_grads(grads, name, attn, connector, cname, dres, t_q_in, t_kv_in, q, k
 
 def block_backward(blk, tape, dout):
     """dout: T [N, T, C] dense, the gradient of the loss w.r.t. `block_forward`'s output -> (dx T [N, T, C], grads):
-    grads = {parameter name relative to the block: fp32 tensor} for every name of `trainable_names(blk)`."""
+    grads = {parameter name relative to the block: fp32 tensor} for every name of `trainable_names(blk)`, plus
+    `__dcontext__`: fp32 [N, 2, ctx_dim], the gradient w.r.t. the context tokens through the bbox adapter's to_k / to_v
+    (what the conditioning stage's trainable tensors receive; attn2's path to token 0 ends in frozen tensors only)."""
     t, g = tape, {}
     n, tok, c = dout.shape
     ff = blk.ff
@@ -157,8 +159,13 @@ def block_backward(blk, tape, dout):
                                     None, t.q_a, t.k_a, t.v_a, t.a_a, t.y_a, (ca.heads, ca.scale))
     # to_k / to_v saw the 2 N context tokens: a handful of rows -> fp32 FMA chains (mobi_linear_f32) instead of the matrix cores
     ctx32 = _rows(t.ctx_t).float()
-    for nm, dd in (("to_k", dk_a), ("to_v", dv_a)):
-        g[f"cond_adapter_attn.{nm}.weight"] = ops.linear_f32(_rows(dd).float().t().contiguous(), ctx32.t().contiguous())
+    dctx = None                                  # d loss / d context tokens [2 N, ctx_dim] fp32, through to_k and to_v
+    for nm, dd, lin in (("to_k", dk_a, ca.to_k), ("to_v", dv_a, ca.to_v)):
+        d32 = _rows(dd).float().contiguous()
+        g[f"cond_adapter_attn.{nm}.weight"] = ops.linear_f32(d32.t().contiguous(), ctx32.t().contiguous())
+        part = ops.linear_f32(d32, lin.weight.detach().float().t().contiguous())
+        dctx = part if dctx is None else ops.lincomb4([dctx, part], [1.0, 1.0])
+    g["__dcontext__"] = dctx.view(n, 2, -1)
     dx2, g["cond_adapter_norm.weight"], g["cond_adapter_norm.bias"] = ops.layernorm_bwd(
         t.x2, dxn_a, blk.cond_adapter_norm.affine()[0], blk.cond_adapter_norm.eps, dx_add=dx3)
     # ---- attn2 adds a per-image constant: identity for the data gradient.  attn1 (frozen): x2 = to_out(attention(qkv(LN1(x)))) + x
@@ -230,6 +237,8 @@ def _st_backward(st, tape, dout, grads, prefix):
     dt = dt.view(n, h * w, dt.shape[3])
     for i in reversed(range(len(tapes))):
         dt, g = block_backward(st.transformer_blocks[i], tapes[i], dt)
+        dc = g.pop("__dcontext__")
+        grads["__dcontext__"] = dc if "__dcontext__" not in grads else ops.lincomb4([grads["__dcontext__"], dc], [1.0, 1.0])
         grads.update({f"{prefix}.transformer_blocks.{i}.{k}": v for k, v in g.items()})
     dxn = ops.igemm(dt.view(n, h, w, dt.shape[2]), _conv_dgrad_pack(st.proj_in))
     g, b = st.norm.affine()
@@ -341,4 +350,65 @@ def loss_and_gradients(net, x_noisy, timesteps, context, target, loss_scale=1.0)
     grads = unet_backward(net, tape, deps)
     if loss_scale != 1.0:
         grads = {name: ops.lincomb4([g.contiguous()], [1.0 / loss_scale]) for name, g in grads.items()}
-    return loss, grads
+    return loss, grads                            # (grads["__dcontext__"]: the gradient w.r.t. the context tokens)
+
+
+# ======================================================================================================================
+# The conditioning stage's trainable part (ddpm.py:1635-1647 of the reference): the 3-D box embedder and `bbox_uncond_vector`
+# ======================================================================================================================
+def bbox_embedder_forward(emb, bbox):
+    """BBoxEmbedder.forward (ldm/modules/encoders/modules.py:85-91 of the reference) with a tape: bbox fp32 [B, 8, 3] ->
+    (token fp32 [B, 1, 768], tape).  Fourier features, then Linear -> Linear, SiLU, Linear, SiLU, Linear as fp32 GEMV chains."""
+    from ._lib import ACT_SILU
+    from .ldm.modules.encoders.modules import fourier_features
+    e = fourier_features(bbox.float(), emb.num_freqs).reshape(bbox.shape[0], -1).contiguous()
+    gemv = lambda lin, x, pre=0: ops.skinny_linear(x.contiguous(), *lin.skinny(), pre_act=pre)
+    h0 = gemv(emb.bbox_proj, e)
+    z1 = gemv(emb.second_linear[0], h0)
+    z2 = gemv(emb.second_linear[2], z1, ACT_SILU)
+    out = gemv(emb.second_linear[4], z2, ACT_SILU)
+    return out.unsqueeze(1), (e, h0, z1, z2)
+
+
+def bbox_embedder_backward(emb, tape, dtoken):
+    """dtoken: fp32 [B, 1, 768] -> {`bbox_proj.weight`, ..., `second_linear.4.bias`: fp32 gradient} (8 tensors).  A handful of rows:
+    every product is an fp32 FMA chain (mobi_linear_f32)."""
+    e, h0, z1, z2 = tape
+    silu = lambda z: z * torch.sigmoid(z)          # (recomputed activations: [B, 512] fp32 elementwise, the GEMV's pre-activation)
+    g = {}
+    ones = torch.ones((1, dtoken.shape[0]), device=dtoken.device, dtype=torch.float32)
+
+    def layer(name, lin, dy, x, need_dx=True):
+        g[name + ".weight"] = ops.linear_f32(dy.t().contiguous(), x.t().contiguous())
+        g[name + ".bias"] = ops.linear_f32(dy.t().contiguous(), ones).reshape(-1)
+        return ops.linear_f32(dy, lin.weight.detach().float().t().contiguous()) if need_dx else None
+    dy = dtoken.reshape(dtoken.shape[0], -1).float().contiguous()
+    da2 = layer("second_linear.4", emb.second_linear[4], dy, silu(z2))
+    dz2 = ops.silu_bwd_f32(z2.contiguous(), da2)
+    da1 = layer("second_linear.2", emb.second_linear[2], dz2, silu(z1))
+    dz1 = ops.silu_bwd_f32(z1.contiguous(), da1)
+    dh0 = layer("second_linear.0", emb.second_linear[0], dz1, h0)
+    layer("bbox_proj", emb.bbox_proj, dh0, e, need_dx=False)
+    return g
+
+
+class AdamW:
+    """torch.optim.AdamW's update (what `configure_optimizers` returns, ddpm.py:1649) on the engine: fp32 master parameters
+    updated in place by `mobi_adamw_step`, moments kept per parameter name."""
+
+    def __init__(self, named_params, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
+        self.params = dict(named_params)
+        self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
+        self.state, self.steps = {}, 0
+
+    def step(self, grads):
+        """grads: {name: fp32 tensor}; names without an entry are left alone."""
+        self.steps += 1
+        for name, p in self.params.items():
+            if name not in grads:
+                continue
+            st = self.state.setdefault(name, (torch.zeros_like(p.data, dtype=torch.float32), torch.zeros_like(p.data, dtype=torch.float32)))
+            ops.adamw_step(p.data, grads[name].reshape(p.shape).contiguous(), st[0], st[1], self.steps, self.lr, self.betas, self.eps,
+                           self.weight_decay)
+            torch.autograd.graph.increment_version(p)          # the packed 16-bit copies are keyed on the version counter
+        return self

@@ -121,6 +121,7 @@ def test_transformer_block_backward_vs_autograd(dtype, c, heads, n, side):
     out, tape = train.block_forward(blk, xd, ctx.cuda())
     assert rel(out.float(), ref_out.detach(), "fwd") < TOL_DX[dtype]
     dx, grads = train.block_backward(blk, tape, rd)
+    grads.pop("__dcontext__")
     assert sorted(grads) == sorted(names)
     assert rel(dx.float(), x.grad, "dx") < TOL_DX[dtype]
     worst = max(rel(grads[k], ps["b." + k].grad, "dw") for k in names)
@@ -176,10 +177,15 @@ def test_unet_training_step_gradients_vs_autograd(dtype):
     names = train.trainable_names(net)
     assert len(names) == 432
     ps = {k: (v.clone().requires_grad_(True) if k in set(names) else v) for k, v in sd.items()}
+    ctx = ctx.clone().requires_grad_(True)
     ref = ounet.unet_forward(ps, cfg, x, t, ctx)
     ref_loss = torch.mean((ref - noise) ** 2)
     ref_loss.backward()
-    loss, grads = train.loss_and_gradients(net, x.cuda(), t.cuda(), ctx.cuda(), noise.cuda(), loss_scale=256.0)
+    loss, grads = train.loss_and_gradients(net, x.cuda(), t.cuda(), ctx.detach().cuda(), noise.cuda(), loss_scale=256.0)
+    # the gradient w.r.t. the 3-D box token (context token 1: what the conditioning stage's trainable tensors receive; token 0
+    # also feeds attn2, whose path ends in frozen tensors and is not followed)
+    dctx = grads.pop("__dcontext__")
+    assert rel(dctx[:, 1], ctx.grad[:, 1], "dcontext") < TOL_UNET[dtype][1]
     assert sorted(grads) == sorted(names)
     assert abs(float(loss) - float(ref_loss.detach())) / float(ref_loss.detach()) < TOL_DX[dtype]
     # every tensor on its own, and all of them as one vector
@@ -190,3 +196,44 @@ def test_unet_training_step_gradients_vs_autograd(dtype):
     record("all_adapter_gradients", whole)
     assert whole < TOL_UNET[dtype][0], whole
     assert max(errs.values()) < TOL_UNET[dtype][1], max(errs.items(), key=lambda kv: kv[1])
+
+
+def test_bbox_embedder_backward_and_adamw(ops):
+    """The conditioning stage's trainable part (ddpm.py:1635-1647 of the reference): BBoxEmbedder (modules.py:63-91) forward with a
+    tape and its backward pass against torch.autograd on the same fp32 layers; one AdamW update (`mobi_adamw_step`) against
+    torch.optim.AdamW over three steps."""
+    import mobi_amd
+    from mobi_amd import train
+    from mobi_amd.ldm.modules.encoders.modules import BBoxEmbedder, fourier_features
+    mobi_amd.set_engine_dtype(torch.float16)
+    emb = BBoxEmbedder()
+    W.fill_module_(emb, seed=61)
+    ref = {k: v.detach().clone().requires_grad_(True) for k, v in emb.state_dict().items()}
+    emb = emb.cuda()
+    bbox = W.synth_input("bw.bbox", (6, 8, 3), kind="uniform") * 0.5 + 0.5
+    dtok = W.synth_input("bw.dtok", (6, 1, 768))
+    e = fourier_features(bbox, 4).reshape(6, -1)
+    h = F.linear(e, ref["bbox_proj.weight"], ref["bbox_proj.bias"])
+    h = F.silu(F.linear(h, ref["second_linear.0.weight"], ref["second_linear.0.bias"]))
+    h = F.silu(F.linear(h, ref["second_linear.2.weight"], ref["second_linear.2.bias"]))
+    tok = F.linear(h, ref["second_linear.4.weight"], ref["second_linear.4.bias"]).unsqueeze(1)
+    tok.backward(dtok)
+    got, tape = train.bbox_embedder_forward(emb, bbox.cuda())
+    assert rel(got, tok.detach()) < 1e-3                      # (the forward GEMVs read the 16-bit weight copies)
+    grads = train.bbox_embedder_backward(emb, tape, dtok.cuda())
+    assert sorted(grads) == sorted(ref)
+    for k in ref:
+        assert rel(grads[k], ref[k].grad, "dw") < 2e-3, k
+    # AdamW
+    p_ref = torch.nn.Parameter(W.synth_input("bw.adam.p", (257, 33)).clone())
+    opt = torch.optim.AdamW([p_ref], lr=3e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2)
+    p_eng = torch.nn.Parameter(p_ref.detach().clone().cuda())
+    mine = train.AdamW({"p": p_eng}, lr=3e-3)
+    v0 = p_eng._version
+    for i in range(3):
+        g = W.synth_input(f"bw.adam.g{i}", (257, 33))
+        p_ref.grad = g.clone()
+        opt.step()
+        mine.step({"p": g.cuda()})
+    assert p_eng._version > v0
+    assert rel(p_eng.detach(), p_ref.detach()) < 1e-6
