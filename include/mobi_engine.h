@@ -322,7 +322,7 @@ int mobi_trunk_add(float* trunk, const void* inc, void* x16, int64_t n, int32_t 
 int mobi_transpose(const void* src, int64_t src_row_stride, void* out, int32_t rows, int32_t cols, int32_t dtype,
                    void* stream);                          /* T [rows][cols] (row stride in elements) -> T [cols][rows] */
 int32_t mobi_backward_partial_blocks(int64_t rows);        /* blocks of per-block partial sums the two calls below use */
-/* out[c] = sum_rows dy[row][c]; partial: f32 [mobi_backward_partial_blocks(rows)][cols] scratch. */
+/* out[c] = sum_rows dy[row][c]; partial: f32 [mobi_backward_partial_blocks(rows) + 64][cols] scratch. */
 int mobi_colsum(const void* dy, int64_t row_stride, int64_t rows, int32_t cols, int32_t dtype, float* partial, float* out,
                 void* stream);
 typedef struct mobi_layernorm_bwd_params {
@@ -331,7 +331,7 @@ typedef struct mobi_layernorm_bwd_params {
   const float* gamma; float eps;
   const void* dx_add;                       /* T [rows][channels] dense or NULL: added to dx (the residual branch's gradient) */
   void* dx;                                 /* T [rows][channels] dense */
-  float* partial;                           /* f32 [mobi_backward_partial_blocks(rows)][2][channels] scratch */
+  float* partial;                           /* f32 [mobi_backward_partial_blocks(rows) + 64][2][channels] scratch */
   float* dgamma_dbeta;                      /* f32 [2][channels]: d gamma, then d beta */
   int64_t rows; int32_t channels; int32_t dtype;
 } mobi_layernorm_bwd_params;
@@ -365,6 +365,9 @@ typedef struct mobi_attention_bwd_params {
   float* lse; float* dvec;                                 /* f32 [image][heads][tq] scratch each */
   int32_t images, heads, dh, tq, tk;                       /* dh <= 160 */
   float scale; int32_t dtype;
+  int32_t force_vector;                                    /* 1: the fp32 vector-ALU passes (any shape; A/B and tests); 0: the
+                                                              matrix-core passes where they apply (dh % 8 == 0, 16-padded width
+                                                              16 / 32 / 48 / 64 / 80 / 160, 16-byte aligned rows), else vector */
 } mobi_attention_bwd_params;
 int mobi_attention_bwd(const mobi_attention_bwd_params* p, void* stream);
 

@@ -89,7 +89,7 @@ class AttentionBwdParams(C.Structure):
                 ("v", vp), ("v_img_stride", i64), ("v_row_stride", i64), ("o", vp), ("o_img_stride", i64), ("o_row_stride", i64),
                 ("dout", vp), ("dout_img_stride", i64), ("dout_row_stride", i64), ("dq", vp), ("dk", vp), ("dv", vp),
                 ("lse", vp), ("dvec", vp), ("images", i32), ("heads", i32), ("dh", i32), ("tq", i32), ("tk", i32),
-                ("scale", f32), ("dtype", i32)]
+                ("scale", f32), ("dtype", i32), ("force_vector", i32)]
 
 
 class CtxAttentionParams(C.Structure):

@@ -58,14 +58,28 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ dy, l
   }
 }
 
-// out[i] = sum_b partial[b][i] (ascending b)
+// out[i] = sum_b partial[b][i]: blockIdx.y owns a contiguous range of the nblk rows (ascending b inside it); gridDim.y == 1 writes the
+// result, otherwise a second call sums the gridDim.y partial rows -- fixed order either way
 __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ partial, float* __restrict__ out, int nblk,
                                                               long long len) {
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
   if (i >= len) return;
+  const int per = (nblk + gridDim.y - 1) / gridDim.y;
+  const int b0 = blockIdx.y * per, b1 = b0 + per < nblk ? b0 + per : nblk;
   float s = 0.f;
-  for (int b = 0; b < nblk; ++b) s += partial[(long long)b * len + i];
-  out[i] = s;
+  for (int b = b0; b < b1; ++b) s += partial[(long long)b * len + i];
+  out[(long long)blockIdx.y * len + i] = s;
+}
+
+static void reduce_partials(const float* partial, float* scratch, float* out, int nblk, long long len, hipStream_t st) {
+  // scratch: >= 64 * len floats when nblk > 64
+  const unsigned gx = (unsigned)((len + 255) / 256);
+  if (nblk <= 64) {
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(gx, 1), dim3(256), 0, st, partial, out, nblk, len);
+    return;
+  }
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3(gx, 64), dim3(256), 0, st, partial, scratch, nblk, len);
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3(gx, 1), dim3(256), 0, st, scratch, out, 64, len);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -359,6 +373,203 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnBwdArgs a) 
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// The same two passes on the matrix cores (MFMA 32x32x16; head dims whose 16-padded width is 16 KD, KD in {1..5, 10}).
+// Layouts as in the forward attention / feed-forward kernels: the wave's own 32 rows (queries in the dQ pass, keys in the
+// dK | dV pass) are the B operand and stay in registers, the other side's 32-row tiles go through LDS as the A operand;
+// D^T[row of A][own row] accumulates in fp32, and an accumulator turned into the next product's B operand keeps its own
+// k order (k slot (h, j) of step s = row 16 s + 8 (j >> 2) + 4 h + (j & 3)), which the A side reads accordingly from a
+// TRANSPOSED copy of the tile.
+//   dQ pass, per 32-key tile:  S^T = K Q^T, dP^T = V dO^T (A = K / V rows);  dS^T = P^T (dP^T - D) scale;  dQ^T += K^T dS^T
+//   dK | dV pass, per 32-query tile:  S = Q K^T, dP = dO V^T (A = Q / dO rows);  dV^T += dO^T P,  dK^T += Q^T dS
+// Rows beyond the tensors are staged as zeros (and L = +1e30 for missing queries, so their P is 0); missing keys are masked in P.
+constexpr int BM_PITCH_PAD = 8;      // row-major tiles: dhp + 8 elements per row
+constexpr int BM_TP = 36;            // transposed tiles: 32 + 4 elements per row
+
+template <typename T, int KD>
+__device__ __forceinline__ void bm_stage(T* row_major, T* transposed, const T* src, long long row_stride, int rows_valid, int dh, int tid) {
+  constexpr int DHP = 16 * KD, PITCH = DHP + BM_PITCH_PAD;
+  for (int i = tid; i < 32 * DHP; i += 256) {
+    const int r = i / DHP, d = i - r * DHP;
+    const T v = (r < rows_valid && d < dh) ? src[(long long)r * row_stride + d] : (T)0.0f;
+    row_major[r * PITCH + d] = v;
+    if (transposed) transposed[d * BM_TP + r] = v;
+  }
+}
+
+template <typename T, int KD>
+__global__ __launch_bounds__(256) void attn_bwd_dq_mfma_kernel(const AttnBwdArgs a) {
+  typedef typename Vec8<T>::type frag_t;
+  constexpr int DHP = 16 * KD, MD = (KD + 1) / 2, PITCH = DHP + BM_PITCH_PAD;
+  __shared__ __attribute__((aligned(16))) T sK[32 * PITCH], sV[32 * PITCH], sKT[32 * MD * BM_TP];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, ql = lane & 31, half = lane >> 5;
+  const int h = blockIdx.y, img = blockIdx.z;
+  const int q = blockIdx.x * 128 + wave * 32 + ql;
+  const bool qok = q < a.tq;
+  for (int i = tid; i < 32 * MD * BM_TP; i += 256) sKT[i] = (T)0.0f;       // rows d >= DHP stay zero
+  const T* qp = reinterpret_cast<const T*>(a.q) + img * a.q_is + (long long)(qok ? q : 0) * a.q_rs + h * a.dh;
+  const T* dp_ = reinterpret_cast<const T*>(a.dout) + img * a.do_is + (long long)(qok ? q : 0) * a.do_rs + h * a.dh;
+  frag_t qf[KD], dof[KD];
+#pragma unroll
+  for (int s = 0; s < KD; ++s) {
+    const int d0 = 16 * s + 8 * half;
+    const bool ok = qok && d0 < a.dh;
+    qf[s] = ok ? __builtin_bit_cast(frag_t, ld16(qp + d0)) : __builtin_bit_cast(frag_t, u32x4{0u, 0u, 0u, 0u});
+    dof[s] = ok ? __builtin_bit_cast(frag_t, ld16(dp_ + d0)) : __builtin_bit_cast(frag_t, u32x4{0u, 0u, 0u, 0u});
+  }
+  const long long sidx = ((long long)img * a.heads + h) * a.tq + (qok ? q : 0);
+  const float L = qok ? a.lse[sidx] : 1.0e30f, D = qok ? a.dvec[sidx] : 0.f;
+  f32x16 acc[MD];
+#pragma unroll
+  for (int m = 0; m < MD; ++m)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+  for (int k0 = 0; k0 < a.tk; k0 += 32) {
+    const int kv = min(32, a.tk - k0);
+    __syncthreads();
+    bm_stage<T, KD>(sK, sKT, reinterpret_cast<const T*>(a.k) + img * a.k_is + (long long)k0 * a.k_rs + h * a.dh, a.k_rs, kv, a.dh, tid);
+    bm_stage<T, KD>(sV, nullptr, reinterpret_cast<const T*>(a.v) + img * a.v_is + (long long)k0 * a.v_rs + h * a.dh, a.v_rs, kv, a.dh, tid);
+    __syncthreads();
+    f32x16 st, dpt;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { st[r] = 0.f; dpt[r] = 0.f; }
+#pragma unroll
+    for (int s = 0; s < KD; ++s) {
+      const frag_t kf = __builtin_bit_cast(frag_t, ld16(sK + ql * PITCH + 16 * s + 8 * half));
+      const frag_t vf = __builtin_bit_cast(frag_t, ld16(sV + ql * PITCH + 16 * s + 8 * half));
+      st = mfma32(kf, qf[s], st);
+      dpt = mfma32(vf, dof[s], dpt);
+    }
+    // lane (query, half), register r: key k0 + (r & 3) + 8 (r >> 2) + 4 half
+    float ds[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int key = (r & 3) + 8 * (r >> 2) + 4 * half;
+      const float p = key < kv ? __expf(st[r] * a.scale - L) : 0.f;
+      ds[r] = p * (dpt[r] - D) * a.scale;
+    }
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      const float v8[8] = {ds[8 * s2], ds[8 * s2 + 1], ds[8 * s2 + 2], ds[8 * s2 + 3], ds[8 * s2 + 4], ds[8 * s2 + 5], ds[8 * s2 + 6], ds[8 * s2 + 7]};
+      const frag_t bf = __builtin_bit_cast(frag_t, pack8<T>(v8));
+#pragma unroll
+      for (int m = 0; m < MD; ++m) {
+        // A row = channel 32 m + ql; its k slots (half, j): keys 16 s2 + 8 (j >> 2) + 4 half + (j & 3)
+        const T* tp = sKT + (32 * m + ql) * BM_TP + 16 * s2 + 4 * half;
+        const u32x2 lo = *reinterpret_cast<const u32x2*>(tp), hi = *reinterpret_cast<const u32x2*>(tp + 8);
+        acc[m] = mfma32(__builtin_bit_cast(frag_t, u32x4{lo[0], lo[1], hi[0], hi[1]}), bf, acc[m]);
+      }
+    }
+  }
+  if (qok) {
+    T* out = reinterpret_cast<T*>(a.dq) + ((long long)img * a.tq + q) * (a.heads * a.dh) + h * a.dh;
+#pragma unroll
+    for (int m = 0; m < MD; ++m)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int d0 = 32 * m + 8 * g + 4 * half;
+        if (d0 < a.dh) {
+          const float v4[4] = {acc[m][4 * g], acc[m][4 * g + 1], acc[m][4 * g + 2], acc[m][4 * g + 3]};
+          *reinterpret_cast<u32x2*>(out + d0) = pack4<T>(v4);
+        }
+      }
+  }
+}
+
+template <typename T, int KD>
+__global__ __launch_bounds__(256) void attn_bwd_dkv_mfma_kernel(const AttnBwdArgs a) {
+  typedef typename Vec8<T>::type frag_t;
+  constexpr int DHP = 16 * KD, MD = (KD + 1) / 2, PITCH = DHP + BM_PITCH_PAD;
+  __shared__ __attribute__((aligned(16))) T sQ[32 * PITCH], sO[32 * PITCH], sQT[32 * MD * BM_TP], sOT[32 * MD * BM_TP];
+  __shared__ __attribute__((aligned(16))) float sL[32], sD[32];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, kl = lane & 31, half = lane >> 5;
+  const int h = blockIdx.y, img = blockIdx.z;
+  const int key = blockIdx.x * 128 + wave * 32 + kl;
+  const bool kok = key < a.tk;
+  for (int i = tid; i < 32 * MD * BM_TP; i += 256) { sQT[i] = (T)0.0f; sOT[i] = (T)0.0f; }
+  const T* kp = reinterpret_cast<const T*>(a.k) + img * a.k_is + (long long)(kok ? key : 0) * a.k_rs + h * a.dh;
+  const T* vp = reinterpret_cast<const T*>(a.v) + img * a.v_is + (long long)(kok ? key : 0) * a.v_rs + h * a.dh;
+  frag_t kf[KD], vf[KD];
+#pragma unroll
+  for (int s = 0; s < KD; ++s) {
+    const int d0 = 16 * s + 8 * half;
+    const bool ok = kok && d0 < a.dh;
+    kf[s] = ok ? __builtin_bit_cast(frag_t, ld16(kp + d0)) : __builtin_bit_cast(frag_t, u32x4{0u, 0u, 0u, 0u});
+    vf[s] = ok ? __builtin_bit_cast(frag_t, ld16(vp + d0)) : __builtin_bit_cast(frag_t, u32x4{0u, 0u, 0u, 0u});
+  }
+  f32x16 ak[MD], av[MD];
+#pragma unroll
+  for (int m = 0; m < MD; ++m)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { ak[m][r] = 0.f; av[m][r] = 0.f; }
+  for (int q0 = 0; q0 < a.tq; q0 += 32) {
+    const int qv = min(32, a.tq - q0);
+    __syncthreads();
+    bm_stage<T, KD>(sQ, sQT, reinterpret_cast<const T*>(a.q) + img * a.q_is + (long long)q0 * a.q_rs + h * a.dh, a.q_rs, qv, a.dh, tid);
+    bm_stage<T, KD>(sO, sOT, reinterpret_cast<const T*>(a.dout) + img * a.do_is + (long long)q0 * a.do_rs + h * a.dh, a.do_rs, qv, a.dh, tid);
+    if (tid < 32) {
+      const long long sidx = ((long long)img * a.heads + h) * a.tq + q0 + tid;
+      sL[tid] = tid < qv ? a.lse[sidx] : 1.0e30f;
+      sD[tid] = tid < qv ? a.dvec[sidx] : 0.f;
+    }
+    __syncthreads();
+    f32x16 st, dpt;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { st[r] = 0.f; dpt[r] = 0.f; }
+#pragma unroll
+    for (int s = 0; s < KD; ++s) {
+      const frag_t qf = __builtin_bit_cast(frag_t, ld16(sQ + kl * PITCH + 16 * s + 8 * half));
+      const frag_t of = __builtin_bit_cast(frag_t, ld16(sO + kl * PITCH + 16 * s + 8 * half));
+      st = mfma32(qf, kf[s], st);
+      dpt = mfma32(of, vf[s], dpt);
+    }
+    // lane (key, half), register r: query q0 + (r & 3) + 8 (r >> 2) + 4 half
+    float pr[16], ds[16];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const f32x4 l4 = *reinterpret_cast<const f32x4*>(sL + 8 * g + 4 * half), d4 = *reinterpret_cast<const f32x4*>(sD + 8 * g + 4 * half);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float p = __expf(st[4 * g + j] * a.scale - l4[j]);
+        pr[4 * g + j] = p;
+        ds[4 * g + j] = p * (dpt[4 * g + j] - d4[j]) * a.scale;
+      }
+    }
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      const float p8[8] = {pr[8 * s2], pr[8 * s2 + 1], pr[8 * s2 + 2], pr[8 * s2 + 3], pr[8 * s2 + 4], pr[8 * s2 + 5], pr[8 * s2 + 6], pr[8 * s2 + 7]};
+      const float d8[8] = {ds[8 * s2], ds[8 * s2 + 1], ds[8 * s2 + 2], ds[8 * s2 + 3], ds[8 * s2 + 4], ds[8 * s2 + 5], ds[8 * s2 + 6], ds[8 * s2 + 7]};
+      const frag_t pf = __builtin_bit_cast(frag_t, pack8<T>(p8)), df = __builtin_bit_cast(frag_t, pack8<T>(d8));
+#pragma unroll
+      for (int m = 0; m < MD; ++m) {
+        const T* to = sOT + (32 * m + kl) * BM_TP + 16 * s2 + 4 * half;
+        const T* tq_ = sQT + (32 * m + kl) * BM_TP + 16 * s2 + 4 * half;
+        const u32x2 olo = *reinterpret_cast<const u32x2*>(to), ohi = *reinterpret_cast<const u32x2*>(to + 8);
+        const u32x2 qlo = *reinterpret_cast<const u32x2*>(tq_), qhi = *reinterpret_cast<const u32x2*>(tq_ + 8);
+        av[m] = mfma32(__builtin_bit_cast(frag_t, u32x4{olo[0], olo[1], ohi[0], ohi[1]}), pf, av[m]);
+        ak[m] = mfma32(__builtin_bit_cast(frag_t, u32x4{qlo[0], qlo[1], qhi[0], qhi[1]}), df, ak[m]);
+      }
+    }
+  }
+  if (kok) {
+    const long long off = ((long long)img * a.tk + key) * (a.heads * a.dh) + h * a.dh;
+    T* outk = reinterpret_cast<T*>(a.dk) + off;
+    T* outv = reinterpret_cast<T*>(a.dv) + off;
+#pragma unroll
+    for (int m = 0; m < MD; ++m)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int d0 = 32 * m + 8 * g + 4 * half;
+        if (d0 < a.dh) {
+          const float k4[4] = {ak[m][4 * g], ak[m][4 * g + 1], ak[m][4 * g + 2], ak[m][4 * g + 3]};
+          const float v4[4] = {av[m][4 * g], av[m][4 * g + 1], av[m][4 * g + 2], av[m][4 * g + 3]};
+          *reinterpret_cast<u32x2*>(outk + d0) = pack4<T>(k4);
+          *reinterpret_cast<u32x2*>(outv + d0) = pack4<T>(v4);
+        }
+      }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // GroupNorm (32 groups) (+ SiLU) backward, data gradient only (the affine parameters of the UNet's GroupNorms are frozen):
 //   z = xh gamma + beta, y = act(z);  dxh = dy act'(z) gamma;  dx = rstd (dxh - mean_g(dxh) - xh mean_g(dxh xh)) (+ dx_add)
 // One block per (image, group); statistics re-derived from x (mean, then variance about the mean), four passes over the
@@ -491,8 +702,10 @@ extern "C" int mobi_transpose(const void* src, int64_t src_row_stride, void* out
 }
 
 extern "C" int32_t mobi_backward_partial_blocks(int64_t rows) {
-  const int64_t b = (rows + 255) / 256;
-  return (int32_t)(b < 1 ? 1 : (b > 256 ? 256 : b));
+  // 16 rows per block (4 per wave) up to 4,096 blocks: with 256 rows per block a [65536, 320] LayerNorm backward ran as
+  // 1,024 latency chains of 64 rows each -- 0.9 ms, 0.14 TB/s (rocprofv3 of tools/train_bench.py)
+  const int64_t b = (rows + 15) / 16;
+  return (int32_t)(b < 1 ? 1 : (b > 4096 ? 4096 : b));
 }
 
 extern "C" int mobi_colsum(const void* dy, int64_t row_stride, int64_t rows, int32_t cols, int32_t dtype, float* partial,
@@ -506,7 +719,7 @@ extern "C" int mobi_colsum(const void* dy, int64_t row_stride, int64_t rows, int
     hipLaunchKernelGGL((colsum_kernel<f16_t>), dim3(nblk), dim3(256), 0, ST(stream), reinterpret_cast<const f16_t*>(dy), row_stride, partial, rows, cols, rpb);
   else
     hipLaunchKernelGGL((colsum_kernel<bf16_t>), dim3(nblk), dim3(256), 0, ST(stream), reinterpret_cast<const bf16_t*>(dy), row_stride, partial, rows, cols, rpb);
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3((cols + 255) / 256), dim3(256), 0, ST(stream), partial, out, nblk, (long long)cols);
+  reduce_partials(partial, partial + (long long)nblk * cols, out, nblk, (long long)cols, ST(stream));
   MOBI_CHECK_LAUNCH();
   return MOBI_OK;
 }
@@ -528,8 +741,7 @@ extern "C" int mobi_layernorm_bwd(const mobi_layernorm_bwd_params* p, void* stre
                        reinterpret_cast<const bf16_t*>(p->dy), ds, p->gamma, p->eps, reinterpret_cast<const bf16_t*>(p->dx_add),
                        reinterpret_cast<bf16_t*>(p->dx), p->partial, (long long)p->rows, p->channels, rpb);
   // partial is [nblk][2][C]: d gamma = sum of the [.][0][.] planes, d beta of the [.][1][.] planes
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3((2 * p->channels + 255) / 256), dim3(256), 0, ST(stream), p->partial, p->dgamma_dbeta, nblk,
-                     (long long)2 * p->channels);
+  reduce_partials(p->partial, p->partial + (long long)nblk * 2 * p->channels, p->dgamma_dbeta, nblk, (long long)2 * p->channels, ST(stream));
   MOBI_CHECK_LAUNCH();
   return MOBI_OK;
 }
@@ -573,8 +785,36 @@ extern "C" int mobi_attention_bwd(const mobi_attention_bwd_params* p, void* stre
   a.heads = p->heads; a.dh = p->dh; a.tq = p->tq; a.tk = p->tk; a.scale = p->scale;
   const dim3 gq((p->tq + BW_TILE - 1) / BW_TILE, p->heads, p->images), gk((p->tk + BW_TILE - 1) / BW_TILE, p->heads, p->images);
   BW_DISPATCH(p->dtype, attn_bwd_stats_kernel, gq, a);
-  BW_DISPATCH(p->dtype, attn_bwd_dq_kernel, gq, a);
-  BW_DISPATCH(p->dtype, attn_bwd_dkv_kernel, gk, a);
+  // the matrix-core passes need 8-element pieces of a head row to be 16-byte aligned loads: dh % 8 == 0, strides % 8 == 0
+  const int kd = (p->dh + 15) / 16;
+  const bool al = p->dh % 8 == 0 && ((p->q_row_stride | p->k_row_stride | p->v_row_stride | p->dout_row_stride | p->q_img_stride |
+                                      p->k_img_stride | p->v_img_stride | p->dout_img_stride) & 7) == 0 &&
+                  ((reinterpret_cast<uintptr_t>(p->q) | reinterpret_cast<uintptr_t>(p->k) | reinterpret_cast<uintptr_t>(p->v) |
+                    reinterpret_cast<uintptr_t>(p->dout)) & 15) == 0;
+  const dim3 gq4((p->tq + 127) / 128, p->heads, p->images), gk4((p->tk + 127) / 128, p->heads, p->images);
+#define BM_CASE(KD_)                                                                                                       \
+  case KD_:                                                                                                                \
+    if (p->dtype == MOBI_F16) {                                                                                            \
+      hipLaunchKernelGGL((attn_bwd_dq_mfma_kernel<f16_t, KD_>), gq4, dim3(256), 0, ST(stream), a);                         \
+      hipLaunchKernelGGL((attn_bwd_dkv_mfma_kernel<f16_t, KD_>), gk4, dim3(256), 0, ST(stream), a);                        \
+    } else {                                                                                                               \
+      hipLaunchKernelGGL((attn_bwd_dq_mfma_kernel<bf16_t, KD_>), gq4, dim3(256), 0, ST(stream), a);                        \
+      hipLaunchKernelGGL((attn_bwd_dkv_mfma_kernel<bf16_t, KD_>), gk4, dim3(256), 0, ST(stream), a);                       \
+    }                                                                                                                      \
+    break;
+  bool done = false;
+  if (al && !p->force_vector) {
+    done = true;
+    switch (kd) {
+      BM_CASE(1) BM_CASE(2) BM_CASE(3) BM_CASE(4) BM_CASE(5) BM_CASE(10)
+      default: done = false;
+    }
+  }
+#undef BM_CASE
+  if (!done) {
+    BW_DISPATCH(p->dtype, attn_bwd_dq_kernel, gq, a);
+    BW_DISPATCH(p->dtype, attn_bwd_dkv_kernel, gk, a);
+  }
   MOBI_CHECK_LAUNCH();
   return MOBI_OK;
 }

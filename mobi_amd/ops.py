@@ -458,7 +458,7 @@ def colsum(dy):
     lib = _lib.load()
     assert dy.dim() == 2 and dy.stride(1) == 1
     rows, cols = dy.shape
-    part = torch.empty((lib.mobi_backward_partial_blocks(rows), cols), device=dy.device, dtype=torch.float32)
+    part = torch.empty((lib.mobi_backward_partial_blocks(rows) + 64, cols), device=dy.device, dtype=torch.float32)
     out = torch.empty(cols, device=dy.device, dtype=torch.float32)
     _lib.check(lib.mobi_colsum(_ptr(dy), dy.stride(0), rows, cols, _dt(dy.dtype), _ptr(part), _ptr(out), _stream()), "mobi_colsum")
     return out
@@ -485,7 +485,7 @@ def layernorm_bwd(x, dy, gamma, eps, dx_add=None):
     n, t, c = x.shape
     x2, dy2 = x.reshape(n * t, c), dy.reshape(n * t, c)                       # (views when dense, copies when strided)
     dx = torch.empty((n, t, c), device=x.device, dtype=x.dtype)
-    nb = lib.mobi_backward_partial_blocks(n * t)
+    nb = lib.mobi_backward_partial_blocks(n * t) + 64
     part = torch.empty((nb, 2, c), device=x.device, dtype=torch.float32)
     dgb = torch.empty((2, c), device=x.device, dtype=torch.float32)
     p = _lib.LayerNormBwdParams()
@@ -566,7 +566,7 @@ def geglu_bwd(pre, dh):
     return dpre
 
 
-def attention_bwd(q, k, v, o, dout, heads, scale):
+def attention_bwd(q, k, v, o, dout, heads, scale, force_vector=False):
     """q: T [N, Tq, >= C] view, k / v: T [N, Tk, >= C] views (channel stride 1), o / dout: [N, Tq, C] -> (dq, dk, dv) dense T."""
     lib = _lib.load()
     n, tq, tk = q.shape[0], q.shape[1], k.shape[1]
@@ -582,6 +582,7 @@ def attention_bwd(q, k, v, o, dout, heads, scale):
         setattr(p, name + "_row_stride", t_.stride(1))
     p.dq, p.dk, p.dv, p.lse, p.dvec = _ptr(dq), _ptr(dk), _ptr(dv), _ptr(lse[0]), _ptr(lse[1])
     p.images, p.heads, p.dh, p.tq, p.tk, p.scale, p.dtype = n, heads, c // heads, tq, tk, scale, _dt(q.dtype)
+    p.force_vector = int(force_vector)
     _lib.check(lib.mobi_attention_bwd(C.byref(p), _stream()), "mobi_attention_bwd")
     return dq, dk, dv
 

@@ -76,7 +76,8 @@ def test_geglu_forward_backward(ops, dtype):
 
 
 @pytest.mark.parametrize("dtype", DT)
-@pytest.mark.parametrize("heads,dh,tq,tk", [(8, 40, 256, 256), (2, 160, 64, 64), (8, 8, 100, 70), (8, 40, 64, 2), (4, 80, 33, 129)])
+@pytest.mark.parametrize("heads,dh,tq,tk", [(8, 40, 256, 256), (2, 160, 64, 64), (8, 8, 100, 70), (8, 40, 64, 2), (4, 80, 33, 129),
+                                            (8, 16, 130, 300), (4, 64, 257, 96), (2, 32, 4096, 2), (3, 24, 50, 50)])
 def test_attention_backward(ops, dtype, heads, dh, tq, tk):
     n, c = 2, heads * dh
     qf, qd = rnd(f"bw.at.q{dh}.{tq}", (n, tq, c), dtype)
@@ -90,9 +91,10 @@ def test_attention_backward(ops, dtype, heads, dh, tq, tk):
     o = o.permute(0, 2, 1, 3).reshape(n, tq, c)
     o.backward(dof)
     od = o.detach().to(dtype).cuda()
-    dq, dk, dv = ops.attention_bwd(qd, kd, vd, od, dod, heads, scale)
-    for got, want, nm in ((dq, q.grad, "dq"), (dk, k.grad, "dk"), (dv, v.grad, "dv")):
-        assert rel(got.float(), want, nm) < TOL1[dtype], nm
+    for force_vector in (False, True):           # the matrix-core passes (where they apply) and the fp32 vector-ALU passes
+        dq, dk, dv = ops.attention_bwd(qd, kd, vd, od, dod, heads, scale, force_vector=force_vector)
+        for got, want, nm in ((dq, q.grad, "dq"), (dk, k.grad, "dk"), (dv, v.grad, "dv")):
+            assert rel(got.float(), want, nm) < TOL1[dtype] * (1.0 if force_vector else 1.5), (nm, force_vector)
 
 
 @pytest.mark.parametrize("dtype", DT)
