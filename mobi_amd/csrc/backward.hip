@@ -396,6 +396,74 @@ __device__ __forceinline__ void bm_stage(T* row_major, T* transposed, const T* s
   }
 }
 
+// pass 1 on the matrix cores: L = log-sum-exp of the scaled scores (online maximum / sum over the key tiles, a query per lane),
+// D = do . o
+template <typename T, int KD>
+__global__ __launch_bounds__(256) void attn_bwd_stats_mfma_kernel(const AttnBwdArgs a) {
+  typedef typename Vec8<T>::type frag_t;
+  constexpr int DHP = 16 * KD, PITCH = DHP + BM_PITCH_PAD;
+  __shared__ __attribute__((aligned(16))) T sK[32 * PITCH];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, ql = lane & 31, half = lane >> 5;
+  const int h = blockIdx.y, img = blockIdx.z;
+  const int q = blockIdx.x * 128 + wave * 32 + ql;
+  const bool qok = q < a.tq;
+  const T* qp = reinterpret_cast<const T*>(a.q) + img * a.q_is + (long long)(qok ? q : 0) * a.q_rs + h * a.dh;
+  const T* dp_ = reinterpret_cast<const T*>(a.dout) + img * a.do_is + (long long)(qok ? q : 0) * a.do_rs + h * a.dh;
+  const T* op_ = reinterpret_cast<const T*>(a.o) + img * a.o_is + (long long)(qok ? q : 0) * a.o_rs + h * a.dh;
+  frag_t qf[KD];
+  float dd = 0.f;
+#pragma unroll
+  for (int s = 0; s < KD; ++s) {
+    const int d0 = 16 * s + 8 * half;
+    const bool ok = qok && d0 < a.dh;
+    qf[s] = ok ? __builtin_bit_cast(frag_t, ld16(qp + d0)) : __builtin_bit_cast(frag_t, u32x4{0u, 0u, 0u, 0u});
+    if (ok) {
+      float x[8], y[8];
+      unpack8<T>(ld16(dp_ + d0), x);
+      unpack8<T>(ld16(op_ + d0), y);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) dd += x[j] * y[j];
+    }
+  }
+  dd += __shfl_xor(dd, 32, 64);
+  float m = -3.0e38f, l = 0.f;
+  for (int k0 = 0; k0 < a.tk; k0 += 32) {
+    const int kv = min(32, a.tk - k0);
+    __syncthreads();
+    bm_stage<T, KD>(sK, nullptr, reinterpret_cast<const T*>(a.k) + img * a.k_is + (long long)k0 * a.k_rs + h * a.dh, a.k_rs, kv, a.dh, tid);
+    __syncthreads();
+    f32x16 st;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) st[r] = 0.f;
+#pragma unroll
+    for (int s = 0; s < KD; ++s) st = mfma32(__builtin_bit_cast(frag_t, ld16(sK + ql * PITCH + 16 * s + 8 * half)), qf[s], st);
+    float tm = -3.0e38f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int key = (r & 3) + 8 * (r >> 2) + 4 * half;
+      st[r] = key < kv ? st[r] * a.scale : -3.0e38f;
+      tm = fmaxf(tm, st[r]);
+    }
+    const float mn = fmaxf(m, tm);
+    float ts = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) ts += __expf(st[r] - mn);
+    l = l * __expf(m - mn) + ts;
+    m = mn;
+  }
+  {                                                 // the two lanes of a query combine their halves of the keys
+    const float m2 = __shfl_xor(m, 32, 64), l2 = __shfl_xor(l, 32, 64);
+    const float mn = fmaxf(m, m2);
+    l = l * __expf(m - mn) + l2 * __expf(m2 - mn);
+    m = mn;
+  }
+  if (qok && half == 0) {
+    const long long idx = ((long long)img * a.heads + h) * a.tq + q;
+    a.lse[idx] = m + __logf(l);
+    a.dvec[idx] = dd;
+  }
+}
+
 template <typename T, int KD>
 __global__ __launch_bounds__(256) void attn_bwd_dq_mfma_kernel(const AttnBwdArgs a) {
   typedef typename Vec8<T>::type frag_t;
@@ -784,20 +852,22 @@ extern "C" int mobi_attention_bwd(const mobi_attention_bwd_params* p, void* stre
   a.dq = p->dq; a.dk = p->dk; a.dv = p->dv; a.lse = p->lse; a.dvec = p->dvec;
   a.heads = p->heads; a.dh = p->dh; a.tq = p->tq; a.tk = p->tk; a.scale = p->scale;
   const dim3 gq((p->tq + BW_TILE - 1) / BW_TILE, p->heads, p->images), gk((p->tk + BW_TILE - 1) / BW_TILE, p->heads, p->images);
-  BW_DISPATCH(p->dtype, attn_bwd_stats_kernel, gq, a);
   // the matrix-core passes need 8-element pieces of a head row to be 16-byte aligned loads: dh % 8 == 0, strides % 8 == 0
   const int kd = (p->dh + 15) / 16;
   const bool al = p->dh % 8 == 0 && ((p->q_row_stride | p->k_row_stride | p->v_row_stride | p->dout_row_stride | p->q_img_stride |
                                       p->k_img_stride | p->v_img_stride | p->dout_img_stride) & 7) == 0 &&
+                  ((p->o_row_stride | p->o_img_stride) & 7) == 0 &&
                   ((reinterpret_cast<uintptr_t>(p->q) | reinterpret_cast<uintptr_t>(p->k) | reinterpret_cast<uintptr_t>(p->v) |
-                    reinterpret_cast<uintptr_t>(p->dout)) & 15) == 0;
+                    reinterpret_cast<uintptr_t>(p->dout) | reinterpret_cast<uintptr_t>(p->o)) & 15) == 0;
   const dim3 gq4((p->tq + 127) / 128, p->heads, p->images), gk4((p->tk + 127) / 128, p->heads, p->images);
 #define BM_CASE(KD_)                                                                                                       \
   case KD_:                                                                                                                \
     if (p->dtype == MOBI_F16) {                                                                                            \
+      hipLaunchKernelGGL((attn_bwd_stats_mfma_kernel<f16_t, KD_>), gq4, dim3(256), 0, ST(stream), a);                      \
       hipLaunchKernelGGL((attn_bwd_dq_mfma_kernel<f16_t, KD_>), gq4, dim3(256), 0, ST(stream), a);                         \
       hipLaunchKernelGGL((attn_bwd_dkv_mfma_kernel<f16_t, KD_>), gk4, dim3(256), 0, ST(stream), a);                        \
     } else {                                                                                                               \
+      hipLaunchKernelGGL((attn_bwd_stats_mfma_kernel<bf16_t, KD_>), gq4, dim3(256), 0, ST(stream), a);                     \
       hipLaunchKernelGGL((attn_bwd_dq_mfma_kernel<bf16_t, KD_>), gq4, dim3(256), 0, ST(stream), a);                        \
       hipLaunchKernelGGL((attn_bwd_dkv_mfma_kernel<bf16_t, KD_>), gk4, dim3(256), 0, ST(stream), a);                       \
     }                                                                                                                      \
@@ -812,6 +882,7 @@ extern "C" int mobi_attention_bwd(const mobi_attention_bwd_params* p, void* stre
   }
 #undef BM_CASE
   if (!done) {
+    BW_DISPATCH(p->dtype, attn_bwd_stats_kernel, gq, a);
     BW_DISPATCH(p->dtype, attn_bwd_dq_kernel, gq, a);
     BW_DISPATCH(p->dtype, attn_bwd_dkv_kernel, gk, a);
   }
