@@ -299,6 +299,11 @@ typedef struct mobi_row_chain_params {
 size_t mobi_row_chain_adapter_image_bytes(int32_t channels);
 int mobi_row_chain_adapter_image(const float* a, const float* c, const float* u, const float* b, int32_t images,
                                  int32_t heads, int32_t channels, int32_t dtype, void* out, void* stream);
+/* GroupNorm (32 groups, eps) of x (T [images][hw][channels] dense) as two per-image vectors for MOBI_CH_AFFINE_S:
+ * scale = rstd * gamma, shift = beta - mean * rstd * gamma (f32 [images][channels] each): SpatialTransformer.norm in front of
+ * proj_in (attention.py:306 of the reference) when the chain applies it to the rows it holds.  channels % 64 == 0. */
+int mobi_groupnorm_scale_shift(const void* x, const float* gamma, const float* beta, float eps, float* scale, float* shift,
+                               int32_t images, int32_t hw, int32_t channels, int32_t dtype, void* stream);
 size_t mobi_row_chain_weight_bytes(int32_t channels);
 int mobi_row_chain_supported(int32_t channels, int32_t rows_per_image);
 int mobi_row_chain(const mobi_row_chain_params* p, void* stream);

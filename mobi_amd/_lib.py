@@ -183,6 +183,7 @@ SYMBOLS = {
     "mobi_ff_geglu": (C.c_int, [C.POINTER(FfGegluParams), vp]),
     "mobi_ff_geglu_packed_bytes": (C.c_size_t, [i32, i32]),
     "mobi_row_chain": (C.c_int, [C.POINTER(RowChainParams), vp]),
+    "mobi_groupnorm_scale_shift": (C.c_int, [vp, vp, vp, f32, vp, vp, i32, i32, i32, i32, vp]),
     "mobi_row_chain_weight_bytes": (C.c_size_t, [i32]),
     "mobi_row_chain_supported": (C.c_int, [i32, i32]),
     "mobi_row_chain_adapter_image_bytes": (C.c_size_t, [i32]),

@@ -39,7 +39,7 @@ constexpr int CH_TAB_PAD = (CH_TAB + 1023) / 1024 * 1024;
 constexpr int CH_QD = 5;                          // fragment queue depth: divides CH_FR (the queue runs on across chunks)
 static_assert(CH_FR % CH_QD == 0, "queue slot of fragment f is f % QD in every chunk");
 constexpr int CH_MAXP = 4;                        // products per program
-constexpr int CH_VEC = CH_MAXP * 2 * CH_C * 4;    // their bias / row-sum vectors (fp32) in LDS
+constexpr int CH_VEC = (CH_MAXP * 2 + 2) * CH_C * 4;   // their bias / row-sum vectors, + the AFFINE_S scale / shift (fp32) in LDS
 static_assert(CH_FR % 4 == 0, "chunk pieces are dealt to four waves");
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
@@ -126,6 +126,50 @@ __global__ __launch_bounds__(256) void chain_adapter_image_kernel(const float* _
   }
   __syncthreads();
   for (int i = tid; i < CH_TAB_PAD / 16; i += 256) st16(out + (long long)img * CH_TAB_PAD + i * 16, ld16(tab + i * 16));
+}
+
+// GroupNorm (32 groups) of x [image][hw][C] folded to two per-image vectors for MOBI_CH_AFFINE_S: scale = rstd gamma,
+// shift = beta - mean rstd gamma (mean, then the variance about the mean: gn_stats_kernel's arithmetic).  One block per
+// (group, image); a thread reads whole pixels of the group (C / 32 consecutive channels).
+template <typename T>
+__global__ __launch_bounds__(256) void gn_scale_shift_kernel(const T* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                             float eps, float* __restrict__ scale, float* __restrict__ shift, int hw, int C) {
+  __shared__ float red[4];
+  const int G = C / 32, g = blockIdx.x, img = blockIdx.y, tid = threadIdx.x;
+  const T* base = x + (long long)img * hw * C + g * G;
+  auto block_sum = [&](float v) {
+    v = wave_sum(v);
+    __syncthreads();
+    if ((tid & 63) == 0) red[tid >> 6] = v;
+    __syncthreads();
+    return (red[0] + red[1]) + (red[2] + red[3]);
+  };
+  const float inv_m = 1.0f / ((float)G * (float)hw);
+  float s = 0.f;
+  for (int p = tid; p < hw; p += 256)
+    for (int c = 0; c < G; c += 2) {
+      const unsigned w = *reinterpret_cast<const unsigned*>(base + (long long)p * C + c);
+      typedef T T2 __attribute__((ext_vector_type(2)));
+      const T2 v = __builtin_bit_cast(T2, w);
+      s += (float)v[0] + (float)v[1];
+    }
+  const float mean = block_sum(s) * inv_m;
+  s = 0.f;
+  for (int p = tid; p < hw; p += 256)
+    for (int c = 0; c < G; c += 2) {
+      const unsigned w = *reinterpret_cast<const unsigned*>(base + (long long)p * C + c);
+      typedef T T2 __attribute__((ext_vector_type(2)));
+      const T2 v = __builtin_bit_cast(T2, w);
+      const float d0 = (float)v[0] - mean, d1 = (float)v[1] - mean;
+      s += d0 * d0 + d1 * d1;
+    }
+  const float rstd = rsqrtf(block_sum(s) * inv_m + eps);
+  if (tid < G) {
+    const int c = g * G + tid;
+    const float sc = rstd * gamma[c];
+    scale[(long long)img * C + c] = sc;
+    shift[(long long)img * C + c] = beta[c] - mean * sc;
+  }
 }
 
 template <typename T>
@@ -238,6 +282,18 @@ __global__ __launch_bounds__(256, 1) void row_chain_kernel(const mobi_row_chain_
         }
       }
       ++k;
+    }
+  }
+  if (op0 < nops && a.prog[kind][op0].code == MOBI_CH_AFFINE_S && wave == 3) {
+    const mobi_chain_op& op = a.prog[kind][op0];
+    float* dstv = s_vec + (2 * CH_MAXP) * CH_C;
+    const __amdgpu_buffer_rsrc_t r_sc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(op.bias + (long long)img * CH_C), 0, CH_C * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_sh = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(op.svec + (long long)img * CH_C), 0, CH_C * 4, 0x00020000);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r_sc, (lds_ptr_t)dstv, 16, lane16, 0, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r_sh, (lds_ptr_t)(dstv + CH_C), 16, lane16, 0, 0, 0);
+    if (lane < (CH_C * 4 - 1024) / 16) {
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(r_sc, (lds_ptr_t)(dstv + 256), 16, lane16, 1024, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(r_sh, (lds_ptr_t)(dstv + CH_C + 256), 16, lane16, 1024, 0, 0);
     }
   }
   // Everything requested so far (the operand rows, tables, vectors, the first chunks) has landed for every wave behind
@@ -491,8 +547,9 @@ __global__ __launch_bounds__(256, 1) void row_chain_kernel(const mobi_row_chain_
   // head: [AFFINE_S] and the first product, straight-line (see `xr` above)
   if (op0 < nops && a.prog[kind][op0].code == MOBI_CH_AFFINE_S) {
     const mobi_chain_op& op = a.prog[kind][op0];
-    const float* sc = op.bias + (long long)img * CH_C + ch_lane;
-    const float* sh = op.svec + (long long)img * CH_C + ch_lane;
+    const float* sc = s_vec + (2 * CH_MAXP) * CH_C + ch_lane;            // this image's scale / shift, staged above
+    const float* sh = sc + CH_C;
+    (void)op;
 #pragma unroll
     for (int ks = 0; ks < CH_KS; ++ks) {
       const f32x4 a0 = *reinterpret_cast<const f32x4*>(sc + 16 * ks), a1 = *reinterpret_cast<const f32x4*>(sc + 16 * ks + 4);
@@ -585,6 +642,20 @@ extern "C" int mobi_row_chain_adapter_image(const float* a, const float* c, cons
   unsigned char* o = reinterpret_cast<unsigned char*>(out);
   if (dtype == MOBI_F16) hipLaunchKernelGGL((chain_adapter_image_kernel<f16_t>), dim3(images), dim3(256), 0, st, a, c, u, b, heads, o);
   else hipLaunchKernelGGL((chain_adapter_image_kernel<bf16_t>), dim3(images), dim3(256), 0, st, a, c, u, b, heads, o);
+  MOBI_CHECK_LAUNCH();
+  return MOBI_OK;
+}
+
+extern "C" int mobi_groupnorm_scale_shift(const void* x, const float* gamma, const float* beta, float eps, float* scale, float* shift,
+                                          int32_t images, int32_t hw, int32_t channels, int32_t dtype, void* stream) {
+  using namespace mobi;
+  if (!x || !gamma || !beta || !scale || !shift || images <= 0 || hw <= 0) return MOBI_ERR_ARG;
+  if (dtype != MOBI_F16 && dtype != MOBI_BF16) return MOBI_ERR_ARG;
+  if (channels <= 0 || channels % 64) return MOBI_ERR_UNSUPPORTED;        // (pairs of channels per 4-byte load: C / 32 even)
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const dim3 grid(32, images);
+  if (dtype == MOBI_F16) hipLaunchKernelGGL((gn_scale_shift_kernel<f16_t>), grid, dim3(256), 0, st, reinterpret_cast<const f16_t*>(x), gamma, beta, eps, scale, shift, hw, channels);
+  else hipLaunchKernelGGL((gn_scale_shift_kernel<bf16_t>), grid, dim3(256), 0, st, reinterpret_cast<const bf16_t*>(x), gamma, beta, eps, scale, shift, hw, channels);
   MOBI_CHECK_LAUNCH();
   return MOBI_OK;
 }

@@ -36,6 +36,10 @@ FUSED_FF_MIN_ROWS = int(os.environ.get("MOBI_FUSED_FF_MIN_ROWS", "24576"))   # 1
 FUSED_LN = os.environ.get("MOBI_FUSED_LN", "1") != "0"      # A/B: 0 = the cross-modal LayerNorms as launches of their own
 ROW_CHAIN = os.environ.get("MOBI_ROW_CHAIN", "1") != "0"    # A/B: 0 = the launches between the attention kernels one by one
 ROW_CHAIN_MIN_ROWS = int(os.environ.get("MOBI_ROW_CHAIN_MIN_ROWS", "24576"))   # 128 rows per workgroup: 192 workgroups
+# GroupNorm, proj_in, norm1 and the q | k | v projection of a C = 320 block as ONE chain launch (+ a statistics pass): built, tested,
+# and SLOWER than the four launches (19.90 against 19.61 ms per step, profiles/r04_ab_prechain.txt: four products at the chain
+# kernel's 46 cycles per MFMA lose against the tuned igemm launches) -- off unless MOBI_PRE_CHAIN=1
+PRE_CHAIN = os.environ.get("MOBI_PRE_CHAIN", "0") == "1"
 
 
 def _store_in_place(old, new):
@@ -337,8 +341,8 @@ class BasicTransformerBlock(nn.Module):
         ops.linear(al, self._folded(lid, self.cross_modal_connector_lidar, "lidar"), residual=xl, out=xl)
         return self.ff(x, residual=x, norm=self.norm3)
 
-    def forward(self, x, context=None):
-        return self._forward(x, context)
+    def forward(self, x, context=None, qkv=None):
+        return self._forward(x, context, qkv=qkv)
 
     def _context_terms(self, ctx):
         """Everything that depends on the conditioning tokens only -- attn2's per-image vector and the bbox
@@ -435,12 +439,18 @@ class BasicTransformerBlock(nn.Module):
         b = ops.linear_f32(v[:, 1].contiguous(), w, b0)
         return a, a.sum(-1).contiguous(), c, u, b
 
-    def _forward(self, x, context=None):
-        """x: engine tokens [N,T,C]; context: fp32 [N, n_ctx, context_dim]."""
+    def _forward(self, x, context=None, qkv=None):
+        """x: engine tokens [N,T,C]; context: fp32 [N, n_ctx, context_dim]; qkv: attn1's stacked projections of norm1(x)
+        [N, T, 3C] when the caller has them already (SpatialTransformer's pre-attention chain; q carries scale * log2 e)."""
         ctx = context.float().contiguous()
         ref_vec, ctx_kv, adapter, adapter_image = self._context_terms(ctx)
         # attn1 (self) + attn2 (reference token; norm2 / to_q cancel out of a one-key softmax)
-        a = self.attn1.self_attention(self._ln(self.norm1, x))
+        if qkv is not None:
+            c = self.attn1.inner_dim
+            a = ops.attention(qkv[..., :c], qkv[..., c:2 * c], qkv[..., 2 * c:], self.attn1.heads, self.attn1.scale, v_rows=True,
+                              q_log2_scaled=True)
+        else:
+            a = self.attn1.self_attention(self._ln(self.norm1, x))
         if self._chain_ok(x, adapter, adapter_image):
             return self._forward_chained(x, a, ref_vec, adapter_image)
         x = ops.linear(a, self.attn1.to_out[0].packed(), residual=x, rowvec=ref_vec, rowvec_has_bias=True)
@@ -493,10 +503,50 @@ class SpatialTransformer(nn.Module):
                                    bbox_cond=bbox_cond, multimodal=multimodal) for _ in range(depth)])
         self.proj_out = zero_module(Conv2d(inner_dim, in_channels, kernel_size=1, stride=1, padding=0))
 
+    def _pre_weights(self):
+        """Chunk images for the pre-attention chain: proj_in, and attn1's to_q / to_k / to_v of the first block with its norm1
+        (and, for q, scale * log2 e) folded in."""
+        blk = self.transformer_blocks[0]
+        a1, n1 = blk.attn1, blk.norm1
+        ps = [self.proj_in.weight, self.proj_in.bias, a1.to_q.weight, a1.to_k.weight, a1.to_v.weight, n1.weight, n1.bias]
+        dtype = engine_dtype()
+        key = tuple(p._version for p in ps) + (ps[0].data_ptr(), ps[0].device, dtype)
+        c = self.__dict__.setdefault("_pre_cache", {})
+        if c.get("key") != key:
+            dev = ps[0].device
+            pk = lambda w, b=None, **kw: ops.pack_chain_weight(w, b, dtype, dev, **kw)
+            ln = (n1.weight, n1.bias)
+            c["key"] = key
+            c["val"] = {"proj_in": pk(self.proj_in.weight[:, :, 0, 0], self.proj_in.bias),
+                        "q": pk(a1.to_q.weight, ln=ln, scale=a1.scale * ops.LOG2E), "k": pk(a1.to_k.weight, ln=ln),
+                        "v": pk(a1.to_v.weight, ln=ln)}
+        return c["val"]
+
+    def _pre_chain_ok(self, x):
+        n, h, w, c = x.shape
+        return (ROW_CHAIN and PRE_CHAIN and len(self.transformer_blocks) == 1 and c == self.proj_in.weight.shape[0] and x.is_contiguous()
+                and n * h * w >= ROW_CHAIN_MIN_ROWS and ops.row_chain_supported(c, h * w) and c % 64 == 0)
+
     def forward(self, x, context=None):
         x, ext = enter(x)
         n, h, w, c = x.shape
         g, b = self.norm.affine()
+        if self._pre_chain_ok(x):
+            # GroupNorm -> proj_in -> norm1 -> to_q | to_k | to_v as ONE chain launch on the token rows (+ a statistics pass that
+            # turns the GroupNorm into a per-image scale / shift): attention.py:306-307 and :234 of the reference
+            blk = self.transformer_blocks[0]
+            cw = self._pre_weights()
+            scale, shift = ops.groupnorm_scale_shift(x, g, b, self.norm.eps)
+            t = torch.empty((n, h * w, c), device=x.device, dtype=x.dtype)
+            qkv = torch.empty((n, h * w, 3 * c), device=x.device, dtype=x.dtype)
+            prog = ops.ChainProgram().load(x.view(n, h * w, c), "s").affine(scale, shift).product(cw["proj_in"], to_s=True, dst=t)
+            prog.rowstats(blk.norm1.eps).product(cw["q"], fold=True, dst=qkv[..., :c]).product(cw["k"], fold=True, dst=qkv[..., c:2 * c])
+            prog.product(cw["v"], fold=True, dst=qkv[..., 2 * c:])
+            rows = n * h * w
+            ops.row_chain([prog], n, h * w, x.dtype, flops=2.0 * rows * c * c * 4, nbytes=2.0 * rows * c * 5.0, note=f"pre_attn1 rows={rows}")
+            t = blk(t, context=context, qkv=qkv)
+            y = ops.igemm(t.view(n, h, w, t.shape[2]), self.proj_out.packed(), residual=x)
+            return leave(y, ext)
         t = ops.igemm(ops.groupnorm(x, g, b, self.norm.eps, silu=False), self.proj_in.packed())
         t = t.view(n, h * w, t.shape[3])
         for block in self.transformer_blocks:

@@ -318,6 +318,19 @@ def pack_chain_weight(w, bias, dtype, device, ln=None, scale=1.0):
     return ChainWeight(img, bd.float().contiguous().to(device), svec)
 
 
+def groupnorm_scale_shift(x, gamma, beta, eps):
+    """x: T [N, T, C] or [N, H, W, C] dense -> (scale, shift) fp32 [N, C]: GroupNorm(32 groups) as y = x * scale + shift."""
+    lib = _lib.load()
+    assert x.is_contiguous()
+    n, c = x.shape[0], x.shape[-1]
+    hw = x.numel() // (n * c)
+    scale = torch.empty((n, c), device=x.device, dtype=torch.float32)
+    shift = torch.empty((n, c), device=x.device, dtype=torch.float32)
+    _lib.check(lib.mobi_groupnorm_scale_shift(_ptr(x), _ptr(gamma), _ptr(beta), eps, _ptr(scale), _ptr(shift), n, hw, c, _dt(x.dtype),
+                                              _stream()), "mobi_groupnorm_scale_shift")
+    return scale, shift
+
+
 class ChainProgram:
     """A list of mobi_chain_op; the methods mirror the operation codes (include/mobi_engine.h): the row state `s` (every
     product's operand; what adapter / rowstats / store work on) and a residual `r` that a `resid` product consumes."""

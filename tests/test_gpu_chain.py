@@ -188,3 +188,30 @@ def test_routing_thresholds_at_their_boundary_rows(dtype, monkeypatch):
         y2 = blk(x, context=ctx)
         monkeypatch.setattr(A, "ROW_CHAIN_MIN_ROWS", 24576)
         assert rel(y.float(), y2.float()) < 2 * TOL[dtype], n
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_spatial_transformer_pre_chain_equals_launches(dtype, monkeypatch):
+    """SpatialTransformer at C = 320 with GroupNorm -> proj_in -> norm1 -> q | k | v as one chain launch (+ the statistics pass)
+    against the four launches, same module, same input; the GroupNorm scale / shift vectors against torch."""
+    import mobi_amd
+    from mobi_amd import ops as O
+    from mobi_amd.ldm.modules import attention as A
+    mobi_amd.set_engine_dtype(dtype)
+    st = A.SpatialTransformer(C, 8, 40, depth=1, context_dim=768, bbox_cond=True, multimodal=True)
+    W.fill_module_(st, seed=47)
+    st = st.cuda()
+    n, side = 6, 64
+    xf, x = rnd("chain.st.x", (n, side, side, C), dtype, 1.5)
+    ctx = W.synth_input("chain.st.ctx", (n, 2, 768)).cuda()
+    g, b = st.norm.affine()
+    sc, sh = O.groupnorm_scale_shift(x, g, b, st.norm.eps)
+    ref = F.group_norm(xf.permute(0, 3, 1, 2), 32, g.cpu(), b.cpu(), st.norm.eps).permute(0, 2, 3, 1)
+    got = xf * sc.cpu()[:, None, None, :] + sh.cpu()[:, None, None, :]
+    assert rel(got, ref) < 1e-5
+    monkeypatch.setattr(A, "PRE_CHAIN", True)
+    assert st._pre_chain_ok(x)
+    y1 = st(x, context=ctx)
+    monkeypatch.setattr(A, "PRE_CHAIN", False)
+    y0 = st(x, context=ctx)
+    assert bool(torch.isfinite(y1).all()) and rel(y1.float(), y0.float()) < 2 * TOL[dtype]
