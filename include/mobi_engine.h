@@ -347,8 +347,12 @@ int mobi_geglu_bwd(const void* pre, const void* dh, void* dpre, int64_t rows, in
 /* GroupNorm (32 groups) (+ SiLU) backward, data gradient only (the UNet's GroupNorm parameters are frozen):
  * x, dy, dx (and dx_add, or NULL): T [image][hw][channels] dense.  Replaces autograd through GroupNorm32 + SiLU
  * (util.py:199-216, openaimodel.py:211-236) and Normalize (attention.py:77-78). */
+size_t mobi_groupnorm_bwd_workspace_floats(int32_t images, int32_t hw, int32_t channels);
+/* ws: mobi_groupnorm_bwd_workspace_floats() floats of scratch -> three coalesced passes (statistics, gradient sums, result), every
+ * reduction in a fixed order; ws == NULL: one block per (image, group), four strided passes (any shape; the A/B partner). */
 int mobi_groupnorm_bwd(const void* x, const void* dy, const float* gamma, const float* beta, float eps, int32_t silu,
-                       const void* dx_add, void* dx, int32_t images, int32_t hw, int32_t channels, int32_t dtype, void* stream);
+                       const void* dx_add, void* dx, int32_t images, int32_t hw, int32_t channels, int32_t dtype, float* ws,
+                       void* stream);
 /* out[image][y][x][c] = sum of the 2 x 2 pixels src[image][2y..][2x..][c]: the backward of F.interpolate(nearest, x2)
  * (openaimodel.py:116).  src: T [image][2h][2w][channels]. */
 int mobi_sumpool2(const void* src, void* out, int32_t images, int32_t h, int32_t w, int32_t channels, int32_t dtype, void* stream);

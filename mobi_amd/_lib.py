@@ -196,7 +196,8 @@ SYMBOLS = {
     "mobi_geglu_fwd": (C.c_int, [vp, vp, i64, i32, i32, vp]),
     "mobi_geglu_bwd": (C.c_int, [vp, vp, vp, i64, i32, i32, vp]),
     "mobi_attention_bwd": (C.c_int, [C.POINTER(AttentionBwdParams), vp]),
-    "mobi_groupnorm_bwd": (C.c_int, [vp, vp, vp, vp, f32, i32, vp, vp, i32, i32, i32, i32, vp]),
+    "mobi_groupnorm_bwd_workspace_floats": (C.c_size_t, [i32, i32, i32]),
+    "mobi_groupnorm_bwd": (C.c_int, [vp, vp, vp, vp, f32, i32, vp, vp, i32, i32, i32, i32, vp, vp]),
     "mobi_sumpool2": (C.c_int, [vp, vp, i32, i32, i32, i32, i32, vp]),
     "mobi_add": (C.c_int, [vp, vp, vp, i64, i32, vp]),
     "mobi_silu_bwd_f32": (C.c_int, [vp, vp, vp, i64, vp]),

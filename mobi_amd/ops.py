@@ -512,14 +512,15 @@ def layernorm_bwd(x, dy, gamma, eps, dx_add=None):
     return dx, dgb[0], dgb[1]
 
 
-def groupnorm_bwd(x, dy, gamma, beta, eps, silu, dx_add=None):
+def groupnorm_bwd(x, dy, gamma, beta, eps, silu, dx_add=None, one_block_per_group=False):
     """x, dy: T [N, H, W, C] dense -> dx (+ dx_add) of GroupNorm(32 groups)(+ SiLU); the affine parameters are frozen."""
     lib = _lib.load()
     n, h, w, c = x.shape
     assert x.is_contiguous() and dy.is_contiguous() and dy.shape == x.shape and (dx_add is None or dx_add.is_contiguous())
     dx = torch.empty_like(x)
+    ws = None if one_block_per_group else torch.empty(lib.mobi_groupnorm_bwd_workspace_floats(n, h * w, c), device=x.device, dtype=torch.float32)
     _lib.check(lib.mobi_groupnorm_bwd(_ptr(x), _ptr(dy), _ptr(gamma), _ptr(beta), eps, int(silu), _ptr(dx_add), _ptr(dx), n, h * w, c,
-                                      _dt(x.dtype), _stream()), "mobi_groupnorm_bwd")
+                                      _dt(x.dtype), _ptr(ws), _stream()), "mobi_groupnorm_bwd")
     return dx
 
 

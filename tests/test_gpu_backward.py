@@ -135,7 +135,7 @@ def test_transformer_block_backward_vs_autograd(dtype, c, heads, n, side):
 
 @pytest.mark.parametrize("dtype", DT)
 def test_groupnorm_backward_and_sumpool(ops, dtype):
-    for c, hw, silu in ((64, 64, True), (320, 256, True), (128, 100, False)):
+    for c, hw, silu in ((64, 64, True), (320, 256, True), (128, 100, False), (960, 1024, True), (2560, 64, True)):
         n, side = 2, int(hw ** 0.5)
         xf, xd = rnd(f"bw.gn.x{c}", (n, side, side, c), dtype, 1.5)
         dyf, dyd = rnd(f"bw.gn.dy{c}", (n, side, side, c), dtype)
@@ -146,8 +146,9 @@ def test_groupnorm_backward_and_sumpool(ops, dtype):
         y = F.group_norm(x.permute(0, 3, 1, 2), 32, g, b, 1e-5)
         y = F.silu(y) if silu else y
         y.backward(dyf.permute(0, 3, 1, 2))
-        dx = ops.groupnorm_bwd(xd, dyd, g.cuda(), b.cuda(), 1e-5, silu, dx_add=addd)
-        assert rel(dx.float(), x.grad + addf) < TOL1[dtype], (c, silu)
+        for obg in (False, True):                # three coalesced passes; one block per (image, group)
+            dx = ops.groupnorm_bwd(xd, dyd, g.cuda(), b.cuda(), 1e-5, silu, dx_add=addd, one_block_per_group=obg)
+            assert rel(dx.float(), x.grad + addf) < TOL1[dtype], (c, silu, obg)
     sf, sd_ = rnd("bw.pool", (2, 8, 12, 64), dtype)
     want = sf.view(2, 4, 2, 6, 2, 64).sum((2, 4))
     assert rel(ops.sumpool2(sd_).float(), want) < TOL1[dtype]
@@ -276,6 +277,6 @@ def test_training_loop_follows_the_reference_trajectory():
         eng_opt.step(grads)
         eng_losses.append(float(el))
     for a, b in zip(eng_losses, ref_losses):
-        assert abs(a - b) <= 4e-3 * abs(b), (eng_losses, ref_losses)
+        assert abs(a - b) <= 1e-3 * abs(b), (eng_losses, ref_losses)       # measured 1.1e-4
     assert all(eng_losses[i + 1] < eng_losses[i] for i in range(3)), eng_losses
     record("training_loop_last_loss_rel_diff", abs(eng_losses[-1] - ref_losses[-1]) / ref_losses[-1])
