@@ -130,7 +130,7 @@ int mobi_igemm_plan_splits(const mobi_igemm_params* p);
  * the persistent direct-to-LDS kernels (256-pixel tiles; ping-pong schedule where the register epilogue applies),
  * or the register-staged kernel with 256- or 128-pixel tiles.  Negative = the error mobi_igemm would return. */
 enum { MOBI_IGEMM_STAGED_128 = 0, MOBI_IGEMM_STAGED_256 = 1, MOBI_IGEMM_DIRECT_LDS = 2, MOBI_IGEMM_PINGPONG = 3,
-       MOBI_IGEMM_RING_128 = 4, MOBI_IGEMM_RING_256 = 5, MOBI_IGEMM_RING_128W = 6 };
+       MOBI_IGEMM_RING_128 = 4, MOBI_IGEMM_RING_256 = 5, MOBI_IGEMM_RING_128W = 6, MOBI_IGEMM_SMALL = 7 };
 int mobi_igemm_kernel_variant(const mobi_igemm_params* p);
 size_t mobi_igemm_workspace_bytes(const mobi_igemm_params* p, int32_t splits);
 

@@ -21,6 +21,7 @@
 
 #include "common.h"
 #include "tuning.h"
+#include "igemm_small.h"
 
 // A/B switch (build with -DMOBI_IGEMM_FENCE=1): pin the load / MFMA / LDS-write phases of a k step
 #ifndef MOBI_FRAG2
@@ -132,6 +133,7 @@ struct IgemmArgs {
   int sm;                  // 128-pixel tiles on the LDS-DMA ring kernel (igemm_ring_kernel<.., false>)
   int wide;                // ring kernel with eight waves: 2 = 256 x 320 (256) tiles, 1 = 128 x 320 (256) tiles
   int hw_shift, w_shift;   // log2(hw_out), log2(wout) when both are powers of two (ping-pong kernel), else -1
+  int small;               // 32 | 64: the operands-in-registers kernel of csrc/igemm_small.hip with that square tile (0: not)
 };
 
 // (a macro, not a function of `a`: a reference to the kernel-argument struct makes the compiler keep a copy of it in scratch)
@@ -2450,6 +2452,32 @@ static int launch_igemm(const mobi_igemm_params* p, const IgemmArgs& a, int grou
   return MOBI_OK;
 }
 
+// Small 1 x 1 problems go to csrc/igemm_small.hip (coalesced loads, a wave-private LDS transposition, k split over the block's
+// four waves, no slabs): returns its tile (32), or 0.  Rule (tools/small_lab.py, graph-timed on cold operands,
+// profiles/r04_small_lab.txt): up to 1.8 GFLOP of 2 M N K -- 1.0 GFLOP at K = 320, where a wave has a single batch and the LDS
+// kernels' launch is a 10-step loop (8192 x 320 x 320: 16.6 against 12.6 us; 4096 x 320 x 320: 9.9 against 11.8).
+// MOBI_IGEMM_SMALL_MFLOP overrides the cap; MOBI_IGEMM_SMALL=0 never; 32: every eligible launch whatever its size (A/B, tests).
+constexpr int SMALL_MFLOP_DEFAULT = 1800, SMALL_MFLOP_K320 = 1000;
+static int small_tile(const mobi_igemm_params* p) {
+  if (tuning().small == 0) return 0;
+  // a forced tile geometry (the A/B knobs of the LDS kernels) keeps the launch on them unless this kernel is forced too
+  if (tuning().small < 0 && (tuning().wm == 2 || tuning().wm == 4 || tuning().wide >= 0 || tuning().sm == 0)) return 0;
+  if (p->kh != 1 || p->kw != 1 || p->stride != 1 || p->upsample || p->groups != 1 || p->epilogue != MOBI_EPI_NONE ||
+      p->k_order != 0 || p->split_k > 1 || p->c1 != 0)
+    return 0;
+  if (p->out_mode != MOBI_OUT_ROWS && p->out_mode != MOBI_OUT_ROWS_F32) return 0;
+  if (p->hout != p->hin || p->wout != p->win) return 0;
+  const int K = p->c0, N = p->n_packed;
+  if (K % 320 || N != p->cout || N % 32) return 0;
+  const long long hw = (long long)p->hin * p->win, M = (long long)p->batch * hw;
+  const long long ips = p->src_img_stride ? p->src_img_stride / p->c0 : hw;
+  if ((((long long)p->batch - 1) * ips + hw) * K * 2 >= 0x7fffffffLL || (long long)N * K * 2 >= 0x7fffffffLL) return 0;
+  if (tuning().small > 0) return 32;
+  const int cap = tuning().small_mflop >= 0 ? tuning().small_mflop : (K == 320 ? SMALL_MFLOP_K320 : SMALL_MFLOP_DEFAULT);
+  if (2.0 * (double)M * N * K > 1e6 * cap) return 0;
+  return 32;
+}
+
 // split-K plan: only when the tile grid cannot fill the chip and k is long
 static int plan_splits(long long M, int n_packed, int ktot) {
   const int bn = (n_packed % 160) == 0 ? 160 : 128;
@@ -2479,6 +2507,11 @@ extern "C" int mobi_debug_set_phases(void* buf) {
 
 extern "C" int mobi_igemm_plan_splits(const mobi_igemm_params* p) {
   if (!p || p->groups != 1 || p->epilogue != MOBI_EPI_NONE || p->out_mode == MOBI_OUT_TRANSPOSED) return 1;
+  {
+    mobi_igemm_params q = *p;
+    q.split_k = 0;
+    if (mobi::small_tile(&q)) return 1;
+  }
   return mobi::plan_splits((long long)p->batch * p->hout * p->wout, p->n_packed, p->kh * p->kw * (p->c0 + p->c1));
 }
 
@@ -2671,7 +2704,24 @@ static int igemm_prepare(const mobi_igemm_params* p, mobi::IgemmArgs& a) {
         (!p->rowvec || (!p->bias && a.hw_out % 128 == 0)) && a.M % 256 == 0 && p->n_packed % bnw == 0 && p->scale == 1.0f)
       a.ring_direct = 1;
   }
+  a.small = small_tile(p);
   return MOBI_OK;
+}
+
+static int launch_small(const mobi_igemm_params* p, const mobi::IgemmArgs& a, hipStream_t st) {
+  mobi::SmallGemmArgs s;
+  s.src0 = a.src0;
+  s.hw = a.hw_out; s.img_pix_stride = a.img_pix_stride;
+  s.weight = a.weight;
+  s.M = a.M; s.N = a.n_packed; s.K = a.ktot;
+  s.bias = a.bias; s.rowvec = a.rowvec; s.rowvec_stride = a.rowvec_stride;
+  s.residual = a.residual; s.res_img_stride = a.res_img_stride;
+  s.out = a.out; s.out_img_stride = a.out_img_stride; s.out_f32 = a.out_mode == MOBI_OUT_ROWS_F32;
+  s.scale = a.scale;
+  s.tiles_m = (a.M + a.small - 1) / a.small; s.tiles_n = a.n_packed / a.small;
+  const long long wbytes = (long long)a.n_packed * a.ktot * 2, abytes = (long long)a.M * a.ktot * 2;
+  s.n_major = wbytes > abytes;
+  return mobi::launch_small_gemm(s, p->dtype, st);
 }
 
 extern "C" int mobi_igemm(const mobi_igemm_params* p, void* stream) {
@@ -2680,6 +2730,7 @@ extern "C" int mobi_igemm(const mobi_igemm_params* p, void* stream) {
   const int rc = igemm_prepare(p, a);
   if (rc != MOBI_OK) return rc;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (a.small) return launch_small(p, a, st);
   return p->dtype == MOBI_F16 ? launch_igemm<f16_t>(p, a, p->groups, st) : launch_igemm<bf16_t>(p, a, p->groups, st);
 }
 
@@ -2687,6 +2738,7 @@ extern "C" int mobi_igemm_kernel_variant(const mobi_igemm_params* p) {
   mobi::IgemmArgs a;
   const int rc = igemm_prepare(p, a);
   if (rc != MOBI_OK) return rc;
+  if (a.small) return MOBI_IGEMM_SMALL;
   if (a.wide) return a.wide == 2 ? MOBI_IGEMM_RING_256 : MOBI_IGEMM_RING_128W;
   if (a.wm == 4 && a.fast && a.glds) return a.pp ? MOBI_IGEMM_PINGPONG : MOBI_IGEMM_DIRECT_LDS;
   if (a.wm == 4) return MOBI_IGEMM_STAGED_256;

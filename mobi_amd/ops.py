@@ -667,7 +667,7 @@ def igemm(x, pw: Packed, *, x2=None, stride=1, pad=None, upsample=False, hout=No
         + out.numel() * out.element_size() + (0 if residual is None else residual.numel() * 2)
     tag = ""
     if _PROFILE is not None:
-        kern = ("staged128", "staged256", "direct_lds", "pingpong", "ring128", "ring256", "ring128w")[lib.mobi_igemm_kernel_variant(C.byref(p))]
+        kern = ("staged128", "staged256", "direct_lds", "pingpong", "ring128", "ring256", "ring128w", "small")[lib.mobi_igemm_kernel_variant(C.byref(p))]
         tag = f"kern={kern} m={n * hout * wout} n={pw.n_packed} k={pw.kh * pw.kw * pw.cin} tap={pw.kh}x{pw.kw} " \
               f"split={splits} mode={out_mode}"
     with _Timed("igemm", flops, nbytes, tag):

@@ -993,3 +993,60 @@ def test_ff_geglu_fused(ops, dtype, rows, hidden, residual):
     y3 = ops.ff_geglu(xs, pf, residual=xs if residual else None, ln=(gam, bet, 1e-5))
     y4 = ops.ff_geglu(ops.layernorm(xs.view(1, rows, c), gam, bet, 1e-5).view(rows, c), pf, residual=xs if residual else None)
     assert rel(y3.float(), y4.float()) < TOL[dtype] / 2
+
+
+# (images, h, w, cin, cin2, cout, residual, rowvec, out f32, scale, strided sources)
+SMALL_CASES = [
+    (4, 8, 8, 1280, 0, 1280, True, False, False, 1.0, False),     # the 8 x 8 level's to_out (+ residual): four k batches per wave
+    (2, 16, 16, 320, 0, 320, True, True, False, 1.0, False),      # one batch per wave, residual + per-image vector
+    (3, 7, 9, 640, 0, 704, False, False, False, 1.0, False),      # ragged rows (189), 704 = 11 x 64 columns
+    (2, 16, 8, 1920, 0, 640, True, False, False, 1.0, False),     # six batches per wave: the request ring wraps
+    (2, 8, 8, 640, 0, 96, False, True, True, 0.5, False),         # fp32 output, scale, 96 columns
+    (5, 1, 257, 960, 0, 320, True, False, False, 1.0, True),      # token rows of 257 per image, strided images
+]
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("tile", ["32", None])
+@pytest.mark.parametrize("case", SMALL_CASES, ids=[f"small{i}" for i in range(len(SMALL_CASES))])
+def test_igemm_small(ops, dtype, case, tile, tune):
+    """The small-problem kernel of the 1 x 1 case (csrc/igemm_small.hip), forced and as routed: against
+    fp32 torch, against the LDS-ring kernels (same products, another summation order), and bit for bit on repetition."""
+    from mobi_amd import _lib
+    n, h, w, cin, cin2, cout, res, rowvec, f32, scale, strided = case
+    name = "small." + ".".join(str(v) for v in case)
+    xf, xd = rnd(name + ".x", (n, h, w, cin), dtype)
+    if strided:
+        big = torch.zeros((n, h * w + 3, 1, cin), device="cuda", dtype=dtype)
+        big[:, :h * w] = xd.view(n, h * w, 1, cin)
+        xd = big[:, :h * w].view(n, h * w, 1, cin)
+        xd = xd.as_strided((n, h, w, cin), (xd.stride(0), w * cin, cin, 1))
+    x2f, x2d = rnd(name + ".x2", (n, h, w, cin2), dtype) if cin2 else (None, None)
+    wf = torch.from_numpy(W.synth_param(name + ".weight", (cout, cin + cin2, 1, 1))).to(dtype).float()
+    bias = torch.from_numpy(W.synth_param(name + ".bias", (cout,)))
+    rf, rd = rnd(name + ".res", (n, h, w, cout), dtype) if res else (None, None)
+    rv = W.synth_input(name + ".rv", (n, cout)) if rowvec else None
+    ref = _conv_ref(xf if x2f is None else torch.cat([xf, x2f], 3), wf, None, 1, (0, 0)) * scale + bias
+    if rv is not None:
+        ref = ref + rv[:, None, None, :]
+    if rf is not None:
+        ref = ref + rf
+    pw = ops.pack_conv(wf, bias, dtype, "cuda")
+    kw = dict(x2=x2d, residual=rd, rowvec=None if rv is None else rv.cuda(), scale=scale,
+              out_mode=ops.OUT_ROWS_F32 if f32 else ops.OUT_ROWS)
+    if tile is None:
+        tune.delenv("MOBI_IGEMM_SMALL")
+    else:
+        tune.setenv("MOBI_IGEMM_SMALL", tile)
+    sink = []
+    ops.set_profiler(sink)
+    y = ops.igemm(xd, pw, **kw)
+    ops.set_profiler(None)
+    assert "kern=small" in sink[-1][-1], sink[-1]                  # every case is small enough to be routed here by itself
+    assert torch.isfinite(y.float()).all() and rel(y.float(), ref) < (2e-6 if f32 else TOL[dtype]), (case, tile)
+    assert torch.equal(y, ops.igemm(xd, pw, **kw))
+    tune.setenv("MOBI_IGEMM_SMALL", "0")
+    z = ops.igemm(xd, pw, **kw)
+    ulp = 2.0 ** (-7 if dtype == torch.bfloat16 else -10)
+    d = (y.float() - z.float()).abs() / z.float().abs().clamp_min(1.0)
+    assert float(d.max()) <= (1e-5 if f32 else 2 * ulp), (case, tile)

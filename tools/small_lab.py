@@ -1,0 +1,86 @@
+#!/usr/bin/env python3
+"""A/B of the small-problem kernel (csrc/igemm_small.hip) against the LDS-ring kernels (+ their split-K reduce
+launch) on the 1 x 1 launches of both steps: graph-timed microseconds per launch on COLD operands (the launches of a graph
+rotate through enough copies of weights and activations to exceed the 256-MB Infinity Cache), interleaved, best of three.
+    python tools/small_lab.py [--set 256|512|all]"""
+import argparse
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+# (rows, cin, cout, residual) -- the transformer blocks' linears and the ResBlock skip convolutions
+SHAPES_256 = [(256, 1280, 1280, True), (1024, 640, 640, True), (512, 1280, 1280, True), (4096, 320, 320, True),
+              (2048, 640, 640, True), (8192, 320, 320, True), (256, 1280, 2560, False), (1024, 640, 1280, False),
+              (4096, 320, 640, False), (8192, 320, 960, False), (2048, 640, 1920, False), (512, 1280, 3840, False),
+              (64, 1280, 1280, True), (128, 1280, 1280, True), (128, 2560, 1280, False), (512, 2560, 1280, False),
+              (2048, 2560, 640, False), (512, 5120, 1280, True), (8192, 1280, 320, True), (2048, 2560, 640, True)]
+SHAPES_512 = [(2048, 1280, 1280, True), (4096, 1280, 1280, True), (8192, 640, 640, True), (16384, 640, 640, True),
+              (2048, 1280, 2560, False), (8192, 640, 1280, False), (1024, 1280, 1280, True), (512, 1280, 1280, True),
+              (4096, 1280, 3840, False), (16384, 640, 1920, False), (32768, 320, 320, True), (1024, 2560, 1280, False),
+              (4096, 2560, 1280, False), (4096, 5120, 1280, True), (16384, 2560, 640, True), (65536, 320, 320, True)]
+
+
+def graph_time(fns, reps=2):
+    for f in fns:
+        f()
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for f in fns:
+            f()
+    g.replay()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        g.replay()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e3 / (reps * len(fns))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--set", default="all")
+    ap.add_argument("--dtype", default="bf16")
+    a = ap.parse_args()
+    from mobi_amd import _lib, build, ops
+    build.build(verbose=False)
+    reload_ = _lib.load().mobi_tuning_reload
+    dt = torch.bfloat16 if a.dtype == "bf16" else torch.float16
+    gen = torch.Generator().manual_seed(0)
+    shapes = {"256": SHAPES_256, "512": SHAPES_512, "all": SHAPES_256 + SHAPES_512}[a.set]
+    variants = (("ring", {"MOBI_IGEMM_SMALL": "0"}), ("small", {"MOBI_IGEMM_SMALL": "32"}))
+    for rows, cin, cout, res in shapes:
+        per = (rows * cin + cout * cin + rows * cout * (2 if res else 1)) * 2
+        copies = max(4, min(96, int(400e6 / per) + 1))
+        w0 = torch.randn(cout, cin, 1, 1, generator=gen) / cin ** 0.5
+        b0 = torch.randn(cout, generator=gen) * 0.1
+        pws = [ops.pack_conv(w0, b0, dt, "cuda") for _ in range(copies)]
+        xs = [torch.randn(1, rows, 1, cin, generator=gen).cuda().to(dt) for _ in range(min(copies, 8))]
+        xs = [xs[i % len(xs)].clone() for i in range(copies)]
+        rs = [torch.randn(1, rows, 1, cout, generator=gen).cuda().to(dt) if res else None for _ in range(copies)]
+        outs_ = [torch.empty(1, rows, 1, cout, device="cuda", dtype=dt) for _ in range(copies)]
+        fns = [(lambda i=i: ops.igemm(xs[i], pws[i], residual=rs[i], out=outs_[i])) for i in range(copies)]
+        best, first = {}, {}
+        for rep in range(3):
+            for tag, env in variants:
+                os.environ.update(env)
+                reload_()
+                if rep == 0:
+                    first[tag] = fns[0]().float().clone()
+                best[tag] = min(best.get(tag, 1e30), graph_time(fns))
+                for k_ in env:
+                    os.environ.pop(k_, None)
+        reload_()
+        d = max(float((first["ring"] - o).abs().max()) for o in first.values())
+        fl = 2.0 * rows * cin * cout
+        print(f"m={rows:6d} k={cin:5d} n={cout:5d} {fl / 1e9:6.2f} GF res={int(res)}: " +
+              " | ".join(f"{t} {best[t]:6.1f} us {fl / best[t] / 1e6:5.0f} TF/s" for t, _ in variants) + f" | max diff {d:.3g}", flush=True)
+
+
+if __name__ == "__main__":
+    main()
