@@ -309,8 +309,18 @@ def main():
 
         gather_stat = {}
 
+        phases = os.environ.get("MOBI_E2E_PHASES") == "1"         # development: device-synchronised phase times on stderr
+        stamps = []
+
+        def stamp(name):
+            if phases:
+                torch.cuda.synchronize()
+                stamps.append((name, time.perf_counter()))
+
         def e2e(batch):
+            stamp("start")
             data = model.get_input(batch, model.first_stage_key, force_c_encode=True, return_vae_rec=True)   # :416
+            stamp("get_input")
             n = data["z"].shape[0]
             uc_ = torch.cat([model.learnable_vector.repeat(n, 1, 1), model.bbox_uncond_vector.repeat(n, 1, 1)], dim=1)
             smp, _ = sampler.sample(S=args.ddim_steps, batch_size=n, shape=[4, side, side], conditioning=data["cond"],
@@ -318,8 +328,11 @@ def main():
                                     unconditional_conditioning=uc_ if cfg else None,
                                     test_model_kwargs={"inpaint_image": data["z"][:, 4:8],
                                                        "inpaint_mask": data["z"][:, [8]]})                   # :447-461
+            stamp("sample")
             h_cam, h_lid = model.decode_sample(smp, data.get("z_lidar"))                                      # :463
+            stamp("decode_sample")
             log, _ = model.log_data(batch, data, h_cam, h_lid, log_metrics=False, return_sample=True, split="test")  # :464
+            stamp("log_data")
             log = {k: log[k] for k in ("image_sample", "lidar_sample")}
             if backend != "nccl":
                 log = {k: v.cpu() for k, v in log.items()}
@@ -336,6 +349,11 @@ def main():
                 res = mdist.gather_decoded(log, B * world)
                 gather_stat["s"] = time.perf_counter() - tg
             gather_stat["bytes_per_rank"] = sum(v.numel() * v.element_size() for v in log.values())
+            stamp("gather")
+            if phases and rank == 0:
+                print("e2e phases (ms): " + ", ".join(f"{b[0]} {1e3 * (b[1] - a_[1]):.1f}" for a_, b in zip(stamps, stamps[1:])),
+                      file=sys.stderr)
+            stamps.clear()
             return res
 
         with torch.no_grad():
