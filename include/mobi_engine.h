@@ -37,8 +37,10 @@ extern "C" {
  *   2  mobi_attention_params.q_log2_scaled; mobi_two_key_adapter_params.ln_out / ln_gamma / ln_beta / ln_eps;
  *      mobi_ff_geglu_params (struct id 14); mobi_two_key_adapter_fuses_ln(channels, total_rows)
  *   3  mobi_row_chain_params / mobi_chain_op (struct ids 15, 16), mobi_row_chain*; the backward entry points
- *      (mobi_layernorm_bwd_params 17, mobi_attention_bwd_params 18) */
-#define MOBI_ABI_VERSION 3
+ *      (mobi_layernorm_bwd_params 17, mobi_attention_bwd_params 18)
+ *   4  mobi_groupnorm_bwd takes a workspace (mobi_groupnorm_bwd_workspace_floats); mobi_igemm_kernel_variant may answer
+ *      MOBI_IGEMM_SMALL */
+#define MOBI_ABI_VERSION 4
 
 enum { MOBI_OK = 0, MOBI_ERR_ARG = -1, MOBI_ERR_UNSUPPORTED = -2, MOBI_ERR_LAUNCH = -3, MOBI_ERR_ALIGN = -4 };
 enum { MOBI_F16 = 0, MOBI_BF16 = 1 };

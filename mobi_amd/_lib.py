@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libmobi_hip.so")
 
 MOBI_F16, MOBI_BF16 = 0, 1
-ABI_VERSION = 3            # include/mobi_engine.h MOBI_ABI_VERSION
+ABI_VERSION = 4            # include/mobi_engine.h MOBI_ABI_VERSION
 EPI_NONE, EPI_GEGLU = 0, 1
 OUT_ROWS, OUT_TRANSPOSED, OUT_ROWS_F32 = 0, 1, 2
 ACT_NONE, ACT_SILU, ACT_GELU = 0, 1, 2

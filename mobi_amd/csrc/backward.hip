@@ -86,13 +86,14 @@ static void reduce_partials(const float* partial, float* scratch, float* out, in
 // LayerNorm backward over the last axis (nn.LayerNorm, attention.py:213-223): one wave per row
 //   xh = (x - mean) rstd,  g = dy gamma,  dx = rstd (g - mean(g) - xh mean(g xh)) (+ dx_add)
 //   partial[block][0][c] = sum_rows dy xh,  partial[block][1][c] = sum_rows dy   (the block's rows, fixed order)
-template <typename T>
+// MAXV = channels per lane (C <= 64 MAXV): 5 / 10 / 20 for the UNet's widths, 24 for anything else up to 1536 -- the loops are
+// unrolled over it, and at C = 320 nineteen of twenty-four predicated iterations were the kernel's time
+template <typename T, int MAXV>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict__ x, long long x_stride, const T* __restrict__ dy,
                                                             long long dy_stride, const float* __restrict__ gamma, float eps,
                                                             const T* __restrict__ dx_add, T* __restrict__ dx, float* __restrict__ partial,
                                                             long long rows, int C, int rows_per_block) {
-  constexpr int MAXV = 24;                         // channels per lane: C <= 1536
-  __shared__ float red[4][2][1536];
+  __shared__ float red[4][2][64 * MAXV];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float ag[MAXV], ab[MAXV];
 #pragma unroll
@@ -970,14 +971,18 @@ extern "C" int mobi_layernorm_bwd(const mobi_layernorm_bwd_params* p, void* stre
   const int nblk = mobi_backward_partial_blocks(p->rows);
   const int rpb = (int)((p->rows + nblk - 1) / nblk);
   const long long xs = p->x_row_stride ? p->x_row_stride : p->channels, ds = p->dy_row_stride ? p->dy_row_stride : p->channels;
-  if (p->dtype == MOBI_F16)
-    hipLaunchKernelGGL((layernorm_bwd_kernel<f16_t>), dim3(nblk), dim3(256), 0, ST(stream), reinterpret_cast<const f16_t*>(p->x), xs,
-                       reinterpret_cast<const f16_t*>(p->dy), ds, p->gamma, p->eps, reinterpret_cast<const f16_t*>(p->dx_add),
-                       reinterpret_cast<f16_t*>(p->dx), p->partial, (long long)p->rows, p->channels, rpb);
-  else
-    hipLaunchKernelGGL((layernorm_bwd_kernel<bf16_t>), dim3(nblk), dim3(256), 0, ST(stream), reinterpret_cast<const bf16_t*>(p->x), xs,
-                       reinterpret_cast<const bf16_t*>(p->dy), ds, p->gamma, p->eps, reinterpret_cast<const bf16_t*>(p->dx_add),
-                       reinterpret_cast<bf16_t*>(p->dx), p->partial, (long long)p->rows, p->channels, rpb);
+#define MOBI_LNB_LAUNCH(T_, MAXV_)                                                                                                   \
+  hipLaunchKernelGGL((layernorm_bwd_kernel<T_, MAXV_>), dim3(nblk), dim3(256), 0, ST(stream), reinterpret_cast<const T_*>(p->x), xs, \
+                     reinterpret_cast<const T_*>(p->dy), ds, p->gamma, p->eps, reinterpret_cast<const T_*>(p->dx_add),                \
+                     reinterpret_cast<T_*>(p->dx), p->partial, (long long)p->rows, p->channels, rpb)
+#define MOBI_LNB_BY_C(T_)                                                                                       \
+  do {                                                                                                          \
+    if (p->channels <= 320) MOBI_LNB_LAUNCH(T_, 5); else if (p->channels <= 640) MOBI_LNB_LAUNCH(T_, 10);       \
+    else if (p->channels <= 1280) MOBI_LNB_LAUNCH(T_, 20); else MOBI_LNB_LAUNCH(T_, 24);                        \
+  } while (0)
+  if (p->dtype == MOBI_F16) MOBI_LNB_BY_C(f16_t); else MOBI_LNB_BY_C(bf16_t);
+#undef MOBI_LNB_BY_C
+#undef MOBI_LNB_LAUNCH
   // partial is [nblk][2][C]: d gamma = sum of the [.][0][.] planes, d beta of the [.][1][.] planes
   reduce_partials(p->partial, p->partial + (long long)nblk * 2 * p->channels, p->dgamma_dbeta, nblk, (long long)2 * p->channels, ST(stream));
   MOBI_CHECK_LAUNCH();

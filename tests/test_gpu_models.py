@@ -133,6 +133,11 @@ def test_unet_full_width(dtype, monkeypatch):
     del sd
     y = net.cuda()(x.cuda(), t.cuda(), context=ctx.cuda())
     assert rel_l2(y.cpu(), ref) < TOL_NET[dtype]
+    # ... and against the REFERENCE's own UNetModel at production width on the same inputs (tests/golden/unet_full_width16.npz,
+    # tests/golden/make_golden_full_width.py; the oracle is 1.6e-6 from it)
+    import os
+    gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "unet_full_width16.npz"))
+    assert rel_l2(y.cpu(), torch.from_numpy(gold["y"])) < TOL_NET[dtype]
     # the same network with the one-launch feed-forward (+ norm3 inside it) at the 320-channel level: production takes it
     # from 24576 token rows on (mobi_amd/ldm/modules/attention.py), this latent has 512
     from mobi_amd.ldm.modules import attention as A

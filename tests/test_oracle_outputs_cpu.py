@@ -33,3 +33,14 @@ def test_sample_recomputed_live():
         assert _close(oc.full_width16(live=True), torch.from_numpy(f["full_width16"]))
     tr = oc.trajectories10(live=True, only=("ddim_1.0",))
     assert _close(tr["ddim_1.0"], torch.from_numpy(f["traj10_ddim_1.0"])) and int(tr["n_pred_x0"]) == int(f["traj10_n_pred_x0"])
+
+
+def test_full_width_oracle_output_against_the_reference():
+    """The oracle's full-width case (1.04 B parameters, one camera / lidar pair at 16 x 16) against the REFERENCE's own
+    UNetModel at production width (tests/golden/unet_full_width16.npz, made by tests/golden/make_golden_full_width.py from
+    /root/reference): the production-width graph is pinned to the reference directly, not only through the reduced-width
+    goldens.  Measured 1.6e-6 (two fp32 graphs, different summation orders)."""
+    ref = np.load(os.path.join(os.path.dirname(oc.PATH), "unet_full_width16.npz"))
+    assert int(ref["n_params"]) == 1039929604 and ref["y"].shape == (2, 4, 16, 16)
+    a, b = torch.from_numpy(dict(np.load(oc.PATH))["full_width16"]).double(), torch.from_numpy(ref["y"]).double()
+    assert float((a - b).norm() / b.norm()) < 1e-5
