@@ -39,7 +39,7 @@ extern "C" {
  *   3  mobi_row_chain_params / mobi_chain_op (struct ids 15, 16), mobi_row_chain*; the backward entry points
  *      (mobi_layernorm_bwd_params 17, mobi_attention_bwd_params 18)
  *   4  mobi_groupnorm_bwd takes a workspace (mobi_groupnorm_bwd_workspace_floats); mobi_igemm_kernel_variant may answer
- *      MOBI_IGEMM_SMALL */
+ *      MOBI_IGEMM_SMALL; mobi_tile_weights */
 #define MOBI_ABI_VERSION 4
 
 enum { MOBI_OK = 0, MOBI_ERR_ARG = -1, MOBI_ERR_UNSUPPORTED = -2, MOBI_ERR_LAUNCH = -3, MOBI_ERR_ALIGN = -4 };
@@ -327,7 +327,10 @@ int mobi_trunk_add(float* trunk, const void* inc, void* x16, int64_t n, int32_t 
  * Correct and bit-reproducible (fixed-order reductions), not tuned: fp32 vector arithmetic on LDS tiles.
  * ------------------------------------------------------------------------- */
 int mobi_transpose(const void* src, int64_t src_row_stride, void* out, int32_t rows, int32_t cols, int32_t dtype,
-                   void* stream);                          /* T [rows][cols] (row stride in elements) -> T [cols][rows] */
+                   void* stream);
+/* w: T [n][k] (n % 16 == 0, k % 32 == 0) -> out: the same values as mobi_igemm_params.weight_tiled wants them ([n / 16][k / 32]
+ * blocks of 1 KiB, layout above).  A load-time step of the sampling path; in training it runs after every optimizer update. */
+int mobi_tile_weights(const void* w, void* out, int32_t n, int32_t k, void* stream);                          /* T [rows][cols] (row stride in elements) -> T [cols][rows] */
 int32_t mobi_backward_partial_blocks(int64_t rows);        /* blocks of per-block partial sums the two calls below use */
 /* out[c] = sum_rows dy[row][c]; partial: f32 [mobi_backward_partial_blocks(rows) + 64][cols] scratch. */
 int mobi_colsum(const void* dy, int64_t row_stride, int64_t rows, int32_t cols, int32_t dtype, float* partial, float* out,

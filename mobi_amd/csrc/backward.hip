@@ -45,6 +45,25 @@ __global__ __launch_bounds__(256) void transpose_kernel(const T* __restrict__ sr
   }
 }
 
+// W [n][k] (16-bit) -> the ring kernels' 1-KiB request images (mobi_igemm_params.weight_tiled): block (p, s) = rows 16 p .. 16 p + 15,
+// k 32 s .. 32 s + 31, row r's 16-byte chunk c at slot c ^ P[(r >> 2) & 3], P = {0, 2, 3, 1}.  One 16-byte chunk per thread.
+// (ops.tile_weights did this with torch.gather over an int64 index tensor: 11 ms of every training step, whose 432 adapter
+// tensors are re-packed after each optimizer update.)
+__global__ __launch_bounds__(256) void tile_weights_kernel(const u32x4* __restrict__ src, u32x4* __restrict__ dst, int n, int k) {
+  const long long chunks = (long long)n * (k >> 3);
+  const int steps = k >> 5;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < chunks; i += (long long)gridDim.x * 256) {
+    // destination chunk i = ((p * steps + s) * 16 + r) * 4 + slot
+    const int slot = (int)(i & 3), r = (int)((i >> 2) & 15);
+    const long long ps = i >> 6;
+    const int s = (int)(ps % steps);
+    const long long p = ps / steps;
+    const int perm = (0x1320 >> (4 * ((r >> 2) & 3))) & 3;          // P[(r >> 2) & 3] of {0, 2, 3, 1}
+    const int c = slot ^ perm;
+    dst[i] = src[((p * 16 + r) * (long long)k + 32 * s + 8 * c) >> 3];
+  }
+}
+
 // column sums of dy [rows][cols] (T) -> partial [gridDim.x][cols] fp32 (fixed order within a block)
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ dy, long long stride, float* __restrict__ partial,
@@ -936,6 +955,20 @@ extern "C" int mobi_transpose(const void* src, int64_t src_row_stride, void* out
   else
     hipLaunchKernelGGL((transpose_kernel<bf16_t>), grid, dim3(256), 0, ST(stream), reinterpret_cast<const bf16_t*>(src), src_row_stride,
                        reinterpret_cast<bf16_t*>(out), rows, cols);
+  MOBI_CHECK_LAUNCH();
+  return MOBI_OK;
+}
+
+extern "C" int mobi_tile_weights(const void* w, void* out, int32_t n, int32_t k, void* stream) {
+  using namespace mobi;
+  if (!w || !out || n <= 0 || k <= 0) return MOBI_ERR_ARG;
+  if ((n & 15) || (k & 31)) return MOBI_ERR_UNSUPPORTED;
+  if ((reinterpret_cast<uintptr_t>(w) | reinterpret_cast<uintptr_t>(out)) & 15) return MOBI_ERR_ALIGN;
+  const long long chunks = (long long)n * (k >> 3);
+  long long blocks = (chunks + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(tile_weights_kernel, dim3((unsigned)blocks), dim3(256), 0, ST(stream), reinterpret_cast<const u32x4*>(w),
+                     reinterpret_cast<u32x4*>(out), n, k);
   MOBI_CHECK_LAUNCH();
   return MOBI_OK;
 }

@@ -136,6 +136,7 @@ class Packed:
 
 
 TILED_WEIGHTS = True
+TILE_WEIGHTS_TORCH = False                # tests: the torch restatement of mobi_tile_weights
 _RING_PERM = (0, 2, 3, 1)              # 16-byte slot permutation of the ring kernels' LDS rows, per (row >> 2) & 3
 
 
@@ -147,6 +148,10 @@ def tile_weights(w):
     n, k = w.shape
     if n % 16 or k % 32:
         return None
+    if w.is_cuda and w.is_contiguous() and w.element_size() == 2 and not TILE_WEIGHTS_TORCH:
+        out = torch.empty((n // 16, k // 32, 16, 4, 8), device=w.device, dtype=w.dtype)
+        _lib.check(_lib.load().mobi_tile_weights(_ptr(w), _ptr(out), n, k, _stream()), "mobi_tile_weights")
+        return out
     v = w.reshape(n // 16, 16, k // 32, 4, 8)                                   # [piece, row, step, chunk, 8]
     r = torch.arange(16, device=w.device)
     perm = torch.tensor(_RING_PERM, device=w.device)[(r >> 2) & 3]              # [16]

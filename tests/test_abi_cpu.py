@@ -224,3 +224,50 @@ def test_shipped_library_has_no_scratch_and_no_dev_kernels():
                 assert dev_only not in asm, (o, dev_only)
             if o.endswith(("igemm.o", "attention.o")):
                 assert "v_mfma_f32_16x16x32" in asm or "v_mfma_f32_32x32x16" in asm
+
+
+def test_igemm_plan_routes_small_problems_at_the_boundary(lib, monkeypatch):
+    """The launch plan is host logic (no launch): `mobi_igemm_kernel_variant` / `mobi_igemm_plan_splits` at the rows either
+    side of the small-problem kernel's caps (1.8 GFLOP of 2 M N K, 1.0 GFLOP at K = 320), its shape rules, and the A/B knobs."""
+    from mobi_amd import _lib
+    SMALL, RING128 = 7, 4
+
+    def plan(rows, k, n, **kw):
+        p = _lib.IgemmParams()
+        p.src0 = p.weight = p.out = 4096
+        p.c0, p.batch, p.hin, p.win, p.hout, p.wout = k, 1, rows, 1, rows, 1
+        p.kh = p.kw = p.stride = p.groups = 1
+        p.n_packed = p.cout = n
+        p.scale, p.dtype = 1.0, 1
+        for key, v in kw.items():
+            setattr(p, key, v)
+        return lib.mobi_igemm_kernel_variant(C.byref(p)), lib.mobi_igemm_plan_splits(C.byref(p))
+
+    for key in ("MOBI_IGEMM_SMALL", "MOBI_IGEMM_SMALL_MFLOP", "MOBI_IGEMM_WM", "MOBI_IGEMM_WIDE", "MOBI_IGEMM_SM"):
+        monkeypatch.delenv(key, raising=False)
+    lib.mobi_tuning_reload()
+    try:
+        assert plan(512, 1280, 1280) == (SMALL, 1)                       # 1.68 GFLOP: the 8 x 8 level's linears, no split-K slabs
+        assert plan(544, 1280, 1280)[0] == SMALL                         # 1.78 GFLOP, ragged rows
+        assert plan(576, 1280, 1280)[0] != SMALL                         # 1.89 GFLOP: back on the LDS-ring kernel (+ its split-K plan)
+        assert plan(4096, 320, 320)[0] == SMALL                          # K = 320: 0.84 GFLOP
+        assert plan(8192, 320, 320)[0] == RING128                        # K = 320: 1.68 GFLOP is above that width's cap
+        assert plan(256, 1280, 1280, c1=1280, src1=4096)[0] != SMALL     # two sources
+        assert plan(256, 1296 - 16, 1280)[0] == SMALL and plan(256, 1024, 1280)[0] != SMALL     # K % 320
+        assert plan(256, 1280, 1296)[0] != SMALL                         # N % 32
+        assert plan(256, 1280, 1280, epilogue=1, n_packed=2560)[0] != SMALL                       # GEGLU
+        assert plan(256, 1280, 1280, out_mode=1)[0] != SMALL             # transposed output
+        assert plan(256, 1280, 1280, out_mode=2)[0] == SMALL             # fp32 rows
+        monkeypatch.setenv("MOBI_IGEMM_SMALL", "0")
+        lib.mobi_tuning_reload()
+        assert plan(256, 1280, 1280)[0] == RING128 and plan(256, 1280, 1280)[1] > 1
+        monkeypatch.setenv("MOBI_IGEMM_SMALL", "32")
+        lib.mobi_tuning_reload()
+        assert plan(65536, 320, 320)[0] == SMALL                         # forced: whatever the size
+        monkeypatch.delenv("MOBI_IGEMM_SMALL")
+        monkeypatch.setenv("MOBI_IGEMM_WM", "2")                         # a forced tile geometry keeps the launch on the LDS kernels
+        lib.mobi_tuning_reload()
+        assert plan(256, 1280, 1280)[0] == RING128
+    finally:
+        monkeypatch.undo()
+        lib.mobi_tuning_reload()

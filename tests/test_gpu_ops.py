@@ -1050,3 +1050,16 @@ def test_igemm_small(ops, dtype, case, tile, tune):
     ulp = 2.0 ** (-7 if dtype == torch.bfloat16 else -10)
     d = (y.float() - z.float()).abs() / z.float().abs().clamp_min(1.0)
     assert float(d.max()) <= (1e-5 if f32 else 2 * ulp), (case, tile)
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_tile_weights_native_equals_restatement(ops, dtype, monkeypatch):
+    """mobi_tile_weights (the ring kernels' 1-KiB request images) against the torch.gather restatement it replaces: bit for bit."""
+    for n, k in ((16, 32), (320, 320), (1280, 11520), (48, 2880)):
+        w = (W.synth_input(f"tile.{n}.{k}", (n, k))).to(dtype).cuda()
+        native = ops.tile_weights(w)
+        monkeypatch.setattr(ops, "TILE_WEIGHTS_TORCH", True)
+        restated = ops.tile_weights(w)
+        monkeypatch.setattr(ops, "TILE_WEIGHTS_TORCH", False)
+        assert native.shape == restated.shape == (n // 16, k // 32, 16, 4, 8) and torch.equal(native, restated)
+    assert ops.tile_weights(torch.zeros(24, 32, device="cuda", dtype=dtype)) is None
