@@ -417,7 +417,8 @@ def main():
         dom = max(by_variant, key=lambda v: by_variant[v]["ms"]) if by_variant else "igemm"
         dk = by_variant.get(dom, ig)
         kname = {"pingpong": "igemm_pp_kernel", "direct_lds": "igemm_glds_kernel", "staged128": "igemm_kernel",
-                 "staged256": "igemm_kernel", "ring128": "igemm_ring_kernel", "ring256": "igemm_ring_kernel", "ring128w": "igemm_ring_kernel"}.get(dom, "igemm_kernel")
+                 "staged256": "igemm_kernel", "ring128": "igemm_ring_kernel", "ring256": "igemm_ring_kernel", "ring128w": "igemm_ring_kernel",
+                 "small": "small_gemm_kernel"}.get(dom, "igemm_kernel")
         ach = dk["flops"] / (dk["ms"] * 1e-3) / 1e12
         # which roof bounds the kernel's launches of this step taken together: their matrix time at the dense peak against
         # their algorithmic bytes at the HBM peak (both ideal); MFMA for every variant on these workloads
