@@ -362,12 +362,20 @@ def main():
                 args.ddim_steps = 2
                 e2e(make_batch(99))                                     # short warm-up pass (weight packs, allocator)
                 args.ddim_steps = sampler_steps
-            batch_t = make_batch(7)                                     # other images: no cached conditioning tokens
-            barrier()
-            t0 = time.perf_counter()
-            out = e2e(batch_t)
-            barrier()
-            e2e_dt = time.perf_counter() - t0
+            # two timed passes over different images (no cached conditioning tokens): the FIRST still pays one-off costs the
+            # short warm-up pass does not reach (allocator growth at DDIM-50's working set, first use of some code objects --
+            # it read 5.97 against 6.6 objects/s on two boxes of the same build); the reported figure is the SECOND, the first
+            # rides along as `objects_per_s_first_pass`
+            e2e_first = None
+            for seed in (7, 8):
+                batch_t = make_batch(seed)
+                barrier()
+                t0 = time.perf_counter()
+                out = e2e(batch_t)
+                barrier()
+                e2e_dt = time.perf_counter() - t0
+                if e2e_first is None:
+                    e2e_first = e2e_dt
             if "events" in gather_stat:                                 # (read after the timed region's closing barrier)
                 ev0, ev1 = gather_stat.pop("events")
                 gather_stat["s"] = ev0.elapsed_time(ev1) * 1e-3
@@ -377,6 +385,11 @@ def main():
             e2e_dt = float(tmax.item())
         assert out["image_sample"].shape == (B * world, 3, R, R) and out["lidar_sample"].shape == (B * world, 2, R, R)
         objects_per_s = B * world / e2e_dt
+        if world > 1:
+            tmax = torch.tensor([e2e_first], device=red_dev)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            e2e_first = float(tmax.item())
+        objects_per_s_first = B * world / e2e_first
         sampler.make_schedule(args.ddim_steps, ddim_eta=0.0, verbose=False)
 
     roofline = None
@@ -568,6 +581,7 @@ def main():
         }
         if objects_per_s is not None:
             out["objects_per_s"] = round(objects_per_s, 4)
+            out["objects_per_s_first_pass"] = round(objects_per_s_first, 4)
             out["e2e"] = (f"{B} objects/GPU, the harness's calls (inference_test_bench.py:416-464): get_input (4 VAE encodes, CLIP "
                           f"ViT-L/14 tower + mapper + box embedder, 2 reconstruction decodes) + DDIM-{args.ddim_steps} + decode_sample + "
                           f"log_data (2 VAE decodes, range de-normalisation, uint8 collages on the device) + all-gather of the decoded samples")

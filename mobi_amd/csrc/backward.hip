@@ -447,7 +447,7 @@ template <typename T, int KD>
 __global__ __launch_bounds__(256) void attn_bwd_stats_mfma_kernel(const AttnBwdArgs a) {
   typedef typename Vec8<T>::type frag_t;
   constexpr int DHP = 16 * KD, PITCH = DHP + BM_PITCH_PAD;
-  __shared__ __attribute__((aligned(16))) T sK[32 * PITCH];
+  __shared__ __attribute__((aligned(16))) T sK2[2][32 * PITCH];          // two tiles: tile t + 1 is written while tile t is read
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, ql = lane & 31, half = lane >> 5;
   const int h = blockIdx.y, img = blockIdx.z;
   const int q = blockIdx.x * 128 + wave * 32 + ql;
@@ -475,12 +475,13 @@ __global__ __launch_bounds__(256) void attn_bwd_stats_mfma_kernel(const AttnBwdA
   const T* kbase = reinterpret_cast<const T*>(a.k) + img * a.k_is + h * a.dh;
   BmRegs<KD> gk;
   bm_fetch<T, KD>(gk, kbase, a.k_rs, min(32, a.tk), a.dh, tid);
-  for (int k0 = 0; k0 < a.tk; k0 += 32) {
+  bm_put<T, KD>(gk, sK2[0], nullptr, tid);
+  __syncthreads();
+  for (int k0 = 0, it = 0; k0 < a.tk; k0 += 32, ++it) {
     const int kv = min(32, a.tk - k0);
-    __syncthreads();
-    bm_put<T, KD>(gk, sK, nullptr, tid);
-    __syncthreads();
-    if (k0 + 32 < a.tk) bm_fetch<T, KD>(gk, kbase + (long long)(k0 + 32) * a.k_rs, a.k_rs, min(32, a.tk - k0 - 32), a.dh, tid);
+    const T* sK = sK2[it & 1];
+    const bool more = k0 + 32 < a.tk;
+    if (more) bm_fetch<T, KD>(gk, kbase + (long long)(k0 + 32) * a.k_rs, a.k_rs, min(32, a.tk - k0 - 32), a.dh, tid);
     f32x16 st;
 #pragma unroll
     for (int r = 0; r < 16; ++r) st[r] = 0.f;
@@ -499,6 +500,8 @@ __global__ __launch_bounds__(256) void attn_bwd_stats_mfma_kernel(const AttnBwdA
     for (int r = 0; r < 16; ++r) ts += __expf(st[r] - mn);
     l = l * __expf(m - mn) + ts;
     m = mn;
+    if (more) bm_put<T, KD>(gk, sK2[(it + 1) & 1], nullptr, tid);      // the other tile: everyone was done with it a barrier ago
+    __syncthreads();
   }
   {                                                 // the two lanes of a query combine their halves of the keys
     const float m2 = __shfl_xor(m, 32, 64), l2 = __shfl_xor(l, 32, 64);
@@ -517,12 +520,12 @@ template <typename T, int KD>
 __global__ __launch_bounds__(256) void attn_bwd_dq_mfma_kernel(const AttnBwdArgs a) {
   typedef typename Vec8<T>::type frag_t;
   constexpr int DHP = 16 * KD, MD = (KD + 1) / 2, PITCH = DHP + BM_PITCH_PAD;
-  __shared__ __attribute__((aligned(16))) T sK[32 * PITCH], sV[32 * PITCH], sKT[32 * MD * BM_TP];
+  __shared__ __attribute__((aligned(16))) T sK2[2][32 * PITCH], sV2[2][32 * PITCH], sKT2[2][32 * MD * BM_TP];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, ql = lane & 31, half = lane >> 5;
   const int h = blockIdx.y, img = blockIdx.z;
   const int q = blockIdx.x * 128 + wave * 32 + ql;
   const bool qok = q < a.tq;
-  for (int i = tid; i < 32 * MD * BM_TP; i += 256) sKT[i] = (T)0.0f;       // rows d >= DHP stay zero
+  for (int i = tid; i < 2 * 32 * MD * BM_TP; i += 256) (&sKT2[0][0])[i] = (T)0.0f;       // rows d >= DHP stay zero
   const T* qp = reinterpret_cast<const T*>(a.q) + img * a.q_is + (long long)(qok ? q : 0) * a.q_rs + h * a.dh;
   const T* dp_ = reinterpret_cast<const T*>(a.dout) + img * a.do_is + (long long)(qok ? q : 0) * a.do_rs + h * a.dh;
   frag_t qf[KD], dof[KD];
@@ -545,13 +548,19 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_mfma_kernel(const AttnBwdArgs
   BmRegs<KD> gk, gv;
   bm_fetch<T, KD>(gk, kbase, a.k_rs, min(32, a.tk), a.dh, tid);
   bm_fetch<T, KD>(gv, vbase, a.v_rs, min(32, a.tk), a.dh, tid);
-  for (int k0 = 0; k0 < a.tk; k0 += 32) {
+  __syncthreads();                                  // the zeroed transposed tiles
+  bm_put<T, KD>(gk, sK2[0], sKT2[0], tid);
+  bm_put<T, KD>(gv, sV2[0], nullptr, tid);
+  __syncthreads();
+  // ONE barrier per tile: tile t + 1 goes into the other LDS set behind the products of tile t (its rows were requested
+  // before them), which every wave stopped reading at the previous barrier
+  for (int k0 = 0, it = 0; k0 < a.tk; k0 += 32, ++it) {
     const int kv = min(32, a.tk - k0);
-    __syncthreads();
-    bm_put<T, KD>(gk, sK, sKT, tid);
-    bm_put<T, KD>(gv, sV, nullptr, tid);
-    __syncthreads();
-    if (k0 + 32 < a.tk) {
+    const T* sK = sK2[it & 1];
+    const T* sV = sV2[it & 1];
+    const T* sKT = sKT2[it & 1];
+    const bool more = k0 + 32 < a.tk;
+    if (more) {
       const int kn = min(32, a.tk - k0 - 32);
       bm_fetch<T, KD>(gk, kbase + (long long)(k0 + 32) * a.k_rs, a.k_rs, kn, a.dh, tid);
       bm_fetch<T, KD>(gv, vbase + (long long)(k0 + 32) * a.v_rs, a.v_rs, kn, a.dh, tid);
@@ -586,6 +595,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_mfma_kernel(const AttnBwdArgs
         acc[m] = mfma32(__builtin_bit_cast(frag_t, u32x4{lo[0], lo[1], hi[0], hi[1]}), bf, acc[m]);
       }
     }
+    if (more) {
+      bm_put<T, KD>(gk, sK2[(it + 1) & 1], sKT2[(it + 1) & 1], tid);
+      bm_put<T, KD>(gv, sV2[(it + 1) & 1], nullptr, tid);
+    }
+    __syncthreads();
   }
   if (qok) {
     T* out = reinterpret_cast<T*>(a.dq) + ((long long)img * a.tq + q) * (a.heads * a.dh) + h * a.dh;
@@ -606,13 +620,13 @@ template <typename T, int KD>
 __global__ __launch_bounds__(256) void attn_bwd_dkv_mfma_kernel(const AttnBwdArgs a) {
   typedef typename Vec8<T>::type frag_t;
   constexpr int DHP = 16 * KD, MD = (KD + 1) / 2, PITCH = DHP + BM_PITCH_PAD;
-  __shared__ __attribute__((aligned(16))) T sQ[32 * PITCH], sO[32 * PITCH], sQT[32 * MD * BM_TP], sOT[32 * MD * BM_TP];
-  __shared__ __attribute__((aligned(16))) float sL[32], sD[32];
+  __shared__ __attribute__((aligned(16))) T sQ2[2][32 * PITCH], sO2[2][32 * PITCH], sQT2[2][32 * MD * BM_TP], sOT2[2][32 * MD * BM_TP];
+  __shared__ __attribute__((aligned(16))) float sL2[2][32], sD2[2][32];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, kl = lane & 31, half = lane >> 5;
   const int h = blockIdx.y, img = blockIdx.z;
   const int key = blockIdx.x * 128 + wave * 32 + kl;
   const bool kok = key < a.tk;
-  for (int i = tid; i < 32 * MD * BM_TP; i += 256) { sQT[i] = (T)0.0f; sOT[i] = (T)0.0f; }
+  for (int i = tid; i < 2 * 32 * MD * BM_TP; i += 256) { (&sQT2[0][0])[i] = (T)0.0f; (&sOT2[0][0])[i] = (T)0.0f; }
   const T* kp = reinterpret_cast<const T*>(a.k) + img * a.k_is + (long long)(kok ? key : 0) * a.k_rs + h * a.dh;
   const T* vp = reinterpret_cast<const T*>(a.v) + img * a.v_is + (long long)(kok ? key : 0) * a.v_rs + h * a.dh;
   frag_t kf[KD], vf[KD];
@@ -635,13 +649,20 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_mfma_kernel(const AttnBwdArg
   bm_fetch<T, KD>(gq, qbase, a.q_rs, min(32, a.tq), a.dh, tid);
   bm_fetch<T, KD>(go, obase, a.do_rs, min(32, a.tq), a.dh, tid);
   float gl = (tid < 32 && tid < a.tq) ? a.lse[sbase + tid] : 1.0e30f, gd = (tid < 32 && tid < a.tq) ? a.dvec[sbase + tid] : 0.f;
-  for (int q0 = 0; q0 < a.tq; q0 += 32) {
-    __syncthreads();
-    bm_put<T, KD>(gq, sQ, sQT, tid);
-    bm_put<T, KD>(go, sO, sOT, tid);
-    if (tid < 32) { sL[tid] = gl; sD[tid] = gd; }
-    __syncthreads();
-    if (q0 + 32 < a.tq) {
+  __syncthreads();                                  // the zeroed transposed tiles
+  bm_put<T, KD>(gq, sQ2[0], sQT2[0], tid);
+  bm_put<T, KD>(go, sO2[0], sOT2[0], tid);
+  if (tid < 32) { sL2[0][tid] = gl; sD2[0][tid] = gd; }
+  __syncthreads();
+  for (int q0 = 0, it = 0; q0 < a.tq; q0 += 32, ++it) {      // one barrier per tile, as in the dQ pass
+    const T* sQ = sQ2[it & 1];
+    const T* sO = sO2[it & 1];
+    const T* sQT = sQT2[it & 1];
+    const T* sOT = sOT2[it & 1];
+    const float* sL = sL2[it & 1];
+    const float* sD = sD2[it & 1];
+    const bool more = q0 + 32 < a.tq;
+    if (more) {
       const int qn = min(32, a.tq - q0 - 32);
       bm_fetch<T, KD>(gq, qbase + (long long)(q0 + 32) * a.q_rs, a.q_rs, qn, a.dh, tid);
       bm_fetch<T, KD>(go, obase + (long long)(q0 + 32) * a.do_rs, a.do_rs, qn, a.dh, tid);
@@ -685,6 +706,13 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_mfma_kernel(const AttnBwdArg
         ak[m] = mfma32(__builtin_bit_cast(frag_t, u32x4{qlo[0], qlo[1], qhi[0], qhi[1]}), df, ak[m]);
       }
     }
+    if (more) {
+      const int nx = (it + 1) & 1;
+      bm_put<T, KD>(gq, sQ2[nx], sQT2[nx], tid);
+      bm_put<T, KD>(go, sO2[nx], sOT2[nx], tid);
+      if (tid < 32) { sL2[nx][tid] = gl; sD2[nx][tid] = gd; }
+    }
+    __syncthreads();
   }
   if (kok) {
     const long long off = ((long long)img * a.tk + key) * (a.heads * a.dh) + h * a.dh;
