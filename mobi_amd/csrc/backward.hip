@@ -403,11 +403,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnBwdArgs a) 
 //   dK | dV pass, per 32-query tile:  S = Q K^T, dP = dO V^T (A = Q / dO rows);  dV^T += dO^T P,  dK^T += Q^T dS
 // Rows beyond the tensors are staged as zeros (and L = +1e30 for missing queries, so their P is 0); missing keys are masked in P.
 constexpr int BM_PITCH_PAD = 8;      // row-major tiles: dhp + 8 elements per row
-constexpr int BM_TP = 36;            // transposed tiles: 32 + 4 elements per row
 
 // Staging of a 32-row tile, split in two so that the NEXT tile's rows are in flight while the current tile is multiplied:
 // bm_fetch requests 16-byte pieces (a thread: piece tid + 256 j of the tile's 32 x 2 KD pieces, zeros beyond the rows / the
-// head width), bm_put writes them to LDS behind the barrier -- row-major, and transposed where a product consumes accumulators.
+// head width), bm_put writes them to LDS (row-major only: the transposed operands are READ transposed, bm_frag_t below -- the
+// first form kept transposed copies, eight 2-byte LDS writes per piece).
 // (The first form staged element by element and requested a tile only once the previous one was done: 128 exposed load
 // latencies per 4096-row pass, 2.1 + 2.8 ms per launch at 64 x 64 x 16.)
 template <int KD>
@@ -423,22 +423,27 @@ __device__ __forceinline__ void bm_fetch(BmRegs<KD>& g, const T* src, long long 
     g.v[j] = (p < 32 * 2 * KD && r < rows_valid && 8 * c < dh) ? ld16(src + (long long)r * row_stride + 8 * c) : u32x4{0u, 0u, 0u, 0u};
   }
 }
-template <typename T, int KD>
-__device__ __forceinline__ void bm_put(const BmRegs<KD>& g, T* row_major, T* transposed, int tid) {
-  typedef typename Vec8<T>::type V;
-  constexpr int DHP = 16 * KD, PITCH = DHP + BM_PITCH_PAD;
+template <typename T, int KD, int PITCH>
+__device__ __forceinline__ void bm_put(const BmRegs<KD>& g, T* row_major, int tid) {
 #pragma unroll
   for (int j = 0; j < BmRegs<KD>::NP; ++j) {
     const int p = tid + 256 * j, r = p / (2 * KD), c = p - r * (2 * KD);
-    if (p < 32 * 2 * KD) {
-      st16(row_major + r * PITCH + 8 * c, g.v[j]);
-      if (transposed) {
-        const V e = __builtin_bit_cast(V, g.v[j]);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) transposed[(8 * c + i) * BM_TP + r] = e[i];
-      }
-    }
+    if (p < 32 * 2 * KD) st16(row_major + r * PITCH + 8 * c, g.v[j]);
   }
+}
+// A^T fragments straight from a ROW-MAJOR tile (ds_read_b64_tr_b16: per 16-lane group a block of 4 rows x 16 columns comes back
+// column-major): the A operand of a product that consumes an accumulator -- row = channel 32 m + (lane & 31), its k slots
+// (half, j) = tile rows 16 s2 + 8 (j >> 2) + 4 half + (j & 3), the accumulator's own order.  Lane 4 q + p of a group addresses
+// tile row q of the block, columns 4 p .. 4 p + 3; two reads (rows + 0..3 and + 8..11).  The tile's pitch covers 32 MD columns
+// (columns beyond the head width are zeros or padding: they only reach output rows that are never stored).
+template <typename T, int PITCH>
+__device__ __forceinline__ typename Vec8<T>::type bm_frag_t(const T* tile, int s2, int m, int lane) {
+  typedef __attribute__((address_space(3))) s16x4* lds4_t;
+  const int l16 = lane & 15, grp = lane >> 4, half = lane >> 5;
+  const T* tb = tile + (16 * s2 + 4 * half + (l16 >> 2)) * PITCH + 32 * m + 16 * (grp & 1) + 4 * (l16 & 3);
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4_t)(tb));
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4_t)(tb + 8 * PITCH));
+  return __builtin_bit_cast(typename Vec8<T>::type, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
 }
 
 // pass 1 on the matrix cores: L = log-sum-exp of the scaled scores (online maximum / sum over the key tiles, a query per lane),
@@ -475,7 +480,7 @@ __global__ __launch_bounds__(256) void attn_bwd_stats_mfma_kernel(const AttnBwdA
   const T* kbase = reinterpret_cast<const T*>(a.k) + img * a.k_is + h * a.dh;
   BmRegs<KD> gk;
   bm_fetch<T, KD>(gk, kbase, a.k_rs, min(32, a.tk), a.dh, tid);
-  bm_put<T, KD>(gk, sK2[0], nullptr, tid);
+  bm_put<T, KD, PITCH>(gk, sK2[0], tid);
   __syncthreads();
   for (int k0 = 0, it = 0; k0 < a.tk; k0 += 32, ++it) {
     const int kv = min(32, a.tk - k0);
@@ -500,7 +505,7 @@ __global__ __launch_bounds__(256) void attn_bwd_stats_mfma_kernel(const AttnBwdA
     for (int r = 0; r < 16; ++r) ts += __expf(st[r] - mn);
     l = l * __expf(m - mn) + ts;
     m = mn;
-    if (more) bm_put<T, KD>(gk, sK2[(it + 1) & 1], nullptr, tid);      // the other tile: everyone was done with it a barrier ago
+    if (more) bm_put<T, KD, PITCH>(gk, sK2[(it + 1) & 1], tid);      // the other tile: everyone was done with it a barrier ago
     __syncthreads();
   }
   {                                                 // the two lanes of a query combine their halves of the keys
@@ -519,13 +524,13 @@ __global__ __launch_bounds__(256) void attn_bwd_stats_mfma_kernel(const AttnBwdA
 template <typename T, int KD>
 __global__ __launch_bounds__(256) void attn_bwd_dq_mfma_kernel(const AttnBwdArgs a) {
   typedef typename Vec8<T>::type frag_t;
-  constexpr int DHP = 16 * KD, MD = (KD + 1) / 2, PITCH = DHP + BM_PITCH_PAD;
-  __shared__ __attribute__((aligned(16))) T sK2[2][32 * PITCH], sV2[2][32 * PITCH], sKT2[2][32 * MD * BM_TP];
+  constexpr int DHP = 16 * KD, MD = (KD + 1) / 2, PITCH = 32 * MD + BM_PITCH_PAD;      // 32 MD >= DHP columns: see bm_frag_t
+  __shared__ __attribute__((aligned(16))) T sK2[2][32 * PITCH], sV2[2][32 * PITCH];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, ql = lane & 31, half = lane >> 5;
   const int h = blockIdx.y, img = blockIdx.z;
   const int q = blockIdx.x * 128 + wave * 32 + ql;
   const bool qok = q < a.tq;
-  for (int i = tid; i < 2 * 32 * MD * BM_TP; i += 256) (&sKT2[0][0])[i] = (T)0.0f;       // rows d >= DHP stay zero
+  for (int i = tid; i < 2 * 32 * PITCH; i += 256) (&sK2[0][0])[i] = (T)0.0f;             // columns >= DHP stay zero
   const T* qp = reinterpret_cast<const T*>(a.q) + img * a.q_is + (long long)(qok ? q : 0) * a.q_rs + h * a.dh;
   const T* dp_ = reinterpret_cast<const T*>(a.dout) + img * a.do_is + (long long)(qok ? q : 0) * a.do_rs + h * a.dh;
   frag_t qf[KD], dof[KD];
@@ -549,8 +554,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_mfma_kernel(const AttnBwdArgs
   bm_fetch<T, KD>(gk, kbase, a.k_rs, min(32, a.tk), a.dh, tid);
   bm_fetch<T, KD>(gv, vbase, a.v_rs, min(32, a.tk), a.dh, tid);
   __syncthreads();                                  // the zeroed transposed tiles
-  bm_put<T, KD>(gk, sK2[0], sKT2[0], tid);
-  bm_put<T, KD>(gv, sV2[0], nullptr, tid);
+  bm_put<T, KD, PITCH>(gk, sK2[0], tid);
+  bm_put<T, KD, PITCH>(gv, sV2[0], tid);
   __syncthreads();
   // ONE barrier per tile: tile t + 1 goes into the other LDS set behind the products of tile t (its rows were requested
   // before them), which every wave stopped reading at the previous barrier
@@ -558,7 +563,6 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_mfma_kernel(const AttnBwdArgs
     const int kv = min(32, a.tk - k0);
     const T* sK = sK2[it & 1];
     const T* sV = sV2[it & 1];
-    const T* sKT = sKT2[it & 1];
     const bool more = k0 + 32 < a.tk;
     if (more) {
       const int kn = min(32, a.tk - k0 - 32);
@@ -588,16 +592,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_mfma_kernel(const AttnBwdArgs
       const float v8[8] = {ds[8 * s2], ds[8 * s2 + 1], ds[8 * s2 + 2], ds[8 * s2 + 3], ds[8 * s2 + 4], ds[8 * s2 + 5], ds[8 * s2 + 6], ds[8 * s2 + 7]};
       const frag_t bf = __builtin_bit_cast(frag_t, pack8<T>(v8));
 #pragma unroll
-      for (int m = 0; m < MD; ++m) {
-        // A row = channel 32 m + ql; its k slots (half, j): keys 16 s2 + 8 (j >> 2) + 4 half + (j & 3)
-        const T* tp = sKT + (32 * m + ql) * BM_TP + 16 * s2 + 4 * half;
-        const u32x2 lo = *reinterpret_cast<const u32x2*>(tp), hi = *reinterpret_cast<const u32x2*>(tp + 8);
-        acc[m] = mfma32(__builtin_bit_cast(frag_t, u32x4{lo[0], lo[1], hi[0], hi[1]}), bf, acc[m]);
-      }
+      for (int m = 0; m < MD; ++m) acc[m] = mfma32(bm_frag_t<T, PITCH>(sK, s2, m, lane), bf, acc[m]);   // K^T: row = channel 32 m + ql
     }
     if (more) {
-      bm_put<T, KD>(gk, sK2[(it + 1) & 1], sKT2[(it + 1) & 1], tid);
-      bm_put<T, KD>(gv, sV2[(it + 1) & 1], nullptr, tid);
+      bm_put<T, KD, PITCH>(gk, sK2[(it + 1) & 1], tid);
+      bm_put<T, KD, PITCH>(gv, sV2[(it + 1) & 1], tid);
     }
     __syncthreads();
   }
@@ -619,14 +618,14 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_mfma_kernel(const AttnBwdArgs
 template <typename T, int KD>
 __global__ __launch_bounds__(256) void attn_bwd_dkv_mfma_kernel(const AttnBwdArgs a) {
   typedef typename Vec8<T>::type frag_t;
-  constexpr int DHP = 16 * KD, MD = (KD + 1) / 2, PITCH = DHP + BM_PITCH_PAD;
-  __shared__ __attribute__((aligned(16))) T sQ2[2][32 * PITCH], sO2[2][32 * PITCH], sQT2[2][32 * MD * BM_TP], sOT2[2][32 * MD * BM_TP];
+  constexpr int DHP = 16 * KD, MD = (KD + 1) / 2, PITCH = 32 * MD + BM_PITCH_PAD;
+  __shared__ __attribute__((aligned(16))) T sQ2[2][32 * PITCH], sO2[2][32 * PITCH];
   __shared__ __attribute__((aligned(16))) float sL2[2][32], sD2[2][32];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, kl = lane & 31, half = lane >> 5;
   const int h = blockIdx.y, img = blockIdx.z;
   const int key = blockIdx.x * 128 + wave * 32 + kl;
   const bool kok = key < a.tk;
-  for (int i = tid; i < 2 * 32 * MD * BM_TP; i += 256) { (&sQT2[0][0])[i] = (T)0.0f; (&sOT2[0][0])[i] = (T)0.0f; }
+  for (int i = tid; i < 2 * 32 * PITCH; i += 256) { (&sQ2[0][0])[i] = (T)0.0f; (&sO2[0][0])[i] = (T)0.0f; }
   const T* kp = reinterpret_cast<const T*>(a.k) + img * a.k_is + (long long)(kok ? key : 0) * a.k_rs + h * a.dh;
   const T* vp = reinterpret_cast<const T*>(a.v) + img * a.v_is + (long long)(kok ? key : 0) * a.v_rs + h * a.dh;
   frag_t kf[KD], vf[KD];
@@ -650,15 +649,13 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_mfma_kernel(const AttnBwdArg
   bm_fetch<T, KD>(go, obase, a.do_rs, min(32, a.tq), a.dh, tid);
   float gl = (tid < 32 && tid < a.tq) ? a.lse[sbase + tid] : 1.0e30f, gd = (tid < 32 && tid < a.tq) ? a.dvec[sbase + tid] : 0.f;
   __syncthreads();                                  // the zeroed transposed tiles
-  bm_put<T, KD>(gq, sQ2[0], sQT2[0], tid);
-  bm_put<T, KD>(go, sO2[0], sOT2[0], tid);
+  bm_put<T, KD, PITCH>(gq, sQ2[0], tid);
+  bm_put<T, KD, PITCH>(go, sO2[0], tid);
   if (tid < 32) { sL2[0][tid] = gl; sD2[0][tid] = gd; }
   __syncthreads();
   for (int q0 = 0, it = 0; q0 < a.tq; q0 += 32, ++it) {      // one barrier per tile, as in the dQ pass
     const T* sQ = sQ2[it & 1];
     const T* sO = sO2[it & 1];
-    const T* sQT = sQT2[it & 1];
-    const T* sOT = sOT2[it & 1];
     const float* sL = sL2[it & 1];
     const float* sD = sD2[it & 1];
     const bool more = q0 + 32 < a.tq;
@@ -698,18 +695,14 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_mfma_kernel(const AttnBwdArg
       const frag_t pf = __builtin_bit_cast(frag_t, pack8<T>(p8)), df = __builtin_bit_cast(frag_t, pack8<T>(d8));
 #pragma unroll
       for (int m = 0; m < MD; ++m) {
-        const T* to = sOT + (32 * m + kl) * BM_TP + 16 * s2 + 4 * half;
-        const T* tq_ = sQT + (32 * m + kl) * BM_TP + 16 * s2 + 4 * half;
-        const u32x2 olo = *reinterpret_cast<const u32x2*>(to), ohi = *reinterpret_cast<const u32x2*>(to + 8);
-        const u32x2 qlo = *reinterpret_cast<const u32x2*>(tq_), qhi = *reinterpret_cast<const u32x2*>(tq_ + 8);
-        av[m] = mfma32(__builtin_bit_cast(frag_t, u32x4{olo[0], olo[1], ohi[0], ohi[1]}), pf, av[m]);
-        ak[m] = mfma32(__builtin_bit_cast(frag_t, u32x4{qlo[0], qlo[1], qhi[0], qhi[1]}), df, ak[m]);
+        av[m] = mfma32(bm_frag_t<T, PITCH>(sO, s2, m, lane), pf, av[m]);          // dO^T P
+        ak[m] = mfma32(bm_frag_t<T, PITCH>(sQ, s2, m, lane), df, ak[m]);          // Q^T dS
       }
     }
     if (more) {
       const int nx = (it + 1) & 1;
-      bm_put<T, KD>(gq, sQ2[nx], sQT2[nx], tid);
-      bm_put<T, KD>(go, sO2[nx], sOT2[nx], tid);
+      bm_put<T, KD, PITCH>(gq, sQ2[nx], tid);
+      bm_put<T, KD, PITCH>(go, sO2[nx], tid);
       if (tid < 32) { sL2[nx][tid] = gl; sD2[nx][tid] = gd; }
     }
     __syncthreads();
