@@ -514,12 +514,25 @@ __device__ __forceinline__ unsigned pack2(float lo, float hi) {
 
 // QSH: the head dim leaves a padded channel in the last k-step (dh % 16 == 8: 8, 24, 40, 72); the shift then rides in
 // that channel of Q' against a column of ones in the K image instead of sixteen C-operand registers.
-template <typename T, int KS, int NW, bool QSH>
+// H16 (padded head dims with an odd number of k-steps, i.e. dh = 40 / 72: the last 32-channel block of O^T holds 8 channels and
+// the denominator): that block's P.V runs on MFMA 16x16x32 -- D[16 channels][16 queries], two per 32-key half, 16 cycles each
+// instead of two 32-cycle 32x32x16 on a block that is 3/4 padding (12 instead of 14 MFMA-equivalents per wave tile at dh = 40).
+// P arrives in the score product's lane order (lane = query l & 31, its 16 keys of the half in 8 packed registers); the
+// 16x16x32 B operand wants lane = query l & 15 with four lane groups of 8 keys: v_permlane16_swap of the half's first four
+// packed registers against its last four gives both operands (queries 0-15 and 16-31), each lane group holding the keys
+// 16 (G & 1) + 4 (G >> 1) + (e & 3) + 8 (e >> 2) -- the rows the V^T fragment's transposed reads then address.
+// MEASURED (tools/ab_attn_h16.sh, profiles/r04_ab_attn_h16.txt): correct (every attention test passes on it) and SLOWER --
+// 485-487 against 474-476 us on [16, 4096 x 4096, 8 x 40], 20.72 against 20.52 ms per step: the loop's vector time equals its
+// matrix time (r03 counters), and the eight swaps (+ the moves around them) cost the vector side more than the two
+// MFMA-equivalents save the matrix side.  Off by default (MOBI_ATTN_H16=1 selects it), kept for the record and the A/B.
+template <typename T, int KS, int NW, bool QSH, bool H16 = false>
 __global__ __launch_bounds__(64 * NW, (KS <= 2 && (QSH || (KS & 1))) ? 4 : KS == 2 ? 3 : (KS == 3 && NW == 8 && QSH) ? 4 : KS == 3 ? 3 : 2)
 void attention_rows_kernel(const AttnArgs a) {
   constexpr int NTHR = 64 * NW;
   typedef typename Vec8<T>::type frag_t;
+  static_assert(!H16 || (QSH && (KS & 1) && KS >= 3), "H16: dh % 32 == 8, at least one full 32-channel block");
   constexpr int DT = (KS + 1) / 2;
+  constexpr int DT32 = H16 ? DT - 1 : DT;      // 32-channel blocks of O^T on MFMA 32x32x16
   constexpr int KSTR = KS * 32 + 16;
   constexpr int VSTR = (DT & 1) ? DT * 64 : DT * 64 + 64;
   constexpr int K_BYTES = 64 * KSTR, V_BYTES = 64 * VSTR, IMG_BYTES = K_BYTES + V_BYTES;
@@ -624,11 +637,13 @@ void attention_rows_kernel(const AttnArgs a) {
     }
   };
 
-  f32x16 o[DT];
+  f32x16 o[DT32];
 #pragma unroll
-  for (int d = 0; d < DT; ++d)
+  for (int d = 0; d < DT32; ++d)
 #pragma unroll
     for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
+  // H16: channels 32 DT32 + 4 (lane >> 4) + (0..3) of query (lane & 15) [ox] / 16 + (lane & 15) [oy]
+  f32x4 ox = {0.f, 0.f, 0.f, 0.f}, oy = {0.f, 0.f, 0.f, 0.f};
   f32x16 cm;                               // minus the shift of this lane's query column, in all sixteen registers
 #pragma unroll
   for (int r = 0; r < 16; ++r) cm[r] = 0.f;
@@ -641,6 +656,23 @@ void attention_rows_kernel(const AttnArgs a) {
   const int l16 = lane & 15, grp = lane >> 4;
   const int k_lane = ql * KSTR + half * 16;
   const int v_lane = (4 * half + (l16 >> 2)) * VSTR + (16 * (grp & 1) + 4 * (l16 & 3)) * 2;
+  const int v16_lane = (16 * (grp & 1) + 4 * (grp >> 1) + (l16 >> 2)) * VSTR + (32 * DT32 + 4 * (l16 & 3)) * 2;
+  // V^T fragment of the 16-channel block for the 32 keys of half kt (A operand of MFMA 16x16x32)
+  auto read_v16 = [&](int boff, int kt) -> frag_t {
+    const unsigned char* vb = ldsV + boff + v16_lane + kt * 32 * VSTR;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4_t)(vb));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4_t)(vb + 8 * VSTR));
+    return __builtin_bit_cast(frag_t, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+  };
+  // the half's packed P as the two 16x16x32 B operands (queries 0-15, 16-31)
+  auto swap_p = [&](const unsigned (&pwh)[8], u32x4& px, u32x4& py) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const auto r = __builtin_amdgcn_permlane16_swap(pwh[i], pwh[4 + i], false, false);
+      px[i] = r[0];
+      py[i] = r[1];
+    }
+  };
   const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
   // S'^T of one 32-key half from its LDS image (KS MFMAs), keys past the end masked
@@ -683,9 +715,14 @@ void attention_rows_kernel(const AttnArgs a) {
       const float alpha = __builtin_amdgcn_exp2f(-d);
       l_run *= alpha;
 #pragma unroll
-      for (int dd = 0; dd < DT; ++dd)
+      for (int dd = 0; dd < DT32; ++dd)
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[dd][r] *= alpha;
+      if constexpr (H16) {
+        const float ax = __shfl(alpha, l16, 64), ay = __shfl(alpha, 16 + l16, 64);      // lanes 0-31 hold the queries' factors
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { ox[r] *= ax; oy[r] *= ay; }
+      }
     }
     if (has_pending) {
 #pragma unroll
@@ -721,7 +758,7 @@ void attention_rows_kernel(const AttnArgs a) {
     if constexpr (RAGGED) {
       // the last, ragged tile: one half at a time on the exact path (masked scores, their maximum, probabilities), no
       // speculation and no interleaving -- it runs once
-      s16x8 vr_[2][DT];
+      s16x8 vr_[2][DT32];
 #pragma unroll
       for (int kt = 0; kt < 2; ++kt) {
         scores_half(ragged_tag, boff, key0, kt, s[0]);
@@ -730,7 +767,7 @@ void attention_rows_kernel(const AttnArgs a) {
         for (int st = 0; st < 2; ++st) {
           const unsigned char* vb = ldsV + boff + v_lane + (kt * 32 + st * 16) * VSTR;
 #pragma unroll
-          for (int d = 0; d < DT; ++d) {
+          for (int d = 0; d < DT32; ++d) {
             const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4_t)(vb + d * 64));
             const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4_t)(vb + d * 64 + 8 * VSTR));
             vr_[st][d] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
@@ -740,8 +777,15 @@ void attention_rows_kernel(const AttnArgs a) {
         for (int st = 0; st < 2; ++st) {
           const u32x4 pu = {pw[0][st * 4], pw[0][st * 4 + 1], pw[0][st * 4 + 2], pw[0][st * 4 + 3]};
 #pragma unroll
-          for (int d = 0; d < DT; ++d)
+          for (int d = 0; d < DT32; ++d)
             o[d] = mfma32(__builtin_bit_cast(frag_t, vr_[st][d]), __builtin_bit_cast(frag_t, pu), o[d]);
+        }
+        if constexpr (H16) {
+          u32x4 px, py;
+          swap_p(pw[0], px, py);
+          const frag_t va = read_v16(boff, kt);
+          ox = mfma16(va, __builtin_bit_cast(frag_t, px), ox);
+          oy = mfma16(va, __builtin_bit_cast(frag_t, py), oy);
         }
       }
       return;
@@ -775,26 +819,37 @@ void attention_rows_kernel(const AttnArgs a) {
     }
     if (more && !(MOBI_ATTN_RDBG & 2)) load_tile(key0 + 64);
     // V^T fragments one 16-key group (2 DT reads) ahead of the MFMAs that use them
-    s16x8 vf[2][DT];
+    s16x8 vf[2][DT32];
     auto read_v = [&](int kt, int st) {
       const unsigned char* vb = ldsV + boff + v_lane + (kt * 32 + st * 16) * VSTR;
 #pragma unroll
-      for (int d = 0; d < DT; ++d) {
+      for (int d = 0; d < DT32; ++d) {
         const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4_t)(vb + d * 64));
         const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4_t)(vb + d * 64 + 8 * VSTR));
         vf[st][d] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
       }
     };
     read_v(0, 0);
+    frag_t v16a, v16b;                       // H16: the 16-channel block's V^T fragments of the two halves
+    u32x4 px, py;
+    if constexpr (H16) v16a = read_v16(boff, 0);
     __builtin_amdgcn_sched_barrier(0);
     orr = 0u;
     psum = 0.f;
+    // 2 DT MFMA slots in both forms; H16: the last two are the 16x16x32 pair (queries 0-15, 16-31) of the 16-channel block
 #pragma unroll
     for (int m = 0; m < 2 * DT; ++m) {
-      const int st = m / DT, d = m - st * DT;
-      const u32x4 pu = {pw[0][st * 4], pw[0][st * 4 + 1], pw[0][st * 4 + 2], pw[0][st * 4 + 3]};
-      o[d] = mfma32(__builtin_bit_cast(frag_t, vf[st][d]), __builtin_bit_cast(frag_t, pu), o[d]);
-      if (m == 0) read_v(0, 1);
+      if (!H16 || m < 2 * DT32) {
+        const int st = m / DT32, d = m - st * DT32;
+        const u32x4 pu = {pw[0][st * 4], pw[0][st * 4 + 1], pw[0][st * 4 + 2], pw[0][st * 4 + 3]};
+        o[d] = mfma32(__builtin_bit_cast(frag_t, vf[st][d]), __builtin_bit_cast(frag_t, pu), o[d]);
+        if (m == 0) read_v(0, 1);
+      } else if (m == 2 * DT32) {
+        ox = mfma16(v16a, __builtin_bit_cast(frag_t, px), ox);
+        v16b = read_v16(boff, 1);
+      } else {
+        oy = mfma16(v16a, __builtin_bit_cast(frag_t, py), oy);
+      }
 #pragma unroll
       for (int i = (8 * m) / (2 * DT); i < (8 * (m + 1)) / (2 * DT); ++i) {
         const float e0 = __builtin_amdgcn_exp2f(s[1][2 * i]), e1 = __builtin_amdgcn_exp2f(s[1][2 * i + 1]);
@@ -802,7 +857,8 @@ void attention_rows_kernel(const AttnArgs a) {
         if (TESTED) orr |= pw[1][i];
         if (!ONES) psum += e0 + e1;
       }
-      if (m == DT) read_v(1, 0);
+      if (m == DT32) read_v(1, 0);
+      if (H16 && m == 2 * DT32 - 1) swap_p(pw[0], px, py);
       __builtin_amdgcn_sched_barrier(0);
     }
     if (TESTED && !__all((orr & 0x40004000u) == 0u)) {
@@ -813,12 +869,19 @@ void attention_rows_kernel(const AttnArgs a) {
     }
     if (more && !((MOBI_ATTN_RDBG & 2) && t > 0)) store_tile(IMG_BYTES - boff);
     __builtin_amdgcn_sched_barrier(0);
+    if constexpr (H16) swap_p(pw[1], px, py);
 #pragma unroll
     for (int m = 0; m < 2 * DT; ++m) {
-      const int st = m / DT, d = m - st * DT;
-      const u32x4 pu = {pw[1][st * 4], pw[1][st * 4 + 1], pw[1][st * 4 + 2], pw[1][st * 4 + 3]};
-      o[d] = mfma32(__builtin_bit_cast(frag_t, vf[st][d]), __builtin_bit_cast(frag_t, pu), o[d]);
-      if (m == 0) read_v(1, 1);
+      if (!H16 || m < 2 * DT32) {
+        const int st = m / DT32, d = m - st * DT32;
+        const u32x4 pu = {pw[1][st * 4], pw[1][st * 4 + 1], pw[1][st * 4 + 2], pw[1][st * 4 + 3]};
+        o[d] = mfma32(__builtin_bit_cast(frag_t, vf[st][d]), __builtin_bit_cast(frag_t, pu), o[d]);
+        if (m == 0) read_v(1, 1);
+      } else if (m == 2 * DT32) {
+        ox = mfma16(v16b, __builtin_bit_cast(frag_t, px), ox);
+      } else {
+        oy = mfma16(v16b, __builtin_bit_cast(frag_t, py), oy);
+      }
       __builtin_amdgcn_sched_barrier(0);
     }
     if (!(MOBI_ATTN_RDBG & 16)) __syncthreads();
@@ -851,23 +914,31 @@ void attention_rows_kernel(const AttnArgs a) {
     }
     if (nfull < ntiles) tile(std::true_type{}, std::true_type{}, nfull);
     // the denominator: row dh of O^T (lane-half 0, register (dh % 32) / 2 of tile dh / 32) or the running sum
-    if (ONES) {
-      float lsum = 0.f;
+    if constexpr (H16) {
+      // channel dh = 32 DT32 + 8: register 0 of lane group 2 (lanes 32-47) of ox (queries 0-15) / oy (16-31)
+      const float dx = __shfl(ox[0], 32 + l16, 64), dy = __shfl(oy[0], 32 + l16, 64);
+      l_tot = ql < 16 ? dx : dy;
+    } else {
+      if (ONES) {
+        float lsum = 0.f;
 #pragma unroll
-      for (int d = 0; d < DT; ++d)
+        for (int d = 0; d < DT; ++d)
 #pragma unroll
-        for (int g = 0; g < 4; ++g)
-          if (d * 32 + g * 8 == dh) lsum = o[d][g * 4];
-      l_run = half == 0 ? lsum : 0.f;
+          for (int g = 0; g < 4; ++g)
+            if (d * 32 + g * 8 == dh) lsum = o[d][g * 4];
+        l_run = half == 0 ? lsum : 0.f;
+      }
+      l_tot = l_run + __shfl_xor(l_run, 32, 64);
     }
-    l_tot = l_run + __shfl_xor(l_run, 32, 64);
     if (tested) break;
     const bool bad = !(l_tot > 0.f && l_tot < 1.0e30f);
     if (!__syncthreads_or(bad ? 1 : 0)) break;
 #pragma unroll
-    for (int d = 0; d < DT; ++d)
+    for (int d = 0; d < DT32; ++d)
 #pragma unroll
       for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { ox[r] = 0.f; oy[r] = 0.f; }
 #pragma unroll
     for (int r = 0; r < 16; ++r) cm[r] = 0.f;
     if (qsh_lane) qf[KS - 1][0] = (T)0.0f;
@@ -880,7 +951,7 @@ void attention_rows_kernel(const AttnArgs a) {
   if (qrow < a.tq) {
     T* orow = op + (long long)qrow * a.out_row;
 #pragma unroll
-    for (int d = 0; d < DT; ++d)
+    for (int d = 0; d < DT32; ++d)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int d0 = d * 32 + g * 8 + half * 4;
@@ -891,6 +962,22 @@ void attention_rows_kernel(const AttnArgs a) {
           *reinterpret_cast<u32x2*>(orow + d0) = pack4<T>(f);
         }
       }
+  }
+  if constexpr (H16) {
+    // the 16-channel block: lane holds channels 32 DT32 + 4 (lane >> 4) + (0..3) of query l16 (ox) and 16 + l16 (oy)
+    const float invx = 1.0f / __shfl(l_tot, l16, 64), invy = 1.0f / __shfl(l_tot, 16 + l16, 64);
+    const int d0 = 32 * DT32 + 4 * grp;
+    if (d0 < dh) {
+      const int qx = q0 + l16, qy = q0 + 16 + l16;
+      if (qx < a.tq) {
+        const float f[4] = {ox[0] * invx, ox[1] * invx, ox[2] * invx, ox[3] * invx};
+        *reinterpret_cast<u32x2*>(op + (long long)qx * a.out_row + d0) = pack4<T>(f);
+      }
+      if (qy < a.tq) {
+        const float f[4] = {oy[0] * invy, oy[1] * invy, oy[2] * invy, oy[3] * invy};
+        *reinterpret_cast<u32x2*>(op + (long long)qy * a.out_row + d0) = pack4<T>(f);
+      }
+    }
   }
 }
 
@@ -1967,6 +2054,9 @@ __global__ __launch_bounds__(512, 2) void attention_sp_kernel(const AttnArgs a) 
 
 #endif  // MOBI_DEV
 
+// (the H16 instantiation exists for KS = 3 only; the trait keeps the other KS_ expansions of the dispatch macro well-formed)
+template <int KS_> struct mobi_attn_h16_ok { static constexpr bool value = KS_ == 3; static constexpr int ks = 3; };
+
 template <typename T, int VVEC>
 static int launch_attention_v(const mobi_attention_params* p, const AttnArgs& a, hipStream_t st) {
   dim3 grid((p->tq + 127) / 128, p->heads, p->images), block(256);
@@ -1988,7 +2078,11 @@ static int launch_attention_v(const mobi_attention_params* p, const AttnArgs& a,
 #endif
 #define MOBI_ATTN_ROWS_K(KERNEL_, KS_)                                                                   \
   do {                                                                                                   \
-    if (qsh) {                                                                                           \
+    if (qsh && KS_ == 3 && tuning().attn_h16 == 1 && mobi_attn_h16_ok<KS_>::value) {                     \
+      /* dh = 40, MOBI_ATTN_H16=1 (A/B, measured SLOWER): the last 16 channels of O^T on MFMA 16x16x32 */ \
+      if (nw8) hipLaunchKernelGGL((attention_rows_kernel<T, mobi_attn_h16_ok<KS_>::ks, 8, true, true>), gridr, blockr, 0, st, a); \
+      else hipLaunchKernelGGL((attention_rows_kernel<T, mobi_attn_h16_ok<KS_>::ks, 4, true, true>), gridr, blockr, 0, st, a);     \
+    } else if (qsh) {                                                                                    \
       if (nw8) hipLaunchKernelGGL((KERNEL_<T, KS_, 8, true>), gridr, blockr, 0, st, a);                   \
       else hipLaunchKernelGGL((KERNEL_<T, KS_, 4, true>), gridr, blockr, 0, st, a);                       \
     } else {                                                                                             \

@@ -26,6 +26,7 @@ struct Tuning {
   int attn_nw;          // MOBI_ATTN_NW               4 | 8: waves per attention block
   int attn_sp;          // MOBI_ATTN_SP               1: software-pipelined attention kernel (dh 33..48)
   int tka_rows;         // MOBI_TKA_ROWS              rows per block of the register two-key adapter kernel (sweeps)
+  int attn_h16;         // MOBI_ATTN_H16              1: dh = 40 attention runs the P.V of its last (3/4 padded) channel block on MFMA 16x16x32 (A/B: measured slower)
   int attn_xcd;         // MOBI_ATTN_XCD              0: attention workgroups in hardware order (A/B of the XCD-aware map)
   int cout_mfma;        // MOBI_COUT_MFMA             0: few-output-channel convolutions on the one-wave-per-pixel kernel (A/B)
   int skinny_mfma;      // MOBI_SKINNY_MFMA           0: fp32-row linears on the vector-ALU kernel (A/B)

@@ -245,6 +245,15 @@ def test_attention(ops, dtype, heads, dh, tq, tk, v_rows, tune):
     y2 = ops.attention(qsf.cuda(), kd, vt, heads, 123.0, v_rows=v_rows, q_log2_scaled=True)
     assert rel(y2.float(), ref2) < TOL[dtype]
     if v_rows and dh <= 80:
+        if dh == 40:
+            # the A/B partner that runs the last (3/4 padded) channel block's P.V on MFMA 16x16x32 (MOBI_ATTN_H16=1), both block sizes
+            tune.setenv("MOBI_ATTN_H16", "1")
+            for nw in ("4", "8"):
+                tune.setenv("MOBI_ATTN_NW", nw)
+                yh = ops.attention(qd, kd, vt, heads, dh ** -0.5, v_rows=v_rows)
+                assert rel(yh.float(), ref) < TOL[dtype], nw
+            tune.delenv("MOBI_ATTN_H16")
+            tune.delenv("MOBI_ATTN_NW")
         tune.setenv("MOBI_ATTN_NW", "8")
         y8 = ops.attention(qd, kd, vt, heads, dh ** -0.5, v_rows=v_rows)
         assert rel(y8.float(), ref) < TOL[dtype]
@@ -302,6 +311,13 @@ def test_attention_shift_path(ops, dtype, nw, dh, tq, tk, kind, tune):
     tol = {"huge": {torch.float16: 1.5e-2, torch.bfloat16: 1.2e-1}[dtype]}.get(
         kind, TOL[dtype] * (2.5 if kind in ("ramp", "spike", "peaky") else 1.5))
     assert rel(y.float(), ref) < tol
+    if dh == 40:
+        # the same inputs through the 16x16x32 form of the last channel block (MOBI_ATTN_H16=1: ragged last tile, raised shifts,
+        # the block's second pass)
+        tune.setenv("MOBI_ATTN_H16", "1")
+        yh = ops.attention(qd, kd, vd, heads, dh ** -0.5, v_rows=True)
+        tune.delenv("MOBI_ATTN_H16")
+        assert torch.isfinite(yh.float()).all() and rel(yh.float(), ref) < tol
     if kind in ("huge", "peaky"):
         # the form the transformer blocks use -- Q' handed over already scaled (q_log2_scaled), so the kernel adds no
         # rounding of its own -- against a reference built from the SAME rounded Q': the one-kernel bound holds on the very
