@@ -2452,29 +2452,40 @@ static int launch_igemm(const mobi_igemm_params* p, const IgemmArgs& a, int grou
   return MOBI_OK;
 }
 
-// Small 1 x 1 problems go to csrc/igemm_small.hip (coalesced loads, a wave-private LDS transposition, k split over the block's
-// four waves, no slabs): returns its tile (32), or 0.  Rule (tools/small_lab.py, graph-timed on cold operands,
-// profiles/r04_small_lab.txt): up to 1.8 GFLOP of 2 M N K -- 1.0 GFLOP at K = 320, where a wave has a single batch and the LDS
-// kernels' launch is a 10-step loop (8192 x 320 x 320: 16.6 against 12.6 us; 4096 x 320 x 320: 9.9 against 11.8).
-// MOBI_IGEMM_SMALL_MFLOP overrides the cap; MOBI_IGEMM_SMALL=0 never; 32: every eligible launch whatever its size (A/B, tests).
-constexpr int SMALL_MFLOP_DEFAULT = 1800, SMALL_MFLOP_K320 = 1000;
+// Small problems go to csrc/igemm_small.hip (coalesced loads, a wave-private LDS transposition, k split over the block's four
+// waves, no slabs): returns its tile (32), or 0.  Rules (tools/small_lab.py, graph-timed on cold operands,
+// profiles/r04_small_lab.txt):
+//   1 x 1: up to 1.8 GFLOP of 2 M N K -- 1.0 GFLOP at K = 320, where a wave has a single batch and the LDS kernels' launch is a
+//          10-step loop (8192 x 320 x 320: 16.6 against 12.6 us; 4096 x 320 x 320: 9.9 against 11.8);
+//   3 x 3 (pad 1, stride 1): NOT routed (MOBI_IGEMM_SMALL_CONV_M output pixels, default 0) -- built for the 4 x 4 levels of
+//          `mobi_nusc_256` (128 pixels, 30-60 MB of weights per launch) and measured SLOWER there: 36.1 against 24.7 us
+//          (1280 -> 1280), 66 against 35 (2560 -> 1280): a wave walks 36-72 batches one HBM latency after the other, and 160
+//          blocks of four waves are 2.5 waves per CU (profiles/r04_small_lab_conv.txt).  Kept for tests and the A/B.
+// MOBI_IGEMM_SMALL_MFLOP overrides the 1 x 1 cap; MOBI_IGEMM_SMALL=0 never; 32: every eligible launch whatever its size (A/B, tests).
+constexpr int SMALL_MFLOP_DEFAULT = 1800, SMALL_MFLOP_K320 = 1000, SMALL_CONV_M_DEFAULT = 0;
 static int small_tile(const mobi_igemm_params* p) {
   if (tuning().small == 0) return 0;
   // a forced tile geometry (the A/B knobs of the LDS kernels) keeps the launch on them unless this kernel is forced too
   if (tuning().small < 0 && (tuning().wm == 2 || tuning().wm == 4 || tuning().wide >= 0 || tuning().sm == 0)) return 0;
-  if (p->kh != 1 || p->kw != 1 || p->stride != 1 || p->upsample || p->groups != 1 || p->epilogue != MOBI_EPI_NONE ||
-      p->k_order != 0 || p->split_k > 1 || p->c1 != 0)
-    return 0;
+  const bool conv3 = p->kh == 3 && p->kw == 3 && p->pad_h == 1 && p->pad_w == 1;
+  if (!(p->kh == 1 && p->kw == 1) && !conv3) return 0;
+  if (p->stride != 1 || p->upsample || p->groups != 1 || p->epilogue != MOBI_EPI_NONE || p->k_order != 0 || p->split_k > 1) return 0;
   if (p->out_mode != MOBI_OUT_ROWS && p->out_mode != MOBI_OUT_ROWS_F32) return 0;
   if (p->hout != p->hin || p->wout != p->win) return 0;
-  const int K = p->c0, N = p->n_packed;
-  if (K % 320 || N != p->cout || N % 32) return 0;
+  const int ct = p->c0 + p->c1, N = p->n_packed;
+  const long long K = (long long)ct * p->kh * p->kw;
+  if (ct % 320 || (p->c1 > 0 && p->c0 % 80) || N != p->cout || N % 32) return 0;
   const long long hw = (long long)p->hin * p->win, M = (long long)p->batch * hw;
   const long long ips = p->src_img_stride ? p->src_img_stride / p->c0 : hw;
-  if ((((long long)p->batch - 1) * ips + hw) * K * 2 >= 0x7fffffffLL || (long long)N * K * 2 >= 0x7fffffffLL) return 0;
+  const long long cmax = p->c0 > p->c1 ? p->c0 : p->c1;
+  if ((((long long)p->batch - 1) * ips + hw) * cmax * 2 >= 0x7fffffffLL || (long long)N * K * 2 >= 0x7fffffffLL) return 0;
   if (tuning().small > 0) return 32;
+  if (conv3) {
+    const int cap_m = tuning().small_conv_m >= 0 ? tuning().small_conv_m : SMALL_CONV_M_DEFAULT;
+    return M <= cap_m ? 32 : 0;
+  }
   const int cap = tuning().small_mflop >= 0 ? tuning().small_mflop : (K == 320 ? SMALL_MFLOP_K320 : SMALL_MFLOP_DEFAULT);
-  if (2.0 * (double)M * N * K > 1e6 * cap) return 0;
+  if (2.0 * (double)M * N * (double)K > 1e6 * cap) return 0;
   return 32;
 }
 
@@ -2710,7 +2721,8 @@ static int igemm_prepare(const mobi_igemm_params* p, mobi::IgemmArgs& a) {
 
 static int launch_small(const mobi_igemm_params* p, const mobi::IgemmArgs& a, hipStream_t st) {
   mobi::SmallGemmArgs s;
-  s.src0 = a.src0;
+  s.src0 = a.src0; s.src1 = a.src1; s.c0 = a.c0; s.c1 = a.c1;
+  s.taps = a.kh * a.kw; s.hin = a.hin; s.win = a.win;
   s.hw = a.hw_out; s.img_pix_stride = a.img_pix_stride;
   s.weight = a.weight;
   s.M = a.M; s.N = a.n_packed; s.K = a.ktot;

@@ -6,10 +6,13 @@
 namespace mobi {
 
 struct SmallGemmArgs {
-  const void* src0;                     // T [image][pixel][K]
+  const void* src0; const void* src1;   // T [image][pixel][c0 | c1]: channels [0, c0) of a pixel from src0, [c0, c0 + c1) from src1
+  int c0, c1;
+  int taps;                             // 1: 1 x 1;  9: 3 x 3, pad 1, stride 1 (k = tap * (c0 + c1) + channel)
+  int hin, win;                         // image height / width (hw = hin * win)
   int hw;                               // pixel rows per image
   int img_pix_stride;                   // pixels between images of the sources
-  const void* weight;                   // T [N][K]
+  const void* weight;                   // T [N][K], K = taps * (c0 + c1)
   int M, N, K;
   const float* bias; const float* rowvec; int rowvec_stride;
   const void* residual; long long res_img_stride;

@@ -15,8 +15,12 @@
 //   * the four partial tiles meet in LDS and are summed in the fixed order wave 0 + 1 + 2 + 3, then scale, bias, per-image
 //     vector, residual, one rounding, 16-byte stores: no second launch, bit-reproducible.
 //
-// One source (c1 == 0), K % 320 == 0 (a wave's quarter is whole batches; the UNet's widths are 320 * 2^i), N % 32 == 0,
-// operands within 2 GB; M may be ragged.
+// K % 320 == 0 (a wave's quarter is whole batches; the UNet's widths are 320 * 2^i), N % 32 == 0, operands within 2 GB; M may
+// be ragged; one or two sources (channel concat, c0 % 80 == 0: a batch never straddles them).
+// TAPS = 9: the same for 3 x 3 convolutions (pad 1, stride 1) with a handful of pixels -- the 4 x 4 / 8 x 8 levels of
+// `mobi_nusc_256`, where a launch streams 30-60 MB of weights for 128 output pixels: k runs tap-major (k = tap * C + c, the
+// packed weights' order), a batch lies inside one tap, the token row of a batch is the tap's neighbour pixel (a zero piece
+// outside the image: a 9-bit mask per row).
 #include "common.h"
 #include "igemm_small.h"
 
@@ -40,8 +44,11 @@ struct SmallBatch {
 // the wave's own LDS traffic only: its counter, and nothing moves across for the compiler
 #define MOBI_SMALL_LDS_FENCE() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 
-template <typename T, int NPRE>
-__global__ __launch_bounds__(256, NPRE == 4 ? 2 : 3) void small_gemm_kernel(const SmallGemmArgs a) {
+// GENERAL = false: 1 x 1, one source -- a token row's byte offset is computed once (the hot instantiations: the generic
+// addressing costs them 5-8 % per launch, measured).  GENERAL = true: two sources and / or TAPS = 9.
+template <typename T, int NPRE, int TAPS, bool GENERAL>
+__global__ __launch_bounds__(256, (NPRE == 4 || TAPS == 9) ? 2 : 3) void small_gemm_kernel(const SmallGemmArgs a) {
+  static_assert(GENERAL || TAPS == 1, "the 3 x 3 form uses the general addressing");
   typedef typename Vec8<T>::type V;
   constexpr int TILE = 32, PITCH = TILE + 4;
   constexpr int RED_BYTES = 4 * TILE * PITCH * 4, LDS_BYTES = 4 * SM_STAGE > RED_BYTES ? 4 * SM_STAGE : RED_BYTES;
@@ -54,28 +61,59 @@ __global__ __launch_bounds__(256, NPRE == 4 ? 2 : 3) void small_gemm_kernel(cons
   const int m0 = (a.n_major ? tr : tq) * TILE, n0 = (a.n_major ? tq : tr) * TILE;
 
   // piece p = 64 j + lane of an operand's 32 x 10 pieces: row p / 10, 16-byte piece p % 10
-  int woff[5], xoff[5], loff[5];
+  int woff[5], xpix[5], c16[5], loff[5], tapmask[5];
 #pragma unroll
   for (int j = 0; j < 5; ++j) {
     const int p = 64 * j + lane, row = p / 10, c = p - row * 10;
     loff[j] = row * SM_RP + c * 16;
+    c16[j] = c * 16;
     woff[j] = ((n0 + row) * a.K + 8 * c) * 2;
     int m = m0 + row;
     m = m < a.M ? m : a.M - 1;                       // ragged last tile: a valid row, never stored
-    const int img = m / a.hw;
-    xoff[j] = ((img * a.img_pix_stride + (m - img * a.hw)) * a.K + 8 * c) * 2;
+    const int img = m / a.hw, rem = m - img * a.hw;
+    xpix[j] = GENERAL ? img * a.img_pix_stride + rem : ((img * a.img_pix_stride + rem) * a.K + 8 * c) * 2;   // !GENERAL: bytes
+    tapmask[j] = 0x1ff;
+    if (TAPS == 9) {
+      const int y = rem / a.win, x = rem - y * a.win;
+      int mk = 0;
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
+        mk |= (yy >= 0 && yy < a.hin && xx >= 0 && xx < a.win) ? (1 << t) : 0;
+      }
+      tapmask[j] = mk;
+    }
   }
   const int nb = a.K / 320;                          // batches per wave
-  const unsigned char* wsrc = reinterpret_cast<const unsigned char*>(a.weight) + (long long)wave * (a.K >> 2) * 2;
-  const unsigned char* xsrc = reinterpret_cast<const unsigned char*>(a.src0) + (long long)wave * (a.K >> 2) * 2;
+  const int kbase = wave * (a.K >> 2);
+  const int ct = a.c0 + a.c1;
+  const unsigned char* wsrc = reinterpret_cast<const unsigned char*>(a.weight) + (long long)kbase * 2;
   SmallBatch<T> g[NPRE];
   auto request = [&](SmallBatch<T>& f, int b) {
     const unsigned char* wp = wsrc + b * 160;
-    const unsigned char* xp = xsrc + b * 160;
+    if constexpr (!GENERAL) {
+      const unsigned char* xp = reinterpret_cast<const unsigned char*>(a.src0) + (long long)kbase * 2 + b * 160;
+#pragma unroll
+      for (int j = 0; j < 5; ++j) {
+        f.w[j] = *reinterpret_cast<const V*>(wp + woff[j]);
+        f.x[j] = *reinterpret_cast<const V*>(xp + xpix[j]);
+      }
+      return;
+    }
+    // wave-uniform: the batch's tap, source and channel offset
+    const int k = kbase + b * 80;
+    const int tap = TAPS == 1 ? 0 : k / ct;
+    const int cc = k - tap * ct;
+    const bool second = cc >= a.c0;
+    const unsigned char* xs = reinterpret_cast<const unsigned char*>(second ? a.src1 : a.src0);
+    const int cs = second ? a.c1 : a.c0, ccs = second ? cc - a.c0 : cc;
+    const int dpix = TAPS == 1 ? 0 : (tap / 3 - 1) * a.win + (tap % 3 - 1);
 #pragma unroll
     for (int j = 0; j < 5; ++j) {
       f.w[j] = *reinterpret_cast<const V*>(wp + woff[j]);
-      f.x[j] = *reinterpret_cast<const V*>(xp + xoff[j]);
+      const int off = ((xpix[j] + dpix) * cs + ccs) * 2 + c16[j];
+      if (TAPS == 1 || ((tapmask[j] >> tap) & 1)) f.x[j] = *reinterpret_cast<const V*>(xs + off);
+      else f.x[j] = __builtin_bit_cast(V, u32x4{0u, 0u, 0u, 0u});
     }
   };
 #pragma unroll
@@ -175,9 +213,16 @@ __global__ __launch_bounds__(256, NPRE == 4 ? 2 : 3) void small_gemm_kernel(cons
 int launch_small_gemm(const SmallGemmArgs& a, int dtype, hipStream_t st) {
   const dim3 grid((unsigned)(a.tiles_m * a.tiles_n)), block(256);
   const int nb = a.K / 320;
-#define MOBI_SMALL_LAUNCH(T_, NPRE_) hipLaunchKernelGGL((small_gemm_kernel<T_, NPRE_>), grid, block, 0, st, a)
-#define MOBI_SMALL_BY_NB(T_) \
-  do { if (nb == 1) MOBI_SMALL_LAUNCH(T_, 1); else if (nb == 2) MOBI_SMALL_LAUNCH(T_, 2); else MOBI_SMALL_LAUNCH(T_, 4); } while (0)
+#define MOBI_SMALL_LAUNCH(T_, NPRE_, TAPS_, GEN_) \
+  hipLaunchKernelGGL((small_gemm_kernel<T_, NPRE_, TAPS_, GEN_>), grid, block, 0, st, a)
+#define MOBI_SMALL_BY_NB(T_)                                                                              \
+  do {                                                                                                    \
+    if (a.taps == 9) MOBI_SMALL_LAUNCH(T_, 2, 9, true);    /* (a ring of four batches spills beside the tap masks) */ \
+    else if (a.c1 > 0) MOBI_SMALL_LAUNCH(T_, 4, 1, true);                                                 \
+    else if (nb == 1) MOBI_SMALL_LAUNCH(T_, 1, 1, false);                                                 \
+    else if (nb == 2) MOBI_SMALL_LAUNCH(T_, 2, 1, false);                                                 \
+    else MOBI_SMALL_LAUNCH(T_, 4, 1, false);                                                              \
+  } while (0)
   if (dtype == MOBI_F16) MOBI_SMALL_BY_NB(f16_t); else MOBI_SMALL_BY_NB(bf16_t);
 #undef MOBI_SMALL_BY_NB
 #undef MOBI_SMALL_LAUNCH

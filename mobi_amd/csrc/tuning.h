@@ -21,7 +21,8 @@ struct Tuning {
   int n_major;          // MOBI_IGEMM_N_MAJOR         0: igemm work lists always walk the channel tiles of a pixel tile first (A/B); 1: never
   int sm64;             // MOBI_IGEMM_SM64            0: 128-pixel tiles always on the 32-deep-step ring kernel (A/B)
   int small;            // MOBI_IGEMM_SMALL           0: never the small-problem kernel (igemm_small.hip); 32: every eligible launch (A/B)
-  int small_mflop;      // MOBI_IGEMM_SMALL_MFLOP     largest 2 M N K (MFLOP) routed to it (sweeps)
+  int small_mflop;      // MOBI_IGEMM_SMALL_MFLOP     largest 2 M N K (MFLOP) of a 1 x 1 launch routed to it (sweeps)
+  int small_conv_m;     // MOBI_IGEMM_SMALL_CONV_M    most output pixels of a 3 x 3 launch routed to it (sweeps)
   int tka_mfma;         // MOBI_TKA_MFMA              0: two-key adapter on the vector-ALU kernel; 2 / 1: the LDS-tile kernel to C = 320 / 640 (A/B)
   int attn_nw;          // MOBI_ATTN_NW               4 | 8: waves per attention block
   int attn_sp;          // MOBI_ATTN_SP               1: software-pipelined attention kernel (dh 33..48)

@@ -33,6 +33,7 @@ void read_env() {
   g_tuning.n_major = env_int("MOBI_IGEMM_N_MAJOR");
   g_tuning.small = env_int("MOBI_IGEMM_SMALL");
   g_tuning.small_mflop = env_int("MOBI_IGEMM_SMALL_MFLOP");
+  g_tuning.small_conv_m = env_int("MOBI_IGEMM_SMALL_CONV_M");
   g_tuning.tka_mfma = env_int("MOBI_TKA_MFMA");
   g_tuning.attn_nw = env_int("MOBI_ATTN_NW");
   g_tuning.attn_sp = env_int("MOBI_ATTN_SP");

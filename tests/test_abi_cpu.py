@@ -243,7 +243,7 @@ def test_igemm_plan_routes_small_problems_at_the_boundary(lib, monkeypatch):
             setattr(p, key, v)
         return lib.mobi_igemm_kernel_variant(C.byref(p)), lib.mobi_igemm_plan_splits(C.byref(p))
 
-    for key in ("MOBI_IGEMM_SMALL", "MOBI_IGEMM_SMALL_MFLOP", "MOBI_IGEMM_WM", "MOBI_IGEMM_WIDE", "MOBI_IGEMM_SM"):
+    for key in ("MOBI_IGEMM_SMALL", "MOBI_IGEMM_SMALL_MFLOP", "MOBI_IGEMM_SMALL_CONV_M", "MOBI_IGEMM_WM", "MOBI_IGEMM_WIDE", "MOBI_IGEMM_SM"):
         monkeypatch.delenv(key, raising=False)
     lib.mobi_tuning_reload()
     try:
@@ -252,7 +252,15 @@ def test_igemm_plan_routes_small_problems_at_the_boundary(lib, monkeypatch):
         assert plan(576, 1280, 1280)[0] != SMALL                         # 1.89 GFLOP: back on the LDS-ring kernel (+ its split-K plan)
         assert plan(4096, 320, 320)[0] == SMALL                          # K = 320: 0.84 GFLOP
         assert plan(8192, 320, 320)[0] == RING128                        # K = 320: 1.68 GFLOP is above that width's cap
-        assert plan(256, 1280, 1280, c1=1280, src1=4096)[0] != SMALL     # two sources
+        assert plan(256, 1280, 1280, c1=1280, src1=4096)[0] == SMALL     # two sources, whole 80-channel batches in each
+        assert plan(256, 96, 1280, c1=224, src1=4096)[0] != SMALL        # a batch would straddle the sources (c0 % 80)
+        assert plan(128, 1280, 1280, kh=3, kw=3, pad_h=1, pad_w=1)[0] != SMALL       # 3 x 3: measured slower, not routed ...
+        monkeypatch.setenv("MOBI_IGEMM_SMALL_CONV_M", "256")
+        lib.mobi_tuning_reload()
+        assert plan(128, 1280, 1280, kh=3, kw=3, pad_h=1, pad_w=1)[0] == SMALL       # ... unless asked for (A/B)
+        assert plan(128, 1280, 1280, kh=3, kw=3, pad_h=0, pad_w=0)[0] != SMALL
+        monkeypatch.delenv("MOBI_IGEMM_SMALL_CONV_M")
+        lib.mobi_tuning_reload()
         assert plan(256, 1296 - 16, 1280)[0] == SMALL and plan(256, 1024, 1280)[0] != SMALL     # K % 320
         assert plan(256, 1280, 1296)[0] != SMALL                         # N % 32
         assert plan(256, 1280, 1280, epilogue=1, n_packed=2560)[0] != SMALL                       # GEGLU

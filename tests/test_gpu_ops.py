@@ -1011,7 +1011,7 @@ def test_ff_geglu_fused(ops, dtype, rows, hidden, residual):
     assert rel(y3.float(), y4.float()) < TOL[dtype] / 2
 
 
-# (images, h, w, cin, cin2, cout, residual, rowvec, out f32, scale, strided sources)
+# (images, h, w, cin, cin2, cout, residual, rowvec, out f32, scale, strided sources[, kernel size])
 SMALL_CASES = [
     (4, 8, 8, 1280, 0, 1280, True, False, False, 1.0, False),     # the 8 x 8 level's to_out (+ residual): four k batches per wave
     (2, 16, 16, 320, 0, 320, True, True, False, 1.0, False),      # one batch per wave, residual + per-image vector
@@ -1019,6 +1019,10 @@ SMALL_CASES = [
     (2, 16, 8, 1920, 0, 640, True, False, False, 1.0, False),     # six batches per wave: the request ring wraps
     (2, 8, 8, 640, 0, 96, False, True, True, 0.5, False),         # fp32 output, scale, 96 columns
     (5, 1, 257, 960, 0, 320, True, False, False, 1.0, True),      # token rows of 257 per image, strided images
+    (2, 16, 8, 640, 320, 640, True, False, False, 1.0, False),    # two sources (a ResBlock's skip convolution on a concat)
+    (8, 4, 4, 1280, 0, 1280, False, True, False, 1.0, False, 3),  # 3 x 3 at the 4 x 4 level: every tap mask, a per-image vector
+    (3, 5, 7, 320, 320, 96, True, False, False, 1.0, False, 3),   # 3 x 3 on a concat, ragged rows (105), odd image sides
+    (2, 8, 8, 640, 0, 64, False, False, True, 1.0, False, 3),     # 3 x 3, fp32 output
 ]
 
 
@@ -1029,7 +1033,8 @@ def test_igemm_small(ops, dtype, case, tile, tune):
     """The small-problem kernel of the 1 x 1 case (csrc/igemm_small.hip), forced and as routed: against
     fp32 torch, against the LDS-ring kernels (same products, another summation order), and bit for bit on repetition."""
     from mobi_amd import _lib
-    n, h, w, cin, cin2, cout, res, rowvec, f32, scale, strided = case
+    n, h, w, cin, cin2, cout, res, rowvec, f32, scale, strided = case[:11]
+    ks = case[11] if len(case) > 11 else 1
     name = "small." + ".".join(str(v) for v in case)
     xf, xd = rnd(name + ".x", (n, h, w, cin), dtype)
     if strided:
@@ -1038,11 +1043,11 @@ def test_igemm_small(ops, dtype, case, tile, tune):
         xd = big[:, :h * w].view(n, h * w, 1, cin)
         xd = xd.as_strided((n, h, w, cin), (xd.stride(0), w * cin, cin, 1))
     x2f, x2d = rnd(name + ".x2", (n, h, w, cin2), dtype) if cin2 else (None, None)
-    wf = torch.from_numpy(W.synth_param(name + ".weight", (cout, cin + cin2, 1, 1))).to(dtype).float()
+    wf = torch.from_numpy(W.synth_param(name + ".weight", (cout, cin + cin2, ks, ks))).to(dtype).float()
     bias = torch.from_numpy(W.synth_param(name + ".bias", (cout,)))
     rf, rd = rnd(name + ".res", (n, h, w, cout), dtype) if res else (None, None)
     rv = W.synth_input(name + ".rv", (n, cout)) if rowvec else None
-    ref = _conv_ref(xf if x2f is None else torch.cat([xf, x2f], 3), wf, None, 1, (0, 0)) * scale + bias
+    ref = _conv_ref(xf if x2f is None else torch.cat([xf, x2f], 3), wf, None, 1, (ks // 2, ks // 2)) * scale + bias
     if rv is not None:
         ref = ref + rv[:, None, None, :]
     if rf is not None:
@@ -1052,6 +1057,8 @@ def test_igemm_small(ops, dtype, case, tile, tune):
               out_mode=ops.OUT_ROWS_F32 if f32 else ops.OUT_ROWS)
     if tile is None:
         tune.delenv("MOBI_IGEMM_SMALL")
+        if ks == 3:
+            tune.setenv("MOBI_IGEMM_SMALL_CONV_M", "4096")         # the 3 x 3 form is not routed by default (measured slower)
     else:
         tune.setenv("MOBI_IGEMM_SMALL", tile)
     sink = []

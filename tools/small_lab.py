@@ -23,6 +23,10 @@ SHAPES_512 = [(2048, 1280, 1280, True), (4096, 1280, 1280, True), (8192, 640, 64
               (4096, 2560, 1280, False), (4096, 5120, 1280, True), (16384, 2560, 640, True), (65536, 320, 320, True)]
 
 
+# (images, side, cin, cout): 3 x 3 convolutions with few pixels (the 4 x 4 / 8 x 8 levels)
+CONVS = [(8, 4, 1280, 1280), (8, 4, 2560, 1280), (16, 4, 1280, 1280), (8, 8, 1280, 1280), (16, 8, 1280, 1280), (8, 8, 2560, 1280)]
+
+
 def graph_time(fns, reps=2):
     for f in fns:
         f()
@@ -42,6 +46,33 @@ def graph_time(fns, reps=2):
     return e0.elapsed_time(e1) * 1e3 / (reps * len(fns))
 
 
+def conv_lab(ops, reload_, dt, gen):
+    variants = (("ring", {"MOBI_IGEMM_SMALL": "0"}), ("small", {"MOBI_IGEMM_SMALL": "32"}))
+    for images, side, cin, cout in CONVS:
+        copies = max(4, min(24, int(400e6 / (cout * cin * 9 * 2)) + 1))
+        w0 = torch.randn(cout, cin, 3, 3, generator=gen) / (3 * cin ** 0.5)
+        b0 = torch.randn(cout, generator=gen) * 0.1
+        pws = [ops.pack_conv(w0, b0, dt, "cuda") for _ in range(copies)]
+        xs = [torch.randn(images, side, side, cin, generator=gen).cuda().to(dt) for _ in range(copies)]
+        rv = torch.randn(images, cout, generator=gen).cuda()
+        fns = [(lambda i=i: ops.igemm(xs[i], pws[i], rowvec=rv)) for i in range(copies)]
+        best, first = {}, {}
+        for rep in range(3):
+            for tag, env in variants:
+                os.environ.update(env)
+                reload_()
+                if rep == 0:
+                    first[tag] = fns[0]().float().clone()
+                best[tag] = min(best.get(tag, 1e30), graph_time(fns))
+                for k_ in env:
+                    os.environ.pop(k_, None)
+        reload_()
+        d = float((first["ring"] - first["small"]).abs().max())
+        fl = 2.0 * images * side * side * cin * 9 * cout
+        print(f"conv3x3 {cin}->{cout} {side}x{side}x{images} (m={images * side * side}) {fl / 1e9:6.2f} GF: " +
+              " | ".join(f"{t} {best[t]:6.1f} us {fl / best[t] / 1e6:5.0f} TF/s" for t, _ in variants) + f" | max diff {d:.3g}", flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--set", default="all")
@@ -52,7 +83,9 @@ def main():
     reload_ = _lib.load().mobi_tuning_reload
     dt = torch.bfloat16 if a.dtype == "bf16" else torch.float16
     gen = torch.Generator().manual_seed(0)
-    shapes = {"256": SHAPES_256, "512": SHAPES_512, "all": SHAPES_256 + SHAPES_512}[a.set]
+    shapes = {"256": SHAPES_256, "512": SHAPES_512, "all": SHAPES_256 + SHAPES_512, "conv": []}[a.set]
+    if a.set in ("conv", "all"):
+        conv_lab(ops, reload_, dt, gen)
     variants = (("ring", {"MOBI_IGEMM_SMALL": "0"}), ("small", {"MOBI_IGEMM_SMALL": "32"}))
     for rows, cin, cout, res in shapes:
         per = (rows * cin + cout * cin + rows * cout * (2 if res else 1)) * 2
