@@ -27,6 +27,9 @@ SHAPES_512 = [(2048, 1280, 1280, True), (4096, 1280, 1280, True), (8192, 640, 64
 CONVS = [(8, 4, 1280, 1280), (8, 4, 2560, 1280), (16, 4, 1280, 1280), (8, 8, 1280, 1280), (16, 8, 1280, 1280), (8, 8, 2560, 1280)]
 
 
+COPIES = 0
+
+
 def graph_time(fns, reps=2):
     for f in fns:
         f()
@@ -49,13 +52,13 @@ def graph_time(fns, reps=2):
 def conv_lab(ops, reload_, dt, gen):
     variants = (("ring", {"MOBI_IGEMM_SMALL": "0"}), ("small", {"MOBI_IGEMM_SMALL": "32"}))
     for images, side, cin, cout in CONVS:
-        copies = max(4, min(24, int(400e6 / (cout * cin * 9 * 2)) + 1))
+        copies = COPIES if COPIES > 0 else max(4, min(24, int(400e6 / (cout * cin * 9 * 2)) + 1))
         w0 = torch.randn(cout, cin, 3, 3, generator=gen) / (3 * cin ** 0.5)
         b0 = torch.randn(cout, generator=gen) * 0.1
         pws = [ops.pack_conv(w0, b0, dt, "cuda") for _ in range(copies)]
         xs = [torch.randn(images, side, side, cin, generator=gen).cuda().to(dt) for _ in range(copies)]
         rv = torch.randn(images, cout, generator=gen).cuda()
-        fns = [(lambda i=i: ops.igemm(xs[i], pws[i], rowvec=rv)) for i in range(copies)]
+        fns = [(lambda i=i: ops.igemm(xs[i], pws[i], rowvec=rv)) for i in range(copies)] * (8 if copies == 1 else 1)
         best, first = {}, {}
         for rep in range(3):
             for tag, env in variants:
@@ -77,7 +80,10 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--set", default="all")
     ap.add_argument("--dtype", default="bf16")
+    ap.add_argument("--copies", type=int, default=0, help="operand copies a graph rotates through (0: enough to exceed the Infinity Cache; 1: hot operands)")
     a = ap.parse_args()
+    global COPIES
+    COPIES = a.copies
     from mobi_amd import _lib, build, ops
     build.build(verbose=False)
     reload_ = _lib.load().mobi_tuning_reload
@@ -89,15 +95,15 @@ def main():
     variants = (("ring", {"MOBI_IGEMM_SMALL": "0"}), ("small", {"MOBI_IGEMM_SMALL": "32"}))
     for rows, cin, cout, res in shapes:
         per = (rows * cin + cout * cin + rows * cout * (2 if res else 1)) * 2
-        copies = max(4, min(96, int(400e6 / per) + 1))
+        copies = COPIES if COPIES > 0 else max(4, min(96, int(400e6 / per) + 1))
         w0 = torch.randn(cout, cin, 1, 1, generator=gen) / cin ** 0.5
         b0 = torch.randn(cout, generator=gen) * 0.1
         pws = [ops.pack_conv(w0, b0, dt, "cuda") for _ in range(copies)]
-        xs = [torch.randn(1, rows, 1, cin, generator=gen).cuda().to(dt) for _ in range(min(copies, 8))]
+        xs = [torch.randn(1, rows, 1, cin, generator=gen).cuda().to(dt) for _ in range(max(1, min(copies, 8)))]
         xs = [xs[i % len(xs)].clone() for i in range(copies)]
         rs = [torch.randn(1, rows, 1, cout, generator=gen).cuda().to(dt) if res else None for _ in range(copies)]
         outs_ = [torch.empty(1, rows, 1, cout, device="cuda", dtype=dt) for _ in range(copies)]
-        fns = [(lambda i=i: ops.igemm(xs[i], pws[i], residual=rs[i], out=outs_[i])) for i in range(copies)]
+        fns = [(lambda i=i: ops.igemm(xs[i], pws[i], residual=rs[i], out=outs_[i])) for i in range(copies)] * (8 if copies == 1 else 1)
         best, first = {}, {}
         for rep in range(3):
             for tag, env in variants:
