@@ -63,6 +63,9 @@ class DDPM(nn.Module):
         if learn_logvar:
             raise NotImplementedError("learn_logvar: the engine's backward pass covers the UNet's adapter tensors, not logvar")
         self.learn_logvar = learn_logvar
+        self.use_scheduler = scheduler_config is not None      # ddpm.py:97-99
+        if self.use_scheduler:
+            self.scheduler_config = scheduler_config
         if monitor is not None:
             self.monitor = monitor
         self.register_schedule(given_betas=given_betas, beta_schedule=beta_schedule, timesteps=timesteps,
@@ -443,7 +446,10 @@ class LatentDiffusion(DDPM):
         """ddpm.py:1616-1669 of the reference: AdamW (lr = `self.learning_rate`) over the UNet tensors whose names contain
         `cond_adapter`, `lidar` or `cross_modal`, plus -- with a trainable conditioning stage -- the box embedder and
         `bbox_uncond_vector`; here the engine's AdamW (mobi_amd.train.AdamW, `mobi_adamw_step`), stepped with
-        `self.adapter_grads` after `training_step`.  LR schedulers (`use_scheduler`) are the training harness's: not built."""
+        `self.adapter_grads` after `training_step`.  With a `scheduler_config` (every MObI config: LambdaLinearScheduler, 200 warm-up
+        steps) the return value has the reference's Lightning form `([opt], [{scheduler, interval: "step", frequency: 1}])`, the
+        scheduler a `train.LambdaLR` over the config's schedule object (ddpm.py:1651-1668): call `scheduler.step()` after
+        every optimizer step."""
         from .... import train
         params = {"model.diffusion_model." + n: p for n, p in self.model.diffusion_model.named_parameters()
                   if any(m in n for m in train.TRAINABLE_MARKERS)}
@@ -451,7 +457,12 @@ class LatentDiffusion(DDPM):
             params.update({"cond_stage_model.bbox_embedder." + n: p for n, p in self.cond_stage_model.bbox_embedder.named_parameters()
                            if "class_embedder" not in n})
             params["bbox_uncond_vector"] = self.bbox_uncond_vector
-        return train.AdamW(params, lr=getattr(self, "learning_rate", 1e-4))
+        opt = train.AdamW(params, lr=getattr(self, "learning_rate", 1e-4))
+        if self.use_scheduler:
+            assert "target" in self.scheduler_config
+            schedule = instantiate_from_config(self.scheduler_config)
+            return [opt], [{"scheduler": train.LambdaLR(opt, lr_lambda=schedule.schedule), "interval": "step", "frequency": 1}]
+        return opt
 
     def apply_model(self, x_noisy, t, cond, return_ids=False):
         """x_noisy: fp32 [N, 9, h, w] or the un-concatenated list [x, inpaint_image, inpaint_mask]."""

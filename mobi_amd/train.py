@@ -392,6 +392,24 @@ def bbox_embedder_backward(emb, tape, dtoken):
     return g
 
 
+class LambdaLR:
+    """torch.optim.lr_scheduler.LambdaLR for the engine's optimizer (ddpm.py:1662): the rate is the optimizer's initial rate times
+    `lr_lambda(step)`, set at construction (step 0) and after every `step()`."""
+
+    def __init__(self, optimizer, lr_lambda):
+        self.optimizer, self.lr_lambda = optimizer, lr_lambda
+        self.base_lrs = [optimizer.lr]
+        self.last_epoch = 0
+        optimizer.lr = self.base_lrs[0] * lr_lambda(0)
+
+    def step(self):
+        self.last_epoch += 1
+        self.optimizer.lr = self.base_lrs[0] * self.lr_lambda(self.last_epoch)
+
+    def get_last_lr(self):
+        return [self.optimizer.lr]
+
+
 class AdamW:
     """torch.optim.AdamW's update (what `configure_optimizers` returns, ddpm.py:1649) on the engine: fp32 master parameters
     updated in place by `mobi_adamw_step`, moments kept per parameter name."""
