@@ -101,21 +101,42 @@ def main():
         if rec:
             lines.append(f"HBM traffic of `{fam}` (`{tag}_pmc_traffic.json`, FETCH_SIZE x 2 + WRITE_SIZE, separate `--pmc` passes): "
                          f"{rec['hbm_bytes_per_launch_corrected'] / 1e6:.1f} MB per launch over {rec['launches']} launches.")
-    lines += ["", "Box spread: the pool's boxes fall into two groups about 6 % apart (clocks under load); the same build measured "
-              "19.49-19.52 ms per step on a fast one (`r03_ab_fused_ln.txt`, third block) and 20.7-20.9 on the slow one this set comes from; "
-              "every A/B in this directory is interleaved on one box.",
-              "", "Files:",
-              f"* `{tag}_unet512_b16_bf16_kernel_stats.csv` rocprofv3 stats; `{tag}_bench_unet512_b16_bf16.json` bench line of the same box",
-              f"* `{tag}_launches_one_step.tsv` (`..._nusc256.tsv`) kind, GFLOP, us, algorithmic MB, kernel variant and shape of every launch of one step",
-              f"* `{tag}_pmc_traffic.json` per-kernel-family FETCH_SIZE / WRITE_SIZE (tools/pmc_summary.py)",
-              f"* `{tag}_vae_encode_decode.txt` per-launch times of the VAEs (8 images, 512 x 512, both autoencoders; tools/vae_prof.py)",
-              f"* `{tag}_chain_lab.txt`, `{tag}_chain_stamps.txt` the row-chain kernel against the launches it replaces, its phase stamps and ablations",
-              f"* `{tag}_error_table.txt` measured rel-L2 of every parity assertion of `pytest -m gpu` (MOBI_RECORD_ERRORS)",
-              f"* `{tag}_graph_breakdown.txt` per-kernel time INSIDE the replayed step graph, both workloads (tools/graph_gaps.py)",
-              f"* `{tag}_attention_*.txt` attention lab: ablations, variants, SQ counters; `{tag}_mfma_fill_probe.txt`",
-              f"* `{tag}_gn_lab.txt`, `{tag}_tka_lab.txt`, `{tag}_ff_lab.txt` graph-timed per-shape A/Bs of the GroupNorm / two-key adapter / "
-              "feed-forward kernels; `*_ab_*.txt` interleaved whole-step A/Bs (tools/ab_step.sh) and per-shape A/Bs",
-              f"* the igemm main-loop A/Bs and split-K sweeps of the untouched kernels are round 2's (`r02_ab_wide.txt`, `r02_splitk_sweep_*.txt`)"]
+    ms = bench["ms_per_step"] if bench else None
+    group = "" if ms is None else (" (this set: %.2f ms per step -- the %s group)" % (ms, "fast" if ms < 19.8 else "slow"))
+    lines += ["", "Box spread: the pool's boxes fall into two groups about 6 % apart (clocks under load): 19.2-19.5 ms per step on the fast "
+              f"ones, 20.1-20.9 on the slow ones for the same build{group}; every A/B in this directory is interleaved on one box.",
+              "", "Files of this tag:"]
+    known = [("unet512_b16_bf16_kernel_stats.csv", "rocprofv3 --kernel-trace --stats of the traced bench run (bf16, every launch host-issued)"),
+             ("bench_unet512_b16_bf16.json", "bench line of the same box"),
+             ("launches_one_step.tsv", "kind, GFLOP, us, algorithmic MB, kernel variant and shape of every launch of one mobi_nusc_512 step"),
+             ("launches_one_step_nusc256.tsv", "the same of one mobi_nusc_256 step"),
+             ("pmc_traffic.json", "per-kernel-family FETCH_SIZE / WRITE_SIZE, separate --pmc passes (tools/pmc_summary.py)"),
+             ("vae_encode_decode.txt", "per-launch times of the VAEs (8 images, 512 x 512, both autoencoders; tools/vae_prof.py)"),
+             ("vae_trunk.txt", "the VAE decoders with the fp32 residual trunk"),
+             ("chain_lab.txt", "the row-chain kernel against the launches it replaces"),
+             ("chain_stamps.txt", "its phase stamps and ablations"),
+             ("error_table.txt", "measured rel-L2 of every parity assertion of `pytest -m gpu` (MOBI_RECORD_ERRORS, tools/error_table.py)"),
+             ("parity.json", "end-to-end parity at production width (latent / pixel space, both storage types)"),
+             ("graph_breakdown.txt", "per-kernel time INSIDE the replayed step graph (tools/graph_gaps.py)"),
+             ("nusc256_kernel_stats.csv", "rocprofv3 stats of the mobi_nusc_256 step, every launch host-issued (tools/profile_extra.sh)"),
+             ("train_kernel_stats.csv", "rocprofv3 stats of full-width training steps (tools/train_bench.py via tools/profile_extra.sh)"),
+             ("train_step.txt", "training-step timings, change by change"),
+             ("small_lab.txt", "the small-problem igemm kernel against the LDS-ring kernels per launch (tools/small_lab.py)"),
+             ("small_lab_conv.txt", "its 3 x 3 form (not routed: slower)"),
+             ("small_lab_v1_fragment_loads.txt", "its first form (fragment-shaped global loads), for the record"),
+             ("ab_small.txt", "whole-step A/B of the small-problem kernel (tools/ab_small.sh)"),
+             ("ab_attn_h16.txt", "A/B of the 16x16x32 P.V form of dh = 40 attention (tools/ab_attn_h16.sh: slower, off by default)"),
+             ("ab_row_chain.txt", "whole-step A/B of the row chains"), ("ab_prechain.txt", "the pre-attention chain (slower, off by default)")]
+    have = set(os.listdir(dst))
+    for suffix, what in known:
+        if f"{tag}_{suffix}" in have:
+            lines.append(f"* `{tag}_{suffix}` {what}")
+    listed = {f"{tag}_{sfx}" for sfx, _ in known} | {f"{tag}_README.md"}
+    for name in sorted(have):
+        if name.startswith(tag + "_") and name not in listed:
+            lines.append(f"* `{name}`")
+    lines.append("* the igemm main-loop A/Bs, split-K sweeps and the attention / GroupNorm / adapter / feed-forward labs of the kernels this "
+                 "round left untouched are rounds 2-3's (`r02_*`, `r03_*`)")
     with open(os.path.join(dst, f"{tag}_README.md"), "w") as f:
         f.write("\n".join(lines) + "\n")
     print("\n".join(lines[:16]))
