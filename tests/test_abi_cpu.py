@@ -55,6 +55,11 @@ def test_argument_validation_without_gpu(lib):
     assert lib.mobi_groupnorm(C.byref(g), None) == -2                  # channels % 32 != 0
     assert lib.mobi_groupnorm_workspace_bytes(2, 4096) == 2 * 64 * 32 * 2 * 4
     assert lib.mobi_groupnorm_workspace_bytes(0, 10) == 0
+    assert lib.mobi_tile_weights(16, 4096, 24, 32, None) == -2         # rows % 16
+    assert lib.mobi_tile_weights(16, 4096, 32, 48, None) == -2         # k % 32
+    assert lib.mobi_tile_weights(16, 4104, 32, 32, None) == -4         # 16-byte alignment
+    assert lib.mobi_tile_weights(None, 4096, 32, 32, None) == -1
+    assert lib.mobi_groupnorm_bwd_workspace_floats(2, 4096, 320) == 2 * 32 * 4 + 2 * 16 * 2 * 320
     rc = _lib.RowChainParams()                                          # mobi_row_chain: shape, program and pointer checks
     rc.dtype, rc.channels, rc.images, rc.rows_per_image, rc.nprog = 0, 640, 2, 1024, 1
     assert lib.mobi_row_chain(C.byref(rc), None) == -2                 # C = 320 only

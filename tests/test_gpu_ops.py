@@ -1023,6 +1023,9 @@ SMALL_CASES = [
     (8, 4, 4, 1280, 0, 1280, False, True, False, 1.0, False, 3),  # 3 x 3 at the 4 x 4 level: every tap mask, a per-image vector
     (3, 5, 7, 320, 320, 96, True, False, False, 1.0, False, 3),   # 3 x 3 on a concat, ragged rows (105), odd image sides
     (2, 8, 8, 640, 0, 64, False, False, True, 1.0, False, 3),     # 3 x 3, fp32 output
+    (1, 1, 1, 320, 0, 32, True, True, False, 1.0, False),         # ONE row, one tile, one batch per wave
+    (1, 1, 33, 1280, 0, 32, False, False, False, 2.0, False),     # 33 rows: a full tile and a one-row tile
+    (1, 1, 1, 320, 0, 32, False, False, False, 1.0, False, 3),    # 3 x 3 on a single pixel: only the centre tap is inside
 ]
 
 
