@@ -2064,7 +2064,10 @@ static int launch_attention_v(const mobi_attention_params* p, const AttnArgs& a,
   if constexpr (VVEC == 2) {
     // 8-wave blocks (256 queries per staged K / V tile) for the big launches
     const long long blocks8 = (long long)((p->tq + 255) / 256) * p->heads * p->images;
-    int nw8 = blocks8 >= 1024 && ks <= 5;             // measured -5.5 % on [16 | 8 images, 4096 x 4096, 8 x 40]
+    // measured -5.5 % on [16 | 8 images, 4096 x 4096, 8 x 40]; round 4 (tools/kbench.py attn, MOBI_ATTN_NW=4 | 8): from ONE block
+    // per CU on -- [8, 1024 x 1024, 8 x 80] 30.8 against 33.0 us, [16, ...] 62.9 against 66.3, [16, 1024 x 1024, 8 x 40] 34.2
+    // against 41.4, [2, 4096 x 4096, 8 x 40] 69.2 against 76.8; with 128 blocks (4 images at 1024 x 1024) they lose (26.3 vs 22.0)
+    int nw8 = blocks8 >= (tuning().attn_nw8_blocks > 0 ? tuning().attn_nw8_blocks : 256) && ks <= 5;
     if (tuning().attn_nw > 0) nw8 = ks <= 5 && tuning().attn_nw == 8;       // tests / A-B: 8 forces, 4 forbids
     if (ks <= 5 && tuning().attn_v3 != 0) {           // the reduced-instruction kernel (MOBI_ATTN_V3=0: the kernel below)
       dim3 gridr((p->tq + (nw8 ? 255 : 127)) / (nw8 ? 256 : 128), p->heads, p->images), blockr(nw8 ? 512 : 256);

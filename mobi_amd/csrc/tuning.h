@@ -27,6 +27,7 @@ struct Tuning {
   int attn_nw;          // MOBI_ATTN_NW               4 | 8: waves per attention block
   int attn_sp;          // MOBI_ATTN_SP               1: software-pipelined attention kernel (dh 33..48)
   int tka_rows;         // MOBI_TKA_ROWS              rows per block of the register two-key adapter kernel (sweeps)
+  int attn_nw8_blocks;  // MOBI_ATTN_NW8_BLOCKS       8-wave attention blocks from this many blocks on (default 256; 1024 = rounds 1-3; A/B)
   int attn_h16;         // MOBI_ATTN_H16              1: dh = 40 attention runs the P.V of its last (3/4 padded) channel block on MFMA 16x16x32 (A/B: measured slower)
   int attn_xcd;         // MOBI_ATTN_XCD              0: attention workgroups in hardware order (A/B of the XCD-aware map)
   int cout_mfma;        // MOBI_COUT_MFMA             0: few-output-channel convolutions on the one-wave-per-pixel kernel (A/B)

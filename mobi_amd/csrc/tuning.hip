@@ -43,6 +43,7 @@ void read_env() {
   g_tuning.cout_mfma = env_int("MOBI_COUT_MFMA");
   g_tuning.attn_xcd = env_int("MOBI_ATTN_XCD");
   g_tuning.attn_h16 = env_int("MOBI_ATTN_H16");
+  g_tuning.attn_nw8_blocks = env_int("MOBI_ATTN_NW8_BLOCKS");
   g_tuning.tka_rows = env_int("MOBI_TKA_ROWS");
 }
 }  // namespace
