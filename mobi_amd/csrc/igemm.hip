@@ -2496,10 +2496,15 @@ static int plan_splits(long long M, int n_packed, int ktot) {
   const int nk = (ktot + 63) / 64;
   if (tiles >= 384 || nk < 16) return 1;
   if (tiles >= 256 && nk < 40) return 1;        // measured (tools/sweep_split.py): one full wave of blocks, short k
-  long long s = (512 + tiles - 1) / tiles;
+  const long long target = tuning().split_target > 0 ? tuning().split_target : 512;      // MOBI_IGEMM_SPLIT_TARGET (sweeps)
+  long long s = (target + tiles - 1) / tiles;
   const long long cap = tiles <= 16 ? 16 : 8;               // a handful of tiles (the 4x4 / 8x8 levels): measured best at 16
   if (s > cap) s = cap;
   if (s > nk / 8) s = nk / 8;
+  // one round of 128-pixel tiles and a very long k range per split (the 16 x 16 level's 1280 -> 1280 and 2560 -> 1280 3 x 3
+  // convolutions: 90 / 180 k-tiles per split at s = 2): twice the splits -- 114.7 against 126.3 us and 198.8 against 225.3
+  // (tools/sweep_split.py), -0.08 ms per step; MOBI_IGEMM_SPLIT_LONGK=0 keeps the old plan (A/B)
+  if (tiles >= 128 && tiles <= 256 && s >= 2 && nk / s >= 80 && tuning().split_longk != 0) s *= 2;
   return s < 2 ? 1 : (int)s;
 }
 

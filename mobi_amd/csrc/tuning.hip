@@ -31,6 +31,8 @@ void read_env() {
   g_tuning.w_tiled = env_int("MOBI_IGEMM_WTILED");
   g_tuning.sm64 = env_int("MOBI_IGEMM_SM64");
   g_tuning.n_major = env_int("MOBI_IGEMM_N_MAJOR");
+  g_tuning.split_target = env_int("MOBI_IGEMM_SPLIT_TARGET");
+  g_tuning.split_longk = env_int("MOBI_IGEMM_SPLIT_LONGK");
   g_tuning.small = env_int("MOBI_IGEMM_SMALL");
   g_tuning.small_mflop = env_int("MOBI_IGEMM_SMALL_MFLOP");
   g_tuning.small_conv_m = env_int("MOBI_IGEMM_SMALL_CONV_M");
