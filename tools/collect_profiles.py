@@ -56,6 +56,12 @@ def main():
     roof = bench["roofline"]
     kname = roof["kernel"]
     dom = [r for r in rows if kname in r["Name"]]
+    # igemm_ring_kernel has two geometries in one name: the dominant variant is the eight-wave 256 x 320 (256) tile (<..., 8, 8>),
+    # the four-wave 128 x 160 tile (<..., 4, 4>, the small-m launches) is another family of the bench line
+    var = max(roof.get("igemm_ms_by_variant", {"": 0}), key=lambda v: roof.get("igemm_ms_by_variant", {"": 0})[v])
+    if kname == "igemm_ring_kernel" and var in ("ring256", "ring128"):
+        want = ", 8, 8>" if var == "ring256" else ", 4, 4>"
+        dom = [r for r in dom if want in r["Name"]] or dom
     calls = sum(int(r["Calls"]) for r in dom)
     tot_ns = sum(float(r["TotalDurationNs"]) for r in dom)
     lines = [f"# Profiles of round {tag[1:].lstrip('0')} (MI355X, 1 GPU) -- tag {tag}", "",
