@@ -125,12 +125,16 @@ def main():
              ("parity.json", "end-to-end parity at production width (latent / pixel space, both storage types)"),
              ("graph_breakdown.txt", "per-kernel time INSIDE the replayed step graph (tools/graph_gaps.py)"),
              ("nusc256_kernel_stats.csv", "rocprofv3 stats of the mobi_nusc_256 step, every launch host-issued (tools/profile_extra.sh)"),
+             ("nusc256_pmc_traffic.json", "FETCH_SIZE / WRITE_SIZE per kernel family of the mobi_nusc_256 step (small_gemm_kernel: 11.4 MB per launch)"),
              ("train_kernel_stats.csv", "rocprofv3 stats of full-width training steps (tools/train_bench.py via tools/profile_extra.sh)"),
              ("train_step.txt", "training-step timings, change by change"),
              ("small_lab.txt", "the small-problem igemm kernel against the LDS-ring kernels per launch (tools/small_lab.py)"),
              ("small_lab_conv.txt", "its 3 x 3 form (not routed: slower)"),
              ("small_lab_v1_fragment_loads.txt", "its first form (fragment-shaped global loads), for the record"),
              ("ab_small.txt", "whole-step A/B of the small-problem kernel (tools/ab_small.sh)"),
+             ("ab_split_longk.txt", "whole-step A/B of the long-k split-K rule"), ("ab_attn_nw8.txt", "whole-step A/B of the 8-wave attention block rule"),
+             ("splitk_sweep_512.txt", "split-K sweep of the mobi_nusc_512 step's small-m shapes on the current build (tools/sweep_split.py)"),
+             ("splitk_sweep_256.txt", "the same for mobi_nusc_256"),
              ("ab_attn_h16.txt", "A/B of the 16x16x32 P.V form of dh = 40 attention (tools/ab_attn_h16.sh: slower, off by default)"),
              ("ab_row_chain.txt", "whole-step A/B of the row chains"), ("ab_prechain.txt", "the pre-attention chain (slower, off by default)")]
     have = set(os.listdir(dst))

@@ -16,7 +16,7 @@ import sys
 FAMILIES = ["igemm_pp_kernel", "igemm_ring64_kernel", "igemm_ring_kernel", "igemm_halo_kernel", "igemm_glds_kernel", "igemm_kernel",
             "igemm_splitk_reduce_kernel", "attention_rows_kernel", "attention_pipe_kernel", "attention_kernel", "ff_geglu_kernel",
             "gn_regs_kernel", "gn_stats_kernel", "gn_apply_kernel", "layernorm_kernel", "ctx_attention_kernel", "two_key_adapter",
-            "row_chain_kernel"]
+            "row_chain_kernel", "small_gemm_kernel"]
 
 
 def family(name):
