@@ -86,7 +86,8 @@ def stub_main(args, world, rank):
     """MOBI_BENCH_STUB=1: the launcher / timing / reduction / JSON contract with a CPU stand-in for the step
     (tests/test_bench_launcher_cpu.py drives `bench.py --gpus 2` through it on gloo, no GPU needed)."""
     import torch.distributed as dist
-    if world > 1:
+    torch.set_num_threads(1)                      # N ranks x the default intra-op pool oversubscribes a small host: the rank-dependent
+    if world > 1:                                 # sleeps below, not thread contention, must decide the per-rank times
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend=os.environ.get("MOBI_BENCH_BACKEND", "gloo"))
     a = torch.randn(64, 64)
