@@ -2322,8 +2322,26 @@ __global__ __launch_bounds__(256) void igemm_splitk_reduce_kernel(const IgemmArg
     float o[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) o[j] = 0.f;
-    for (int s = 0; s < a.splits; ++s) {
-      const float* p = a.split_ws + ((long long)s * a.M + m) * a.n_packed + n;
+    // four slabs requested at once, summed in ascending order (the same sums as one at a time: a launch with 8-16 splits and a
+    // few thousand items per CU was a chain of 8-16 dependent L2 round trips)
+    const long long slab = (long long)a.M * a.n_packed;
+    const float* p0 = a.split_ws + (long long)m * a.n_packed + n;
+    int s = 0;
+    for (; s + 4 <= a.splits; s += 4) {
+      f32x4 v[4][2];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const float* p = p0 + (s + u) * slab;
+        v[u][0] = *reinterpret_cast<const f32x4*>(p);
+        v[u][1] = *reinterpret_cast<const f32x4*>(p + 4);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { o[j] += v[u][0][j]; o[4 + j] += v[u][1][j]; }
+    }
+    for (; s < a.splits; ++s) {
+      const float* p = p0 + s * slab;
       const f32x4 v0 = *reinterpret_cast<const f32x4*>(p), v1 = *reinterpret_cast<const f32x4*>(p + 4);
 #pragma unroll
       for (int j = 0; j < 4; ++j) { o[j] += v0[j]; o[4 + j] += v1[j]; }
