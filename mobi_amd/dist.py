@@ -64,6 +64,24 @@ def gather_decoded(images: Dict[str, torch.Tensor], n_objects: int) -> Dict[str,
     return {k: gather_objects(v, n_objects) for k, v in images.items()}
 
 
+def check_same_layout(names: List[str], numels: List[int], device) -> None:
+    """Every rank must bring the SAME tensors in the same order to a bucketed collective: buckets are cut by name order and
+    size, so a rank with another key set would all-reduce buffers of another length (a hang on RCCL, an error on gloo) or sum
+    different parameters into each other.  One tiny collective up front: the MAX and the MIN over the ranks of a 62-bit digest
+    of (name, numel)* must agree; raises on every rank otherwise."""
+    import hashlib
+    rank, ws = world()
+    if ws == 1:
+        return
+    h = hashlib.sha1(";".join(f"{k}:{n}" for k, n in zip(names, numels)).encode()).digest()
+    d = int.from_bytes(h[:8], "big") >> 2
+    t = torch.tensor([d, -d], dtype=torch.int64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    if int(t[0]) != -int(t[1]):
+        raise RuntimeError(f"rank {rank}: the ranks hold different gradient sets ({len(names)} tensors here) -- every rank must pass "
+                           f"the same names and sizes to allreduce_gradients (zeros for a branch it did not take)")
+
+
 def allreduce_gradients(grads: Dict[str, torch.Tensor], bucket_bytes: int = 256 << 20, average: bool = True) -> Dict[str, torch.Tensor]:
     """The gradient collective of the training step (the reference wraps the model in DDP, main.py:510 -- Lightning's
     `ddp` strategy): every rank holds the gradients of ITS objects; after the call every rank holds their sum (or mean).
@@ -75,6 +93,7 @@ def allreduce_gradients(grads: Dict[str, torch.Tensor], bucket_bytes: int = 256 
     if ws == 1:
         return grads
     names = sorted(grads)
+    check_same_layout(names, [grads[k].numel() for k in names], grads[names[0]].device if names else torch.device("cpu"))
     i = 0
     while i < len(names):
         bucket, size = [], 0

@@ -437,10 +437,43 @@ class LatentDiffusion(DDPM):
             elif bbox_tape is not None:
                 eg = train.bbox_embedder_backward(self.cond_stage_model.bbox_embedder, bbox_tape, dbox.unsqueeze(1))
                 named.update({"cond_stage_model.bbox_embedder." + k: v for k, v in eg.items()})
-        if allreduce:
-            mdist.allreduce_gradients(named)
+        # every rank brings the SAME tensors to the collective, whatever ITS draw was: an unconditional draw has a gradient for
+        # `bbox_uncond_vector` and none for the box embedder, a conditional one the other way round, and the draws are per
+        # process (the buckets of allreduce_gradients are cut by name and size) -- the branch not taken contributes zeros, which
+        # is also what DDP sums for a parameter that a rank's graph did not reach
+        # (a tensor NO rank has a gradient for stays absent, as under DDP, where its `.grad` stays None and AdamW skips it;
+        #  one process alone completes nothing)
+        if allreduce and mdist.world()[1] > 1:
+            mdist.allreduce_gradients(self._complete_cond_stage_grads(named, x.device, across_ranks=True))
         self.adapter_grads = named
         return self.l_simple_weight * mse
+
+    def _cond_stage_trainables(self):
+        """{name: parameter} of the conditioning stage's trainable tensors (ddpm.py:1635-1647): the 3-D box embedder's Linear
+        layers and `bbox_uncond_vector` -- the same set `configure_optimizers` hands to AdamW."""
+        out = {}
+        if self.cond_stage_trainable and "ref_bbox" in self.cond_stage_key and hasattr(self.cond_stage_model, "bbox_embedder"):
+            out.update({"cond_stage_model.bbox_embedder." + n: p for n, p in self.cond_stage_model.bbox_embedder.named_parameters()
+                        if "class_embedder" not in n})
+            out["bbox_uncond_vector"] = self.bbox_uncond_vector
+        return out
+
+    def _complete_cond_stage_grads(self, named, device, across_ranks=False):
+        """Zeros for every conditioning-stage tensor `named` has no gradient for (the branch this rank's draw did not take).
+        across_ranks: only the tensors SOME rank has a gradient for (one MAX all-reduce of a presence mask, in the fixed
+        order of `_cond_stage_trainables`) -- every rank ends up with the same key set."""
+        tr = self._cond_stage_trainables()
+        keys = list(tr)
+        present = torch.tensor([1 if k in named else 0 for k in keys], dtype=torch.int32, device=device)
+        if across_ranks and keys:
+            import torch.distributed as tdist
+            tdist.all_reduce(present, op=tdist.ReduceOp.MAX)
+        elif keys:
+            present.fill_(1)
+        for k, have in zip(keys, present.tolist()):
+            if have and k not in named:
+                named[k] = torch.zeros(tuple(tr[k].shape), device=device, dtype=torch.float32)
+        return named
 
     def configure_optimizers(self):
         """ddpm.py:1616-1669 of the reference: AdamW (lr = `self.learning_rate`) over the UNet tensors whose names contain
@@ -453,10 +486,7 @@ class LatentDiffusion(DDPM):
         from .... import train
         params = {"model.diffusion_model." + n: p for n, p in self.model.diffusion_model.named_parameters()
                   if any(m in n for m in train.TRAINABLE_MARKERS)}
-        if self.cond_stage_trainable and "ref_bbox" in self.cond_stage_key and hasattr(self.cond_stage_model, "bbox_embedder"):
-            params.update({"cond_stage_model.bbox_embedder." + n: p for n, p in self.cond_stage_model.bbox_embedder.named_parameters()
-                           if "class_embedder" not in n})
-            params["bbox_uncond_vector"] = self.bbox_uncond_vector
+        params.update(self._cond_stage_trainables())
         opt = train.AdamW(params, lr=getattr(self, "learning_rate", 1e-4))
         if self.use_scheduler:
             assert "target" in self.scheduler_config

@@ -429,4 +429,8 @@ class AdamW:
             ops.adamw_step(p.data, grads[name].reshape(p.shape).contiguous(), st[0], st[1], self.steps, self.lr, self.betas, self.eps,
                            self.weight_decay)
             torch.autograd.graph.increment_version(p)          # the packed 16-bit copies are keyed on the version counter
+        # captured step graphs read the OLD packed copies: a new weights epoch drops them (samplers key their graphs on it, so
+        # training-then-sampling re-captures without the caller having to refresh any fingerprint)
+        from .ldm.modules.diffusionmodules.util import WEIGHTS_EPOCH
+        WEIGHTS_EPOCH[0] += 1
         return self

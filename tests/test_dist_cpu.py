@@ -94,3 +94,74 @@ def test_gradient_allreduce_gloo_world2():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert all(ok for _, ok in res), res
+
+
+def _divergent_worker(rank, world, port, q):
+    """Two ranks whose conditioning draws differ (ddpm.py:1049-1052 draws per process): rank 0 took the unconditional
+    branch (a gradient for `bbox_uncond_vector`), rank 1 the conditional one (gradients for the box embedder)."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import types
+    import torch.nn as nn
+    from mobi_amd import dist as md
+    from mobi_amd.ldm.models.diffusion.ddpm import LatentDiffusion
+
+    class Stand(object):                           # the two methods under test on a stand-in with the attributes they read
+        cond_stage_trainable = True
+        cond_stage_key = ["ref_image", "ref_bbox"]
+        _cond_stage_trainables = LatentDiffusion._cond_stage_trainables
+        _complete_cond_stage_grads = LatentDiffusion._complete_cond_stage_grads
+
+    s = Stand()
+    emb = nn.Module()
+    emb.bbox_proj = nn.Linear(6, 8)
+    emb.class_embedder = nn.Linear(3, 8)           # filtered out, as in configure_optimizers
+    s.cond_stage_model = types.SimpleNamespace(bbox_embedder=emb)
+    s.bbox_uncond_vector = nn.Parameter(torch.zeros(1, 1, 8))
+    unet = {"model.diffusion_model.a.cross_modal.weight": torch.full((4, 4), float(rank + 1))}
+    ok = True
+    # (1) divergent draws: the key sets differ before, agree after; the branch not taken contributed zeros
+    named = dict(unet)
+    if rank == 0:
+        named["bbox_uncond_vector"] = torch.full((1, 1, 8), 2.0)
+    else:
+        named["cond_stage_model.bbox_embedder.bbox_proj.weight"] = torch.full((8, 6), 4.0)
+        named["cond_stage_model.bbox_embedder.bbox_proj.bias"] = torch.full((8,), 6.0)
+    md.allreduce_gradients(s._complete_cond_stage_grads(named, torch.device("cpu"), across_ranks=True))
+    ok = ok and sorted(named) == ["bbox_uncond_vector", "cond_stage_model.bbox_embedder.bbox_proj.bias",
+                                  "cond_stage_model.bbox_embedder.bbox_proj.weight", "model.diffusion_model.a.cross_modal.weight"]
+    ok = ok and torch.allclose(named["bbox_uncond_vector"], torch.full((1, 1, 8), 1.0))
+    ok = ok and torch.allclose(named["cond_stage_model.bbox_embedder.bbox_proj.weight"], torch.full((8, 6), 2.0))
+    ok = ok and torch.allclose(named["cond_stage_model.bbox_embedder.bbox_proj.bias"], torch.full((8,), 3.0))
+    ok = ok and torch.allclose(named["model.diffusion_model.a.cross_modal.weight"], torch.full((4, 4), 1.5))
+    # (2) both ranks unconditional: the embedder stays absent (DDP leaves `.grad` None, AdamW skips it)
+    named = dict(unet)
+    named["bbox_uncond_vector"] = torch.full((1, 1, 8), 2.0)
+    md.allreduce_gradients(s._complete_cond_stage_grads(named, torch.device("cpu"), across_ranks=True))
+    ok = ok and sorted(named) == ["bbox_uncond_vector", "model.diffusion_model.a.cross_modal.weight"]
+    # (3) a rank that arrives with another key set is an error on every rank, not a hang / a sum of unrelated tensors
+    named = dict(unet)
+    if rank == 1:
+        named["extra"] = torch.zeros(3)
+    try:
+        md.allreduce_gradients(named)
+        ok = False
+    except RuntimeError as e:
+        ok = ok and "different gradient sets" in str(e)
+    q.put((rank, bool(ok)))
+    dist.destroy_process_group()
+
+
+def test_training_step_collective_with_divergent_draws_gloo_world2():
+    """ranks whose `u_cond` draws differ used to bring different tensors to the bucketed all-reduce."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_divergent_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok in res), res
