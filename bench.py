@@ -43,8 +43,54 @@ WORKLOADS = {  # BASELINE.json configs[2] / configs[1]
     "mobi_nusc_512": dict(latent=64, objects=8, gflop_per_element=1021.9, gflop_skippable=78.0),
     "mobi_nusc_256": dict(latent=32, objects=4, gflop_per_element=209.7, gflop_skippable=19.5),
 }
-PMC_TRAFFIC = "r04_pmc_traffic.json"   # written by tools/pmc_summary.py from the --pmc passes of this round's build
+PMC_TRAFFIC = "r05_pmc_traffic.json"   # written by tools/pmc_summary.py from the --pmc passes of this round's build
 PEAK_TFLOPS = 2500.0          # dense bf16/fp16 MFMA, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+PARITY_FILES = ("gpurun_out/parity_last.json", "profiles/r05_parity.json")
+NORTH_STAR_REL_L2 = 1e-3
+
+
+def lib_sha16():
+    """sha256 of the engine library this process loads (first 16 hex digits): what a parity record is tied to."""
+    import hashlib
+    from mobi_amd import build
+    with open(build.LIB, "rb") as f:
+        return hashlib.sha256(f.read()).hexdigest()[:16]
+
+
+def parity_record(side, dtype):
+    """End-to-end parity at production width as the GPU suite last MEASURED it (tests/test_gpu_production.py::
+    test_end_to_end_pixel_space writes gpurun_out/parity_last.json; tools/collect_profiles.py copies it to profiles/ with the
+    commit) -- never re-measured here (the oracle run behind it is minutes of CPU).  Every record carries the hash of the library
+    it was measured with: `matches_this_build` says whether that is the library of THIS run.  `meets` = per storage type, whether
+    the latent AND both decoded pictures are within the north star's 1e-3 rel-L2 of the CPU oracle."""
+    for rel_path in PARITY_FILES:
+        try:
+            with open(os.path.join(ROOT, rel_path)) as f:
+                pj = json.load(f)
+            case = "mobi_nusc_512" if side == 64 else "mobi_nusc-mini_256"
+            key = next(k for k in pj if k.startswith(case))
+            rec = pj[key]
+
+            def one(d):
+                r = rec[d]
+                return {"dtype": d, "latent_rel_l2": r["latent_rel_l2"], "pixel_rel_l2_camera": r["pixel_rel_l2_camera"],
+                        "pixel_rel_l2_range": r["pixel_rel_l2_range"]}
+
+            other = "fp16" if dtype == "bf16" else "bf16"
+            sha = pj.get("lib_sha16")
+            parity = {**one(dtype), "other_storage_type": one(other), "case": key, "source": rel_path,
+                      "measured_with_lib_sha16": sha, "measured_at_commit": pj.get("commit"),
+                      "matches_this_build": bool(sha) and sha == lib_sha16()}
+            meets = {d: all(rec[d][q] <= NORTH_STAR_REL_L2 for q in ("latent_rel_l2", "pixel_rel_l2_camera", "pixel_rel_l2_range"))
+                     for d in ("bf16", "fp16") if d in rec}
+            meets["tolerance"] = NORTH_STAR_REL_L2
+            meets["quantities"] = "rel-L2 vs the CPU oracle of the final latent, the decoded camera picture and the decoded range view"
+            return {"parity": parity, "meets": meets}
+        except (OSError, KeyError, StopIteration, ValueError, TypeError):
+            continue
+    return None
 
 
 def build_model(workload, seed=0):
@@ -149,6 +195,8 @@ def main():
     ap.add_argument("--no-plms-line", action="store_true", help="skip the PLMS + CFG 5 (shipped invocation) leg")
     ap.add_argument("--no-fp16-line", action="store_true", help="skip the fp16-storage sub-record (the storage type that "
                     "meets the 1e-3 end-to-end tolerance; only added to a bf16 run)")
+    ap.add_argument("--no-config-lines", action="store_true", help="skip the sub-records of BASELINE configs 2 and 5 "
+                    "(`nusc256`: mobi_nusc_256, 4 objects, 32 x 32, DDIM-50, bf16; `ddim250_fp16`: the DDIM-250 / fp16 per-rank workload)")
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ:
@@ -559,6 +607,85 @@ def main():
         del s16
         mobi_amd.set_engine_dtype(dtype)
 
+    # ---- BASELINE configs 2 and 5 on the same line (the driver times only this invocation) ---------------------------------
+    # config 2: configs/mobi_nusc_256.yaml, batch 4, DDIM-50, bf16 -- the UNet of that config IS this one (the two YAML files
+    # differ in image_size / latent_size only: checked), so the 32 x 32 step runs on the same weights;
+    # config 5: mobi_nusc_all-classes_512 + range_autoencoder, DDIM-250, fp16 -- same model as config 3 (the configs differ in the
+    # dataset's classes), 8 objects per rank, the [1, 5, ..., 997] table; the step time does not depend on the timestep, so a
+    # handful of steps of the 250 are timed.
+    config_lines = {}
+    if args.workload == "mobi_nusc_512" and not args.no_config_lines and not cfg:
+        from mobi_amd.ldm.util import load_config
+
+        def unet_params(name):
+            c = load_config(os.path.join(ROOT, "configs", name), ["model.params.lidar_stage_config.params.ckpt_path=null"])
+            u = dict(c["model"]["params"]["unet_config"]["params"])
+            u.pop("image_size", None)
+            return u
+
+        def timed_steps(smp, n_el, sd, S, label):
+            gg = torch.Generator(device="cpu").manual_seed(4321 + rank)
+            mk2 = lambda *s_: torch.randn(*s_, generator=gg).to(device)
+            x_, inp_ = mk2(n_el, 4, sd, sd), mk2(n_el, 4, sd, sd)
+            m_ = torch.ones(n_el, 1, sd, sd)
+            m_[:, :, sd // 4: 3 * sd // 4, sd // 4: 3 * sd // 4] = 0
+            m_ = m_.to(device)
+            c_ = mk2(n_el, 2, 768)
+            kw_ = {"test_model_kwargs": {"inpaint_image": inp_, "inpaint_mask": m_}}
+            tot = smp.ddim_timesteps.shape[0]
+            desc = list(reversed(smp.ddim_timesteps.tolist()))
+
+            def stp(x__, i):
+                index = tot - 1 - (i % tot)
+                step = int(desc[i % tot])
+                ts = torch.full((n_el,), step, device=device, dtype=torch.long)
+                return smp.p_sample_ddim(x__, c_, ts, index=index, step_value=step, **kw_)[0]
+
+            with torch.no_grad():
+                for i in range(max(args.warmup, 1)):
+                    x_ = stp(x_, i)
+                barrier()
+                t0_ = time.perf_counter()
+                for i in range(args.steps):
+                    x_ = stp(x_, args.warmup + i)
+                barrier()
+                d_ = time.perf_counter() - t0_
+            if world > 1:
+                tm = torch.tensor([d_], device=red_dev)
+                dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+                d_ = float(tm.item())
+            return d_, bool(torch.isfinite(x_).all()), [int(v) for v in smp.ddim_timesteps[:3]] + [int(smp.ddim_timesteps[-1])]
+
+        if unet_params("mobi_nusc_256.yaml") == unet_params("mobi_nusc_512.yaml"):
+            w2 = WORKLOADS["mobi_nusc_256"]
+            s256 = DDIMSampler(model, graph=not args.no_graph)
+            s256.make_schedule(50, ddim_eta=0.0, verbose=False)
+            n2 = 2 * w2["objects"]
+            d2, fin2, _ = timed_steps(s256, n2, w2["latent"], 50, "nusc256")
+            v2 = args.steps / d2 * n2 * world
+            gf2 = w2["gflop_per_element"] - w2["gflop_skippable"]
+            config_lines["nusc256"] = {
+                "config": "BASELINE configs[1]: mobi_nusc_256, 4 objects/GPU (UNet batch 8), latent 32x32, DDIM-50 schedule, cfg_scale 1.0",
+                "dtype": args.dtype, "steps": args.steps, "ms_per_step": round(d2 / args.steps * 1e3, 3), "value": round(v2, 3),
+                "unit": "UNet element-forwards/s", "model_tflops": round(v2 * gf2 / 1e3 / world, 2),
+                "model_frac_of_peak": round(v2 * gf2 / 1e3 / world / PEAK_TFLOPS, 4), "finite": fin2}
+            del s256
+        mobi_amd.set_engine_dtype(torch.float16)
+        s250 = DDIMSampler(model, graph=not args.no_graph)
+        s250.make_schedule(250, ddim_eta=0.0, verbose=False)
+        d5, fin5, tab5 = timed_steps(s250, N, side, 250, "ddim250_fp16")
+        v5 = args.steps / d5 * N * world
+        config_lines["ddim250_fp16"] = {
+            "config": f"BASELINE configs[4], per rank: mobi_nusc_all-classes_512 (= the mobi_nusc_512 model), {B} objects/GPU (UNet batch "
+                      f"{N}), latent {side}x{side}, DDIM-250 schedule, fp16 storage, cfg_scale 1.0",
+            "dtype": "fp16", "steps": args.steps, "ddim_timesteps_first3_last": tab5,
+            "ms_per_step": round(d5 / args.steps * 1e3, 3), "value": round(v5, 3), "unit": "UNet element-forwards/s",
+            "sampling_s_per_batch_ddim250": round(d5 / args.steps * 250, 3),
+            "model_frac_of_peak": round(v5 * (wl["gflop_per_element"] - wl["gflop_skippable"]) / 1e3 / world / PEAK_TFLOPS, 4),
+            "finite": fin5}
+        del s250
+        mobi_amd.set_engine_dtype(dtype)
+
     if rank == 0:
         steps_per_s = args.steps / dt
         value = steps_per_s * elems * world
@@ -590,19 +717,13 @@ def main():
             out["plms_cfg5"] = plms_line
         if fp16_line:
             out["fp16"] = fp16_line
+        out.update(config_lines)
         # end-to-end parity at production width, from the committed measurement of the GPU suite (never re-measured here: the
         # oracle run behind it takes minutes of CPU): both storage types, the benched one first
-        try:
-            with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r04_parity.json")) as f:
-                pj = json.load(f)
-            key = next(k for k in pj if k.startswith("mobi_nusc_512" if side == 64 else "mobi_nusc-mini_256"))
-            mk = lambda d: {"dtype": d, "latent_rel_l2": pj[key][d]["latent_rel_l2"],
-                            "pixel_rel_l2": max(pj[key][d]["pixel_rel_l2_camera"], pj[key][d]["pixel_rel_l2_range"])}
-            other = "fp16" if args.dtype == "bf16" else "bf16"
-            out["parity"] = {**mk(args.dtype), "other_storage_type": mk(other), "case": key,
-                             "source": "profiles/r04_parity.json (tests/test_gpu_production.py::test_end_to_end_pixel_space)"}
-        except (OSError, KeyError, StopIteration, ValueError):
-            pass
+        par = parity_record(side, args.dtype)
+        if par:
+            out["parity"] = par["parity"]
+            out["meets_north_star_tolerance"] = par["meets"]
         out["headline_frac_of_peak"] = out["model_frac_of_peak"]     # the model-level fraction; roofline.frac is one kernel's
         if world > 1:
             out["ranks_seen"] = dist.get_world_size()

@@ -39,8 +39,10 @@ extern "C" {
  *   3  mobi_row_chain_params / mobi_chain_op (struct ids 15, 16), mobi_row_chain*; the backward entry points
  *      (mobi_layernorm_bwd_params 17, mobi_attention_bwd_params 18)
  *   4  mobi_groupnorm_bwd takes a workspace (mobi_groupnorm_bwd_workspace_floats); mobi_igemm_kernel_variant may answer
- *      MOBI_IGEMM_SMALL; mobi_tile_weights */
-#define MOBI_ABI_VERSION 4
+ *      MOBI_IGEMM_SMALL; mobi_tile_weights
+ *   5  mobi_igemm_params.sync + mobi_igemm_sync_bytes (split-K finished inside the launch); mobi_igemm_params.groups may be
+ *      any divisor of batch */
+#define MOBI_ABI_VERSION 5
 
 enum { MOBI_OK = 0, MOBI_ERR_ARG = -1, MOBI_ERR_UNSUPPORTED = -2, MOBI_ERR_LAUNCH = -3, MOBI_ERR_ALIGN = -4 };
 enum { MOBI_F16 = 0, MOBI_BF16 = 1 };
@@ -92,7 +94,9 @@ typedef struct mobi_igemm_params {
                                            bottom / right edge are zero as well          */
   int64_t src_img_stride;  /* elements between images of src0/src1; 0 = dense           */
   const void* weight;    /* T [groups][n_packed][kh*kw*(c0+c1)], k contiguous, k = tap*C + c */
-  int32_t groups;        /* 1: one weight matrix; == batch: one weight matrix per image  */
+  int32_t groups;        /* 1: one weight matrix; a divisor g of batch: image i is multiplied by matrix i / (batch / g)
+                            (== batch: one matrix per image; 2: the camera images' and the lidar images' projections of a
+                            [camera images ; lidar images] batch as ONE launch, ldm/modules/attention.py:245-263)         */
   int64_t w_group_stride;/* elements between the per-group weight matrices              */
   int32_t n_packed;      /* rows of W; GEGLU: n_packed = 2 * cout, every 16 rows = 8 value rows
                             then the 8 gate rows of the same 8 outputs (cout % 8 == 0)    */
@@ -123,6 +127,11 @@ typedef struct mobi_igemm_params {
                             k 32 s .. 32 s + 31 -- row r at bytes 64 r, its four 16-byte chunks c at slot c ^ P[(r >> 2) & 3],
                             P = {0, 2, 3, 1}.  The LDS-DMA main loops then fetch one contiguous KiB per request instead of
                             sixteen 64-byte row segments (a CU's request path takes ~60 against ~25 B per clock).  NULL: W only. */
+  void* sync;            /* split_k > 1, optional: mobi_igemm_sync_bytes(p, split_k) bytes of int32 arrival counters, ZERO
+                            before the launch and zero again after it (one buffer can serve every launch of a stream).
+                            With it the launch finishes its own split: the workgroup that arrives LAST at an output tile sums
+                            the tile's slabs (same order, same sums as the reduce launch: bit-identical) and applies the
+                            epilogue -- no second launch.  NULL (or a kernel variant that cannot): the reduce launch.        */
 } mobi_igemm_params;
 
 int mobi_igemm(const mobi_igemm_params* p, void* stream);
@@ -135,6 +144,7 @@ enum { MOBI_IGEMM_STAGED_128 = 0, MOBI_IGEMM_STAGED_256 = 1, MOBI_IGEMM_DIRECT_L
        MOBI_IGEMM_RING_128 = 4, MOBI_IGEMM_RING_256 = 5, MOBI_IGEMM_RING_128W = 6, MOBI_IGEMM_SMALL = 7 };
 int mobi_igemm_kernel_variant(const mobi_igemm_params* p);
 size_t mobi_igemm_workspace_bytes(const mobi_igemm_params* p, int32_t splits);
+size_t mobi_igemm_sync_bytes(const mobi_igemm_params* p, int32_t splits);
 
 /* ---------------------------------------------------------------------------
  * GroupNorm (32 groups) with optional fused SiLU over one or two

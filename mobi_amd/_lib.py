@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libmobi_hip.so")
 
 MOBI_F16, MOBI_BF16 = 0, 1
-ABI_VERSION = 4            # include/mobi_engine.h MOBI_ABI_VERSION
+ABI_VERSION = 5            # include/mobi_engine.h MOBI_ABI_VERSION
 EPI_NONE, EPI_GEGLU = 0, 1
 OUT_ROWS, OUT_TRANSPOSED, OUT_ROWS_F32 = 0, 1, 2
 ACT_NONE, ACT_SILU, ACT_GELU = 0, 1, 2
@@ -34,7 +34,7 @@ class IgemmParams(C.Structure):
                 ("w_group_stride", i64), ("n_packed", i32), ("cout", i32), ("bias", vp), ("rowvec", vp), ("rowvec_stride", i32),
                 ("residual", vp), ("res_img_stride", i64), ("out", vp), ("out_img_stride", i64),
                 ("out_mode", i32), ("epilogue", i32), ("scale", f32), ("dtype", i32), ("split_k", i32), ("ws", vp), ("k_order", i32),
-                ("weight_tiled", vp)]
+                ("weight_tiled", vp), ("sync", vp)]
 
 
 class GroupNormParams(C.Structure):
@@ -169,6 +169,7 @@ SYMBOLS = {
     "mobi_igemm_plan_splits": (C.c_int, [C.POINTER(IgemmParams)]),
     "mobi_igemm_kernel_variant": (C.c_int, [C.POINTER(IgemmParams)]),
     "mobi_igemm_workspace_bytes": (C.c_size_t, [C.POINTER(IgemmParams), i32]),
+    "mobi_igemm_sync_bytes": (C.c_size_t, [C.POINTER(IgemmParams), i32]),
     "mobi_groupnorm_workspace_bytes": (C.c_size_t, [i32, i32]),
     "mobi_groupnorm": (C.c_int, [C.POINTER(GroupNormParams), vp]),
     "mobi_layernorm": (C.c_int, [C.POINTER(LayerNormParams), vp]),

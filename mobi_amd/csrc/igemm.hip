@@ -123,6 +123,9 @@ struct IgemmArgs {
   int wm;                  // waves along the pixel axis (2 or 4): block tile = 64*wm pixels
   int splits, nk_per;      // split-K: blockIdx.y owns k-tiles [y*nk_per, (y+1)*nk_per)
   float* split_ws;         // f32 [splits][M][n_packed] partial sums (NULL: single pass)
+  int sync_mode;           // 0: no `sync`; 1: device-coherent slab traffic; 2: a tile's blocks share one XCD's L2 (see splitk_arrive_and_finish)
+  int* sync;               // split-K finished inside the launch: one arrival counter per output tile (zero before and after
+                           // the launch), or NULL: the slabs are summed by igemm_splitk_reduce_kernel (a second launch)
   int ring_direct;         // 256 x 320 ring tiles: register epilogue (full tiles, row-major T output, bias OR per-image vector)
   int sm_direct;           // 128 x 160 ring tiles: register epilogue / register slab stores (full tiles)
   const void* w_tiled;     // W as 1-KiB request images (ring kernels), or NULL
@@ -150,6 +153,8 @@ __device__ __forceinline__ void ld8f(const float* p, float (&f)[8]) {
   const f32x4 a = *reinterpret_cast<const f32x4*>(p), b = *reinterpret_cast<const f32x4*>(p + 4);
   f[0] = a[0]; f[1] = a[1]; f[2] = a[2]; f[3] = a[3]; f[4] = b[0]; f[5] = b[1]; f[6] = b[2]; f[7] = b[3];
 }
+
+__device__ __forceinline__ void vm_store16_dev(void* p, const u32x4& v);      // device-coherent 16-byte store (below)
 
 // ---------------------------------------------------------------------------------------------------------
 // Epilogue shared by both main-loop variants: accumulators -> per-wave fp32 LDS tile -> coalesced 16-byte rows
@@ -278,8 +283,13 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& a, float* stage,
           if (m >= a.M || n >= a.n_packed) continue;
           const float* sp = stage + row * STAGE_STRIDE + cg * 8;
           float* d = wsp + (long long)m * a.n_packed + n;
-          *reinterpret_cast<f32x4*>(d) = *reinterpret_cast<const f32x4*>(sp);
-          *reinterpret_cast<f32x4*>(d + 4) = *reinterpret_cast<const f32x4*>(sp + 4);
+          if (a.sync_mode == 1) {                              // finished inside the launch, device-coherent slab stores
+            vm_store16_dev(d, *reinterpret_cast<const u32x4*>(sp));
+            vm_store16_dev(d + 4, *reinterpret_cast<const u32x4*>(sp + 4));
+          } else {
+            *reinterpret_cast<f32x4*>(d) = *reinterpret_cast<const f32x4*>(sp);
+            *reinterpret_cast<f32x4*>(d + 4) = *reinterpret_cast<const f32x4*>(sp + 4);
+          }
         }
       } else if (a.epilogue == MOBI_EPI_GEGLU) {
         // packed columns: per 16-column MFMA tile, 8 value columns then the 8 gate columns of the same outputs
@@ -391,6 +401,135 @@ __device__ __forceinline__ void vm_store16(void* p, const u32x4& v) {
 __device__ __forceinline__ void vm_store8(void* p, const u32x2& v) {
   asm volatile("global_store_dwordx2 %0, %1, off" : : "v"(p), "v"(v) : "memory");
 }
+
+// =========================================================================================================
+// Split-K finished INSIDE the launch (no reduce launch, no host round trip between the partial sums and the epilogue).
+// Every block of a split launch writes its fp32 slab tile, then ARRIVES at its output tile's counter; the block that
+// arrives last sums the tile's slabs in ascending split order -- the same sums in the same order as
+// igemm_splitk_reduce_kernel, so the result is bit-identical to the two-launch form and does not depend on who
+// arrived last -- applies the epilogue (bias, per-image vector, residual, one rounding) and returns the counter to zero.
+// Nobody waits for anybody: a block that is not last simply ends.
+//
+// Coherence without cache-wide fences.  The eight XCDs' L2s are not coherent with each other, and an agent-scope
+// release / acquire pair (buffer_wbl2 + buffer_inv: what __threadfence() emits) writes back and invalidates WHOLE L2s --
+// round 2 measured that form at 13.55 against 7.58 ms per mobi_nusc_256 step.  Here only the slab traffic itself is made
+// device-coherent: slab stores and slab loads carry sc1 (device scope: written through to / fetched from the memory
+// side, which is where the counter's device-scope atomic lives too), every wave drains its stores (vmcnt(0)) before the
+// block's single arrival, and nothing else of the launch (operands, outputs) changes its cache policy.
+// =========================================================================================================
+__device__ __forceinline__ void vm_store16_dev(void* p, const u32x4& v) {
+  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(p), "v"(v) : "memory");
+}
+// one 16-byte slab store: device-coherent when the launch finishes its own split (wave-uniform choice)
+__device__ __forceinline__ void slab_store16(bool dev, void* p, const u32x4& v) {
+  if (dev) vm_store16_dev(p, v); else vm_store16(p, v);
+}
+
+// The arithmetic of igemm_splitk_reduce_kernel on rows [m0, m0 + bm) x columns [n0, n0 + bn) of the output, by the
+// THREADS threads of one block, for at most FOUR slabs (the host keeps launches with more splits on the reduce launch: one
+// block summing 8-16 slabs of its tile is a chain of memory round trips that the other 255 CUs spend idle -- measured
+// 54.6 against 22.3 us at 16 splits, profiles/r05_fused_split_lab.txt).  Four items (16-byte column groups) per thread
+// and pass, every slab piece of the pass requested before the first is used.  DEV: slab loads with sc1.
+template <typename T, int THREADS, bool DEV>
+__device__ __forceinline__ void splitk_finish_tile(const IgemmArgs& a, int m0, int bm, int n0, int bn) {
+  const int m1 = min(a.M, m0 + bm), n1 = min(a.cout, n0 + bn);
+  if (m1 <= m0 || n1 <= n0) return;
+  const int vpr = (n1 - n0) >> 3;                            // cout % 8 == 0 (host check), tiles start at multiples of 8
+  const int total = (m1 - m0) * vpr;
+  T* __restrict__ outT = reinterpret_cast<T*>(a.out);
+  float* __restrict__ outF = reinterpret_cast<float*>(a.out);
+  const T* __restrict__ resid = reinterpret_cast<const T*>(a.residual);
+  const int S = a.splits;                                    // 2 .. 4
+  const unsigned slab_bytes = (unsigned)a.M * (unsigned)a.n_packed * 4u;     // S * slab_bytes < 2^32 (host check)
+  // slab pieces through a buffer descriptor: loads the compiler itself waits for (an inline-asm load's destination may be
+  // copied -- spilled, moved to an accumulator register -- before a hand-placed wait), with the cache policy in the instruction
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(a.split_ws, 0, (int)(slab_bytes * (unsigned)S), 0x00020000);
+  constexpr int AUX = DEV ? 16 : 0;                          // sc1
+  constexpr int IB = 2;
+  for (int i0 = threadIdx.x; i0 < total; i0 += IB * THREADS) {
+    u32x4 v[IB][4][2];
+    int mm[IB], nn[IB];
+#pragma unroll
+    for (int b = 0; b < IB; ++b) {
+      const int i = min(i0 + b * THREADS, total - 1);        // (past the end: a harmless duplicate of the last item, not stored)
+      const int mr = i / vpr;
+      mm[b] = m0 + mr; nn[b] = n0 + (i - mr * vpr) * 8;
+      const unsigned off = ((unsigned)mm[b] * (unsigned)a.n_packed + (unsigned)nn[b]) * 4u;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (u < S) {
+          v[b][u][0] = __builtin_amdgcn_raw_buffer_load_b128(rs, off + (unsigned)u * slab_bytes, 0, AUX);
+          v[b][u][1] = __builtin_amdgcn_raw_buffer_load_b128(rs, off + (unsigned)u * slab_bytes + 16u, 0, AUX);
+        }
+      }
+    }
+#pragma unroll
+    for (int b = 0; b < IB; ++b) {
+      if (i0 + b * THREADS >= total) break;
+      const int m = mm[b], n = nn[b];
+      float o[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] = 0.f;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (u < S) {                                         // ascending split order: the reduce launch's sums
+          const f32x4 x0 = __builtin_bit_cast(f32x4, v[b][u][0]), x1 = __builtin_bit_cast(f32x4, v[b][u][1]);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { o[j] += x0[j]; o[4 + j] += x1[j]; }
+        }
+      }
+      const int img = m / a.hw_out, rem = m - img * a.hw_out;
+      if (a.bias) {
+        float bb[8];
+        ld8f(a.bias + n, bb);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] += bb[j];
+      }
+      if (a.rowvec) {
+        float rv[8];
+        ld8f(a.rowvec + (long long)img * a.rowvec_stride + n, rv);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] += rv[j];
+      }
+      if (resid) {
+        float rf[8];
+        unpack8<T>(ld16(resid + (long long)img * a.res_img_stride + (long long)rem * a.cout + n), rf);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] += rf[j];
+      }
+      const long long off = (long long)img * a.out_img_stride + (long long)rem * a.cout + n;
+      if (a.out_mode == MOBI_OUT_ROWS_F32) {
+        *reinterpret_cast<f32x4*>(outF + off) = f32x4{o[0], o[1], o[2], o[3]};
+        *reinterpret_cast<f32x4*>(outF + off + 4) = f32x4{o[4], o[5], o[6], o[7]};
+      } else {
+        st16(outT + off, pack8<T>(o));
+      }
+    }
+  }
+}
+
+// arrive + finish: `sync_mode` 1 = device-coherent slab traffic (sc1 stores / loads, a device-scope counter: correct wherever
+// the blocks of a tile run); 2 = the blocks of a tile share ONE XCD's L2 (the host has checked that the grid deals them so:
+// consecutive workgroup ids go round the eight XCDs, so blocks (x, y) of a grid whose x extent is a multiple of 8 land on XCD
+// x % 8 for every y): plain stores, an L2 atomic, loads that bypass only the CU's own vector cache
+template <typename T, int THREADS>
+__device__ __forceinline__ void splitk_arrive_and_finish(const IgemmArgs& a, int tile, int m0, int bm, int n0, int bn, int* s_flag) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // this wave's slab stores have been acknowledged
+  __syncthreads();                                           // ... and so have every other wave's of the block
+  if (threadIdx.x == 0) {
+    *s_flag = a.sync_mode == 2 ? __hip_atomic_fetch_add(a.sync + tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
+                               : __hip_atomic_fetch_add(a.sync + tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __syncthreads();
+  if (*s_flag != a.splits - 1) return;                       // not the last to arrive: done
+  if (threadIdx.x == 0) {
+    if (a.sync_mode == 2) __hip_atomic_store(a.sync + tile, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    else __hip_atomic_store(a.sync + tile, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  if (a.sync_mode == 2) splitk_finish_tile<T, THREADS, false>(a, m0, bm, n0, bn);
+  else splitk_finish_tile<T, THREADS, true>(a, m0, bm, n0, bn);
+}
+
 // wait until at most n (wave-uniform; rounded DOWN to an encoded value, which only waits longer) vector-memory
 // operations of this wave are outstanding
 __device__ __forceinline__ void wait_vmcnt_le(int n) {
@@ -1334,6 +1473,7 @@ __global__ __launch_bounds__(512, 2) void igemm_pp_kernel(const IgemmArgs a) {
   constexpr int PIECES = 4 + WJ;
   constexpr unsigned OOB = 0x80000000u;                      // beyond every descriptor (extents < 2^31, host check)
   __shared__ __attribute__((aligned(16))) unsigned char lds[3 * STAGE];
+  __shared__ int s_arrive;                                   // split-K finished inside the launch: the arrival order
   typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1518,7 +1658,7 @@ __global__ __launch_bounds__(512, 2) void igemm_pp_kernel(const IgemmArgs a) {
     for (int mi = 0; mi < 4; ++mi) {
       float* rowp = wsp + (long long)(mw0 + mi * 16 + r16) * a.n_packed + nw0 + g4 * 4;
 #pragma unroll
-      for (int ni = 0; ni < NT; ++ni) vm_store16(rowp + ni * 16, __builtin_bit_cast(u32x4, acc[ni][mi]));
+      for (int ni = 0; ni < NT; ++ni) slab_store16(a.sync_mode == 1, rowp + ni * 16, __builtin_bit_cast(u32x4, acc[ni][mi]));
     }
     return 4 * NT;
   };
@@ -1730,6 +1870,15 @@ __global__ __launch_bounds__(512, 2) void igemm_pp_kernel(const IgemmArgs a) {
   MOBI_STAMP_AT(2);
   wait_vmcnt_le(vm_issued - mk_req);
   finish_tile(p_nw0, p_mw0);
+  if constexpr (SLAB) {
+    // split-K finished inside the launch (the host sets `sync` only when every block owns exactly ONE output tile): the
+    // block that arrives last at the tile sums its slabs and applies the epilogue
+    if (a.sync) {
+      const int L = xcd_remap(blockIdx.x, nblk);
+      MOBI_TILE_OF_M(L, ftm, ftn);
+      splitk_arrive_and_finish<T, 512>(a, L, ftm * BM, BM, ftn * BN, BN, &s_arrive);
+    }
+  }
 #if MOBI_STAMP
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // the stamp then covers this wave's stores too
   MOBI_STAMP_AT(3);
@@ -1789,6 +1938,7 @@ __global__ __launch_bounds__(NW * 64, 2) void igemm_ring_kernel(const IgemmArgs 
   constexpr int LDS_BYTES = RING > NW * STAGE_BYTES ? RING : NW * STAGE_BYTES;
   constexpr unsigned OOB = 0x80000000u;
   __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
+  __shared__ int s_arrive;                                   // split-K finished inside the launch: the arrival order
   typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1801,7 +1951,8 @@ __global__ __launch_bounds__(NW * 64, 2) void igemm_ring_kernel(const IgemmArgs 
   const int m0 = tile_m * BM, n0 = tile_n * BN;
   MOBI_STAMP_AT(0);
   const bool w_tiled = a.w_tiled != nullptr;                 // (wave-uniform) weights as 1-KiB request images
-  const T* wgt = w_tiled ? reinterpret_cast<const T*>(a.w_tiled) : reinterpret_cast<const T*>(a.weight) + (long long)group * a.w_group_stride;
+  // (request images of stacked per-group matrices: a group's image has as many elements as its matrix and follows the previous one's)
+  const T* wgt = (w_tiled ? reinterpret_cast<const T*>(a.w_tiled) : reinterpret_cast<const T*>(a.weight)) + (long long)group * a.w_group_stride;
   const __amdgpu_buffer_rsrc_t rx0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.src0), 0, a.src0_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rx1 =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.src1 ? a.src1 : a.src0), 0, a.src1 ? a.src1_bytes : 0, 0x00020000);
@@ -2051,7 +2202,10 @@ __global__ __launch_bounds__(NW * 64, 2) void igemm_ring_kernel(const IgemmArgs 
         for (int mi = 0; mi < 4; ++mi) {
           float* rowp = wsp + (long long)(mw0 + mi * 16 + r16) * a.n_packed + nw0 + g4 * 4;
 #pragma unroll
-          for (int ni = 0; ni < NT; ++ni) vm_store16(rowp + ni * 16, __builtin_bit_cast(u32x4, acc[ni][mi]));
+          for (int ni = 0; ni < NT; ++ni) slab_store16(a.sync_mode == 1, rowp + ni * 16, __builtin_bit_cast(u32x4, acc[ni][mi]));
+        }
+        if (a.sync) {                                          // split-K finished inside the launch by the tile's last block
+          splitk_arrive_and_finish<T, NW * 64>(a, tile_m * a.tiles_n + tile_n, m0, BM, n0, BN, &s_arrive);
         }
       } else {
         DirectEpiRegs<NT> q;
@@ -2104,6 +2258,11 @@ __global__ __launch_bounds__(NW * 64, 2) void igemm_ring_kernel(const IgemmArgs 
       for (int j = 0; j < 4; ++j) part[i][j] = acc[i][4 * h + j];
     igemm_epilogue<T, NT, TR, 32, MT == 4>(a, stage, part, lane, group, n0 + wn * WAVE_N, m0 + wm * MT * 16 + 64 * h);
   }
+  if constexpr (!TR) {
+    if (a.split_ws && a.sync) {                              // split-K finished inside the launch by the tile's last block
+      splitk_arrive_and_finish<T, NW * 64>(a, tile_m * a.tiles_n + tile_n, m0, BM, n0, BN, &s_arrive);
+    }
+  }
 #if MOBI_STAMP                                                // (eight-wave geometry: tools/stamp_ring.py)
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   MOBI_STAMP_AT(3);
@@ -2146,6 +2305,7 @@ __global__ __launch_bounds__(256, 1) void igemm_ring64_kernel(const IgemmArgs a)
   constexpr int LDS_BYTES = RING > NW * STAGE_BYTES ? RING : NW * STAGE_BYTES;
   constexpr unsigned OOB = 0x80000000u;
   __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
+  __shared__ int s_arrive;                                   // split-K finished inside the launch: the arrival order
   typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -2288,7 +2448,10 @@ __global__ __launch_bounds__(256, 1) void igemm_ring64_kernel(const IgemmArgs a)
         for (int mi = 0; mi < 4; ++mi) {
           float* rowp = wsp + (long long)(mw0 + mi * 16 + r16) * a.n_packed + nw0 + g4 * 4;
 #pragma unroll
-          for (int ni = 0; ni < NT; ++ni) vm_store16(rowp + ni * 16, __builtin_bit_cast(u32x4, acc[ni][mi]));
+          for (int ni = 0; ni < NT; ++ni) slab_store16(a.sync_mode == 1, rowp + ni * 16, __builtin_bit_cast(u32x4, acc[ni][mi]));
+        }
+        if (a.sync) {                                          // split-K finished inside the launch by the tile's last block
+          splitk_arrive_and_finish<T, NW * 64>(a, tile_m * a.tiles_n + tile_n, m0, BM, n0, BN, &s_arrive);
         }
       } else {
         DirectEpiRegs<NT> q;
@@ -2306,6 +2469,11 @@ __global__ __launch_bounds__(256, 1) void igemm_ring64_kernel(const IgemmArgs a)
   __syncthreads();
   float* stage = reinterpret_cast<float*>(lds) + wave * (STAGE_BYTES / 4);
   igemm_epilogue<T, NT, TR, 32, true>(a, stage, acc, lane, group, n0 + wn * WAVE_N, m0 + wm * 64);
+  if constexpr (!TR) {
+    if (a.split_ws && a.sync) {
+      splitk_arrive_and_finish<T, NW * 64>(a, tile_m * a.tiles_n + tile_n, m0, BM, n0, BN, &s_arrive);
+    }
+  }
 }
 
 // split-K finish: sum the partial slabs, then the ordinary epilogue (bias, per-image vector, residual)
@@ -2461,7 +2629,7 @@ static int launch_igemm(const mobi_igemm_params* p, const IgemmArgs& a, int grou
 #undef MOBI_IGEMM_BY_FAST
 #undef MOBI_IGEMM_LAUNCH
   MOBI_CHECK_LAUNCH();
-  if (a.split_ws) {
+  if (a.split_ws && !a.sync) {                               // (with `sync` the tile's last block has summed the slabs)
     long long blocks = ((long long)a.M * (a.cout >> 3) + 255) / 256;
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL((igemm_splitk_reduce_kernel<T>), dim3((unsigned)blocks), dim3(256), 0, st, a);
@@ -2554,6 +2722,14 @@ extern "C" size_t mobi_igemm_workspace_bytes(const mobi_igemm_params* p, int32_t
   return (size_t)splits * p->batch * p->hout * p->wout * p->n_packed * sizeof(float);
 }
 
+// arrival counters of a split launch that finishes itself: one int per output tile of the SMALLEST tile geometry (128 pixels
+// x 128 channels), whichever kernel runs it
+extern "C" size_t mobi_igemm_sync_bytes(const mobi_igemm_params* p, int32_t splits) {
+  if (!p || splits <= 1) return 0;
+  const size_t m = (size_t)p->batch * p->hout * p->wout;
+  return ((m + 127) / 128) * (((size_t)p->n_packed + 127) / 128) * sizeof(int32_t);
+}
+
 // argument checks + launch plan (tile height, addressing path, main-loop variant, split-K ranges, epilogue kind)
 static int igemm_prepare(const mobi_igemm_params* p, mobi::IgemmArgs& a) {
   using namespace mobi;
@@ -2562,7 +2738,6 @@ static int igemm_prepare(const mobi_igemm_params* p, mobi::IgemmArgs& a) {
   if (p->c0 <= 0 || (p->c0 & 31) || p->c1 < 0 || (p->c1 & 31) || (p->c1 > 0 && !p->src1)) return MOBI_ERR_UNSUPPORTED;
   if (p->batch <= 0 || p->hin <= 0 || p->win <= 0 || p->hout <= 0 || p->wout <= 0) return MOBI_ERR_ARG;
   if (p->kh <= 0 || p->kw <= 0 || p->stride <= 0 || p->groups <= 0 || p->batch % p->groups) return MOBI_ERR_ARG;
-  if (p->groups != 1 && p->groups != p->batch) return MOBI_ERR_UNSUPPORTED;
   if (p->cout <= 0 || p->n_packed <= 0) return MOBI_ERR_ARG;
   if (p->upsample != 0 && p->upsample != 1) return MOBI_ERR_ARG;
   const bool geglu = p->epilogue == MOBI_EPI_GEGLU;
@@ -2691,7 +2866,9 @@ static int igemm_prepare(const mobi_igemm_params* p, mobi::IgemmArgs& a) {
 #ifndef MOBI_DEV
     // launches of the 256-pixel geometry that the ping-pong kernel's register epilogue does not take (transposed / fp32
     // output, ragged tiles, bias AND per-image vector, per-image weights): the ring kernel's LDS-staged epilogue does
-    if (!pick && a.wm == 4 && !a.pp) pick = 2;
+    // (a source of fewer than 64 channels into a wide layer -- the UNet's 9-channel input, padded to 32: a tap per k-step --
+    //  stays on the register-staged kernel: 38 against 104 us on 9 -> 320 at 64 x 64 x 16)
+    if (!pick && a.wm == 4 && !a.pp && (a.C >= 64 || p->out_mode != MOBI_OUT_ROWS || p->n_packed < 256)) pick = 2;
 #endif
     if (pick) {
       a.wide = pick;
@@ -2719,13 +2896,16 @@ static int igemm_prepare(const mobi_igemm_params* p, mobi::IgemmArgs& a) {
   a.sm64 = a.sm && a.C % 64 == 0 && (p->c1 == 0 || p->c0 % 64 == 0) && a.nk_per >= 1 &&
            (long long)a.tiles_m * a.tiles_n * a.splits * p->groups <= (long long)compute_units() && tuning().sm64 != 0;
   if (tuning().sm64 == 1 && a.sm && a.C % 64 == 0 && (p->c1 == 0 || p->c0 % 64 == 0)) a.sm64 = 1;
-  a.w_tiled = (p->weight_tiled && !a.sm64 && (a.sm || a.wide) && p->groups == 1 && p->k_order == 0 && p->n_packed % 16 == 0 &&
+  a.w_tiled = (p->weight_tiled && !a.sm64 && (a.sm || a.wide) &&
+               (p->groups == 1 || p->w_group_stride == (long long)p->n_packed * a.ktot) && p->k_order == 0 && p->n_packed % 16 == 0 &&
                a.ktot % 32 == 0 && !(reinterpret_cast<uintptr_t>(p->weight_tiled) & 15) && tuning().w_tiled != 0)
                   ? p->weight_tiled : nullptr;
   // 128 x 160 ring tiles: register epilogue / slab stores when every tile is full (the staged epilogue keeps ragged tiles,
   // transposed / fp32 output, bias AND per-image vector)
+  // (groups: every group's rows are whole tiles -- a.M is the rows of ONE group -- and the epilogue addresses rows, residual and
+  //  per-image vector through the group's first image; the bias is shared by the groups)
   a.sm_direct = (a.sm || a.wide == 1) && (p->out_mode == MOBI_OUT_ROWS || a.split_ws) && p->out_mode != MOBI_OUT_TRANSPOSED &&
-                p->groups == 1 && a.M % 128 == 0 && p->n_packed % (a.wide == 1 ? 2 * bn : bn) == 0 &&
+                a.M % 128 == 0 && p->n_packed % (a.wide == 1 ? 2 * bn : bn) == 0 &&
                 (a.split_ws || !p->rowvec || (!p->bias && a.hw_out % 64 == 0)) && tuning().sm_direct != 0;
   {
     const int bnw = (p->n_packed % 160) == 0 ? 320 : 256;
@@ -2739,6 +2919,24 @@ static int igemm_prepare(const mobi_igemm_params* p, mobi::IgemmArgs& a) {
       a.ring_direct = 1;
   }
   a.small = small_tile(p);
+  // split-K finished inside the launch: the LDS-DMA kernels (ring tiles of every geometry; the ping-pong kernel when every
+  // block owns exactly one output tile -- its epilogue is deferred into the next tile's loop otherwise); the register-staged
+  // fallback keeps the reduce launch.  MOBI_IGEMM_FUSED_SPLIT=0: never (A/B)
+  // At most FOUR splits (splitk_finish_tile).  MOBI_IGEMM_FUSED_SPLIT: 0 never; 1 device-coherent slab traffic; 2 (default) the
+  // same-XCD form where the grid's x extent (the tile count: one tile per block) is a multiple of 8, the reduce launch elsewhere
+  a.sync = nullptr; a.sync_mode = 0;
+  if (a.split_ws && p->sync && !a.small && tuning().fused_split != 0 && a.splits <= 4 &&
+      (long long)a.splits * a.M * a.n_packed * 4 < 0x7fffffffLL) {
+    if (reinterpret_cast<uintptr_t>(p->sync) & 3) return MOBI_ERR_ALIGN;
+    const long long tiles = (long long)a.tiles_m * a.tiles_n;
+    const bool pp_launch = !a.wide && a.wm == 4 && a.fast && a.glds && a.pp;
+    const bool ring_launch = a.wide || a.sm;
+    const int mode = tuning().fused_split == 1 ? 1 : 2;
+    if ((ring_launch || (pp_launch && tiles <= (long long)compute_units())) && (mode == 1 || tiles % 8 == 0)) {
+      a.sync = reinterpret_cast<int*>(p->sync);
+      a.sync_mode = mode;
+    }
+  }
   return MOBI_OK;
 }
 

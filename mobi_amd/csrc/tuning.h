@@ -21,6 +21,7 @@ struct Tuning {
   int n_major;          // MOBI_IGEMM_N_MAJOR         0: igemm work lists always walk the channel tiles of a pixel tile first (A/B); 1: never
   int sm64;             // MOBI_IGEMM_SM64            0: 128-pixel tiles always on the 32-deep-step ring kernel (A/B)
   int split_target;     // MOBI_IGEMM_SPLIT_TARGET    blocks the split-K plan aims at (default 512; sweeps)
+  int fused_split;      // MOBI_IGEMM_FUSED_SPLIT     0: split-K launches always finish in igemm_splitk_reduce_kernel, also with `sync` given (A/B)
   int split_longk;      // MOBI_IGEMM_SPLIT_LONGK     0: no extra doubling of the splits on one-round launches with >= 80 k-tiles per split (A/B)
   int small;            // MOBI_IGEMM_SMALL           0: never the small-problem kernel (igemm_small.hip); 32: every eligible launch (A/B)
   int small_mflop;      // MOBI_IGEMM_SMALL_MFLOP     largest 2 M N K (MFLOP) of a 1 x 1 launch routed to it (sweeps)

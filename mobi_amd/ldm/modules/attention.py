@@ -35,6 +35,7 @@ FUSED_FF = os.environ.get("MOBI_FUSED_FF", "1") != "0"      # A/B: 0 = GEGLU pro
 FUSED_FF_MIN_ROWS = int(os.environ.get("MOBI_FUSED_FF_MIN_ROWS", "24576"))   # 192 workgroups
 FUSED_LN = os.environ.get("MOBI_FUSED_LN", "1") != "0"      # A/B: 0 = the cross-modal LayerNorms as launches of their own
 ROW_CHAIN = os.environ.get("MOBI_ROW_CHAIN", "1") != "0"    # A/B: 0 = the launches between the attention kernels one by one
+GROUPED_Q = os.environ.get("MOBI_GROUPED_Q", "1") != "0"    # A/B: 0 = the two cross-modal to_q projections as launches of their own
 ROW_CHAIN_MIN_ROWS = int(os.environ.get("MOBI_ROW_CHAIN_MIN_ROWS", "24576"))   # 128 rows per workgroup: 192 workgroups
 # GroupNorm, proj_in, norm1 and the q | k | v projection of a C = 320 block as ONE chain launch (+ a statistics pass): built, tested,
 # and SLOWER than the four launches (19.90 against 19.61 ms per step, profiles/r04_ab_prechain.txt: four products at the chain
@@ -156,12 +157,16 @@ class CrossAttention(nn.Module):
         return ops.attention(qkv[..., :c], qkv[..., c:2 * c], qkv[..., 2 * c:], self.heads, self.scale, v_rows=True,
                              q_log2_scaled=True)
 
-    def token_attention(self, xn, ctx):
+    def token_attention(self, xn, ctx, q=None):
         """Many queries against another token stream `ctx` [N,Tk,Cc] (engine tensor, may be a
-        batch-strided view)."""
+        batch-strided view).  q: to_q(xn) * scale * log2 e when the caller has it already (the grouped launch of
+        BasicTransformerBlock._cross_modal_queries)."""
         c = self.inner_dim
-        q, kv = ops.concurrently(lambda: ops.linear(xn, self._stacked(("to_q",), fold_q=True)),
-                                 lambda: ops.linear(ctx, self._stacked(("to_k", "to_v"))))
+        if q is not None:
+            kv = ops.linear(ctx, self._stacked(("to_k", "to_v")))
+        else:
+            q, kv = ops.concurrently(lambda: ops.linear(xn, self._stacked(("to_q",), fold_q=True)),
+                                     lambda: ops.linear(ctx, self._stacked(("to_k", "to_v"))))
         return ops.attention(q, kv[..., :c], kv[..., c:], self.heads, self.scale, v_rows=True, q_log2_scaled=True)
 
     def context_kv(self, context):
@@ -189,7 +194,7 @@ class CrossAttention(nn.Module):
             bo = bo + extra_bias.detach().float()
         return ops.skinny_linear(ops.skinny_linear(token, wv), wo, bo)
 
-    def attend(self, x, context=None):
+    def attend(self, x, context=None, q=None):
         """Attention output BEFORE `to_out` (the caller applies to_out, possibly folded with a connector)."""
         if context is None:
             return self.self_attention(x)
@@ -197,7 +202,7 @@ class CrossAttention(nn.Module):
             if context.shape[1] > 8:
                 raise NotImplementedError("fp32 contexts with more than 8 tokens")
             return self.few_token_attention(x, context.contiguous())
-        return self.token_attention(x, context)
+        return self.token_attention(x, context, q=q)
 
     def forward(self, x, context=None, mask=None):
         """Reference-compatible call (attention.py:171-194); x: engine tokens [N,T,C];
@@ -267,6 +272,30 @@ class BasicTransformerBlock(nn.Module):
     def _ln(norm, x):
         g, b = norm.affine()
         return ops.layernorm(x, g, b, norm.eps)
+
+    def _cross_modal_queries(self, ln_cam, ln_lidar):
+        """to_q of BOTH cross-modal attentions as ONE grouped launch (mobi_igemm_params.groups = 2) when the two normalised
+        halves are the halves of one [camera images ; lidar images] buffer (ops.two_key_adapter's `ln_pair`): the lidar's
+        queries do not depend on the camera update (attention.py:249-261: only its keys / values do), and one launch over
+        all rows fills the chip where two over half the rows each left half of it idle and needed split-K slabs.
+        -> (q_cam, q_lid) or (None, None)."""
+        cam, lid = self.cross_modal_attn_camera, self.cross_modal_attn_lidar
+        if not (GROUPED_Q and ln_cam is not None and ln_lidar is not None and ln_cam.shape == ln_lidar.shape
+                and ln_cam.is_contiguous() and ln_lidar.is_contiguous() and cam.inner_dim == lid.inner_dim
+                and ln_lidar.data_ptr() == ln_cam.data_ptr() + ln_cam.numel() * ln_cam.element_size()):
+            return None, None
+        dtype = engine_dtype()
+        ws = (cam.to_q.weight, lid.to_q.weight)
+        key = (dtype, cam.scale, lid.scale) + tuple(v for w in ws for v in (w._version, w.data_ptr()))
+        c = self.__dict__.setdefault("_q_pair_cache", {})
+        if c.get("key") != key:
+            w = torch.cat([cam.to_q.weight.detach().float() * (cam.scale * ops.LOG2E),
+                           lid.to_q.weight.detach().float() * (lid.scale * ops.LOG2E)], dim=0)
+            c["key"], c["val"] = key, ops.pack_linear(w, None, dtype, w.device)
+        h, t, ch = ln_cam.shape
+        both = ln_cam.as_strided((2 * h, t, ch), (t * ch, ch, 1))            # [camera images ; lidar images]
+        q = ops.linear(both, c["val"], groups=2)
+        return q[:h], q[h:]
 
     # -- row-resident chains (C = 320: csrc/chain.hip) ---------------------------------------------------------------
     def _chain_weights(self):
@@ -478,12 +507,13 @@ class BasicTransformerBlock(nn.Module):
             if x.shape[0] % 2:
                 raise ValueError("multimodal blocks need camera/lidar samples interleaved on an even batch")
             xc, xl = x[::2], x[1::2]
+            q_cam, q_lid = self._cross_modal_queries(ln_cam, ln_lidar)
             a = self.cross_modal_attn_camera.attend(self._ln(self.cross_modal_norm_camera, xc) if ln_cam is None else ln_cam,
-                                                    context=xl)
+                                                    context=xl, q=q_cam)
             ops.linear(a, self._folded(self.cross_modal_attn_camera, self.cross_modal_connector_camera, "cam"),
                        residual=xc, out=xc)
             a = self.cross_modal_attn_lidar.attend(self._ln(self.cross_modal_norm_lidar, xl) if ln_lidar is None else ln_lidar,
-                                                   context=xc)
+                                                   context=xc, q=q_lid)
             ops.linear(a, self._folded(self.cross_modal_attn_lidar, self.cross_modal_connector_lidar, "lidar"),
                        residual=xl, out=xl)
 

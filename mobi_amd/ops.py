@@ -609,16 +609,42 @@ def attention_bwd(q, k, v, o, dout, heads, scale, force_vector=False):
 # --------------------------------------------------------------------------------------
 # matrix-core ops
 # --------------------------------------------------------------------------------------
+# Split-K launches that finish themselves (mobi_igemm_params.sync: the workgroup that arrives last at an output tile sums the tile's
+# slabs, no reduce launch): built, bit-identical to the two-launch form, and SLOWER -- the last block's serial tail (barrier, L2
+# atomic, two to five dependent rounds of slab loads, stores) costs 4-6 us more than the fully parallel reduce launch it replaces
+# (23.3 -> 27.8 us at 2048 x 1280 x 1280 split 2; profiles/r05_fused_split_lab.txt).  Off; MOBI_FUSED_SPLIT=1 for the A/B.
+FUSED_SPLIT = os.environ.get("MOBI_FUSED_SPLIT", "0") == "1"
+_SYNC = {}
+
+
+def _sync_counters(device, nbytes):
+    """Arrival counters of the split-K launches that finish themselves: int32 zeros, ONE buffer per (device, stream) -- a
+    launch leaves its counters at zero, and the launches of a stream run one after the other, so every launch of the stream
+    can use the same ones (two streams running split launches at the same time must not share them)."""
+    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    buf = _SYNC.get(key)
+    if buf is None or buf.numel() * 4 < nbytes:
+        buf = torch.zeros((max(nbytes // 4 + 1, 1 << 16),), device=device, dtype=torch.int32)
+        _SYNC[key] = buf
+    return buf
+
+
 def igemm(x, pw: Packed, *, x2=None, stride=1, pad=None, upsample=False, hout=None, wout=None, rowvec=None,
           rowvec_has_bias=False, residual=None, out=None, out_mode=OUT_ROWS, scale=1.0, weight_per_image=False,
-          w_group_stride=0, split_k=None):
+          w_group_stride=0, split_k=None, groups=1):
     """x: [N,H,W,C0] (tokens: [N,T,1,C]); x2: optional second source concatenated on channels.
     rowvec: fp32 [N, cout] added per image; rowvec_has_bias: its producer already added this layer's bias (the
-    launch then passes no bias, which keeps it on the register-epilogue kernels)."""
+    launch then passes no bias, which keeps it on the register-epilogue kernels).
+    groups = g > 1: `pw` holds g stacked matrices [g * cout][k]; image i is multiplied by matrix i // (N / g) (ONE launch for
+    the camera images' and the lidar images' projections of a [camera ; lidar] batch); no bias."""
     lib = _lib.load()
     n, hin, win, c0 = x.shape
     c1 = 0 if x2 is None else x2.shape[3]
     assert c0 + c1 == pw.cin, (c0, c1, pw.cin)
+    if groups > 1:
+        assert not weight_per_image and not pw.geglu and pw.bias is None and n % groups == 0 and pw.cout % groups == 0
+        pw = Packed(pw.w, None, pw.kh, pw.kw, pw.cin, pw.cout // groups, pw.n_packed // groups, wt=pw.wt)
+        w_group_stride = pw.n_packed * pw.kh * pw.kw * pw.cin
     ph, pw_ = (pw.kh // 2, pw.kw // 2) if pad is None else pad
     hl, wl = (hin * 2, win * 2) if upsample else (hin, win)
     if hout is None:
@@ -641,7 +667,7 @@ def igemm(x, pw: Packed, *, x2=None, stride=1, pad=None, upsample=False, hout=No
     p.src_img_stride = 0 if s == dense_in else s
     p.weight = _ptr(pw.w)
     p.weight_tiled = None if weight_per_image else _ptr(pw.wt)
-    p.groups = n if weight_per_image else 1
+    p.groups = n if weight_per_image else groups
     p.w_group_stride = w_group_stride
     p.n_packed, p.cout = pw.n_packed, pw.cout
     assert rowvec is not None or not rowvec_has_bias
@@ -667,6 +693,8 @@ def igemm(x, pw: Packed, *, x2=None, stride=1, pad=None, upsample=False, hout=No
     if splits > 1:
         ws = torch.empty(lib.mobi_igemm_workspace_bytes(C.byref(p), splits), device=x.device, dtype=torch.uint8)
         p.split_k, p.ws = splits, _ptr(ws)
+        if FUSED_SPLIT:
+            p.sync = _ptr(_sync_counters(x.device, lib.mobi_igemm_sync_bytes(C.byref(p), splits)))
     flops = 2.0 * n * hout * wout * (pw.n_packed if pw.geglu else pw.cout) * pw.kh * pw.kw * pw.cin
     nbytes = (x.numel() + (0 if x2 is None else x2.numel())) * 2 + pw.w.numel() * 2 * (n if weight_per_image else 1) \
         + out.numel() * out.element_size() + (0 if residual is None else residual.numel() * 2)
@@ -799,8 +827,10 @@ def two_key_adapter(x, a, a_sum, c, u, b, eps, out=None, ln_pair=None):
         assert n % 2 == 0
         for tns in (g0, b0, g1, b1):
             assert tns.dtype == torch.float32 and tns.is_contiguous() and tns.numel() == ch
-        lns = (torch.empty((n // 2, t, ch), device=x.device, dtype=x.dtype),
-               torch.empty((n // 2, t, ch), device=x.device, dtype=x.dtype))
+        # (halves of ONE buffer [camera images ; lidar images]: the cross-modal step multiplies both by their own to_q in one
+        #  grouped launch, mobi_igemm_params.groups = 2)
+        both = torch.empty((n, t, ch), device=x.device, dtype=x.dtype)
+        lns = (both[:n // 2], both[n // 2:])
         for i, (tn, g, bb) in enumerate(((lns[0], g0, b0), (lns[1], g1, b1))):
             p.ln_out[i], p.ln_gamma[i], p.ln_beta[i] = _ptr(tn), _ptr(g), _ptr(bb)
         p.ln_eps = ln_eps

@@ -34,6 +34,18 @@ def main():
         np.savez_compressed(oc.PATH, **out)
         print(f"wrote {oc.PATH}: {sorted(out)} ({os.path.getsize(oc.PATH) / 1e6:.1f} MB)")
         return
+    if "--add-e2e-long" in sys.argv:                    # keep what the file holds, add the 50-step end-to-end cases
+        out = dict(np.load(oc.PATH))
+        cases = [(32, "ddim50"), (32, "plms50_cfg5"), (64, "ddim50")]
+        for side, kind in cases:
+            os.environ.pop("MOBI_ORACLE_LIVE", None)   # (z / cond of the stored 10-step case are read from the file)
+            oc.LIVE = False
+            for k, v in oc.e2e_long(side, kind, live=True).items():
+                out[f"e2e{side}_{kind}_{k}"] = v.numpy().astype(np.float16 if k != "samples" else np.float32)
+            print(f"e2e_long {side} {kind}: {time.time() - t0:.0f} s", flush=True)
+            np.savez_compressed(oc.PATH, **out)
+        print(f"wrote {oc.PATH}: {sorted(out)} ({os.path.getsize(oc.PATH) / 1e6:.1f} MB)")
+        return
     out["prod_64_16"] = oc.prod_forward(64, 16, live=True).numpy()
     print(f"prod 64x64 x 16: {time.time() - t0:.0f} s", flush=True)
     out["prod_32_8"] = oc.prod_forward(32, 8, live=True).numpy()

@@ -174,3 +174,47 @@ def e2e(side, live=False):
         image = pipeline.decode_first_stage(cam_sd, cam_cfg, h_cam, 0.18215)
         rng = pipeline.decode_first_stage(lid_sd, lid_cfg, h_lid, 0.18215)
     return {"z": z, "cond": cond, "samples": samples, "image": image, "range": rng}
+
+
+# ---- the same sequence at the SHIPPED invocation's length (scripts/realism_test_bench.sh:95-102: 50 steps; DDIM at guidance 1, the
+# harness default, and PLMS at guidance 5, what the shipped scripts run) -- VERDICT r04 "missing" #4 -------------------------------
+E2E_LONG = {"ddim50": dict(sampler="ddim", steps=50, scale=1.0), "plms50_cfg5": dict(sampler="plms", steps=50, scale=5.0)}
+
+
+def e2e_uncond(side):
+    """What the harness hands the samplers as `unconditional_conditioning` (inference_test_bench.py:425-431: the learnt
+    `learnable_vector` and `bbox_uncond_vector`, repeated over the batch): two synthetic [1, 1, 768] tokens."""
+    uc = torch.cat([W.synth_input(f"e2e{side}.uc.ref", (1, 1, 768)), W.synth_input(f"e2e{side}.uc.bbox", (1, 1, 768))], dim=1)
+    return uc.repeat(2, 1, 1)
+
+
+def e2e_long(side, kind, live=False):
+    """`e2e(side)`'s 9-channel input, conditioning and x_T through 50 sampler steps (`kind` in E2E_LONG), then
+    decode_sample -> decode_first_stage + clamp, on the CPU oracle at FULL width -> dict(samples, image, range)."""
+    keys = ["samples", "image", "range"]
+    if not live and all(f"e2e{side}_{kind}_{k}" in _file() for k in keys):
+        return {k: torch.from_numpy(_file()[f"e2e{side}_{kind}_{k}"].astype(np.float32)) for k in keys}
+    from oracle import pipeline
+    _threads()
+    spec = E2E_LONG[kind]
+    i = e2e_inputs(side)
+    base = e2e(side)                                          # z, cond of the stored short case (or computed live)
+    z, cond = base["z"], base["cond"]
+    ucfg = ounet.UNetConfig()
+    usd = W.synth_state_dict(ounet.unet_param_shapes(ucfg), E2E_SEEDS["unet"])
+    cam_cfg = ovae.VAEConfig(in_channels=3, out_ch=3, ch=128, lidar_adapter=False)
+    lid_cfg = ovae.VAEConfig(in_channels=2, out_ch=2, ch=128, lidar_adapter=True)
+    cam_sd = W.synth_state_dict(ovae.vae_param_shapes(cam_cfg), E2E_SEEDS["vae"])
+    lid_sd = W.synth_state_dict(ovae.vae_param_shapes(lid_cfg), E2E_SEEDS["vae"])
+    with torch.no_grad():
+        # the un-cropped lidar latent decode_sample pastes the sample back into: the lidar GT encode of e2e()
+        z_lidar = pipeline.encode_modality(lid_sd, lid_cfg, i["rng"], i["rng"] * i["mask"], i["mask"], i["n_lidar_gt"],
+                                           i["n_lidar_inpaint"], 0.18215)
+        eps = lambda x, t, c: ounet.unet_forward(usd, ucfg, x, t, c)
+        fn = osampler.ddim_sample if spec["sampler"] == "ddim" else osampler.plms_sample
+        uc = e2e_uncond(side) if spec["scale"] != 1.0 else None
+        samples, _ = fn(eps, osampler.Schedule(spec["steps"]), cond, i["x_T"], z[:, 4:9].contiguous(), scale=spec["scale"], uncond=uc)
+        h_cam, h_lid = pipeline.decode_sample(samples, z_lidar[:, :4], side)
+        image = pipeline.decode_first_stage(cam_sd, cam_cfg, h_cam, 0.18215)
+        rng = pipeline.decode_first_stage(lid_sd, lid_cfg, h_lid, 0.18215)
+    return {"samples": samples, "image": image, "range": rng}

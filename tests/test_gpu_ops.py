@@ -1089,3 +1089,76 @@ def test_tile_weights_native_equals_restatement(ops, dtype, monkeypatch):
         monkeypatch.setattr(ops, "TILE_WEIGHTS_TORCH", False)
         assert native.shape == restated.shape == (n // 16, k // 32, 16, 4, 8) and torch.equal(native, restated)
     assert ops.tile_weights(torch.zeros(24, 32, device="cuda", dtype=dtype)) is None
+
+
+# (images, h, cin, cout, k, split, what)
+SELF_FINISH_CASES = [
+    (4, 16, 1280, 1280, 1, 2, "ring tiles, 64-deep steps, register slab stores (one round of blocks)"),
+    (16, 16, 1280, 1280, 1, 2, "ring tiles, 32-deep steps, two blocks per CU"),
+    (16, 16, 1280, 1280, 1, 3, "three splits: the splits of a tile land on different XCDs' L2s"),
+    (2, 10, 640, 320, 3, 4, "ragged tiles (200 rows): LDS-staged slab stores"),
+    (7, 8, 1280, 1280, 3, 3, "448 rows: 4 x 8 tiles of 128 x 160 (the last one ragged)"),
+    (16, 8, 1280, 1280, 3, 4, "ping-pong kernel, slabs from the accumulators, one tile per block"),
+    (16, 8, 1280, 1280, 3, 8, "more than four splits: the reduce launch (unchanged)"),
+    (16, 16, 1280, 1280, 3, 4, "256 x 320 ring tiles with slabs (the 16 x 16 level's 3 x 3 convolutions)"),
+    (16, 16, 640, 1280, 3, None, "the library's own plan"),
+]
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("mode", ["1", "2"], ids=["device_coherent", "same_xcd"])
+@pytest.mark.parametrize("case", SELF_FINISH_CASES, ids=[f"sf{i}" for i in range(len(SELF_FINISH_CASES))])
+def test_igemm_split_k_finishes_itself(ops, dtype, case, mode, tune):
+    """Split-K finished INSIDE the launch (mobi_igemm_params.sync): the workgroup that arrives last at an output tile sums
+    the tile's fp32 slabs in split order and applies the epilogue.  Against the two-launch form (slabs + reduce launch):
+    BIT-identical (the same sums in the same order, whoever arrives last); the arrival counters are zero again after every
+    launch; repeated launches on recycled workspace memory with OTHER inputs in between never read a stale slab; fp32 output."""
+    n, h, cin, cout, k, split, _what = case
+    tune.setenv("MOBI_IGEMM_FUSED_SPLIT", mode)           # 1: sc1 slab traffic + device-scope counter; 2: the same-XCD form (default)
+    xf, xd = rnd("sf.x", (n, h, h, cin), dtype)
+    x2f, x2d = rnd("sf.x2", (n, h, h, cin), dtype, scale=-0.7)
+    rf, rd = rnd("sf.res", (n, h, h, cout), dtype)
+    wf = torch.from_numpy(W.synth_param("sf.weight", (cout, cin, k, k))).to(dtype).float()
+    bias = torch.from_numpy(W.synth_param("sf.bias", (cout,)))
+    rv = W.synth_input("sf.rowvec", (n, cout)).cuda()
+    pw = ops.pack_conv(wf, bias, dtype, "cuda")
+    was = ops.FUSED_SPLIT
+    try:
+        ops.FUSED_SPLIT = False
+        two = [ops.igemm(x_, pw, rowvec=rv, residual=rd, split_k=split).clone() for x_ in (xd, x2d)]
+        two32 = ops.igemm(xd, pw, residual=rd, split_k=split, out_mode=ops.OUT_ROWS_F32).clone()
+        ref = _conv_ref(xf, wf, bias, pad=(k // 2, k // 2)) + rv.cpu()[:, None, None, :] + rf
+        assert rel(two[0].float(), ref) < TOL[dtype]
+        ops.FUSED_SPLIT = True
+        for rep in range(6):                              # the caching allocator hands the same workspace block out again
+            for i, x_ in enumerate((xd, x2d)):
+                y = ops.igemm(x_, pw, rowvec=rv, residual=rd, split_k=split)
+                assert torch.equal(y, two[i]), (rep, i, float((y.float() - two[i].float()).abs().max()))
+        y32 = ops.igemm(xd, pw, residual=rd, split_k=split, out_mode=ops.OUT_ROWS_F32)
+        assert y32.dtype == torch.float32 and torch.equal(y32, two32)
+    finally:
+        ops.FUSED_SPLIT = was
+    torch.cuda.synchronize()
+    for buf in ops._SYNC.values():
+        assert int(buf.abs().sum()) == 0                  # every launch left its counters at zero
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("n,t,c", [(16, 256, 1280), (8, 1024, 640), (4, 100, 320), (2, 64, 1280)])
+def test_igemm_groups_of_images(ops, dtype, n, t, c):
+    """mobi_igemm_params.groups = 2: the first half of the images times the first stacked matrix, the second half times the
+    second -- the cross-modal to_q of the camera images and of the lidar images as ONE launch (attention.py:245-263 of the
+    reference computes them as two Linear calls).  Against fp32 torch; full tiles (register epilogue, request images) and
+    ragged ones (LDS-staged epilogue)."""
+    xf, xd = rnd("grp.x", (n, t, c), dtype)
+    w0 = torch.from_numpy(W.synth_param("grp.w0", (c, c))).to(dtype).float()
+    w1 = torch.from_numpy(W.synth_param("grp.w1", (c, c))).to(dtype).float()
+    pw = ops.pack_linear(torch.cat([w0, w1], 0), None, dtype, "cuda")
+    y = ops.linear(xd, pw, groups=2)
+    assert y.shape == (n, t, c)
+    h = n // 2
+    assert rel(y[:h].float(), xf[:h] @ w0.t()) < TOL[dtype]
+    assert rel(y[h:].float(), xf[h:] @ w1.t()) < TOL[dtype]
+    # the same through a per-matrix launch (another kernel may run it: sums in another order, a few flipped roundings)
+    y0 = ops.linear(xd[:h].contiguous(), ops.pack_linear(w0, None, dtype, "cuda"), split_k=1)
+    assert rel(y[:h].float(), y0.float()) < 0.1 * TOL[dtype]
