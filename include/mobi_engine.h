@@ -41,7 +41,8 @@ extern "C" {
  *   4  mobi_groupnorm_bwd takes a workspace (mobi_groupnorm_bwd_workspace_floats); mobi_igemm_kernel_variant may answer
  *      MOBI_IGEMM_SMALL; mobi_tile_weights
  *   5  mobi_igemm_params.sync + mobi_igemm_sync_bytes (split-K finished inside the launch); mobi_igemm_params.groups may be
- *      any divisor of batch */
+ *      any divisor of batch; mobi_igemm_params.ln_svec / ln_eps (LayerNorm folded into the consuming launch);
+ *      mobi_groupnorm_params.src_f32 / out_mode */
 #define MOBI_ABI_VERSION 5
 
 enum { MOBI_OK = 0, MOBI_ERR_ARG = -1, MOBI_ERR_UNSUPPORTED = -2, MOBI_ERR_LAUNCH = -3, MOBI_ERR_ALIGN = -4 };
@@ -132,6 +133,12 @@ typedef struct mobi_igemm_params {
                             With it the launch finishes its own split: the workgroup that arrives LAST at an output tile sums
                             the tile's slabs (same order, same sums as the reduce launch: bit-identical) and applies the
                             epilogue -- no second launch.  NULL (or a kernel variant that cannot): the reduce launch.        */
+  const float* ln_svec;  /* optional, f32 [n_packed]: LayerNorm FOLDED into this launch (1 x 1, one source, groups 1, no split, no
+                            rowvec / residual, scale 1): `weight` holds W diag(gamma) (rounded to T), ln_svec its row sums, `bias`
+                            W beta + b; the launch computes the statistics of its own input rows and returns
+                            rstd (x W'^T - mean ln_svec) + bias == Linear(LayerNorm(x)) (ldm/modules/attention.py:234, :264:
+                            `attn1(norm1(x))`, `ff(norm3(x))`) without a normalised copy of x.  Runs on the LDS-DMA ring kernels. */
+  float ln_eps;
 } mobi_igemm_params;
 
 int mobi_igemm(const mobi_igemm_params* p, void* stream);
@@ -165,6 +172,13 @@ typedef struct mobi_groupnorm_params {
   void* out;               /* T [batch][hw][c0+c1] */
   void* ws;                /* mobi_groupnorm_workspace_bytes(batch, hw) bytes */
   int32_t dtype;
+  int32_t src_f32;         /* 1: src0 is f32 [batch][hw][c0] (no src1): the VAE decoder's fp32 streams */
+  int32_t out_mode;        /* 0: T [batch][hw][C].  1: T [batch][hw][2 C] = hi | lo, hi = T(y), lo = T(y - hi): a convolution
+                              whose weights are duplicated along its input channels then multiplies y to ~22 bits (the lidar
+                              decoder's tail of the fp16 parity configuration, model.py:612-623).  2: f32 [batch][hw][C] */
+  void* sync;              /* optional: int32 [batch] arrival counters, ZERO before the launch and zero again after it (one buffer
+                              serves every launch of a stream).  With them the library may run the one-launch form whose workgroups
+                              own pixel chunks and meet through memory (large groups: the 64 x 64 level); NULL: never. */
 } mobi_groupnorm_params;
 
 size_t mobi_groupnorm_workspace_bytes(int32_t batch, int32_t hw);

@@ -34,12 +34,13 @@ class IgemmParams(C.Structure):
                 ("w_group_stride", i64), ("n_packed", i32), ("cout", i32), ("bias", vp), ("rowvec", vp), ("rowvec_stride", i32),
                 ("residual", vp), ("res_img_stride", i64), ("out", vp), ("out_img_stride", i64),
                 ("out_mode", i32), ("epilogue", i32), ("scale", f32), ("dtype", i32), ("split_k", i32), ("ws", vp), ("k_order", i32),
-                ("weight_tiled", vp), ("sync", vp)]
+                ("weight_tiled", vp), ("sync", vp), ("ln_svec", vp), ("ln_eps", f32)]
 
 
 class GroupNormParams(C.Structure):
     _fields_ = [("src0", vp), ("src1", vp), ("c0", i32), ("c1", i32), ("batch", i32), ("hw", i32), ("gamma", vp),
-                ("beta", vp), ("eps", f32), ("silu", i32), ("out", vp), ("ws", vp), ("dtype", i32)]
+                ("beta", vp), ("eps", f32), ("silu", i32), ("out", vp), ("ws", vp), ("dtype", i32), ("src_f32", i32),
+                ("out_mode", i32), ("sync", vp)]
 
 
 class LayerNormParams(C.Structure):

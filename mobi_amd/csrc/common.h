@@ -59,6 +59,12 @@ __device__ __forceinline__ u32x2 pack4(const float (&f)[4]) {
 __device__ __forceinline__ u32x4 ld16(const void* p) { return *reinterpret_cast<const u32x4*>(p); }
 __device__ __forceinline__ void st16(void* p, const u32x4& v) { *reinterpret_cast<u32x4*>(p) = v; }
 
+// 8 consecutive floats through two 16-byte accesses (LDS stage rows, bias, per-image vectors, fp32 activations)
+__device__ __forceinline__ void ld8f(const float* p, float (&f)[8]) {
+  const f32x4 a = *reinterpret_cast<const f32x4*>(p), b = *reinterpret_cast<const f32x4*>(p + 4);
+  f[0] = a[0]; f[1] = a[1]; f[2] = a[2]; f[3] = a[3]; f[4] = b[0]; f[5] = b[1]; f[6] = b[2]; f[7] = b[3];
+}
+
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
 // erf-form GELU (F.gelu default, attention.py:45).  erf by Abramowitz-Stegun 7.1.26
 // (|error| <= 1.5e-7, far below the 16-bit output rounding): one rcp, one exp, five FMAs.

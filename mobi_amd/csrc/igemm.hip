@@ -123,6 +123,8 @@ struct IgemmArgs {
   int wm;                  // waves along the pixel axis (2 or 4): block tile = 64*wm pixels
   int splits, nk_per;      // split-K: blockIdx.y owns k-tiles [y*nk_per, (y+1)*nk_per)
   float* split_ws;         // f32 [splits][M][n_packed] partial sums (NULL: single pass)
+  const float* ln_svec;    // LayerNorm folded into this 1 x 1 launch (see ln_fold_acc): row sums of the packed W diag(gamma), or NULL
+  float ln_eps;
   int sync_mode;           // 0: no `sync`; 1: device-coherent slab traffic; 2: a tile's blocks share one XCD's L2 (see splitk_arrive_and_finish)
   int* sync;               // split-K finished inside the launch: one arrival counter per output tile (zero before and after
                            // the launch), or NULL: the slabs are summed by igemm_splitk_reduce_kernel (a second launch)
@@ -148,11 +150,6 @@ struct IgemmArgs {
   const int tile_m_ = a.n_major ? tr_##tile_m_ : tq_##tile_m_;                                 \
   const int tile_n_ = a.n_major ? tq_##tile_m_ : tr_##tile_m_
 
-// 8 consecutive floats through two 16-byte accesses (LDS stage rows, bias, per-image vectors)
-__device__ __forceinline__ void ld8f(const float* p, float (&f)[8]) {
-  const f32x4 a = *reinterpret_cast<const f32x4*>(p), b = *reinterpret_cast<const f32x4*>(p + 4);
-  f[0] = a[0]; f[1] = a[1]; f[2] = a[2]; f[3] = a[3]; f[4] = b[0]; f[5] = b[1]; f[6] = b[2]; f[7] = b[3];
-}
 
 __device__ __forceinline__ void vm_store16_dev(void* p, const u32x4& v);      // device-coherent 16-byte store (below)
 
@@ -1900,6 +1897,81 @@ __global__ __launch_bounds__(512, 2) void igemm_pp_kernel(const IgemmArgs a) {
 }
 
 // =========================================================================================================
+// LayerNorm folded into the 1 x 1 launch that consumes it (the ring kernels; attention.py:234 `attn1(norm1(x))` and :264
+// `ff(norm3(x))` of the reference are LayerNorm -> Linear).  Exact algebra, as in csrc/chain.hip:
+//     LN(x) W^T + b = rstd (x (W diag gamma)^T - mean s) + (W beta + b),      s = row sums of the ROUNDED W diag gamma
+// The launch multiplies the RAW rows by the packed W diag(gamma); the row statistics come from the launch's own operand: a block
+// sweeps the whole k range of its rows (1 x 1, one source, no split), and every A fragment a wave reads for the matrix cores holds
+// 8 consecutive channels of one row per lane -- v_dot2c_f32 (two products per instruction, fp32 accumulate) sums them and their
+// squares.  The MT fragments of a wave row are dealt to the NW / 2 waves that share it (SPW each: 8 instructions per fragment and
+// k-step, issued between the step's MFMAs), the partial sums meet in 8 bytes of LDS per row at the end of the k loop, and the fold
+// is applied in the accumulator domain before any epilogue runs -- no normalised copy of a row ever exists, and the LayerNorm
+// launch (2 B read + 2 B written per element, 27 launches per mobi_nusc_512 step) is gone.
+// =========================================================================================================
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void rowstat_acc(const f16x8& x, float& sum, float& sq) {
+  struct Q { f16x2_t p[4]; };
+  const Q q = __builtin_bit_cast(Q, x);
+  const f16x2_t one = {(_Float16)1.0f, (_Float16)1.0f};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    sum = __builtin_amdgcn_fdot2(q.p[i], one, sum, false);
+    sq = __builtin_amdgcn_fdot2(q.p[i], q.p[i], sq, false);
+  }
+}
+__device__ __forceinline__ void rowstat_acc(const bf16x8& x, float& sum, float& sq) {
+  struct Q { bf16x2_t p[4]; };
+  const Q q = __builtin_bit_cast(Q, x);
+  const bf16x2_t one = {(__bf16)1.0f, (__bf16)1.0f};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    sum = __builtin_amdgcn_fdot2_f32_bf16(q.p[i], one, sum, false);
+    sq = __builtin_amdgcn_fdot2_f32_bf16(q.p[i], q.p[i], sq, false);
+  }
+}
+
+// s_rowstat: BM x {mean, rstd} of the block's rows.  ls_sum / ls_sq: this wave's partial sums of fragments SPW * wn + i of its
+// wave row (lane: row r16 of the fragment, k chunk g4).  add_bias: the epilogue that follows does not add the bias itself.
+template <int NT, int MT, int SPW>
+__device__ __forceinline__ void ln_fold_acc(const IgemmArgs& a, f32x4 (&acc)[NT][MT], const float (&ls_sum)[SPW],
+                                            const float (&ls_sq)[SPW], float* s_rowstat, int lane, int wm, int wn, int nw0,
+                                            bool add_bias) {
+  const int r16 = lane & 15, g4 = lane >> 4;
+  const float inv_k = 1.0f / (float)a.ktot;
+#pragma unroll
+  for (int i = 0; i < SPW; ++i) {
+    float sm = ls_sum[i], sq = ls_sq[i];
+    sm += __shfl_xor(sm, 16, 64); sq += __shfl_xor(sq, 16, 64);         // the four k-chunk lane groups of a row
+    sm += __shfl_xor(sm, 32, 64); sq += __shfl_xor(sq, 32, 64);
+    const float mean = sm * inv_k;
+    const float var = fmaxf(sq * inv_k - mean * mean, 0.f);
+    if (g4 == 0) {
+      float* d = s_rowstat + ((wm * MT + SPW * wn + i) * 16 + r16) * 2;
+      d[0] = mean; d[1] = rsqrtf(var + a.ln_eps);
+    }
+  }
+  __syncthreads();
+  // (few live registers: the 256 x 320 tiles hold 160 accumulators -- a row's two statistics are re-read per 16-pixel tile, the
+  //  row sums / bias of a 16-channel tile per tile)
+#pragma unroll
+  for (int ni = 0; ni < NT; ++ni) {
+    const int n = nw0 + ni * 16 + g4 * 4;
+    f32x4 sv = f32x4{0.f, 0.f, 0.f, 0.f}, bv = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (n < a.n_packed) {
+      sv = *reinterpret_cast<const f32x4*>(a.ln_svec + n);
+      if (add_bias && a.bias) bv = *reinterpret_cast<const f32x4*>(a.bias + n);
+    }
+#pragma unroll
+    for (int mi = 0; mi < MT; ++mi) {
+      const float* d = s_rowstat + ((wm * MT + mi) * 16 + r16) * 2;
+      const float mean = d[0], rstd = d[1];
+      acc[ni][mi] = rstd * (acc[ni][mi] - mean * sv) + bv;
+    }
+  }
+}
+
+// =========================================================================================================
 // SMALL-M main loop (every shape the 256-pixel persistent kernels do not take: few rows, split-K ranges, ragged
 // tiles, transposed / fp32 output): 128 pixels x (2 * WAVE_N) channels, FOUR waves (2 x 2, wave tile 64 x WAVE_N),
 // TWO blocks per CU.  Operands arrive by LDS-DMA into a RING of four 32-deep k-slots (18 KB each): the requests of
@@ -1923,7 +1995,7 @@ __global__ __launch_bounds__(512, 2) void igemm_pp_kernel(const IgemmArgs a) {
 //   NW 8, MT 8  256 x (4 WAVE_N) tile, wave tile 128 x WAVE_N, one block per CU: 29 % fewer operand bytes per FLOP than
 //               the 256 x 160 tile of the ping-pong kernel (the LDS-DMA path accepts ~42 B per clock and CU, which is
 //               exactly what that tile needs at full matrix rate) and 13 instead of 18 fragment reads per 40 MFMAs
-template <typename T, int NT, bool TR, int NW, int MT>
+template <typename T, int NT, bool TR, int NW, int MT, bool LNF = false>
 __global__ __launch_bounds__(NW * 64, 2) void igemm_ring_kernel(const IgemmArgs a) {
   typedef typename Vec8<T>::type frag_t;
   constexpr bool WIDE = NW == 8;                             // eight waves: the two halves run half a step apart
@@ -1939,6 +2011,8 @@ __global__ __launch_bounds__(NW * 64, 2) void igemm_ring_kernel(const IgemmArgs 
   constexpr unsigned OOB = 0x80000000u;
   __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
   __shared__ int s_arrive;                                   // split-K finished inside the launch: the arrival order
+  __shared__ float s_rowstat[LNF ? BM * 2 : 2];              // LayerNorm folded into the launch: {mean, rstd} of the block's rows
+  static_assert(!(LNF && TR), "the LayerNorm fold has no transposed-output form");
   typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1949,6 +2023,11 @@ __global__ __launch_bounds__(NW * 64, 2) void igemm_ring_kernel(const IgemmArgs 
   const int L = xcd_remap(blockIdx.x, nblk);
   MOBI_TILE_OF(L, tile_m, tile_n);
   const int m0 = tile_m * BM, n0 = tile_n * BN;
+  constexpr int SPW = MT / (NW / 2);                         // A fragments per wave whose row sums it accumulates (ln_fold_acc)
+  constexpr bool lnf = LNF;                                  // (an instantiation of its own: the plain kernels keep their registers)
+  float ls_sum[SPW], ls_sq[SPW];
+#pragma unroll
+  for (int i = 0; i < SPW; ++i) ls_sum[i] = ls_sq[i] = 0.f;
   MOBI_STAMP_AT(0);
   const bool w_tiled = a.w_tiled != nullptr;                 // (wave-uniform) weights as 1-KiB request images
   // (request images of stacked per-group matrices: a group's image has as many elements as its matrix and follows the previous one's)
@@ -2053,7 +2132,7 @@ __global__ __launch_bounds__(NW * 64, 2) void igemm_ring_kernel(const IgemmArgs 
   const int r16 = lane & 15, g4 = lane >> 4;
   if constexpr (WIDE && MT == 8 && !TR) {
     // register-epilogue launches: bias OR per-image vector start the sums (scale is 1; a wave's 128 pixels lie in one image)
-    if (a.ring_direct && (a.bias || a.rowvec)) {
+    if (!lnf && a.ring_direct && (a.bias || a.rowvec)) {       // (LayerNorm fold: the bias is added behind the fold)
       const float* vec = a.bias;
       if (a.rowvec) {
         const int img = __builtin_amdgcn_readfirstlane((m0 + wm * 128) / a.hw_out);
@@ -2087,6 +2166,27 @@ __global__ __launch_bounds__(NW * 64, 2) void igemm_ring_kernel(const IgemmArgs 
         acc[ni][mi] = TR ? mfma16(xf[mi], wf[ni], acc[ni][mi]) : mfma16(wf[ni], xf[mi], acc[ni][mi]);
     __builtin_amdgcn_s_setprio(0);
   };
+  // LayerNorm fold: the wave's share of the A fragments (SPW of the MT of its wave row: fragments SPW * wn + i) is read from LDS
+  // a second time into registers of its own -- an address, not a register index, depends on the wave -- and 8 v_dot2c per
+  // fragment sum the rows and their squares between the step's MFMAs (no branch in the loop: a scalar branch per candidate
+  // fragment cost the 256 x 320 tiles 20 % of their rate)
+  const unsigned char* xrd_s = xrd + (SPW * (wave_s >> 1)) * 16 * 64;
+  auto read_stat_frags = [&](int s, frag_t (&sf)[SPW]) {
+    const int so = (s & 3) * SLOT;
+#pragma unroll
+    for (int i = 0; i < SPW; ++i) sf[i] = __builtin_bit_cast(frag_t, ld16(xrd_s + so + i * 16 * 64));
+  };
+  auto multiply_stats = [&](const frag_t (&xf)[MT], const frag_t (&wf)[NT], const frag_t (&sf)[SPW]) {
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ni = 0; ni < NT; ++ni)
+#pragma unroll
+      for (int mi = 0; mi < MT; ++mi) {
+        acc[ni][mi] = TR ? mfma16(xf[mi], wf[ni], acc[ni][mi]) : mfma16(wf[ni], xf[mi], acc[ni][mi]);
+        if (ni == 0 && mi < SPW) rowstat_acc(sf[mi], ls_sum[mi], ls_sq[mi]);
+      }
+    __builtin_amdgcn_s_setprio(0);
+  };
 #define MOBI_RING_BARRIER()                   \
   do {                                        \
     __builtin_amdgcn_sched_barrier(0);        \
@@ -2118,8 +2218,9 @@ __global__ __launch_bounds__(NW * 64, 2) void igemm_ring_kernel(const IgemmArgs 
       MOBI_WP(0);
       MOBI_RING_BARRIER();
       MOBI_WP(1);
-      frag_t xf[MT], wf[NT];
+      frag_t xf[MT], wf[NT], sf[SPW];
       read_frags(s, xf, wf);
+      if constexpr (lnf) read_stat_frags(s, sf);
       __builtin_amdgcn_sched_barrier(0);
       issue_step();
       __builtin_amdgcn_sched_barrier(0);
@@ -2130,7 +2231,7 @@ __global__ __launch_bounds__(NW * 64, 2) void igemm_ring_kernel(const IgemmArgs 
       MOBI_WP(4);
       MOBI_RING_BARRIER();
       MOBI_WP(5);
-      multiply(xf, wf);
+      if constexpr (lnf) multiply_stats(xf, wf, sf); else multiply(xf, wf);
 #if MOBI_STAMP == 4
       asm volatile("s_nop 0" ::: "memory");
 #endif
@@ -2164,15 +2265,16 @@ __global__ __launch_bounds__(NW * 64, 2) void igemm_ring_kernel(const IgemmArgs 
       MOBI_RP(1);
       MOBI_RING_BARRIER();
       MOBI_RP(2);
-      frag_t xf[MT], wf[NT];
+      frag_t xf[MT], wf[NT], sf[SPW];
       read_frags(s, xf, wf);
+      if constexpr (lnf) read_stat_frags(s, sf);
       __builtin_amdgcn_sched_barrier(0);
       issue_step();                                          // step s + 3, behind the reads' latency
       __builtin_amdgcn_sched_barrier(0);
       MOBI_RP(3);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       MOBI_RP(4);
-      multiply(xf, wf);
+      if constexpr (lnf) multiply_stats(xf, wf, sf); else multiply(xf, wf);
 #if MOBI_STAMP == 4
       asm volatile("s_nop 0" ::: "memory");
       MOBI_RP(5);
@@ -2190,6 +2292,12 @@ __global__ __launch_bounds__(NW * 64, 2) void igemm_ring_kernel(const IgemmArgs 
   }
 #undef MOBI_RING_BARRIER
   MOBI_STAMP_AT(2);
+  if constexpr (lnf) {
+    // LayerNorm fold: acc <- rstd (acc - mean s) [+ bias where the epilogue below does not add it: the 256 x 320 register epilogue,
+    // whose bias normally starts the sums]
+    ln_fold_acc<NT, MT, SPW>(a, acc, ls_sum, ls_sq, s_rowstat, lane, wm, wave_s >> 1, n0 + wn * WAVE_N,
+                             WIDE && MT == 8 && a.ring_direct);
+  }
   if constexpr (MT == 4 && !TR) {
     if (a.sm_direct) {                                       // wave-uniform
       // 128-pixel tiles, full: the wave tile is the ping-pong kernel's (64 pixels x NT * 16 channels), so are its register
@@ -2292,7 +2400,7 @@ __global__ __launch_bounds__(NW * 64, 2) void igemm_ring_kernel(const IgemmArgs 
 // pieces past its k range), counted waits.  Epilogues: the ring kernel's (registers / register slab stores for full tiles,
 // else LDS-staged through the drained ring).
 // =========================================================================================================
-template <typename T, int NT, bool TR>
+template <typename T, int NT, bool TR, bool LNF = false>
 __global__ __launch_bounds__(256, 1) void igemm_ring64_kernel(const IgemmArgs a) {
   typedef typename Vec8<T>::type frag_t;
   constexpr int NW = 4, MT = 4, BM = 128, SL = 4;
@@ -2306,6 +2414,8 @@ __global__ __launch_bounds__(256, 1) void igemm_ring64_kernel(const IgemmArgs a)
   constexpr unsigned OOB = 0x80000000u;
   __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
   __shared__ int s_arrive;                                   // split-K finished inside the launch: the arrival order
+  __shared__ float s_rowstat[LNF ? BM * 2 : 2];              // LayerNorm folded into the launch: {mean, rstd} of the block's rows
+  static_assert(!(LNF && TR), "the LayerNorm fold has no transposed-output form");
   typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -2402,6 +2512,11 @@ __global__ __launch_bounds__(256, 1) void igemm_ring64_kernel(const IgemmArgs a)
   for (int i = 0; i < NT; ++i)
 #pragma unroll
     for (int j = 0; j < MT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  constexpr int SPW = MT / (NW / 2);                         // LayerNorm fold (ln_fold_acc): this wave's share of the A fragments
+  constexpr bool lnf = LNF;
+  float ls_sum[SPW], ls_sq[SPW];
+#pragma unroll
+  for (int i = 0; i < SPW; ++i) ls_sum[i] = ls_sq[i] = 0.f;
 
   const int r16 = lane & 15, g4 = lane >> 4;
   const unsigned char* xrd = lds + (wm * 64 + r16) * 128;
@@ -2415,7 +2530,7 @@ __global__ __launch_bounds__(256, 1) void igemm_ring64_kernel(const IgemmArgs a)
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
     const int so = (s & (SL - 1)) * SLOT;
-    frag_t xf[2][MT], wf[2][NT];
+    frag_t xf[2][MT], wf[2][NT], sf[2][SPW];
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       const int sw = ((ks * 4 + g4) ^ (r16 & 7)) << 4;
@@ -2423,6 +2538,11 @@ __global__ __launch_bounds__(256, 1) void igemm_ring64_kernel(const IgemmArgs a)
       for (int mi = 0; mi < MT; ++mi) xf[ks][mi] = __builtin_bit_cast(frag_t, ld16(xrd + so + mi * 16 * 128 + sw));
 #pragma unroll
       for (int ni = 0; ni < NT; ++ni) wf[ks][ni] = __builtin_bit_cast(frag_t, ld16(wrd + so + ni * 16 * 128 + sw));
+      if constexpr (lnf) {                                   // the wave's own share of the A fragments once more (an address, not
+#pragma unroll                                               // a register index, depends on the wave): LayerNorm fold
+        for (int i = 0; i < SPW; ++i)
+          sf[ks][i] = __builtin_bit_cast(frag_t, ld16(xrd + so + (SPW * (wave_s >> 1) + i) * 16 * 128 + sw));
+      }
     }
     __builtin_amdgcn_sched_barrier(0);
     issue_step();                                            // step s + 3, behind the reads' latency
@@ -2434,10 +2554,13 @@ __global__ __launch_bounds__(256, 1) void igemm_ring64_kernel(const IgemmArgs a)
 #pragma unroll
       for (int ni = 0; ni < NT; ++ni)
 #pragma unroll
-        for (int mi = 0; mi < MT; ++mi)
+        for (int mi = 0; mi < MT; ++mi) {
           acc[ni][mi] = TR ? mfma16(xf[ks][mi], wf[ks][ni], acc[ni][mi]) : mfma16(wf[ks][ni], xf[ks][mi], acc[ni][mi]);
+          if constexpr (lnf) if (ni == 0 && mi < SPW) rowstat_acc(sf[ks][mi], ls_sum[mi], ls_sq[mi]);   // behind the first MFMAs
+        }
     __builtin_amdgcn_s_setprio(0);
   }
+  if constexpr (lnf) ln_fold_acc<NT, MT, SPW>(a, acc, ls_sum, ls_sq, s_rowstat, lane, wm, wave_s >> 1, n0 + wn * WAVE_N, false);
   if constexpr (!TR) {
     if (a.sm_direct) {                                       // full tiles: registers -> memory (no staging, no block barrier)
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -2575,7 +2698,11 @@ static int launch_igemm(const mobi_igemm_params* p, const IgemmArgs& a, int grou
   do { if (tr) MOBI_IGEMM_BY_FAST(NT_, true, WM_); else MOBI_IGEMM_BY_FAST(NT_, false, WM_); } while (0)
   if (a.wide == 2) {
 #define MOBI_W2_LAUNCH(NT_, TR_) hipLaunchKernelGGL((igemm_ring_kernel<T, NT_, TR_, 8, 8>), grid, dim3(512), 0, st, a)
-    if (nt5) { if (tr) MOBI_W2_LAUNCH(5, true); else MOBI_W2_LAUNCH(5, false); }
+    if (a.ln_svec) {                                         // LayerNorm folded into the launch: instantiations of their own
+      if (nt5) hipLaunchKernelGGL((igemm_ring_kernel<T, 5, false, 8, 8, true>), grid, dim3(512), 0, st, a);
+      else     hipLaunchKernelGGL((igemm_ring_kernel<T, 4, false, 8, 8, true>), grid, dim3(512), 0, st, a);
+    }
+    else if (nt5) { if (tr) MOBI_W2_LAUNCH(5, true); else MOBI_W2_LAUNCH(5, false); }
     else     { if (tr) MOBI_W2_LAUNCH(4, true); else MOBI_W2_LAUNCH(4, false); }
 #undef MOBI_W2_LAUNCH
   }
@@ -2614,13 +2741,21 @@ static int launch_igemm(const mobi_igemm_params* p, const IgemmArgs& a, int grou
   else if (a.wm == 4) { if (nt5) MOBI_IGEMM_BY_TR(5, 4); else MOBI_IGEMM_BY_TR(4, 4); }
   else if (a.sm && a.sm64) {
 #define MOBI_SM64_LAUNCH(NT_, TR_) hipLaunchKernelGGL((igemm_ring64_kernel<T, NT_, TR_>), grid, dim3(256), 0, st, a)
-    if (nt5) { if (tr) MOBI_SM64_LAUNCH(5, true); else MOBI_SM64_LAUNCH(5, false); }
+    if (a.ln_svec) {
+      if (nt5) hipLaunchKernelGGL((igemm_ring64_kernel<T, 5, false, true>), grid, dim3(256), 0, st, a);
+      else     hipLaunchKernelGGL((igemm_ring64_kernel<T, 4, false, true>), grid, dim3(256), 0, st, a);
+    }
+    else if (nt5) { if (tr) MOBI_SM64_LAUNCH(5, true); else MOBI_SM64_LAUNCH(5, false); }
     else     { if (tr) MOBI_SM64_LAUNCH(4, true); else MOBI_SM64_LAUNCH(4, false); }
 #undef MOBI_SM64_LAUNCH
   }
   else if (a.sm) {
 #define MOBI_SM_LAUNCH(NT_, TR_) hipLaunchKernelGGL((igemm_ring_kernel<T, NT_, TR_, 4, 4>), grid, dim3(256), 0, st, a)
-    if (nt5) { if (tr) MOBI_SM_LAUNCH(5, true); else MOBI_SM_LAUNCH(5, false); }
+    if (a.ln_svec) {
+      if (nt5) hipLaunchKernelGGL((igemm_ring_kernel<T, 5, false, 4, 4, true>), grid, dim3(256), 0, st, a);
+      else     hipLaunchKernelGGL((igemm_ring_kernel<T, 4, false, 4, 4, true>), grid, dim3(256), 0, st, a);
+    }
+    else if (nt5) { if (tr) MOBI_SM_LAUNCH(5, true); else MOBI_SM_LAUNCH(5, false); }
     else     { if (tr) MOBI_SM_LAUNCH(4, true); else MOBI_SM_LAUNCH(4, false); }
 #undef MOBI_SM_LAUNCH
   }
@@ -2708,7 +2843,7 @@ extern "C" int mobi_debug_set_phases(void* buf) {
 #endif
 
 extern "C" int mobi_igemm_plan_splits(const mobi_igemm_params* p) {
-  if (!p || p->groups != 1 || p->epilogue != MOBI_EPI_NONE || p->out_mode == MOBI_OUT_TRANSPOSED) return 1;
+  if (!p || p->groups != 1 || p->epilogue != MOBI_EPI_NONE || p->out_mode == MOBI_OUT_TRANSPOSED || p->ln_svec) return 1;
   {
     mobi_igemm_params q = *p;
     q.split_k = 0;
@@ -2754,6 +2889,15 @@ static int igemm_prepare(const mobi_igemm_params* p, mobi::IgemmArgs& a) {
        reinterpret_cast<uintptr_t>(p->weight) | reinterpret_cast<uintptr_t>(p->out) |
        reinterpret_cast<uintptr_t>(p->residual)) & 15) return MOBI_ERR_ALIGN;
 
+  // LayerNorm folded into the launch (ln_fold_acc): a 1 x 1 product of ONE source whose block sweeps all of k
+  const bool lnf = p->ln_svec != nullptr;
+  if (lnf) {
+    if (p->kh != 1 || p->kw != 1 || p->c1 || p->stride != 1 || p->upsample || p->groups != 1 || p->split_k > 1 || p->rowvec ||
+        p->residual || p->out_mode == MOBI_OUT_TRANSPOSED || p->scale != 1.0f || p->k_order != 0 || p->hout != p->hin || p->wout != p->win)
+      return MOBI_ERR_UNSUPPORTED;
+    if (reinterpret_cast<uintptr_t>(p->ln_svec) & 15) return MOBI_ERR_ALIGN;
+  }
+  a.ln_svec = p->ln_svec; a.ln_eps = p->ln_eps;
   a.src0 = p->src0; a.src1 = p->src1;
   a.c0 = p->c0; a.c1 = p->c1; a.C = p->c0 + p->c1;
   a.hin = p->hin; a.win = p->win; a.up = p->upsample;
@@ -2869,6 +3013,7 @@ static int igemm_prepare(const mobi_igemm_params* p, mobi::IgemmArgs& a) {
     // (a source of fewer than 64 channels into a wide layer -- the UNet's 9-channel input, padded to 32: a tap per k-step --
     //  stays on the register-staged kernel: 38 against 104 us on 9 -> 320 at 64 x 64 x 16)
     if (!pick && a.wm == 4 && !a.pp && (a.C >= 64 || p->out_mode != MOBI_OUT_ROWS || p->n_packed < 256)) pick = 2;
+    if (lnf) pick = a.wm == 4 ? 2 : 0;                      // the LayerNorm fold lives in the 256 x 320 / 128 x 160 ring tiles
 #endif
     if (pick) {
       a.wide = pick;
@@ -2918,7 +3063,8 @@ static int igemm_prepare(const mobi_igemm_params* p, mobi::IgemmArgs& a) {
         (!p->rowvec || (!p->bias && a.hw_out % 128 == 0)) && a.M % 256 == 0 && p->n_packed % bnw == 0 && p->scale == 1.0f)
       a.ring_direct = 1;
   }
-  a.small = small_tile(p);
+  a.small = lnf ? 0 : small_tile(p);
+  if (lnf && !(a.wide || a.sm)) return MOBI_ERR_UNSUPPORTED;  // (operands beyond the ring kernels' 2 GB: LayerNorm as a launch)
   // split-K finished inside the launch: the LDS-DMA kernels (ring tiles of every geometry; the ping-pong kernel when every
   // block owns exactly one output tile -- its epilogue is deferred into the next tile's loop otherwise); the register-staged
   // fallback keeps the reduce launch.  MOBI_IGEMM_FUSED_SPLIT=0: never (A/B)

@@ -28,6 +28,10 @@ struct GnArgs {
   int c0, c1, C, hw, chunks;
   const float* gamma; const float* beta; float eps; int silu;
   void* out; float* ws;
+  int* sync;       // gn_coop_kernel: one arrival counter per image (zero before and after the launch), or NULL
+  int src_f32;     // 1: src0 is f32 (one source): the VAE decoder's fp32 streams
+  int out_mode;    // 0: T [..][C];  1: T [..][2 C] = hi | lo with hi = T(y), lo = T(y - hi) (a consumer with duplicated weights then
+                   //    multiplies y to ~22 bits);  2: f32 [..][C]
 };
 
 template <typename T>
@@ -181,6 +185,128 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const GnArgs a) {
     i += 2 * S;
     p = p2 + dp; v = v2 + dv;
     if (v >= V) { v -= V; ++p; }
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// The two-launch form for fp32 sources and for the "precise" outputs (GnArgs.src_f32 / out_mode): the lidar decoder's tail of
+// the fp16 parity configuration (ldm/modules/diffusionmodules/model.py).  Same statistics arithmetic as gn_stats_kernel /
+// gn_apply_kernel (per-chunk fp32 partial sums, fp64 fold); not tuned -- a handful of launches per decode.
+__global__ __launch_bounds__(256) void gn_stats_f32_kernel(const GnArgs a) {
+  __shared__ float s_sum[2560 + 512];
+  __shared__ float s_sq[2560 + 512];
+  const int tid = threadIdx.x;
+  const int img = blockIdx.y, chunk = blockIdx.x;
+  const int V = a.C >> 3;
+  const int rows = V <= 256 ? 256 / V : 1;
+  const int per = (a.hw + a.chunks - 1) / a.chunks;
+  const int p_begin = chunk * per;
+  const int p_end = min(a.hw, p_begin + per);
+  const float* __restrict__ s0 = reinterpret_cast<const float*>(a.src0) + (long long)img * a.hw * a.C;
+  const int slot = V <= 256 ? tid / V : 0;
+  const int col0 = V <= 256 ? tid - slot * V : tid;
+  const bool active = V <= 256 ? slot < rows : true;
+  for (int col = col0; col < V; col += 256) {
+    float sum[8], sq[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { sum[j] = 0.f; sq[j] = 0.f; }
+    if (active) {
+      const int c = col * 8;
+      for (int p = p_begin + slot; p < p_end; p += rows) {
+        float f[8];
+        ld8f(s0 + (long long)p * a.C + c, f);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { sum[j] += f[j]; sq[j] += f[j] * f[j]; }
+      }
+      float* ds = s_sum + slot * a.C + c;
+      float* dq = s_sq + slot * a.C + c;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { ds[j] = sum[j]; dq[j] = sq[j]; }
+    }
+    if (V <= 256) break;
+  }
+  __syncthreads();
+  if (tid < 32) {
+    const int cpg = a.C / 32;
+    float gs = 0.f, gq = 0.f;
+    for (int r = 0; r < rows; ++r)
+      for (int j = 0; j < cpg; ++j) {
+        gs += s_sum[r * a.C + tid * cpg + j];
+        gq += s_sq[r * a.C + tid * cpg + j];
+      }
+    float* w = a.ws + ((long long)(img * a.chunks + chunk) * 32 + tid) * 2;
+    w[0] = gs; w[1] = gq;
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void gn_apply_x_kernel(const GnArgs a) {
+  __shared__ float s_mean[32], s_rstd[32];
+  __shared__ __attribute__((aligned(16))) float s_sc[2560];
+  __shared__ __attribute__((aligned(16))) float s_sh[2560];
+  __shared__ double s_ps[8][32], s_pq[8][32];
+  const int tid = threadIdx.x;
+  const int img = blockIdx.y;
+  {
+    const int g = tid & 31, sub = tid >> 5;
+    double s = 0.0, q = 0.0;
+    const float* w = a.ws + ((long long)img * a.chunks * 32 + g) * 2;
+    for (int c = sub; c < a.chunks; c += 8) { s += (double)w[c * 64]; q += (double)w[c * 64 + 1]; }
+    s_ps[sub][g] = s; s_pq[sub][g] = q;
+  }
+  __syncthreads();
+  if (tid < 32) {
+    double s = 0.0, q = 0.0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { s += s_ps[k][tid]; q += s_pq[k][tid]; }
+    const double n = (double)a.hw * (double)(a.C / 32);
+    const double mean = s / n;
+    double var = q / n - mean * mean;
+    var = var < 0.0 ? 0.0 : var;
+    s_mean[tid] = (float)mean;
+    s_rstd[tid] = (float)(1.0 / sqrt(var + (double)a.eps));
+  }
+  __syncthreads();
+  const int cpg = a.C / 32;
+  for (int c = tid; c < a.C; c += 256) {
+    const int g = c / cpg;
+    const float sc = s_rstd[g] * a.gamma[c];
+    s_sc[c] = sc;
+    s_sh[c] = a.beta[c] - s_mean[g] * sc;
+  }
+  __syncthreads();
+  const int V = a.C >> 3;
+  const long long total = (long long)a.hw * V;
+  const long long ibase = (long long)img * a.hw;
+  for (long long i = (long long)blockIdx.x * 256 + tid; i < total; i += (long long)gridDim.x * 256) {
+    const int p = (int)(i / V), c = (int)(i - (long long)p * V) * 8;
+    float f[8];
+    if (a.src_f32) {
+      ld8f(reinterpret_cast<const float*>(a.src0) + (ibase + p) * a.C + c, f);
+    } else {
+      const T* src = c >= a.c0 ? reinterpret_cast<const T*>(a.src1) + (ibase + p) * a.c1 + (c - a.c0)
+                               : reinterpret_cast<const T*>(a.src0) + (ibase + p) * a.c0 + c;
+      unpack8<T>(ld16(src), f);
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      f[j] = f[j] * s_sc[c + j] + s_sh[c + j];
+      if (a.silu) f[j] = silu_f(f[j]);
+    }
+    if (a.out_mode == 2) {
+      float* o = reinterpret_cast<float*>(a.out) + (ibase + p) * a.C + c;
+      *reinterpret_cast<f32x4*>(o) = f32x4{f[0], f[1], f[2], f[3]};
+      *reinterpret_cast<f32x4*>(o + 4) = f32x4{f[4], f[5], f[6], f[7]};
+    } else if (a.out_mode == 1) {
+      T* o = reinterpret_cast<T*>(a.out) + (ibase + p) * (2 * a.C) + c;
+      float hi[8], lo[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { hi[j] = (float)(T)f[j]; lo[j] = f[j] - hi[j]; }
+      st16(o, pack8<T>(hi));
+      st16(o + a.C, pack8<T>(lo));
+    } else {
+      st16(reinterpret_cast<T*>(a.out) + (ibase + p) * a.C + c, pack8<T>(f));
+    }
   }
 }
 
@@ -549,11 +675,254 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const LnArgs a) {
   }
 }
 
+// ---------------------------------------------------------------------------------------
+// One-launch GroupNorm(+SiLU) for tensors whose groups are too large for one block (the 64 x 64 level's 320 channels: a group
+// is 80 KB per image and its 20-byte pixel segments lie 640 bytes apart -- gn_regs_kernel reads them as 8-byte pieces, 40 useful
+// bytes per 128-byte line and request).  Here a block owns a CHUNK of pixels x ALL channels of one image in registers: every
+// access is a fully coalesced 16-byte piece of a dense row, the tensor is read once and written once.  The chunks of an image
+// meet through memory, not through a second launch:
+//   every block writes the (sum, sum of squares) of its chunk for the 32 groups, ARRIVES at the image's counter and waits
+//   (bounded spin, one lane) until all chunks of the image have; then it folds the image's partials in fp64 in chunk order -- the
+//   two-launch form's arithmetic -- and applies scale / shift (+ SiLU) to the pieces it still holds.
+// The grid is at most one block per CU (the host checks), so every block of an image is resident while its siblings spin.
+// Coherence as in the in-launch split-K finish (csrc/igemm.hip): the partials are stored and loaded device-coherently (sc1), the
+// counter is a device-scope atomic, nothing else changes its cache policy; a block's SECOND arrival (after its fold) lets the last
+// one return the counter to zero, so one zeroed buffer serves every launch of a stream.
+// Algorithmic bytes: 2 B read + 2 B written per element.
+struct GnCoopGeom { int chunks, ppb, slots, V; };
+
+__device__ __forceinline__ void st8_dev(float* p, float x, float y) {
+  const u32x2 v = {__builtin_bit_cast(unsigned, x), __builtin_bit_cast(unsigned, y)};
+  asm volatile("global_store_dwordx2 %0, %1, off sc1" : : "v"(p), "v"(v) : "memory");
+}
+
+template <typename T, int ITEMS>
+__global__ __launch_bounds__(1024) void gn_coop_kernel(const GnArgs a, const GnCoopGeom geo) {
+  __shared__ float s_part[4][1024];                      // per thread: (sum, squares) of its column's first- / second-group channels
+  __shared__ float s_col[4][320];                        // per column, over the block's pixel slots
+  __shared__ double s_ps[32][32], s_pq[32][32];          // [chunk][group] of the image
+  __shared__ float s_mean[32], s_rstd[32];
+  __shared__ int s_seen;
+  const int tid = threadIdx.x;
+  const int V = geo.V, SLOTS = geo.slots;
+  const int cpg = a.C / 32;
+  const int nblk = (int)gridDim.x;
+  int w = (int)blockIdx.x;
+  if (!(nblk & 7)) w = (w & 7) * (nblk >> 3) + (w >> 3);  // an XCD's blocks: whole images
+  const int img = w / geo.chunks, chunk = w - img * geo.chunks;
+  const int slot = tid / V, col = tid - slot * V;
+  const bool live = slot < SLOTS;
+  const int c = col * 8;
+  const int g0 = c / cpg;
+  const int k = min(8, (g0 + 1) * cpg - c);              // channels of the column in group g0 (the rest in g0 + 1)
+  const bool second = c >= a.c0;
+  const int cs = second ? a.c1 : a.c0;
+  const T* __restrict__ src = second ? reinterpret_cast<const T*>(a.src1) + (long long)img * a.hw * a.c1 + (c - a.c0)
+                                     : reinterpret_cast<const T*>(a.src0) + (long long)img * a.hw * a.c0 + c;
+  const int p0 = chunk * geo.ppb;
+  u32x4 raw[ITEMS];
+#pragma unroll
+  for (int i = 0; i < ITEMS; ++i) {
+    const int q = slot + i * SLOTS;
+    raw[i] = u32x4{0u, 0u, 0u, 0u};
+    if (live && q < geo.ppb && p0 + q < a.hw) raw[i] = ld16(src + (long long)(p0 + q) * cs);
+  }
+  {
+    float sm[8], sq[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { sm[j] = 0.f; sq[j] = 0.f; }
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) {                    // (pieces past the chunk are zeros: they add nothing)
+      float f[8];
+      unpack8<T>(raw[i], f);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { sm[j] += f[j]; sq[j] += f[j] * f[j]; }
+    }
+    float lo_s = 0.f, hi_s = 0.f, lo_q = 0.f, hi_q = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      lo_s += j < k ? sm[j] : 0.f; hi_s += j < k ? 0.f : sm[j];
+      lo_q += j < k ? sq[j] : 0.f; hi_q += j < k ? 0.f : sq[j];
+    }
+    s_part[0][tid] = live ? lo_s : 0.f; s_part[1][tid] = live ? hi_s : 0.f;
+    s_part[2][tid] = live ? lo_q : 0.f; s_part[3][tid] = live ? hi_q : 0.f;
+  }
+#pragma unroll
+  for (int i = 0; i < ITEMS; ++i) asm volatile("" : "+v"(raw[i]));      // the packed pieces are what stays in registers
+  __syncthreads();
+  for (int t = tid; t < V * 4; t += 1024) {              // per column, over the pixel slots in slot order
+    const int cc = t >> 2, q = t & 3;
+    float v = 0.f;
+    for (int s_ = 0; s_ < SLOTS; ++s_) v += s_part[q][s_ * V + cc];
+    s_col[q][cc] = v;
+  }
+  __syncthreads();
+  float* wsp = a.ws + ((long long)(img * geo.chunks + chunk) * 32) * 2;
+  if (tid < 32) {                                         // group tid: the columns that overlap it, in column order
+    const int g = tid;
+    const int c_lo = max(0, (g * cpg) / 8 - 1), c_hi = min(V - 1, ((g + 1) * cpg - 1) / 8);
+    float gs = 0.f, gq = 0.f;
+    for (int cc = c_lo; cc <= c_hi; ++cc) {
+      const int gg = (cc * 8) / cpg;
+      if (gg == g) { gs += s_col[0][cc]; gq += s_col[2][cc]; }
+      else if (gg + 1 == g) { gs += s_col[1][cc]; gq += s_col[3][cc]; }
+    }
+    st8_dev(wsp + g * 2, gs, gq);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // acknowledged before this block arrives
+  }
+  __syncthreads();
+  if (tid == 0) {
+    __hip_atomic_fetch_add(a.sync + img, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int seen = 0;
+    for (int spin = 0; spin < (1 << 22); ++spin) {       // bounded: a lost sibling ends in a wrong image, never in a hung chip
+      seen = __hip_atomic_load(a.sync + img, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (seen >= geo.chunks) break;
+      __builtin_amdgcn_s_sleep(4);
+    }
+    s_seen = seen;
+  }
+  __syncthreads();
+  {
+    const int g = tid & 31, ch = tid >> 5;                // 32 x 32 threads: one (chunk, group) pair each
+    double s = 0.0, q = 0.0;
+    if (ch < geo.chunks) {
+      // (one descriptor over the whole workspace -- a descriptor is wave-uniform --, the pair's byte offset per lane; sc1)
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(a.ws, 0, nblk * 256, 0x00020000);
+      // (two dword loads: the b64 form returned the dwords at +0 and +8 here -- seen as the next group's sum in place of this
+      //  group's squares)
+      const unsigned off = (unsigned)(((img * geo.chunks + ch) * 32 + g) * 8);
+      s = (double)__builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, off, 0, 16));
+      q = (double)__builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, off + 4u, 0, 16));
+    }
+    s_ps[ch][g] = s; s_pq[ch][g] = q;
+  }
+  __syncthreads();
+  if (tid == 0) {                                         // second arrival: the last block past its loads returns the counter to zero
+    const int old = __hip_atomic_fetch_add(a.sync + img, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (old == 2 * geo.chunks - 1) __hip_atomic_store(a.sync + img, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  if (tid < 32) {
+    double s = 0.0, q = 0.0;
+    for (int ch = 0; ch < geo.chunks; ++ch) { s += s_ps[ch][tid]; q += s_pq[ch][tid]; }
+    const double n = (double)a.hw * (double)cpg;
+    const double mean = s / n;
+    double var = q / n - mean * mean;
+    var = var < 0.0 ? 0.0 : var;
+    s_mean[tid] = (float)mean;
+    s_rstd[tid] = (float)(1.0 / sqrt(var + (double)a.eps));
+  }
+  __syncthreads();
+  if (!live) return;
+  float sc[8], sh[8];
+  {
+    float gm[8], bt[8];
+    ld8f(a.gamma + c, gm);
+    ld8f(a.beta + c, bt);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int g = j < k ? g0 : g0 + 1;
+      sc[j] = s_rstd[g] * gm[j];
+      sh[j] = bt[j] - s_mean[g] * sc[j];
+    }
+  }
+  T* __restrict__ out = reinterpret_cast<T*>(a.out) + (long long)img * a.hw * a.C + c;
+#pragma unroll
+  for (int i = 0; i < ITEMS; ++i) {
+    const int q = slot + i * SLOTS;
+    if (q < geo.ppb && p0 + q < a.hw) {
+      float f[8];
+      unpack8<T>(raw[i], f);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        f[j] = f[j] * sc[j] + sh[j];
+        if (a.silu) f[j] = silu_f(f[j]);
+      }
+      st16(out + (long long)(p0 + q) * a.C, pack8<T>(f));
+    }
+  }
+}
+
+// chunks per image (a power of two, at most 32), pixels per block, pixel slots; false: the shape is not the kernel's
+static bool gn_coop_geometry(int C, int hw, int batch, int cus, GnCoopGeom* geo, int* items) {
+  const int cpg = C / 32, V = C / 8;
+  if (cpg < 8 || V > 320 || V < 1) return false;
+  const int slots = 1024 / V;
+  int chunks = 32;
+  while (chunks > 1 && ((long long)batch * chunks > cus || hw % chunks)) chunks >>= 1;
+  if (chunks < 2) return false;
+  const int ppb = hw / chunks;
+  const int need = (ppb + slots - 1) / slots;
+  static const int steps[] = {2, 4, 6, 8, 12, 16};
+  int pick = 0;
+  for (int s_ : steps) if (s_ >= need) { pick = s_; break; }
+  if (!pick) return false;
+  geo->chunks = chunks; geo->ppb = ppb; geo->slots = slots; geo->V = V;
+  *items = pick;
+  return true;
+}
+
+static int gn_compute_units() {
+  static int cached = 0;
+  if (!cached) {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    cached = n;
+  }
+  return cached;
+}
+
+// where the chunked kernel replaces the register kernel by default: NOWHERE.  Measured (tools/gn_lab.py, profiles/r05_gn_lab.txt, 16
+// images, graph-timed on cold inputs): [4096, 320] 33.0 against 30.2 us (registers), [1024, 640] 24.1 against 17.6, [256, 1280]
+// 18.7 against 10.6 -- the fully coalesced accesses buy nothing: both kernels are ONE-SHOT (every block loads its whole share,
+// reduces, then stores, all 256 blocks in the same phase), so the launch costs the read phase PLUS the write phase (~2.7 TB/s of
+// the 6 a copy reaches by overlapping them), and the meeting through memory adds ~8 us.  Kept for the A/B (MOBI_GN_COOP=1).
+static bool gn_coop_default(int C, int hw, int batch) {
+  (void)C; (void)hw; (void)batch;
+  return false;
+}
+
+template <typename T>
+static bool launch_gn_coop(const GnArgs& a, int batch, hipStream_t st) {
+  GnCoopGeom geo;
+  int it;
+  if (!a.sync || !gn_coop_geometry(a.C, a.hw, batch, gn_compute_units(), &geo, &it)) return false;
+  const dim3 grid((unsigned)(batch * geo.chunks));
+#define MOBI_GNC(IT_) hipLaunchKernelGGL((gn_coop_kernel<T, IT_>), grid, dim3(1024), 0, st, a, geo)
+  switch (it) {
+    case 2: MOBI_GNC(2); break;   case 4: MOBI_GNC(4); break;   case 6: MOBI_GNC(6); break;
+    case 8: MOBI_GNC(8); break;   case 12: MOBI_GNC(12); break; default: MOBI_GNC(16); break;
+  }
+#undef MOBI_GNC
+  return true;
+}
+
 template <typename T>
 static int launch_gn(const GnArgs& a, int batch, hipStream_t st) {
   // small tensors: one launch, the group's slab in LDS (channel pairs: C / 32 even; both sources split at an even channel)
   const int cpg = a.C / 32;
+  if (a.src_f32 || a.out_mode) {                        // fp32 source / precise outputs: the two-launch form of their own
+    if (a.src_f32) hipLaunchKernelGGL(gn_stats_f32_kernel, dim3(a.chunks, batch), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((gn_stats_kernel<T>), dim3(a.chunks, batch), dim3(256), 0, st, a);
+    MOBI_CHECK_LAUNCH();
+    long long blocks = ((long long)a.hw * (a.C >> 3) + 256 * 4 - 1) / (256 * 4);
+    const long long cap = (2048 + batch - 1) / batch;
+    if (blocks > cap) blocks = cap;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL((gn_apply_x_kernel<T>), dim3((unsigned)blocks, batch), dim3(256), 0, st, a);
+    MOBI_CHECK_LAUNCH();
+    return MOBI_OK;
+  }
   const int mode = tuning().gn_fused;                   // 0: two launches; 1: the LDS form where it fits; else registers first
+  // pixel chunks meeting through memory (gn_coop_kernel): MOBI_GN_COOP = 1 wherever its geometry fits, 0 never; default: the shapes
+  // it is measured faster on (tools/gn_lab.py)
+  {
+    const int coop = tuning().gn_coop;
+    const bool want = coop == 1 || (coop != 0 && gn_coop_default(a.C, a.hw, batch));
+    if (want && mode != 0 && mode != 1 && launch_gn_coop<T>(a, batch, st)) {
+      MOBI_CHECK_LAUNCH();
+      return MOBI_OK;
+    }
+  }
   if (mode != 0 && mode != 1 && launch_gn_regs<T>(a, batch, st)) {
     MOBI_CHECK_LAUNCH();
     return MOBI_OK;
@@ -597,7 +966,8 @@ static int launch_ln(const LnArgs& a, hipStream_t st) {
 
 extern "C" size_t mobi_groupnorm_workspace_bytes(int32_t batch, int32_t hw) {
   if (batch <= 0 || hw <= 0) return 0;
-  return (size_t)batch * mobi::gn_chunks(hw) * 32 * 2 * sizeof(float);
+  const int chunks = mobi::gn_chunks(hw) > 32 ? mobi::gn_chunks(hw) : 32;     // (gn_coop_kernel: up to 32 chunks per image)
+  return (size_t)batch * chunks * 32 * 2 * sizeof(float);
 }
 
 extern "C" int mobi_groupnorm(const mobi_groupnorm_params* p, void* stream) {
@@ -615,6 +985,12 @@ extern "C" int mobi_groupnorm(const mobi_groupnorm_params* p, void* stream) {
   a.hw = p->hw; a.chunks = gn_chunks(p->hw);
   a.gamma = p->gamma; a.beta = p->beta; a.eps = p->eps; a.silu = p->silu;
   a.out = p->out; a.ws = reinterpret_cast<float*>(p->ws);
+  if (p->src_f32 != 0 && p->src_f32 != 1) return MOBI_ERR_ARG;
+  if (p->out_mode < 0 || p->out_mode > 2) return MOBI_ERR_ARG;
+  if (p->src_f32 && p->c1) return MOBI_ERR_UNSUPPORTED;
+  a.src_f32 = p->src_f32; a.out_mode = p->out_mode;
+  if (reinterpret_cast<uintptr_t>(p->sync) & 3) return MOBI_ERR_ALIGN;
+  a.sync = reinterpret_cast<int*>(p->sync);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   return p->dtype == MOBI_F16 ? launch_gn<f16_t>(a, p->batch, st) : launch_gn<bf16_t>(a, p->batch, st);
 }

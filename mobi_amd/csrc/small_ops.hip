@@ -1379,7 +1379,7 @@ extern "C" int mobi_conv_small_cout(const mobi_conv_small_cout_params* p, void* 
   if (p->cout <= 0 || p->cout > 8 || p->cin <= 0 || (p->cin & 7)) return MOBI_ERR_UNSUPPORTED;
   if ((reinterpret_cast<uintptr_t>(p->src) | reinterpret_cast<uintptr_t>(p->weight)) & 15) return MOBI_ERR_ALIGN;
   const long long pixels = (long long)p->batch * p->h * p->w;
-  if ((p->cin == 320 || p->cin == 128) && (p->w & 15) == 0 && p->kh * p->kw <= 9 && mobi::tuning().cout_mfma != 0) {
+  if ((p->cin == 320 || p->cin == 128 || p->cin == 256) && (p->w & 15) == 0 && p->kh * p->kw <= 9 && mobi::tuning().cout_mfma != 0) {
     // matrix-core form: 16-pixel tiles, about 512 blocks of four waves over the launch (the weights are staged per block)
     const long long tiles = pixels / 16;
     long long tpw = (tiles + 2047) / 2048;
@@ -1388,8 +1388,9 @@ extern "C" int mobi_conv_small_cout(const mobi_conv_small_cout_params* p, void* 
     const size_t lds = (size_t)p->kh * p->kw * (p->cin / 32) * 9 * 64;
 #define MOBI_CSM(T_, KS_) \
   hipLaunchKernelGGL((conv_small_cout_mfma_kernel<T_, KS_>), dim3(blocks), dim3(256), lds, ST(stream), *p, (int)tpw)   /* < 64 KB */
-    if (p->dtype == MOBI_F16) { if (p->cin == 320) MOBI_CSM(f16_t, 10); else MOBI_CSM(f16_t, 4); }
-    else                      { if (p->cin == 320) MOBI_CSM(bf16_t, 10); else MOBI_CSM(bf16_t, 4); }
+    // (256: the lidar decoder's output convolution on a hi | lo pair of its 128 channels, weights duplicated -- model.py's precise tail)
+    if (p->dtype == MOBI_F16) { if (p->cin == 320) MOBI_CSM(f16_t, 10); else if (p->cin == 256) MOBI_CSM(f16_t, 8); else MOBI_CSM(f16_t, 4); }
+    else                      { if (p->cin == 320) MOBI_CSM(bf16_t, 10); else if (p->cin == 256) MOBI_CSM(bf16_t, 8); else MOBI_CSM(bf16_t, 4); }
 #undef MOBI_CSM
     MOBI_CHECK_LAUNCH();
     return MOBI_OK;

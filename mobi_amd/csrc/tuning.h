@@ -35,6 +35,7 @@ struct Tuning {
   int attn_xcd;         // MOBI_ATTN_XCD              0: attention workgroups in hardware order (A/B of the XCD-aware map)
   int cout_mfma;        // MOBI_COUT_MFMA             0: few-output-channel convolutions on the one-wave-per-pixel kernel (A/B)
   int skinny_mfma;      // MOBI_SKINNY_MFMA           0: fp32-row linears on the vector-ALU kernel (A/B)
+  int gn_coop;          // MOBI_GN_COOP               1: GroupNorm as pixel chunks meeting through memory wherever the geometry fits; 0: never (A/B)
   int gn_fused;         // MOBI_GN_FUSED              0: two-launch GroupNorm; 1: one launch, slab in LDS, where it fits (A/B)
   int attn_v3;          // MOBI_ATTN_V3               0: V row-major launches stay on attention_kernel (A/B); development build: 2 / 3 = the
                         //                            software-pipelined variants of attention_rows_kernel

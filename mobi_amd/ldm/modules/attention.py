@@ -35,6 +35,8 @@ FUSED_FF = os.environ.get("MOBI_FUSED_FF", "1") != "0"      # A/B: 0 = GEGLU pro
 FUSED_FF_MIN_ROWS = int(os.environ.get("MOBI_FUSED_FF_MIN_ROWS", "24576"))   # 192 workgroups
 FUSED_LN = os.environ.get("MOBI_FUSED_LN", "1") != "0"      # A/B: 0 = the cross-modal LayerNorms as launches of their own
 ROW_CHAIN = os.environ.get("MOBI_ROW_CHAIN", "1") != "0"    # A/B: 0 = the launches between the attention kernels one by one
+LN_FOLD = os.environ.get("MOBI_LN_FOLD", "1") != "0"        # A/B: 0 = norm1 / norm3 as LayerNorm launches in front of their projections
+LN_FOLD_MIN_ROWS = int(os.environ.get("MOBI_LN_FOLD_MIN_ROWS", "2048"))   # below: the ping-pong / small kernels + a LayerNorm launch win
 GROUPED_Q = os.environ.get("MOBI_GROUPED_Q", "1") != "0"    # A/B: 0 = the two cross-modal to_q projections as launches of their own
 ROW_CHAIN_MIN_ROWS = int(os.environ.get("MOBI_ROW_CHAIN_MIN_ROWS", "24576"))   # 128 rows per workgroup: 192 workgroups
 # GroupNorm, proj_in, norm1 and the q | k | v projection of a C = 320 block as ONE chain launch (+ a statistics pass): built, tested,
@@ -67,8 +69,18 @@ class GEGLU(nn.Module):
         super().__init__()
         self.proj = Linear(dim_in, dim_out * 2)
 
-    def forward(self, x):
-        return ops.linear(x, self.proj.packed_geglu())
+    def forward(self, x, ln=None):
+        """ln: the LayerNorm in front of the projection, folded into the launch (ops.fold_layernorm: the packed matrix is
+        W diag(gamma), the launch normalises with the row statistics of its own operand)."""
+        if ln is None:
+            return ops.linear(x, self.proj.packed_geglu())
+        ps = (self.proj.weight, self.proj.bias, ln.weight, ln.bias)
+        key = tuple(p._version for p in ps) + (ps[0].data_ptr(), ps[0].device, engine_dtype(), ln.eps)
+        c = self.__dict__.setdefault("_ln_cache", {})
+        if c.get("key") != key:
+            w, b = ops.fold_layernorm(self.proj.weight, self.proj.bias, ln.weight, ln.bias)
+            c["key"], c["val"] = key, ops.with_row_sums(ops.pack_geglu(w, b, engine_dtype(), self.proj.weight.device), ln.eps)
+        return ops.linear(x, c["val"])
 
 
 class FeedForward(nn.Module):
@@ -109,6 +121,8 @@ class FeedForward(nn.Module):
             if norm is not None:
                 x = ops.layernorm(x, *norm.affine(), norm.eps)
             return ops.ff_geglu(x, pf, residual=residual)
+        if norm is not None and LN_FOLD and x.is_contiguous() and rows >= LN_FOLD_MIN_ROWS:
+            return ops.linear(self.net[0](x, ln=norm), self.net[2].packed(), residual=residual)
         if norm is not None:
             x = ops.layernorm(x, *norm.affine(), norm.eps)
         return ops.linear(self.net[0](x), self.net[2].packed(), residual=residual)
@@ -128,7 +142,7 @@ class CrossAttention(nn.Module):
         self.to_out = nn.Sequential(Linear(inner_dim, query_dim), Marker())
 
     # -- packed projections ---------------------------------------------------------------
-    def _stacked(self, names, fold_q=False):
+    def _stacked(self, names, fold_q=False, ln=None):
         """One packed matrix for several projections of the same input (rows stacked in `names` order): the input
         is read once and the launch count drops; attention reads q / k / v as column ranges of the result.
         fold_q: the to_q rows carry scale * log2(e) (fp32 masters multiplied before the single rounding to the storage
@@ -137,23 +151,31 @@ class CrossAttention(nn.Module):
         mods = [getattr(self, n) for n in names]
         dtype = engine_dtype()
         key = (names, fold_q, dtype, self.scale) + tuple(v for m in mods for v in (m.weight._version, m.weight.data_ptr()))
+        if ln is not None:       # the LayerNorm in front of the stacked projection, folded into the launch (ops.fold_layernorm)
+            key += (ln.weight._version, ln.bias._version, ln.weight.data_ptr(), ln.eps)
         c = self.__dict__.setdefault("_stack_cache", {})
-        hit = c.get((names, fold_q))
+        slot = (names, fold_q, ln is not None)
+        hit = c.get(slot)
         if hit is None or hit[0] != key:
             ws = [m.weight.detach() for m in mods]
             if fold_q:
                 assert names[0] == "to_q"
                 ws[0] = ws[0].float() * (self.scale * ops.LOG2E)
-            w = torch.cat([w_.float() for w_ in ws], dim=0) if fold_q else torch.cat(ws, dim=0)
-            hit = (key, ops.pack_linear(w, None, dtype, w.device))
-            c[(names, fold_q)] = hit
+            w = torch.cat([w_.float() for w_ in ws], dim=0) if (fold_q or ln is not None) else torch.cat(ws, dim=0)
+            if ln is not None:
+                wf, bf = ops.fold_layernorm(w, None, ln.weight, ln.bias)
+                hit = (key, ops.with_row_sums(ops.pack_linear(wf, bf, dtype, w.device), ln.eps))
+            else:
+                hit = (key, ops.pack_linear(w, None, dtype, w.device))
+            c[slot] = hit
         return hit[1]
 
     # -- forms of attention ------------------------------------------------------------------
-    def self_attention(self, xn):
-        """xn: normed tokens [N,T,C] -> attention output before to_out."""
+    def self_attention(self, xn, ln=None):
+        """xn: normed tokens [N,T,C] -> attention output before to_out.  ln: xn is the RAW token tensor and this LayerNorm is
+        folded into the stacked projection (no LayerNorm launch, no normalised copy)."""
         c = self.inner_dim
-        qkv = ops.linear(xn, self._stacked(("to_q", "to_k", "to_v"), fold_q=True))
+        qkv = ops.linear(xn, self._stacked(("to_q", "to_k", "to_v"), fold_q=True, ln=ln))
         return ops.attention(qkv[..., :c], qkv[..., c:2 * c], qkv[..., 2 * c:], self.heads, self.scale, v_rows=True,
                              q_log2_scaled=True)
 
@@ -478,6 +500,8 @@ class BasicTransformerBlock(nn.Module):
             c = self.attn1.inner_dim
             a = ops.attention(qkv[..., :c], qkv[..., c:2 * c], qkv[..., 2 * c:], self.attn1.heads, self.attn1.scale, v_rows=True,
                               q_log2_scaled=True)
+        elif LN_FOLD and x.is_contiguous() and x.shape[0] * x.shape[1] >= LN_FOLD_MIN_ROWS:
+            a = self.attn1.self_attention(x, ln=self.norm1)
         else:
             a = self.attn1.self_attention(self._ln(self.norm1, x))
         if self._chain_ok(x, adapter, adapter_image):

@@ -32,6 +32,46 @@ def fp32_trunk():
     return engine_dtype() == torch.float16
 
 
+# The lidar decoder's TAIL (model.py:612-623 of the reference: two 1 x 5 ResnetBlocks, two GroupNorm + swish, the 1 x 5 output
+# convolution -- what the range view has on top of the camera decoder) with its activations to ~22 bits: every GroupNorm reads
+# the fp32 stream and writes a hi | lo pair of the storage type, every convolution multiplies the pair by duplicated weights (k
+# doubles) and writes fp32.  End to end (test_end_to_end_pixel_space, fp16): the range view then meets the north star's 1e-3 like
+# the camera picture (numbers in DESIGN.md section 5).  On with the fp32 trunk (fp16 storage); MOBI_VAE_PRECISE_TAIL=0 / 1 forces it.
+_TAIL_ENV = os.environ.get("MOBI_VAE_PRECISE_TAIL", "")
+
+
+def precise_tail():
+    if _TAIL_ENV in ("0", "1"):
+        return _TAIL_ENV == "1"
+    return fp32_trunk()
+
+
+# fp32 STREAMS (round 5): with the trunk in fp32 a ResnetBlock still rounded five tensors to the storage type -- the trunk's copy its
+# first GroupNorm reads, both GroupNorm outputs, conv1's output (read by the second GroupNorm) and conv2's output (the increment
+# added to the trunk).  Only the two GroupNorm outputs HAVE to be 16-bit (they are the convolutions' matrix-core operands): the
+# GroupNorms read fp32 (mobi_groupnorm_params.src_f32), the convolutions write fp32 (MOBI_OUT_ROWS_F32), the trunk update is an fp32
+# add (mobi_lincomb4) -- two roundings per block instead of five, no extra matrix work, twice the bytes on the fp32 tensors.
+# On with the fp32 trunk; MOBI_VAE_FP32_STREAMS=0 / 1 forces it.
+_STREAMS_ENV = os.environ.get("MOBI_VAE_FP32_STREAMS", "")
+
+
+def fp32_streams():
+    if _STREAMS_ENV in ("0", "1"):
+        return _STREAMS_ENV == "1"
+    return fp32_trunk()
+
+
+def _gn32(norm, x32, silu=True):
+    """GroupNorm (+ swish) of an fp32 stream -> the storage type (a convolution's operand)."""
+    g, b = norm.affine()
+    return ops.groupnorm(x32, g, b, norm.eps, silu=silu, dtype=engine_dtype())
+
+
+def _gn_pair(norm, x32, silu=True):
+    g, b = norm.affine()
+    return ops.groupnorm(x32, g, b, norm.eps, silu=silu, out_mode=ops.GN_OUT_SPLIT, dtype=engine_dtype())
+
+
 def Normalize(in_channels, num_groups=32):
     return GroupNorm32(num_groups, in_channels, eps=1e-6)
 
@@ -94,6 +134,21 @@ class ResnetBlock(nn.Module):
             trunk = ops.igemm(x, self.nin_shortcut.packed(), out_mode=OUT_ROWS_F32)
         return ops.trunk_add(trunk, h, x.dtype), trunk
 
+    def forward_stream(self, t32):
+        """The block on an fp32 stream (see fp32_streams): fp32 [N,H,W,Cin] -> fp32 [N,H,W,Cout]."""
+        h32 = ops.igemm(_gn32(self.norm1, t32), self.conv1.packed(), pad=self.conv1.padding, out_mode=OUT_ROWS_F32)
+        d32 = ops.igemm(_gn32(self.norm2, h32), self.conv2.packed(), pad=self.conv2.padding, out_mode=OUT_ROWS_F32)
+        if self.in_channels != self.out_channels:
+            t32 = ops.igemm(ops.trunk_add(t32, None, engine_dtype()), self.nin_shortcut.packed(), out_mode=OUT_ROWS_F32)
+        return ops.lincomb4([t32, d32], [1.0, 1.0])
+
+    def forward_precise(self, t32):
+        """The block on an fp32 stream, activations as hi | lo pairs (see precise_tail): fp32 [N,H,W,C] -> fp32."""
+        assert self.in_channels == self.out_channels
+        h32 = ops.igemm(_gn_pair(self.norm1, t32), self.conv1.packed_dup(), pad=self.conv1.padding, out_mode=OUT_ROWS_F32)
+        d32 = ops.igemm(_gn_pair(self.norm2, h32), self.conv2.packed_dup(), pad=self.conv2.padding, out_mode=OUT_ROWS_F32)
+        return ops.lincomb4([t32, d32], [1.0, 1.0])
+
 
 class AttnBlock(nn.Module):
     """Single-head attention over all h*w positions (model.py:178-202).  c = 512 does not fit the
@@ -126,6 +181,22 @@ class AttnBlock(nn.Module):
         if trunk is not None:
             return ops.trunk_add(trunk, ops.igemm(o, self.proj_out.packed()), x.dtype), trunk
         return leave(ops.igemm(o, self.proj_out.packed(), residual=x), ext)
+
+    def forward_stream(self, t32):
+        """The block on an fp32 stream: fp32 [N,H,W,C] -> fp32 (GroupNorm reads fp32, proj_out writes fp32, fp32 add)."""
+        n, h, w, c = t32.shape
+        t = h * w
+        dt = engine_dtype()
+        hn = _gn32(self.norm, t32, silu=False)
+        q = ops.igemm(hn, self.q.packed()).view(n, t, 1, c)
+        k = ops.igemm(hn, self.k.packed()).view(n, t, c)
+        vt = ops.igemm(hn, self.v.packed(), out_mode=OUT_TRANSPOSED)
+        kw = ops.Packed(k, None, 1, 1, c, t, t)
+        s = ops.igemm(q, kw, weight_per_image=True, w_group_stride=t * c, out_mode=OUT_ROWS_F32, scale=float(int(c) ** (-0.5)))
+        p = ops.softmax_rows(s.view(n * t, t), dt).view(n, t, 1, t)
+        vw = ops.Packed(vt, None, 1, 1, t, c, c)
+        o = ops.igemm(p, vw, weight_per_image=True, w_group_stride=c * t).view(n, h, w, c)
+        return ops.lincomb4([t32, ops.igemm(o, self.proj_out.packed(), out_mode=OUT_ROWS_F32)], [1.0, 1.0])
 
 
 def make_attn(in_channels, attn_type="vanilla"):
@@ -235,6 +306,29 @@ class Decoder(nn.Module):
         """z: fp32 NCHW latent -> fp32 NCHW image; `clamp=(lo, hi)` fuses the torch.clamp the
         harness applies to every decode (ddpm.py:1476,1504)."""
         zin = ops.pack_sources([z.float().contiguous()], engine_dtype())
+        if fp32_trunk() and fp32_streams():
+            dt = engine_dtype()
+            t32 = ops.igemm(zin, self.conv_in.packed_thin(), pad=(1, 1), out_mode=OUT_ROWS_F32)
+            t32 = self.mid.block_2.forward_stream(self.mid.attn_1.forward_stream(self.mid.block_1.forward_stream(t32)))
+            for i_level in reversed(range(self.num_resolutions)):
+                for i_block in range(self.num_res_blocks + 1):
+                    t32 = self.up[i_level].block[i_block].forward_stream(t32)
+                if i_level != 0:
+                    up = self.up[i_level].upsample
+                    t32 = ops.igemm(ops.trunk_add(t32, None, dt), up.conv.packed(), upsample=True, pad=(1, 1), out_mode=OUT_ROWS_F32)
+            if self.lidar_adapter:
+                # the adapter's tail (model.py:612-623): hi | lo operands where precise_tail() says so
+                blk = ResnetBlock.forward_precise if precise_tail() else ResnetBlock.forward_stream
+                t32 = blk(self.res_block_lidar1, t32)
+                g, b = self.norm_out_lidar1.affine()                       # (a new fp32 stream -- model.py:617-618)
+                u32 = ops.groupnorm(t32, g, b, self.norm_out_lidar1.eps, silu=True, out_mode=ops.GN_OUT_F32, dtype=dt)
+                u32 = blk(self.res_block_lidar2, u32)
+                norm, cout = self.norm_out_lidar2, self.conv_out_lidar
+            else:
+                u32, norm, cout = t32, self.norm_out, self.conv_out
+            if precise_tail():
+                return ops.conv_small_cout(_gn_pair(norm, u32), cout.packed_dup(), pad=cout.padding, clamp=clamp)
+            return ops.conv_small_cout(_gn32(norm, u32), cout.packed_tap_major(), pad=cout.padding, clamp=clamp)
         if fp32_trunk():
             dt = engine_dtype()
             t32 = ops.igemm(zin, self.conv_in.packed_thin(), pad=(1, 1), out_mode=OUT_ROWS_F32)
@@ -249,6 +343,13 @@ class Decoder(nn.Module):
                     up = self.up[i_level].upsample
                     t32 = ops.igemm(h, up.conv.packed(), upsample=True, pad=(1, 1), out_mode=OUT_ROWS_F32)
                     h = ops.trunk_add(t32, None, dt)
+            if self.lidar_adapter and precise_tail():
+                t32 = self.res_block_lidar1.forward_precise(t32)
+                g, b = self.norm_out_lidar1.affine()                       # (a new fp32 stream -- model.py:617-618)
+                u32 = ops.groupnorm(t32, g, b, self.norm_out_lidar1.eps, silu=True, out_mode=ops.GN_OUT_F32, dtype=dt)
+                u32 = self.res_block_lidar2.forward_precise(u32)
+                cout = self.conv_out_lidar
+                return ops.conv_small_cout(_gn_pair(self.norm_out_lidar2, u32), cout.packed_dup(), pad=cout.padding, clamp=clamp)
             if self.lidar_adapter:
                 h, t32 = self.res_block_lidar1.forward_trunk(h, t32)
                 # (GroupNorm + swish of the adapter: a new stream, not a residual update -- model.py:617-618)

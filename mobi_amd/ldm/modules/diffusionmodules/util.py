@@ -154,6 +154,12 @@ class Conv2d(_Holder):
         return self._cached("tapmajor", lambda: ops.pack_conv(self.weight, self.bias, engine_dtype(),
                                                               self.weight.device))
 
+    def packed_dup(self):
+        """The weights duplicated along the input channels ([W ; W]): the convolution of a `hi | lo` pair of a tensor
+        (ops.groupnorm(..., out_mode=GN_OUT_SPLIT)) is then W hi + W lo = W y with y to ~22 bits in one launch."""
+        return self._cached("dup", lambda: ops.pack_conv(torch.cat([self.weight, self.weight], dim=1), self.bias, engine_dtype(),
+                                                         self.weight.device))
+
     def packed_thin(self):
         """as packed(), with the (< 32) input channels zero-padded to 32 for ops.pack_sources inputs."""
         return self._cached("thin", lambda: ops.pack_conv_padded_cin(self.weight, self.bias, engine_dtype(),

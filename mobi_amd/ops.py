@@ -129,6 +129,8 @@ class Packed:
     geglu: bool = False
     k_order: int = 0                # 0: k = tap*C + c; 1: 64-channel-chunk major (mobi_igemm_params.k_order)
     wt: Optional[torch.Tensor] = None   # the same matrix as 1-KiB request images (mobi_igemm_params.weight_tiled)
+    svec: Optional[torch.Tensor] = None  # LayerNorm folded in (fold_layernorm): f32 [n_packed] row sums of the rounded W diag(gamma)
+    ln_eps: float = 0.0
 
     def __post_init__(self):
         if self.wt is None and self.k_order == 0 and self.w.dim() == 2 and self.w.is_cuda and TILED_WEIGHTS:
@@ -186,6 +188,24 @@ def pack_conv_padded_cin(weight, bias, dtype, device, cin_pad=32):
 
 def pack_linear(weight, bias, dtype, device):
     return pack_conv(weight[:, :, None, None], bias, dtype, device)
+
+
+def fold_layernorm(weight, bias, gamma, beta):
+    """Linear(LayerNorm(x)) with the LayerNorm's affine part folded into the layer (exact algebra, fp64 on the host, load-time
+    work like the other packs): LN(x) W^T + b = rstd (x (W diag gamma)^T - mean s) + (W beta + b).
+    weight [n, k], bias [n] | None, gamma / beta [k] -> (W diag(gamma) fp32, W beta + b fp32); the row sums `s` are taken from the
+    ROUNDED packed matrix (`with_row_sums`), mobi_igemm applies rstd / mean per row (mobi_igemm_params.ln_svec)."""
+    wd = weight.detach().double().cpu()
+    g, b = gamma.detach().double().cpu(), beta.detach().double().cpu()
+    bd = wd @ b + (0.0 if bias is None else bias.detach().double().cpu())
+    return (wd * g[None, :]).float(), bd.float()
+
+
+def with_row_sums(pw: Packed, eps):
+    """The pack of a LayerNorm-folded layer: + the fp32 row sums of the matrix as the kernels will read it (rounded, packed order)."""
+    pw.svec = pw.w.double().sum(dim=1).float().contiguous()
+    pw.ln_eps = float(eps)
+    return pw
 
 
 def geglu_layout(inner):
@@ -686,6 +706,10 @@ def igemm(x, pw: Packed, *, x2=None, stride=1, pad=None, upsample=False, hout=No
     p.epilogue = EPI_GEGLU if pw.geglu else EPI_NONE
     p.scale = scale
     p.k_order = pw.k_order
+    if pw.svec is not None:                                  # LayerNorm folded into this launch: never split (a block sweeps all of k)
+        assert pw.svec.dtype == torch.float32 and pw.svec.numel() == pw.n_packed and pw.bias is not None and not rowvec_has_bias
+        p.ln_svec, p.ln_eps = _ptr(pw.svec), pw.ln_eps
+        split_k = 1
     if pw.k_order and (c0 % 64 or (c1 and c1 % 64)):
         raise ValueError("chunk-major weights need 64-channel-aligned sources")
     p.dtype = _dt(x.dtype)
@@ -721,17 +745,29 @@ def linear(x, pw: Packed, **kw):
     return y if y.dim() == 3 else y.squeeze(2)
 
 
-def groupnorm(x, gamma, beta, eps, silu, x2=None):
+GN_OUT_T, GN_OUT_SPLIT, GN_OUT_F32 = 0, 1, 2
+
+
+def groupnorm(x, gamma, beta, eps, silu, x2=None, out_mode=GN_OUT_T, dtype=None):
+    """x: T or fp32 (one source) [N,H,W,C].  out_mode GN_OUT_SPLIT: T [N,H,W,2C] = hi | lo (hi = T(y), lo = T(y - hi)) for a
+    consumer whose weights are duplicated along its input channels; GN_OUT_F32: fp32 [N,H,W,C].  dtype: the storage type T when
+    x is fp32."""
     lib = _lib.load()
     n, h, w, c0 = x.shape
     c1 = 0 if x2 is None else x2.shape[3]
     assert x.is_contiguous() and (x2 is None or x2.is_contiguous())
-    out = torch.empty((n, h, w, c0 + c1), device=x.device, dtype=x.dtype)
+    src_f32 = x.dtype == torch.float32
+    t = dtype if dtype is not None else x.dtype
+    assert t in (torch.float16, torch.bfloat16) and not (src_f32 and x2 is not None)
+    oc = (c0 + c1) * (2 if out_mode == GN_OUT_SPLIT else 1)
+    out = torch.empty((n, h, w, oc), device=x.device, dtype=torch.float32 if out_mode == GN_OUT_F32 else t)
     ws = torch.empty(lib.mobi_groupnorm_workspace_bytes(n, h * w), device=x.device, dtype=torch.uint8)
     p = _lib.GroupNormParams()
     p.src0, p.src1, p.c0, p.c1, p.batch, p.hw = _ptr(x), _ptr(x2), c0, c1, n, h * w
     p.gamma, p.beta, p.eps, p.silu = _ptr(gamma), _ptr(beta), eps, int(silu)
-    p.out, p.ws, p.dtype = _ptr(out), _ptr(ws), _dt(x.dtype)
+    p.out, p.ws, p.dtype = _ptr(out), _ptr(ws), _dt(t)
+    p.src_f32, p.out_mode = int(src_f32), out_mode
+    p.sync = _ptr(_sync_counters(x.device, 4 * n))
     # algorithmic bytes: the tensor read once and written once (2 B per element each way)
     with _Timed("groupnorm", 0.0, 2.0 * out.numel() * 2, f"n={n} hw={h * w} c={c0 + c1}"):
         _lib.check(lib.mobi_groupnorm(C.byref(p), _stream()), "mobi_groupnorm")

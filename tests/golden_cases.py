@@ -30,7 +30,7 @@ def load(name):
 
 def record(name, err, tol=float("nan")):
     """When MOBI_RECORD_ERRORS names a file, append (test id, quantity, measured rel-L2, asserted tolerance): the
-    asserted tolerances are kept at <= 2x what is measured on the MI355X (profiles/r02_error_table.txt)."""
+    asserted tolerances are kept at <= 2x what is measured on the MI355X (profiles/r05_error_table.txt)."""
     path = os.environ.get("MOBI_RECORD_ERRORS")
     if path:
         test = os.environ.get("PYTEST_CURRENT_TEST", "").split(" ")[0]

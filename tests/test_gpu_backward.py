@@ -13,7 +13,7 @@ from tests.test_gpu_ops import DT, rnd
 
 pytestmark = pytest.mark.gpu
 # gradients are 16-bit tensors between the kernels (as the activations are): 2x the values measured on the MI355X
-# (profiles/r04_error_table.txt) -- one kernel; the block's data gradient; its worst parameter gradient
+# (profiles/r05_error_table.txt) -- one kernel; the block's data gradient; its worst parameter gradient
 # measured: one kernel 4.0e-4 / 3.3e-3 (fp16 / bf16, attention dK); the block's forward 6.8e-4 / 5.5e-3, its data gradient
 # 9.2e-4 / 7.5e-3, its worst parameter gradient 5.5e-3 / 3.4e-2
 TOL1 = {torch.float16: 8e-4, torch.bfloat16: 6.6e-3}

@@ -2,7 +2,7 @@
 single-token mapper and the bbox MLP as mobi_skinny_linear chains) against tests/golden/cond_producer.npz -- outputs of
 the REFERENCE's FrozenCLIPImageEmbedder / BBoxEmbedder (real ViT-L width: 1024, 16 heads x 64; reduced depth and image
 size), same seeded parameters.  Tolerance: the tower's activations are 16-bit (fp16 5e-3 / bf16 3e-2 rel-L2 on the mapped
-token, measured values in profiles/r02_error_table.txt); the bbox token is fp32 GEMVs on 16-bit weights."""
+token, measured values in profiles/r05_error_table.txt); the bbox token is fp32 GEMVs on 16-bit weights."""
 import pytest
 import torch
 

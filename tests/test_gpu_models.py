@@ -3,7 +3,7 @@
 (2) the CPU oracle on seeded inputs, including the full-width mobi_nusc_512 UNet.
 
 Tolerances (relative L2 against the fp32 reference / oracle, per storage type) are 2x the largest value measured on the
-MI355X for each group (profiles/r02_error_table.txt):
+MI355X for each group (profiles/r05_error_table.txt):
   single operators        fp16 1.3e-3  bf16 1.1e-2     (measured 6.5e-4 / 5.2e-3)
   whole UNet forward      fp16 4e-3    bf16 3e-2       (1.9e-3 / 1.5e-2)
   VAE encode / decode     fp16 4.6e-3  bf16 3.5e-2     (2.3e-3 / 1.7e-2)

@@ -20,7 +20,7 @@ pytestmark = pytest.mark.gpu
 
 DT = [torch.float16, torch.bfloat16]
 # rel-L2 of one kernel against fp32 torch on inputs pre-rounded to the storage type: 2x the largest value measured on the
-# MI355X over every case of this file (fp16 2.5e-4, bf16 2.0e-3: profiles/r02_error_table.txt)
+# MI355X over every case of this file (fp16 2.5e-4, bf16 2.0e-3: profiles/r05_error_table.txt)
 TOL = {torch.float16: 5e-4, torch.bfloat16: 4e-3}
 
 
@@ -88,6 +88,60 @@ def test_groupnorm(ops, dtype, c0, c1, hw, silu, tune):
     tune.setenv("MOBI_GN_FUSED", "1")
     y3 = ops.groupnorm(xd, g.cuda(), b.cuda(), 1e-5, silu, x2=x2d)
     assert rel(y3.float().permute(0, 3, 1, 2), ref) < TOL[dtype]
+    tune.delenv("MOBI_GN_FUSED")
+    tune.setenv("MOBI_GN_COOP", "1")                         # pixel chunks meeting through memory, wherever the geometry fits
+    for _ in range(3):                                       # (the arrival counters return to zero: the same buffer every time)
+        y4 = ops.groupnorm(xd, g.cuda(), b.cuda(), 1e-5, silu, x2=x2d)
+        assert rel(y4.float().permute(0, 3, 1, 2), ref) < TOL[dtype]
+    torch.cuda.synchronize()
+    for buf in ops._SYNC.values():
+        assert int(buf.abs().sum()) == 0
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("n,c,hw", [(16, 320, 4096), (16, 640, 1024), (16, 1280, 256), (8, 320, 1024), (3, 640, 200)])
+def test_groupnorm_chunks_meet_through_memory(ops, dtype, n, c, hw, tune):
+    """gn_coop_kernel at the step's batch sizes (a grid of up to one block per CU, 16 / 32 chunks per image): a block owns a
+    chunk of pixels x all channels, the chunks of an image exchange their partial sums through memory (device-coherent stores /
+    loads, an arrival counter, a bounded spin).  Against fp32 torch and, bit for bit, against itself on repetition."""
+    xf, xd = rnd(f"gnc{c}.{hw}", (n, 1, hw, c), dtype, 2.0)
+    xd = (xf + 0.4).to(dtype).cuda()
+    xf = xd.float().cpu()
+    g = torch.from_numpy(W.synth_param("g.weight", (c,)))
+    b = torch.from_numpy(W.synth_param("g.bias", (c,)))
+    ref = F.silu(F.group_norm(xf.permute(0, 3, 1, 2), 32, g, b, 1e-5))
+    tune.setenv("MOBI_GN_COOP", "1")
+    ys = [ops.groupnorm(xd, g.cuda(), b.cuda(), 1e-5, True) for _ in range(4)]
+    assert rel(ys[0].float().permute(0, 3, 1, 2), ref) < TOL[dtype]
+    assert all(torch.equal(ys[0], y) for y in ys[1:])
+    torch.cuda.synchronize()
+    for buf in ops._SYNC.values():
+        assert int(buf.abs().sum()) == 0
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_groupnorm_fp32_source_and_precise_outputs(ops, dtype):
+    """mobi_groupnorm_params.src_f32 / out_mode (the VAE decoder's fp32 streams and the lidar tail's hi | lo operands,
+    ldm/modules/diffusionmodules/model.py): fp32 in, storage-type out; hi | lo pair (hi + lo = the fp32 result to ~2^-22); fp32 out."""
+    n, hw, c = 2, 1024, 128
+    x = (W.synth_input("gn32.x", (n, 32, 32, c)) * 1.7 + 0.3).cuda()
+    g = torch.from_numpy(W.synth_param("g.weight", (c,)))
+    b = torch.from_numpy(W.synth_param("g.bias", (c,)))
+    ref = F.silu(F.group_norm(x.cpu().double().permute(0, 3, 1, 2), 32, g.double(), b.double(), 1e-6)).permute(0, 2, 3, 1)
+    y = ops.groupnorm(x, g.cuda(), b.cuda(), 1e-6, True, dtype=dtype)
+    assert y.dtype == dtype and rel(y.float(), ref.float()) < TOL[dtype]
+    y32 = ops.groupnorm(x, g.cuda(), b.cuda(), 1e-6, True, out_mode=ops.GN_OUT_F32, dtype=dtype)
+    assert y32.dtype == torch.float32 and rel(y32, ref.float()) < 2e-6
+    pair = ops.groupnorm(x, g.cuda(), b.cuda(), 1e-6, True, out_mode=ops.GN_OUT_SPLIT, dtype=dtype)
+    assert pair.shape == (n, 32, 32, 2 * c) and pair.dtype == dtype
+    assert torch.equal(pair[..., :c], y32.to(dtype))                          # hi = T(y)
+    both = pair[..., :c].double() + pair[..., c:].double()
+    assert rel(both.float(), y32) < (2e-6 if dtype == torch.float16 else 2e-5)  # hi + lo: 22 (fp16) / 16 (bf16) bits of y
+    # the storage-type source through the same kernels
+    xs = x.to(dtype)
+    p2 = ops.groupnorm(xs, g.cuda(), b.cuda(), 1e-6, True, out_mode=ops.GN_OUT_F32)
+    ref2 = F.silu(F.group_norm(xs.cpu().double().permute(0, 3, 1, 2), 32, g.double(), b.double(), 1e-6)).permute(0, 2, 3, 1)
+    assert rel(p2, ref2.float()) < 2e-6
 
 
 @pytest.mark.parametrize("dtype", DT)
@@ -1162,3 +1216,55 @@ def test_igemm_groups_of_images(ops, dtype, n, t, c):
     # the same through a per-matrix launch (another kernel may run it: sums in another order, a few flipped roundings)
     y0 = ops.linear(xd[:h].contiguous(), ops.pack_linear(w0, None, dtype, "cuda"), split_k=1)
     assert rel(y[:h].float(), y0.float()) < 0.1 * TOL[dtype]
+
+
+# (images, tokens, c, n_out, geglu, what)
+LN_FOLD_CASES = [
+    (16, 1024, 640, 1920, False, "256 x 320 ring tiles, register epilogue: norm1 -> [to_q; to_k; to_v] at the 32 x 32 level"),
+    (4, 1024, 640, 1280, True, "the same tiles with the GEGLU register epilogue: norm3 -> GEGLU projection"),
+    (4, 256, 1280, 3840, False, "128 x 160 tiles, 64-deep steps (one round of blocks): the 16 x 16 level"),
+    (16, 256, 1280, 1280, False, "128 x 160 tiles, 32-deep steps, two blocks per CU"),
+    (2, 100, 320, 960, False, "ragged tiles (200 rows): LDS-staged epilogue"),
+    (2, 64, 320, 320, True, "a small problem: kept off the operands-in-registers kernel"),
+]
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("case", LN_FOLD_CASES, ids=[f"lnf{i}" for i in range(len(LN_FOLD_CASES))])
+def test_igemm_layernorm_fold(ops, dtype, case):
+    """mobi_igemm_params.ln_svec: Linear(LayerNorm(x)) as ONE launch on the raw rows (attention.py:234 `attn1(norm1(x))`, :264
+    `ff(norm3(x))` of the reference) -- the packed matrix is W diag(gamma), the launch takes the row statistics from its own A
+    fragments (v_dot2c in the MFMA shadow) and applies rstd (acc - mean s) + (W beta + b) in the accumulator domain.  Against
+    fp32 torch's layer_norm + linear (+ GEGLU) on the same rounded inputs, and against the two-launch form of the engine."""
+    n, t, c, n_out, geglu, _what = case
+    xf, xd = rnd("lnf.x", (n, t, c), dtype, scale=1.5)
+    xf = xf + 0.25                                          # a mean that is not zero
+    xd = xf.to(dtype).cuda()
+    xf = xd.float().cpu()
+    rows = n_out * (2 if geglu else 1)
+    w = torch.from_numpy(W.synth_param("lnf.w", (rows, c)))
+    b = torch.from_numpy(W.synth_param("lnf.b", (rows,)))
+    gamma = 1.0 + 0.3 * torch.from_numpy(W.synth_param("lnf.g", (c,))) * c ** 0.5 * 0.1
+    beta = torch.from_numpy(W.synth_param("lnf.be", (c,))) * 2.0
+    eps = 1e-5
+    wf, bf = ops.fold_layernorm(w, b, gamma, beta)
+    pack = ops.pack_geglu if geglu else ops.pack_linear
+    pw = ops.with_row_sums(pack(wf, bf, dtype, "cuda"), eps)
+    y = ops.linear(xd, pw)
+    # reference: the folded layer as the engine rounds it (W diag(gamma) to the storage type), statistics in fp64
+    wr = wf.to(dtype).double()
+    x64 = xf.double()
+    mean, var = x64.mean(-1, keepdim=True), x64.var(-1, unbiased=False, keepdim=True)
+    rstd = 1.0 / torch.sqrt(var + eps)
+    pre = rstd * (x64 @ wr.t() - mean * wr.sum(1)) + bf.double()
+    ref = pre[..., :n_out] * F.gelu(pre[..., n_out:]) if geglu else pre
+    assert y.shape == ref.shape
+    assert rel(y.float(), ref.float()) < TOL[dtype]
+    # the same layer the reference's way (LayerNorm, then the un-folded Linear): equal up to the storage type's rounding of the
+    # normalised rows, which the fold does not have
+    ln = F.layer_norm(x64, (c,), gamma.double(), beta.double(), eps)
+    pre2 = ln @ w.double().t() + b.double()
+    ref2 = pre2[..., :n_out] * F.gelu(pre2[..., n_out:]) if geglu else pre2
+    assert rel(y.float(), ref2.float()) < 2 * TOL[dtype]
+    y2 = ops.linear(ops.layernorm(xd, gamma.cuda(), beta.cuda(), eps), pack(w, b, dtype, "cuda"))
+    assert rel(y2.float(), ref2.float()) < 2 * TOL[dtype]

@@ -13,7 +13,8 @@ reference ... within a stated fp16 tolerance"), inside the driver-run `-m gpu` s
     256x256 camera image and one 256x256 range view.
   * the ping-pong igemm race screen (tools/race_screen.py).
 
-Tolerances = 2x the values measured on the MI355X (profiles/r02_error_table.txt), stated per storage type.
+Tolerances = at most 2x the values measured on the MI355X (profiles/r05_error_table.txt, written by the suite itself under
+MOBI_RECORD_ERRORS), stated per storage type.
 """
 import functools
 import os
@@ -29,7 +30,7 @@ from tests.test_gpu_models import _unet, _vae
 pytestmark = pytest.mark.gpu
 
 DT = [torch.float16, torch.bfloat16]
-# rel-L2 vs the fp32 CPU oracle, <= 2x the values measured on the MI355X this round (profiles/r02_error_table.txt): full
+# rel-L2 vs the fp32 CPU oracle, <= 2x the values measured on the MI355X (profiles/r05_error_table.txt; first measured in round 2): full
 # width forward fp16 1.36e-3 / bf16 1.07e-2 (worst pair 2.09e-3 / 1.36e-2); VAE 1.76e-3 / 1.43e-2; DDIM-50 3.9e-4 / 2.97e-3
 # without guidance (the 1e-3 of fp16 is the north star's own number), 1.03e-3 / 9.2e-3 with scale 5; DDIM-250 3.5e-4
 TOL_FULL = {torch.float16: 2.6e-3, torch.bfloat16: 1.9e-2}          # one full-width UNet forward
@@ -195,11 +196,14 @@ def test_pingpong_race_screen():
 
 
 # ---- end to end at production width, pixel space (BASELINE config 1's workload; north star: 1e-3 rel-L2) ---------------
-# measured on the MI355X (profiles/r04_error_table.txt, profiles/r04_parity.json): fp16 (decoder trunk in fp32, the default of that
-# storage type) latent 4.1e-4 / 5.2e-4 (64 x 64 / 32 x 32), camera picture 9.1e-4 / 9.8e-4, range view 1.24e-3 / 1.37e-3;
-# bf16 latent 3.5e-3 / 4.0e-3, pictures 0.97 - 1.40e-2.  The fp16 bounds of the latent AND of the camera picture are the north
-# star's 1e-3 itself (the arithmetic is bit-reproducible: fixed-order reductions); the rest is asserted at 2x the measurement.
-TOL_E2E = {(torch.float16, "latent"): 1e-3, (torch.float16, "pixel_camera"): 1e-3, (torch.float16, "pixel_range"): 2.8e-3,
+# measured on the MI355X (profiles/r05_error_table.txt, profiles/r05_parity.json): fp16 (the decoders on fp32 streams, the lidar
+# tail on hi | lo operands: the defaults of that storage type) latent 4.6e-4 / 5.0e-4 (64 x 64 / 32 x 32), camera picture 8.5e-4 /
+# 9.1e-4, range view 1.13e-3 / 1.21e-3 (round 4: 1.24 / 1.37e-3); bf16 latent 3.8e-3 / 4.2e-3, pictures 0.98 - 1.42e-2.  The fp16
+# bounds of the latent AND of the camera picture are the north star's 1e-3 itself (the arithmetic is bit-reproducible: fixed-order
+# reductions).  The range view does not meet it, and profiles/r05_decoder_err.txt says why: on the ORACLE's latent the lidar
+# decoder is at 8.8e-4 (16-bit trunk 1.57e-3, fp32 trunk 1.08e-3, fp32 streams 9.2e-4, + precise tail 8.8e-4), and the sampler's
+# 4.6e-4 of latent error becomes another 7.1e-4 in the range view (3.7e-4 in the camera picture): asserted at 1.5e-3.
+TOL_E2E = {(torch.float16, "latent"): 1e-3, (torch.float16, "pixel_camera"): 1e-3, (torch.float16, "pixel_range"): 1.5e-3,
            (torch.bfloat16, "latent"): 8e-3, (torch.bfloat16, "pixel_camera"): 2.8e-2, (torch.bfloat16, "pixel_range"): 2.8e-2}
 
 

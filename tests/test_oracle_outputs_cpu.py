@@ -23,6 +23,15 @@ def test_file_holds_every_case():
         assert np.isfinite(f[f"vae512_{tag}_moments"]).all() and np.isfinite(f[f"vae512_{tag}_decode"].astype(np.float32)).all()
     for k in ("ddim_1.0", "ddim_5.0", "plms_1.0", "plms_5.0", "mask_eta1"):
         assert f["traj10_" + k].shape == (4, 4, 16, 16) and np.isfinite(f["traj10_" + k]).all()
+    # the 50-step end-to-end cases (tests/oracle_cases.py e2e_long: ~45 minutes of CPU, generated once): present, finite, and
+    # really other trajectories than the 10-step case they share their inputs with
+    for side, kind in ((32, "ddim50"), (32, "plms50_cfg5"), (64, "ddim50")):
+        R = 8 * side
+        smp = f[f"e2e{side}_{kind}_samples"]
+        assert smp.shape == (2, 4, side, side) and smp.dtype == np.float32 and np.isfinite(smp).all()
+        assert f[f"e2e{side}_{kind}_image"].shape == (1, 3, R, R) and f[f"e2e{side}_{kind}_range"].shape == (1, 2, R, R)
+        assert np.abs(f[f"e2e{side}_{kind}_image"].astype(np.float32)).max() <= 1.0
+        assert float(np.abs(smp - f[f"e2e{side}_samples"]).max()) > 1e-3
 
 
 def test_sample_recomputed_live():

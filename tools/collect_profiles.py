@@ -39,6 +39,15 @@ def main():
     cp("vae_prof.txt", "vae_encode_decode.txt")
     cp("chain_lab.txt", "chain_lab.txt")
     cp("chain_stamps.txt", "chain_stamps.txt")
+    # end-to-end parity as the GPU suite of the same build last measured it (tests/test_gpu_production.py writes
+    # gpurun_out/parity_last.json, tied to the library's hash): kept with the commit it was measured at
+    plast = os.path.join(ROOT, "gpurun_out", "parity_last.json")
+    if os.path.exists(plast):
+        import subprocess as sp
+        doc = json.load(open(plast))
+        doc["commit"] = sp.run(["git", "-C", ROOT, "rev-parse", "--short=12", "HEAD"], capture_output=True, text=True).stdout.strip() or None
+        with open(os.path.join(dst, f"{tag}_parity.json"), "w") as f:
+            json.dump(doc, f, indent=1)
     bench = line_of(os.path.join(src, "bench.json"))
     pmc = json.load(open(os.path.join(src, "pmc_traffic.json")))
     rows = list(csv.DictReader(open(os.path.join(src, "kernel_stats.csv"))))
@@ -136,7 +145,13 @@ def main():
              ("splitk_sweep_512.txt", "split-K sweep of the mobi_nusc_512 step's small-m shapes on the current build (tools/sweep_split.py)"),
              ("splitk_sweep_256.txt", "the same for mobi_nusc_256"),
              ("ab_attn_h16.txt", "A/B of the 16x16x32 P.V form of dh = 40 attention (tools/ab_attn_h16.sh: slower, off by default)"),
-             ("ab_row_chain.txt", "whole-step A/B of the row chains"), ("ab_prechain.txt", "the pre-attention chain (slower, off by default)")]
+             ("ab_row_chain.txt", "whole-step A/B of the row chains"), ("ab_prechain.txt", "the pre-attention chain (slower, off by default)"),
+             ("fused_split_lab.txt", "split-K finished inside the launch against slabs + reduce launch (tools/fsplit_lab.py: slower, off by default)"),
+             ("ab_grouped_q_ln_fold.txt", "whole-step A/B of the grouped cross-modal to_q launch and of the LayerNorm fold (tools/ab_cfg.sh)"),
+             ("ln_fold_launches.txt", "per-launch times with the LayerNorm fold on / off"),
+             ("gn_lab.txt", "GroupNorm forms per shape incl. the chunked one-launch kernel (tools/gn_lab.py)"),
+             ("decoder_err.txt", "the decoders' own error on the oracle's latent, by precision option (tools/decoder_err.py)"),
+             ("conc_lab.txt", "two independent half batches on two streams against one batch (tools/conc_lab.py)")]
     have = set(os.listdir(dst))
     for suffix, what in known:
         if f"{tag}_{suffix}" in have:

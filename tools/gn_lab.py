@@ -19,6 +19,12 @@ SHAPES_512 = [(4096, 320, 0, 13), (4096, 640, 320, 2), (4096, 960, 320, 1), (102
               (256, 1920, 640, 1), (256, 2560, 1280, 2), (64, 1280, 0, 12), (64, 2560, 1280, 3)]
 
 
+# mobi_nusc_256 (run with --images 8)
+SHAPES_256 = [(1024, 320, 0, 13), (1024, 640, 320, 2), (1024, 960, 320, 1), (256, 320, 0, 1), (256, 640, 0, 11),
+              (256, 960, 320, 1), (256, 1280, 640, 1), (256, 1920, 640, 1), (64, 640, 0, 1), (64, 1280, 0, 11),
+              (64, 1920, 640, 1), (64, 2560, 1280, 2), (16, 1280, 0, 12), (16, 2560, 1280, 3)]
+
+
 def timeit(fns, iters):
     """Device time per launch: the rotation is captured in a HIP graph (the host cannot issue 5-us kernels fast enough)."""
     side = torch.cuda.Stream()
@@ -51,15 +57,17 @@ def main():
     ap.add_argument("--images", type=int, default=16)
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--iters", type=int, default=24)
+    ap.add_argument("--set", default="512", choices=["512", "256"])
     a = ap.parse_args()
     from mobi_amd import _lib, build, ops
     build.build(verbose=False)
     dt = torch.bfloat16 if a.dtype == "bf16" else torch.float16
     g = torch.Generator(device="cpu").manual_seed(0)
-    forms = (("two-launch", "0"), ("lds", "1"), ("registers", None))
+    # (MOBI_GN_FUSED, MOBI_GN_COOP): the register form without the chunked kernel, and the chunked kernel wherever it fits
+    forms = (("two-launch", ("0", "0")), ("lds", ("1", "0")), ("registers", (None, "0")), ("chunks", (None, "1")))
     total = {t: 0.0 for t, _ in forms}
     print(f"GroupNorm(32)+SiLU, {a.images} images, {a.dtype}; us per launch (algorithmic GB/s at 2 B read + 2 B written)")
-    for hw, c, c1, n in SHAPES_512:
+    for hw, c, c1, n in (SHAPES_512 if a.set == "512" else SHAPES_256):
         mb = a.images * hw * c * 2 / 1e6
         copies = max(2, min(12, int(600 / mb)))               # > 256 MB of distinct inputs where that is cheap
         xs = [(torch.randn(a.images, hw, c, generator=g) * 1.5 + 0.3).to("cuda").to(dt) for _ in range(2)]
@@ -81,16 +89,18 @@ def main():
         best, err = {}, {}
         for rep in range(3):
             for tag, env in forms:
-                if env is None:
-                    os.environ.pop("MOBI_GN_FUSED", None)
-                else:
-                    os.environ["MOBI_GN_FUSED"] = env
+                for var, val in zip(("MOBI_GN_FUSED", "MOBI_GN_COOP"), env):
+                    if val is None:
+                        os.environ.pop(var, None)
+                    else:
+                        os.environ[var] = val
                 _lib.load().mobi_tuning_reload()
                 if rep == 0:
                     out = fns[0]().float().view(a.images, hw, c)
                     err[tag] = float((out - ref).norm() / ref.norm())
                 best[tag] = min(best.get(tag, 1e30), timeit(fns, a.iters))
         os.environ.pop("MOBI_GN_FUSED", None)
+        os.environ.pop("MOBI_GN_COOP", None)
         _lib.load().mobi_tuning_reload()
         for t in total:
             total[t] += best[t] * n
