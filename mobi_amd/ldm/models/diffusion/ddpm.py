@@ -486,7 +486,7 @@ class LatentDiffusion(DDPM):
         from .... import train
         params = {"model.diffusion_model." + n: p for n, p in self.model.diffusion_model.named_parameters()
                   if any(m in n for m in train.TRAINABLE_MARKERS)}
-        params.update(self._cond_stage_trainables())
+        params.update(LatentDiffusion._cond_stage_trainables(self))
         opt = train.AdamW(params, lr=getattr(self, "learning_rate", 1e-4))
         if self.use_scheduler:
             assert "target" in self.scheduler_config

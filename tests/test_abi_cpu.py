@@ -33,7 +33,7 @@ def test_struct_layouts_match(lib):
     for sid, cls in _lib.STRUCT_IDS.items():
         assert lib.mobi_struct_size(sid) == C.sizeof(cls), cls.__name__
     assert lib.mobi_struct_size(99) == 0
-    assert lib.mobi_abi_version() == 4 == _lib.ABI_VERSION
+    assert lib.mobi_abi_version() == 5 == _lib.ABI_VERSION
     assert lib.mobi_error_string(-2) == b"unsupported shape or mode"
 
 
@@ -42,6 +42,15 @@ def test_argument_validation_without_gpu(lib):
     from mobi_amd import _lib
     p = _lib.IgemmParams()
     assert lib.mobi_igemm(C.byref(p), None) == -1                      # null pointers
+    p.src0 = p.weight = p.out = 4096
+    p.c0, p.batch, p.hin, p.win, p.hout, p.wout, p.kh, p.kw, p.stride, p.groups = 64, 4, 8, 8, 8, 8, 3, 3, 1, 1
+    p.pad_h = p.pad_w = 1
+    p.cout = p.n_packed = 64
+    p.scale, p.ln_svec = 1.0, 4096
+    assert lib.mobi_igemm(C.byref(p), None) == -2                      # LayerNorm fold: 1 x 1 launches only
+    p.ln_svec, p.groups = None, 3
+    assert lib.mobi_igemm(C.byref(p), None) == -1                      # groups: a divisor of batch
+    assert lib.mobi_igemm_sync_bytes(C.byref(p), 1) == 0 and lib.mobi_igemm_sync_bytes(C.byref(p), 4) == 2 * 4   # 256 rows x 64 channels
     a = _lib.AttentionParams()
     a.q = a.k = a.vt = a.out = 16
     a.images = a.heads = a.tq = a.tk = 1
@@ -54,6 +63,12 @@ def test_argument_validation_without_gpu(lib):
     g.c0, g.batch, g.hw = 48, 1, 4
     assert lib.mobi_groupnorm(C.byref(g), None) == -2                  # channels % 32 != 0
     assert lib.mobi_groupnorm_workspace_bytes(2, 4096) == 2 * 64 * 32 * 2 * 4
+    assert lib.mobi_groupnorm_workspace_bytes(2, 256) == 2 * 32 * 32 * 2 * 4     # (at least 32 chunks per image: the chunked kernel)
+    g.c0, g.src_f32, g.c1, g.src1 = 64, 1, 32, 16
+    assert lib.mobi_groupnorm(C.byref(g), None) == -2                  # an fp32 source is one source
+    g.c1, g.src1, g.out_mode = 0, None, 3
+    assert lib.mobi_groupnorm(C.byref(g), None) == -1                  # out_mode 0 .. 2
+    g.src_f32, g.out_mode, g.c0 = 0, 0, 48
     assert lib.mobi_groupnorm_workspace_bytes(0, 10) == 0
     assert lib.mobi_tile_weights(16, 4096, 24, 32, None) == -2         # rows % 16
     assert lib.mobi_tile_weights(16, 4096, 32, 48, None) == -2         # k % 32

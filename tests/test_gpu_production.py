@@ -328,12 +328,16 @@ def test_end_to_end_pixel_space(dtype, side):
 
 
 # ---- the same at the shipped invocation's length: 50 steps (VERDICT r04 "missing" #4) ---------------------------------------
-# (dtype, kind, quantity) -> bound = 2x the value measured on the MI355X (profiles/r05_error_table.txt)
+# (dtype, kind, quantity) -> bound: at most 2x the value measured on the MI355X (profiles/r05_error_table.txt); the fp16 DDIM-50
+# bounds of the latent and of the camera picture are the north star's 1e-3 itself.  Measured, fp16: DDIM-50 latent 4.3e-4 / 3.9e-4
+# (32 x 32 / 64 x 64), camera picture 9.0e-4 / 8.4e-4, range view 1.18e-3 / 1.08e-3; PLMS-50 at guidance 5 latent 5.8e-4, camera
+# 1.00e-3, range view 1.71e-3 (guidance multiplies the difference of two UNet evaluations by 5).  bf16: 3.4 - 5.0e-3 / 0.9 - 2.0e-2.
+# (The reference pictures of these cases are stored in fp16: ~1.6e-4 of rounding noise that counts against the engine.)
 TOL_E2E_LONG = {
-    (torch.float16, "ddim50"): dict(latent=2.0e-3, pixel_camera=3.0e-3, pixel_range=3.0e-3),
-    (torch.bfloat16, "ddim50"): dict(latent=1.6e-2, pixel_camera=4.0e-2, pixel_range=4.0e-2),
-    (torch.float16, "plms50_cfg5"): dict(latent=5.0e-3, pixel_camera=8.0e-3, pixel_range=8.0e-3),
-    (torch.bfloat16, "plms50_cfg5"): dict(latent=4.0e-2, pixel_camera=1.0e-1, pixel_range=1.0e-1),
+    (torch.float16, "ddim50"): dict(latent=1.0e-3, pixel_camera=1.0e-3, pixel_range=1.5e-3),
+    (torch.bfloat16, "ddim50"): dict(latent=7.3e-3, pixel_camera=2.1e-2, pixel_range=2.75e-2),
+    (torch.float16, "plms50_cfg5"): dict(latent=1.2e-3, pixel_camera=2.0e-3, pixel_range=3.4e-3),
+    (torch.bfloat16, "plms50_cfg5"): dict(latent=1.0e-2, pixel_camera=1.9e-2, pixel_range=4.0e-2),
 }
 
 
