@@ -83,8 +83,9 @@ def parity_record(side, dtype):
             parity = {**one(dtype), "other_storage_type": one(other), "case": key, "source": rel_path,
                       "measured_with_lib_sha16": sha, "measured_at_commit": pj.get("commit"),
                       "matches_this_build": bool(sha) and sha == lib_sha16()}
-            meets = {d: all(rec[d][q] <= NORTH_STAR_REL_L2 for q in ("latent_rel_l2", "pixel_rel_l2_camera", "pixel_rel_l2_range"))
-                     for d in ("bf16", "fp16") if d in rec}
+            qs = ("latent_rel_l2", "pixel_rel_l2_camera", "pixel_rel_l2_range")
+            meets = {d: all(rec[d][q] <= NORTH_STAR_REL_L2 for q in qs) for d in ("bf16", "fp16") if d in rec}
+            meets["over_tolerance"] = {d: {q: rec[d][q] for q in qs if rec[d][q] > NORTH_STAR_REL_L2} for d in ("bf16", "fp16") if d in rec}
             meets["tolerance"] = NORTH_STAR_REL_L2
             meets["quantities"] = "rel-L2 vs the CPU oracle of the final latent, the decoded camera picture and the decoded range view"
             return {"parity": parity, "meets": meets}

@@ -19,6 +19,8 @@
 //   igemm_kernel       128- / 256-pixel tiles staged through registers: operands beyond 2 GB, chunk-major k
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "common.h"
 #include "tuning.h"
 #include "igemm_small.h"
@@ -2166,25 +2168,31 @@ __global__ __launch_bounds__(NW * 64, 2) void igemm_ring_kernel(const IgemmArgs 
         acc[ni][mi] = TR ? mfma16(xf[mi], wf[ni], acc[ni][mi]) : mfma16(wf[ni], xf[mi], acc[ni][mi]);
     __builtin_amdgcn_s_setprio(0);
   };
-  // LayerNorm fold: the wave's share of the A fragments (SPW of the MT of its wave row: fragments SPW * wn + i) is read from LDS
-  // a second time into registers of its own -- an address, not a register index, depends on the wave -- and 8 v_dot2c per
-  // fragment sum the rows and their squares between the step's MFMAs (no branch in the loop: a scalar branch per candidate
-  // fragment cost the 256 x 320 tiles 20 % of their rate)
-  const unsigned char* xrd_s = xrd + (SPW * (wave_s >> 1)) * 16 * 64;
-  auto read_stat_frags = [&](int s, frag_t (&sf)[SPW]) {
-    const int so = (s & 3) * SLOT;
-#pragma unroll
-    for (int i = 0; i < SPW; ++i) sf[i] = __builtin_bit_cast(frag_t, ld16(xrd_s + so + i * 16 * 64));
-  };
-  auto multiply_stats = [&](const frag_t (&xf)[MT], const frag_t (&wf)[NT], const frag_t (&sf)[SPW]) {
+  // LayerNorm fold: the wave's share of the A fragments (SPW of the MT of its wave row: fragments SPW * wn + i) are among the
+  // fragments it multiplies anyway -- WHICH of them is a register index, so the k loop below is compiled once per wn (a generic
+  // lambda over an integral constant, one scalar branch in front of the loop) and 8 v_dot2c per fragment sum the rows and their
+  // squares between the step's MFMAs.  Two forms lost before this one (profiles/r05_ln_fold_launches.txt): a scalar branch per
+  // candidate fragment INSIDE the loop (+20 % per launch), and a second LDS read of the share into registers of its own (+9 ... 14 %:
+  // two more fragment reads in the LOAD phase, the longer one of the two).
+  auto multiply_stats = [&](const frag_t (&xf)[MT], const frag_t (&wf)[NT], auto wnc) {
+    constexpr int WNC = decltype(wnc)::value;
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int ni = 0; ni < NT; ++ni)
 #pragma unroll
       for (int mi = 0; mi < MT; ++mi) {
         acc[ni][mi] = TR ? mfma16(xf[mi], wf[ni], acc[ni][mi]) : mfma16(wf[ni], xf[mi], acc[ni][mi]);
-        if (ni == 0 && mi < SPW) rowstat_acc(sf[mi], ls_sum[mi], ls_sq[mi]);
+        if (ni == 0 && mi < SPW) rowstat_acc(xf[SPW * WNC + mi], ls_sum[mi], ls_sq[mi]);
       }
+    // the order the scheduler has to keep: one v_dot2c behind every second MFMA (left alone the whole chain is sunk into the
+    // loop's latch block, behind the last MFMA)
+#pragma unroll
+    for (int i = 0; i < 8 * SPW; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+      __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < SPW; ++i) asm volatile("" : "+v"(ls_sum[i]), "+v"(ls_sq[i]));   // (the sums are "used" here: no sinking)
     __builtin_amdgcn_s_setprio(0);
   };
 #define MOBI_RING_BARRIER()                   \
@@ -2195,6 +2203,7 @@ __global__ __launch_bounds__(NW * 64, 2) void igemm_ring_kernel(const IgemmArgs 
   } while (0)
 
   issue_step(); issue_step(); issue_step();
+  auto k_loop = [&](auto wnc) {                              // (wnc: the wave's column index as a constant -- LayerNorm fold only)
   if constexpr (WIDE && MOBI_RING_STAGGER) {
     // Two waves share a SIMD (w and w + 4).  In lockstep both read / request, then both queue on the one matrix
     // pipe; here waves 4-7 run HALF A STEP behind waves 0-3: every step is a LOAD phase (fragment reads, the requests
@@ -2218,9 +2227,8 @@ __global__ __launch_bounds__(NW * 64, 2) void igemm_ring_kernel(const IgemmArgs 
       MOBI_WP(0);
       MOBI_RING_BARRIER();
       MOBI_WP(1);
-      frag_t xf[MT], wf[NT], sf[SPW];
+      frag_t xf[MT], wf[NT];
       read_frags(s, xf, wf);
-      if constexpr (lnf) read_stat_frags(s, sf);
       __builtin_amdgcn_sched_barrier(0);
       issue_step();
       __builtin_amdgcn_sched_barrier(0);
@@ -2231,7 +2239,7 @@ __global__ __launch_bounds__(NW * 64, 2) void igemm_ring_kernel(const IgemmArgs 
       MOBI_WP(4);
       MOBI_RING_BARRIER();
       MOBI_WP(5);
-      if constexpr (lnf) multiply_stats(xf, wf, sf); else multiply(xf, wf);
+      if constexpr (lnf) multiply_stats(xf, wf, wnc); else multiply(xf, wf);
 #if MOBI_STAMP == 4
       asm volatile("s_nop 0" ::: "memory");
 #endif
@@ -2265,16 +2273,15 @@ __global__ __launch_bounds__(NW * 64, 2) void igemm_ring_kernel(const IgemmArgs 
       MOBI_RP(1);
       MOBI_RING_BARRIER();
       MOBI_RP(2);
-      frag_t xf[MT], wf[NT], sf[SPW];
+      frag_t xf[MT], wf[NT];
       read_frags(s, xf, wf);
-      if constexpr (lnf) read_stat_frags(s, sf);
       __builtin_amdgcn_sched_barrier(0);
       issue_step();                                          // step s + 3, behind the reads' latency
       __builtin_amdgcn_sched_barrier(0);
       MOBI_RP(3);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       MOBI_RP(4);
-      if constexpr (lnf) multiply_stats(xf, wf, sf); else multiply(xf, wf);
+      if constexpr (lnf) multiply_stats(xf, wf, wnc); else multiply(xf, wf);
 #if MOBI_STAMP == 4
       asm volatile("s_nop 0" ::: "memory");
       MOBI_RP(5);
@@ -2289,6 +2296,16 @@ __global__ __launch_bounds__(NW * 64, 2) void igemm_ring_kernel(const IgemmArgs 
     }
 #endif
 #undef MOBI_RP
+  }
+  };
+  if constexpr (lnf) {
+    const int wn_s = wave_s >> 1;
+    if (wn_s == 0) k_loop(std::integral_constant<int, 0>{});
+    else if (wn_s == 1 || NW == 4) k_loop(std::integral_constant<int, 1>{});
+    else if (wn_s == 2) k_loop(std::integral_constant<int, NW == 8 ? 2 : 0>{});
+    else k_loop(std::integral_constant<int, NW == 8 ? 3 : 0>{});
+  } else {
+    k_loop(std::integral_constant<int, 0>{});
   }
 #undef MOBI_RING_BARRIER
   MOBI_STAMP_AT(2);
@@ -2523,6 +2540,8 @@ __global__ __launch_bounds__(256, 1) void igemm_ring64_kernel(const IgemmArgs a)
   const unsigned char* wrd = lds + BM * 128 + (wn * WAVE_N + r16) * 128;
 
   issue_step(); issue_step(); issue_step();
+  auto k_loop = [&](auto wnc) {                              // (compiled once per wave column: LayerNorm fold, see igemm_ring_kernel)
+  constexpr int WNC = decltype(wnc)::value;
 #pragma clang loop unroll(disable)
   for (int s = ks_begin; s < ks_end; ++s) {
     wait_step();
@@ -2530,7 +2549,7 @@ __global__ __launch_bounds__(256, 1) void igemm_ring64_kernel(const IgemmArgs a)
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
     const int so = (s & (SL - 1)) * SLOT;
-    frag_t xf[2][MT], wf[2][NT], sf[2][SPW];
+    frag_t xf[2][MT], wf[2][NT];
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       const int sw = ((ks * 4 + g4) ^ (r16 & 7)) << 4;
@@ -2538,11 +2557,6 @@ __global__ __launch_bounds__(256, 1) void igemm_ring64_kernel(const IgemmArgs a)
       for (int mi = 0; mi < MT; ++mi) xf[ks][mi] = __builtin_bit_cast(frag_t, ld16(xrd + so + mi * 16 * 128 + sw));
 #pragma unroll
       for (int ni = 0; ni < NT; ++ni) wf[ks][ni] = __builtin_bit_cast(frag_t, ld16(wrd + so + ni * 16 * 128 + sw));
-      if constexpr (lnf) {                                   // the wave's own share of the A fragments once more (an address, not
-#pragma unroll                                               // a register index, depends on the wave): LayerNorm fold
-        for (int i = 0; i < SPW; ++i)
-          sf[ks][i] = __builtin_bit_cast(frag_t, ld16(xrd + so + (SPW * (wave_s >> 1) + i) * 16 * 128 + sw));
-      }
     }
     __builtin_amdgcn_sched_barrier(0);
     issue_step();                                            // step s + 3, behind the reads' latency
@@ -2556,9 +2570,24 @@ __global__ __launch_bounds__(256, 1) void igemm_ring64_kernel(const IgemmArgs a)
 #pragma unroll
         for (int mi = 0; mi < MT; ++mi) {
           acc[ni][mi] = TR ? mfma16(xf[ks][mi], wf[ks][ni], acc[ni][mi]) : mfma16(wf[ks][ni], xf[ks][mi], acc[ni][mi]);
-          if constexpr (lnf) if (ni == 0 && mi < SPW) rowstat_acc(sf[ks][mi], ls_sum[mi], ls_sq[mi]);   // behind the first MFMAs
+          if constexpr (lnf) if (ni == 0 && mi < SPW) rowstat_acc(xf[ks][SPW * WNC + mi], ls_sum[mi], ls_sq[mi]);
         }
+    if constexpr (lnf) {                                     // one v_dot2c behind every MFMA (see igemm_ring_kernel)
+#pragma unroll
+      for (int i = 0; i < 16 * SPW; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
+      }
+#pragma unroll
+      for (int i = 0; i < SPW; ++i) asm volatile("" : "+v"(ls_sum[i]), "+v"(ls_sq[i]));
+    }
     __builtin_amdgcn_s_setprio(0);
+  }
+  };
+  if constexpr (lnf) {
+    if ((wave_s >> 1) == 0) k_loop(std::integral_constant<int, 0>{}); else k_loop(std::integral_constant<int, 1>{});
+  } else {
+    k_loop(std::integral_constant<int, 0>{});
   }
   if constexpr (lnf) ln_fold_acc<NT, MT, SPW>(a, acc, ls_sum, ls_sq, s_rowstat, lane, wm, wave_s >> 1, n0 + wn * WAVE_N, false);
   if constexpr (!TR) {
