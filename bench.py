@@ -467,20 +467,24 @@ def main():
         # dominant kernel: the implicit-GEMM main loop that takes the most time of the step -- the library says which
         # variant every launch runs (mobi_igemm_kernel_variant): igemm_pp_kernel<...> (persistent direct-to-LDS,
         # ping-pong schedule), igemm_glds_kernel<...> (same geometry, lockstep) or igemm_kernel<...> (register-staged)
-        by_variant = {}
+        # (a launch with a LayerNorm folded in -- tag suffix `_ln`, an instantiation of its own -- belongs to its tile geometry's
+        #  main loop when the dominant kernel is chosen; `families` lists it apart)
+        by_variant, by_variant_split = {}, {}
         for kind, flops, e0, e1, nb, tag in sink:
             if kind != "igemm":
                 continue
             var = tag.split(" ")[0].replace("kern=", "") if tag.startswith("kern=") else "igemm"
-            d = by_variant.setdefault(var, dict(launches=0, flops=0.0, ms=0.0, bytes=0.0))
-            d["launches"] += 1
-            d["flops"] += flops
-            d["ms"] += e0.elapsed_time(e1)
-            d["bytes"] += nb
+            for table, key in ((by_variant, var[:-3] if var.endswith("_ln") else var), (by_variant_split, var)):
+                d = table.setdefault(key, dict(launches=0, flops=0.0, ms=0.0, bytes=0.0))
+                d["launches"] += 1
+                d["flops"] += flops
+                d["ms"] += e0.elapsed_time(e1)
+                d["bytes"] += nb
         dom = max(by_variant, key=lambda v: by_variant[v]["ms"]) if by_variant else "igemm"
         dk = by_variant.get(dom, ig)
         kname = {"pingpong": "igemm_pp_kernel", "direct_lds": "igemm_glds_kernel", "staged128": "igemm_kernel",
                  "staged256": "igemm_kernel", "ring128": "igemm_ring_kernel", "ring256": "igemm_ring_kernel", "ring128w": "igemm_ring_kernel",
+                 "ring256_ln": "igemm_ring_kernel", "ring128_ln": "igemm_ring_kernel",
                  "small": "small_gemm_kernel"}.get(dom, "igemm_kernel")
         ach = dk["flops"] / (dk["ms"] * 1e-3) / 1e12
         # which roof bounds the kernel's launches of this step taken together: their matrix time at the dense peak against
@@ -525,7 +529,7 @@ def main():
         # every family of the step against ITS roof (matrix families: algorithmic FLOP/s over the dense peak; bandwidth
         # families: algorithmic bytes/s over 8 TB/s), and the step if every launch ran at the better of its two roofs
         fam = {}
-        for v, d in by_variant.items():
+        for v, d in by_variant_split.items():
             fam[f"igemm_{v}"] = {"ms": round(d["ms"], 3), "launches": d["launches"],
                                  "tflops": round(d["flops"] / (d["ms"] * 1e-3) / 1e12, 1),
                                  "frac": round(d["flops"] / (d["ms"] * 1e-3) / 1e12 / PEAK_TFLOPS, 4)}

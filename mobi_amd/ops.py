@@ -725,6 +725,8 @@ def igemm(x, pw: Packed, *, x2=None, stride=1, pad=None, upsample=False, hout=No
     tag = ""
     if _PROFILE is not None:
         kern = ("staged128", "staged256", "direct_lds", "pingpong", "ring128", "ring256", "ring128w", "small")[lib.mobi_igemm_kernel_variant(C.byref(p))]
+        if pw.svec is not None:
+            kern += "_ln"                                    # the LayerNorm-folded instantiation (another kernel symbol)
         tag = f"kern={kern} m={n * hout * wout} n={pw.n_packed} k={pw.kh * pw.kw * pw.cin} tap={pw.kh}x{pw.kw} " \
               f"split={splits} mode={out_mode}"
     with _Timed("igemm", flops, nbytes, tag):

@@ -39,6 +39,9 @@ def main():
     cp("vae_prof.txt", "vae_encode_decode.txt")
     cp("chain_lab.txt", "chain_lab.txt")
     cp("chain_stamps.txt", "chain_stamps.txt")
+    for name in ("graph_breakdown.txt", "mall_share.txt", "vae_decode_fp16.txt", "nusc256_kernel_stats.csv", "train_kernel_stats.csv",
+                 "nusc256_pmc_traffic.json", "train_step.txt"):        # tools/profile_more.sh
+        cp(name, name)
     # end-to-end parity as the GPU suite of the same build last measured it (tests/test_gpu_production.py writes
     # gpurun_out/parity_last.json, tied to the library's hash): kept with the commit it was measured at
     plast = os.path.join(ROOT, "gpurun_out", "parity_last.json")
@@ -68,8 +71,9 @@ def main():
     # igemm_ring_kernel has two geometries in one name: the dominant variant is the eight-wave 256 x 320 (256) tile (<..., 8, 8>),
     # the four-wave 128 x 160 tile (<..., 4, 4>, the small-m launches) is another family of the bench line
     var = max(roof.get("igemm_ms_by_variant", {"": 0}), key=lambda v: roof.get("igemm_ms_by_variant", {"": 0})[v])
-    if kname == "igemm_ring_kernel" and var in ("ring256", "ring128"):
-        want = ", 8, 8>" if var == "ring256" else ", 4, 4>"
+    if kname == "igemm_ring_kernel" and var in ("ring256", "ring128", "ring256_ln", "ring128_ln"):
+        # (template arguments: ..., NW, MT, LNF -- the LayerNorm-folded instantiations are kernels of their own)
+        want = (", 8, 8, " if var.startswith("ring256") else ", 4, 4, ") + ("true>" if var.endswith("_ln") else "false>")
         dom = [r for r in dom if want in r["Name"]] or dom
     calls = sum(int(r["Calls"]) for r in dom)
     tot_ns = sum(float(r["TotalDurationNs"]) for r in dom)
@@ -151,7 +155,12 @@ def main():
              ("ln_fold_launches.txt", "per-launch times with the LayerNorm fold on / off"),
              ("gn_lab.txt", "GroupNorm forms per shape incl. the chunked one-launch kernel (tools/gn_lab.py)"),
              ("decoder_err.txt", "the decoders' own error on the oracle's latent, by precision option (tools/decoder_err.py)"),
-             ("conc_lab.txt", "two independent half batches on two streams against one batch (tools/conc_lab.py)")]
+             ("conc_lab.txt", "two independent half batches on two streams against one batch (tools/conc_lab.py)"),
+             ("mall_share.txt", "Infinity-Cache share of the ring kernel's counter traffic: the step's launch against one scaled past 256 MiB (tools/mall_share.sh)"),
+             ("vae_decode_fp16.txt", "fp16 VAE decode / encode of 8 images at 512 x 512 by precision option (fp32 trunk / streams / hi | lo tail)"),
+             ("ab_ln_fold.txt", "whole-step A/B of the shipped LayerNorm fold, both workloads (slow-group box)"),
+             ("ab_chain_ff.txt", "row chains / one-launch feed-forward re-measured against the one-by-one sequences as they are now"),
+             ("tile_geometry_lab.txt", "the small-m 1 x 1 shapes on every tile geometry: ~10 us of fixed cost per launch (tools/wide_lab.py)")]
     have = set(os.listdir(dst))
     for suffix, what in known:
         if f"{tag}_{suffix}" in have:
@@ -160,8 +169,8 @@ def main():
     for name in sorted(have):
         if name.startswith(tag + "_") and name not in listed:
             lines.append(f"* `{name}`")
-    lines.append("* the igemm main-loop A/Bs, split-K sweeps and the attention / GroupNorm / adapter / feed-forward labs of the kernels this "
-                 "round left untouched are rounds 2-3's (`r02_*`, `r03_*`)")
+    lines.append("* the igemm main-loop A/Bs, split-K sweeps and the attention / adapter / feed-forward / row-chain labs of the kernels this "
+                 "round left untouched are rounds 2-4's (`r02_*`, `r03_*`, `r04_*`)")
     with open(os.path.join(dst, f"{tag}_README.md"), "w") as f:
         f.write("\n".join(lines) + "\n")
     print("\n".join(lines[:16]))

@@ -4,7 +4,7 @@ set -u
 OUT=$PWD/gpurun_out/gb
 mkdir -p $OUT
 export TMPDIR=/tmp
-F="--steps 8 --warmup 2 --no-cpu-baseline --no-roofline --no-e2e --no-plms-line --no-fp16-line"
+F="--steps 8 --warmup 2 --no-cpu-baseline --no-roofline --no-e2e --no-plms-line --no-fp16-line --no-config-lines"
 rocprofv3 --kernel-trace --output-format csv -d $OUT/g512 -- python3 bench.py $F > $OUT/b512.json 2> $OUT/g512.err
 python tools/graph_gaps.py $OUT/g512 $(python -c "import json;print(json.loads(open('$OUT/b512.json').read().strip().splitlines()[-1]).get('launches_per_step',460))") > $OUT/breakdown512.txt 2>&1
 rocprofv3 --kernel-trace --output-format csv -d $OUT/g256 -- python3 bench.py --workload mobi_nusc_256 $F > $OUT/b256.json 2> $OUT/g256.err
