@@ -661,6 +661,64 @@ def main():
                 d_ = float(tm.item())
             return d_, bool(torch.isfinite(x_).all()), [int(v) for v in smp.ddim_timesteps[:3]] + [int(smp.ddim_timesteps[-1])]
 
+        def timed_in_flight(smps, n_el, sd):
+            """Every sampler of `smps` owns a request (its own latents, conditioning and step graph; the weights are shared) and
+            a stream; a step = one denoising step of EVERY request, issued round-robin.  What a server with several requests
+            queued gets out of the card: a second stream's launches fill the ramp / drain of the first's."""
+            gg = torch.Generator(device="cpu").manual_seed(8765 + rank)
+            mk2 = lambda *s_: torch.randn(*s_, generator=gg).to(device)
+            reqs = []
+            for smp in smps:
+                m_ = torch.ones(n_el, 1, sd, sd)
+                m_[:, :, sd // 4: 3 * sd // 4, sd // 4: 3 * sd // 4] = 0
+                reqs.append({"smp": smp, "x": mk2(n_el, 4, sd, sd), "c": mk2(n_el, 2, 768), "st": torch.cuda.Stream(device=device),
+                             "kw": {"test_model_kwargs": {"inpaint_image": mk2(n_el, 4, sd, sd), "inpaint_mask": m_.to(device)}}})
+            tot = smps[0].ddim_timesteps.shape[0]
+            desc = list(reversed(smps[0].ddim_timesteps.tolist()))
+
+            def stp_all(i):
+                index = tot - 1 - (i % tot)
+                step = int(desc[i % tot])
+                for r in reqs:
+                    with torch.cuda.stream(r["st"]):
+                        ts = torch.full((n_el,), step, device=device, dtype=torch.long)
+                        r["x"] = r["smp"].p_sample_ddim(r["x"], r["c"], ts, index=index, step_value=step, **r["kw"])[0]
+
+            with torch.no_grad():
+                for r in reqs:
+                    r["st"].wait_stream(torch.cuda.current_stream())
+                for i in range(max(args.warmup, 1)):
+                    stp_all(i)
+                barrier()
+                t0_ = time.perf_counter()
+                for i in range(args.steps):
+                    stp_all(args.warmup + i)
+                barrier()
+                d_ = time.perf_counter() - t0_
+            if world > 1:
+                tm = torch.tensor([d_], device=red_dev)
+                dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+                d_ = float(tm.item())
+            return d_, all(bool(torch.isfinite(r["x"]).all()) for r in reqs)
+
+        def in_flight_record(n_el, sd, gf, what):
+            smps = []
+            for _ in range(2):
+                s_ = DDIMSampler(model, graph=not args.no_graph)
+                s_.make_schedule(50, ddim_eta=0.0, verbose=False)
+                smps.append(s_)
+            d_, fin_ = timed_in_flight(smps, n_el, sd)
+            v_ = args.steps / d_ * 2 * n_el * world
+            return {"config": f"NOT a BASELINE configuration -- TWO independent requests of {what} in flight on two streams (own latents, "
+                              f"conditioning and step graphs, shared weights): the card's throughput when requests queue up",
+                    "dtype": args.dtype, "steps": args.steps, "requests_in_flight": 2,
+                    "ms_per_step_of_both": round(d_ / args.steps * 1e3, 3), "ms_per_step_per_request": round(d_ / args.steps * 1e3 / 2, 3),
+                    "value": round(v_, 3), "unit": "UNet element-forwards/s", "model_tflops": round(v_ * gf / 1e3 / world, 2),
+                    "model_frac_of_peak": round(v_ * gf / 1e3 / world / PEAK_TFLOPS, 4), "finite": fin_}
+
+        if not args.no_graph:
+            config_lines["in_flight2"] = in_flight_record(N, side, wl["gflop_per_element"] - wl["gflop_skippable"],
+                                                          f"this line's batch ({B} objects, UNet batch {N})")
         if unet_params("mobi_nusc_256.yaml") == unet_params("mobi_nusc_512.yaml"):
             w2 = WORKLOADS["mobi_nusc_256"]
             s256 = DDIMSampler(model, graph=not args.no_graph)
@@ -675,6 +733,8 @@ def main():
                 "unit": "UNet element-forwards/s", "model_tflops": round(v2 * gf2 / 1e3 / world, 2),
                 "model_frac_of_peak": round(v2 * gf2 / 1e3 / world / PEAK_TFLOPS, 4), "finite": fin2}
             del s256
+            if not args.no_graph:
+                config_lines["nusc256_in_flight2"] = in_flight_record(n2, w2["latent"], gf2, "configs[1]'s batch (4 objects, UNet batch 8)")
         mobi_amd.set_engine_dtype(torch.float16)
         s250 = DDIMSampler(model, graph=not args.no_graph)
         s250.make_schedule(250, ddim_eta=0.0, verbose=False)

@@ -13,6 +13,7 @@ from contextlib import contextmanager
 from functools import partial
 
 import numpy as np
+import math
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -419,8 +420,12 @@ class LatentDiffusion(DDPM):
         uncond = c is not cond_was_given and self.u_cond_prop < self.u_cond_percent
         t = t_draw if t is None else t
         x_noisy, target = self._noised_input(x, t, noise)
-        if loss_scale is None:                   # fp16 gradients underflow at production sizes without it; bf16 has the range
-            loss_scale = 1024.0 if engine_dtype() == torch.float16 else 1.0
+        if loss_scale is None:
+            # fp16 gradients underflow without it; bf16 has the range.  The gradient that enters the network is
+            # 2 (eps - target) / numel, so the scale follows numel (a power of two near numel / 4: the entering gradient is
+            # O(1) at every batch size) -- measured on the full-width network at 64 x 64, one pair: all 432 gradients 1.6e-2
+            # off with a fixed 256, 1.7e-3 with 8,192 (tests/test_gpu_backward.py, full width)
+            loss_scale = 2.0 ** round(math.log2(max(4, target.numel()) / 4)) if engine_dtype() == torch.float16 else 1.0
         logvar_t = self.logvar[t].to(self.device)                      # (zeros unless a checkpoint says otherwise)
         if bool((logvar_t != 0).any()):
             raise NotImplementedError("per-timestep logvar weights in the backward pass")

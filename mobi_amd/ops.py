@@ -53,7 +53,7 @@ class _Timed:
 # stream, join makes the caller's stream wait on every side stream.  Graph-capture safe (events only).
 # --------------------------------------------------------------------------------------
 _SIDE = {}
-_CONCURRENT = os.environ.get("MOBI_CONCURRENCY", "0") == "1"     # measured: no gain on MI355X (kernels already fill the chip)
+_CONCURRENT = os.environ.get("MOBI_CONCURRENCY", "0") == "1"     # measured: SLOWER inside the step graph (fork / join edges: +0.2 ms per mobi_nusc_512 step, +0.35 per mobi_nusc_256 step, profiles/r05_ab_graph_branches.txt)
 
 
 def set_concurrency(flag):

@@ -201,6 +201,72 @@ def test_unet_training_step_gradients_vs_autograd(dtype):
     assert max(errs.values()) < TOL_UNET[dtype][1], max(errs.items(), key=lambda kv: kv[1])
 
 
+# the same at the production width: (all 432 gradients as one vector, the worst single tensor), 2x the values measured on the
+# MI355X (profiles/r05_error_table.txt): side 16 -- 2.0e-3 / 1.5e-2 (fp16), 1.33e-2 / 6.8e-2 (bf16); side 64 -- 1.67e-3 / 4.6e-3
+# (fp16, loss scale 8192), 1.35e-2 / 2.6e-1 (bf16: the cross-modal to_q / to_k weights of the 32 x 32 level, whose gradients
+# pass through the softmax backward's 8-bit P and dS).  fp16 at side 64 with loss scale 256 UNDERFLOWS (the gradient that
+# enters the network is 2 (eps - target) / 32,768: all 1.6e-2, single tensors wrong by 3x) -- `training_step` scales by
+# numel / 4, see ddpm.py
+TOL_UNET_FULL = {(16, torch.float16): (4e-3, 3e-2), (16, torch.bfloat16): (2.7e-2, 1.4e-1),
+                 (64, torch.float16): (3.4e-3, 1e-2), (64, torch.bfloat16): (2.7e-2, 5.2e-1)}
+
+
+@pytest.mark.parametrize("side,dtype,loss_scale", [(16, torch.float16, 256.0), (16, torch.bfloat16, 1.0),
+                                                   (64, torch.float16, 8192.0), (64, torch.bfloat16, 1.0)])
+def test_unet_training_step_gradients_full_width(side, dtype, loss_scale):
+    """The PRODUCTION network (model_channels 320, 1.04 B parameters) on one camera / lidar pair: loss, the gradient of all 432
+    adapter tensors and of the box token against torch.autograd through the CPU oracle's UNet.  side = 16: the K = 23,040 data
+    gradients and the 1,280-channel levels at their real width; side = 64 (mobi_nusc_512's latent): the T = 4,096 / dh = 40
+    attention backward and the 64 x 64 GroupNorm backward inside the whole network (ddpm.py:1177-1217, 1616-1633 of the
+    reference).  The oracle pass is some 10 s (16) / a minute or two (64) of CPU work."""
+    import mobi_amd
+    from mobi_amd import train
+    from tests.test_gpu_production import _full_width_net, _threads
+    mobi_amd.set_engine_dtype(dtype)
+    _threads()
+    cfg = ounet.UNetConfig()
+    assert cfg.model_channels == 320
+    if side == 64:                               # ~30 GB of saved attention probabilities in the oracle's autograd graph
+        avail = [int(l.split()[1]) for l in open("/proc/meminfo") if l.startswith("MemAvailable")][0] / 2 ** 20
+        if avail < 96:
+            pytest.skip(f"{avail:.0f} GiB of host memory available: the oracle's autograd pass at 64 x 64 needs more")
+    net = _full_width_net()                      # (one synthesis of the 1.04 B weights per test process)
+    sd = {k: v.detach().float().cpu() for k, v in net.state_dict().items()}
+    n = 2
+    x = W.synth_input(f"bw.full{side}.x", (n, 9, side, side))
+    ctx = W.synth_input(f"bw.full{side}.ctx", (n, 2, 768))
+    noise = W.synth_input(f"bw.full{side}.noise", (n, 4, side, side))
+    t = torch.tensor([741, 741], dtype=torch.long)
+    names = train.trainable_names(net)
+    assert len(names) == 432
+    chosen = set(names)
+    ps = {k: (v.clone().requires_grad_(True) if k in chosen else v) for k, v in sd.items()}
+    ctx = ctx.clone().requires_grad_(True)
+    print(f"full width side {side}: oracle forward + autograd on the host ...", flush=True)
+    ref = ounet.unet_forward(ps, cfg, x, t, ctx)
+    ref_loss = torch.mean((ref - noise) ** 2)
+    ref_loss.backward()
+    del ref
+    print(f"full width side {side}: engine step ...", flush=True)
+    loss, grads = train.loss_and_gradients(net, x.cuda(), t.cuda(), ctx.detach().cuda(), noise.cuda(), loss_scale=loss_scale)
+    dctx = grads.pop("__dcontext__")
+    tol_all, tol_one = TOL_UNET_FULL[(side, dtype)]
+    assert rel(dctx[:, 1], ctx.grad[:, 1], "dcontext") < tol_one
+    assert sorted(grads) == sorted(names)
+    assert abs(float(loss) - float(ref_loss.detach())) / float(ref_loss.detach()) < TOL_DX[dtype]
+    errs = {k: rel(grads[k], ps[k].grad, "dw") for k in names}
+    flat_g = torch.cat([grads[k].reshape(-1).double().cpu() for k in names])
+    flat_r = torch.cat([ps[k].grad.reshape(-1).double() for k in names])
+    whole = float((flat_g - flat_r).norm() / flat_r.norm())
+    record("all_adapter_gradients_full_width", whole)
+    worst = max(errs.items(), key=lambda kv: kv[1])
+    record("worst_adapter_gradient_full_width", worst[1])
+    print(f"full width side {side} {dtype} x{loss_scale}: all {whole:.3e} worst {worst[1]:.3e} ({worst[0]}) dcontext "
+          f"{float((dctx[:, 1].double().cpu() - ctx.grad[:, 1].double()).norm() / ctx.grad[:, 1].double().norm()):.3e}")
+    assert whole < tol_all, whole
+    assert worst[1] < tol_one, worst
+
+
 def test_bbox_embedder_backward_and_adamw(ops):
     """The conditioning stage's trainable part (ddpm.py:1635-1647 of the reference): BBoxEmbedder (modules.py:63-91) forward with a
     tape and its backward pass against torch.autograd on the same fp32 layers; one AdamW update (`mobi_adamw_step`) against

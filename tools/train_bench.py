@@ -4,6 +4,7 @@ whole UNet + AdamW on the 432 adapter tensors) -- informational: the backward ke
 
     python tools/train_bench.py [--mc 320] [--side 32] [--n 4] [--dtype bf16] [--iters 3]"""
 import argparse
+import math
 import os
 import sys
 import time
@@ -42,7 +43,7 @@ def main():
     def step(profile=False):
         if profile:
             ops.set_profiler(sink)
-        loss, grads = train.loss_and_gradients(net, x, t, ctx, noise, loss_scale=1.0 if dt == torch.bfloat16 else 1024.0)
+        loss, grads = train.loss_and_gradients(net, x, t, ctx, noise, loss_scale=1.0 if dt == torch.bfloat16 else 2.0 ** round(math.log2(noise.numel() / 4)))
         grads.pop("__dcontext__", None)
         opt.step(grads)
         ops.set_profiler(None)
