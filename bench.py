@@ -84,10 +84,21 @@ def parity_record(side, dtype):
                       "measured_with_lib_sha16": sha, "measured_at_commit": pj.get("commit"),
                       "matches_this_build": bool(sha) and sha == lib_sha16()}
             qs = ("latent_rel_l2", "pixel_rel_l2_camera", "pixel_rel_l2_range")
-            meets = {d: all(rec[d][q] <= NORTH_STAR_REL_L2 for q in qs) for d in ("bf16", "fp16") if d in rec}
-            meets["over_tolerance"] = {d: {q: rec[d][q] for q in qs if rec[d][q] > NORTH_STAR_REL_L2} for d in ("bf16", "fp16") if d in rec}
+            # a storage type MEETS the tolerance when every DDIM run measured for it does -- the DDIM-10 case and, where the suite
+            # wrote it, the DDIM-50 case (every BASELINE configuration samples with DDIM); the shipped script's PLMS-50 at guidance
+            # 5 is reported beside it, as are the runs of every case the file holds
+            runs = {f"{case_key.split(' ')[0]}:{name}": {q: r[q] for q in qs}
+                    for case_key, crec in pj.items() if isinstance(crec, dict)
+                    for name, r in crec.items() if isinstance(r, dict) and all(q in r for q in qs)}
+            ddim = lambda d: [v for k, v in runs.items() if k.split(":")[1] in (d, d + "_ddim50")]
+            meets = {d: all(v[q] <= NORTH_STAR_REL_L2 for v in ddim(d) for q in qs) for d in ("bf16", "fp16") if ddim(d)}
+            meets["over_tolerance"] = {k: {q: v[q] for q in qs if v[q] > NORTH_STAR_REL_L2} for k, v in runs.items()
+                                       if any(v[q] > NORTH_STAR_REL_L2 for q in qs)}
+            meets["runs"] = sorted(runs)
             meets["tolerance"] = NORTH_STAR_REL_L2
-            meets["quantities"] = "rel-L2 vs the CPU oracle of the final latent, the decoded camera picture and the decoded range view"
+            meets["quantities"] = ("rel-L2 vs the CPU oracle of the final latent, the decoded camera picture and the decoded range view; "
+                                   "bf16 / fp16: every DDIM run of the file (10 and 50 steps, both resolutions); *_plms50_cfg5: the shipped "
+                                   "script's sampler, listed under over_tolerance when it is over")
             return {"parity": parity, "meets": meets}
         except (OSError, KeyError, StopIteration, ValueError, TypeError):
             continue

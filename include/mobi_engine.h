@@ -42,7 +42,7 @@ extern "C" {
  *      MOBI_IGEMM_SMALL; mobi_tile_weights
  *   5  mobi_igemm_params.sync + mobi_igemm_sync_bytes (split-K finished inside the launch); mobi_igemm_params.groups may be
  *      any divisor of batch; mobi_igemm_params.ln_svec / ln_eps (LayerNorm folded into the consuming launch);
- *      mobi_groupnorm_params.src_f32 / out_mode */
+ *      mobi_groupnorm_params.src_f32 / out_mode (0..3); mobi_split_f32 */
 #define MOBI_ABI_VERSION 5
 
 enum { MOBI_OK = 0, MOBI_ERR_ARG = -1, MOBI_ERR_UNSUPPORTED = -2, MOBI_ERR_LAUNCH = -3, MOBI_ERR_ALIGN = -4 };
@@ -175,7 +175,9 @@ typedef struct mobi_groupnorm_params {
   int32_t src_f32;         /* 1: src0 is f32 [batch][hw][c0] (no src1): the VAE decoder's fp32 streams */
   int32_t out_mode;        /* 0: T [batch][hw][C].  1: T [batch][hw][2 C] = hi | lo, hi = T(y), lo = T(y - hi): a convolution
                               whose weights are duplicated along its input channels then multiplies y to ~22 bits (the lidar
-                              decoder's tail of the fp16 parity configuration, model.py:612-623).  2: f32 [batch][hw][C] */
+                              decoder's tail of the fp16 parity configuration, model.py:612-623).  2: f32 [batch][hw][C].
+                              3: T [batch][hw][3 C] = hi | lo | hi, for weights [W ; W ; W - T(W)]: the weights' own rounding is
+                              corrected as well (the decoders of the fp16 parity configuration, model.py:559-630) */
   void* sync;              /* optional: int32 [batch] arrival counters, ZERO before the launch and zero again after it (one buffer
                               serves every launch of a stream).  With them the library may run the one-launch form whose workgroups
                               own pixel chunks and meet through memory (large groups: the 64 x 64 level); NULL: never. */
@@ -338,6 +340,10 @@ int mobi_row_chain(const mobi_row_chain_params* p, void* stream);
  * reference run in fp32): trunk (f32, n elements, updated in place) += inc (T), x16 = T(trunk) -- the 16-bit copy the next
  * GroupNorm / convolution reads.  inc == NULL: only the conversion.  n % 8 == 0. */
 int mobi_trunk_add(float* trunk, const void* inc, void* x16, int64_t n, int32_t dtype, void* stream);
+/* The operand form of mobi_groupnorm's out_mode 1 / 3 for an fp32 tensor no GroupNorm stands in front of (the inputs of the
+ * decoders' upsampling convolutions and 1 x 1 shortcuts, model.py:60-80, 136-139 of the reference): x f32 [rows][channels] ->
+ * out T [rows][parts * channels] = hi | lo (parts 2) or hi | lo | hi (parts 3), hi = T(x), lo = T(x - hi).  channels % 8 == 0. */
+int mobi_split_f32(const float* x, void* out, int64_t rows, int32_t channels, int32_t parts, int32_t dtype, void* stream);
 
 /* ---------------------------------------------------------------------------
  * Backward pass of the transformer block (FIRST SLICE: the training step of the adapter

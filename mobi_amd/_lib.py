@@ -191,6 +191,7 @@ SYMBOLS = {
     "mobi_row_chain_adapter_image_bytes": (C.c_size_t, [i32]),
     "mobi_row_chain_adapter_image": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, i32, vp, vp]),
     "mobi_trunk_add": (C.c_int, [vp, vp, vp, i64, i32, vp]),
+    "mobi_split_f32": (C.c_int, [vp, vp, i64, i32, i32, i32, vp]),
     "mobi_transpose": (C.c_int, [vp, i64, vp, i32, i32, i32, vp]),
     "mobi_tile_weights": (C.c_int, [vp, vp, i32, i32, vp]),
     "mobi_backward_partial_blocks": (i32, [i64]),

@@ -31,7 +31,8 @@ struct GnArgs {
   int* sync;       // gn_coop_kernel: one arrival counter per image (zero before and after the launch), or NULL
   int src_f32;     // 1: src0 is f32 (one source): the VAE decoder's fp32 streams
   int out_mode;    // 0: T [..][C];  1: T [..][2 C] = hi | lo with hi = T(y), lo = T(y - hi) (a consumer with duplicated weights then
-                   //    multiplies y to ~22 bits);  2: f32 [..][C]
+                   //    multiplies y to ~22 bits);  2: f32 [..][C];  3: T [..][3 C] = hi | lo | hi (weights [W ; W ; W - T(W)]: the weights'
+                   //    rounding corrected too)
 };
 
 template <typename T>
@@ -297,13 +298,15 @@ __global__ __launch_bounds__(256) void gn_apply_x_kernel(const GnArgs a) {
       float* o = reinterpret_cast<float*>(a.out) + (ibase + p) * a.C + c;
       *reinterpret_cast<f32x4*>(o) = f32x4{f[0], f[1], f[2], f[3]};
       *reinterpret_cast<f32x4*>(o + 4) = f32x4{f[4], f[5], f[6], f[7]};
-    } else if (a.out_mode == 1) {
-      T* o = reinterpret_cast<T*>(a.out) + (ibase + p) * (2 * a.C) + c;
+    } else if (a.out_mode == 1 || a.out_mode == 3) {
+      T* o = reinterpret_cast<T*>(a.out) + (ibase + p) * ((a.out_mode == 3 ? 3 : 2) * a.C) + c;
       float hi[8], lo[8];
 #pragma unroll
       for (int j = 0; j < 8; ++j) { hi[j] = (float)(T)f[j]; lo[j] = f[j] - hi[j]; }
-      st16(o, pack8<T>(hi));
+      const u32x4 h8 = pack8<T>(hi);
+      st16(o, h8);
       st16(o + a.C, pack8<T>(lo));
+      if (a.out_mode == 3) st16(o + 2 * a.C, h8);
     } else {
       st16(reinterpret_cast<T*>(a.out) + (ibase + p) * a.C + c, pack8<T>(f));
     }
@@ -986,7 +989,7 @@ extern "C" int mobi_groupnorm(const mobi_groupnorm_params* p, void* stream) {
   a.gamma = p->gamma; a.beta = p->beta; a.eps = p->eps; a.silu = p->silu;
   a.out = p->out; a.ws = reinterpret_cast<float*>(p->ws);
   if (p->src_f32 != 0 && p->src_f32 != 1) return MOBI_ERR_ARG;
-  if (p->out_mode < 0 || p->out_mode > 2) return MOBI_ERR_ARG;
+  if (p->out_mode < 0 || p->out_mode > 3) return MOBI_ERR_ARG;
   if (p->src_f32 && p->c1) return MOBI_ERR_UNSUPPORTED;
   a.src_f32 = p->src_f32; a.out_mode = p->out_mode;
   if (reinterpret_cast<uintptr_t>(p->sync) & 3) return MOBI_ERR_ALIGN;

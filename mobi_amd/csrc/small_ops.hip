@@ -1458,6 +1458,40 @@ __global__ __launch_bounds__(256) void trunk_add_kernel(float* __restrict__ trun
 }
 }  // namespace mobi
 
+// fp32 rows -> their hi | lo (| hi) split in the storage type (the operand form of mobi_groupnorm's out_mode 1 / 3 for tensors no
+// GroupNorm stands in front of: the inputs of the decoders' upsampling convolutions and 1 x 1 shortcuts).  8 channels per thread.
+namespace mobi {
+template <typename T>
+__global__ __launch_bounds__(256) void split_f32_kernel(const float* __restrict__ x, T* __restrict__ out, long long vecs, int C, int parts) {
+  const int V = C >> 3;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < vecs; i += (long long)gridDim.x * 256) {
+    const long long row = i / V;
+    const int c = (int)(i - row * V) * 8;
+    float f[8], hi[8], lo[8];
+    ld8f(x + row * C + c, f);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { hi[j] = (float)(T)f[j]; lo[j] = f[j] - hi[j]; }
+    T* o = out + row * (long long)(parts * C) + c;
+    const u32x4 h8 = pack8<T>(hi);
+    st16(o, h8);
+    st16(o + C, pack8<T>(lo));
+    if (parts == 3) st16(o + 2 * C, h8);
+  }
+}
+}  // namespace mobi
+
+extern "C" int mobi_split_f32(const float* x, void* out, int64_t rows, int32_t channels, int32_t parts, int32_t dtype, void* stream) {
+  using namespace mobi;
+  if (!x || !out || rows <= 0 || channels <= 0 || (channels & 7) || (parts != 2 && parts != 3) || !DT_OK(dtype)) return MOBI_ERR_ARG;
+  if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(out)) & 15) return MOBI_ERR_ALIGN;
+  const long long vecs = rows * (channels >> 3);
+  const unsigned g = grid_for(vecs, 256, 16384);
+  if (dtype == MOBI_F16) hipLaunchKernelGGL((split_f32_kernel<f16_t>), dim3(g), dim3(256), 0, ST(stream), x, (f16_t*)out, vecs, channels, parts);
+  else hipLaunchKernelGGL((split_f32_kernel<bf16_t>), dim3(g), dim3(256), 0, ST(stream), x, (bf16_t*)out, vecs, channels, parts);
+  MOBI_CHECK_LAUNCH();
+  return MOBI_OK;
+}
+
 extern "C" int mobi_trunk_add(float* trunk, const void* inc, void* x16, int64_t n, int32_t dtype, void* stream) {
   using namespace mobi;
   if (!trunk || !x16 || n <= 0 || (n & 7) || !DT_OK(dtype)) return MOBI_ERR_ARG;

@@ -35,8 +35,8 @@ def fp32_trunk():
 # The lidar decoder's TAIL (model.py:612-623 of the reference: two 1 x 5 ResnetBlocks, two GroupNorm + swish, the 1 x 5 output
 # convolution -- what the range view has on top of the camera decoder) with its activations to ~22 bits: every GroupNorm reads
 # the fp32 stream and writes a hi | lo pair of the storage type, every convolution multiplies the pair by duplicated weights (k
-# doubles) and writes fp32.  End to end (test_end_to_end_pixel_space, fp16): the range view then meets the north star's 1e-3 like
-# the camera picture (numbers in DESIGN.md section 5).  On with the fp32 trunk (fp16 storage); MOBI_VAE_PRECISE_TAIL=0 / 1 forces it.
+# doubles) and writes fp32.  Superseded as the default by precise_level() below (every convolution of both decoders); what the tail
+# ALONE buys is still measurable: MOBI_VAE_PRECISE=0 MOBI_VAE_PRECISE_TAIL=1 (tests/decoder_err.py; numbers in DESIGN.md section 5).
 _TAIL_ENV = os.environ.get("MOBI_VAE_PRECISE_TAIL", "")
 
 
@@ -59,6 +59,40 @@ def fp32_streams():
     if _STREAMS_ENV in ("0", "1"):
         return _STREAMS_ENV == "1"
     return fp32_trunk()
+
+
+# PRECISE DECODERS (round 5): with fp32 streams what is left of a decoder's error are the roundings of the convolutions' 16-bit
+# OPERANDS -- the activations (GroupNorm outputs, the upsampling convolutions' and 1 x 1 shortcuts' inputs, the latent) and the
+# weights, about half each (tests/decoder_err.py: range view 8.8e-4 -> 6.2e-4 with the activations split, -> 1.8e-4 with the
+# weights split too).  Level 1: every convolution multiplies hi | lo activation pairs by duplicated weights [W ; W] (k doubles).
+# Level 2: hi | lo | hi against [W ; W ; W - T(W)] (k triples): T(W) hi + T(W) lo + (W - T(W)) hi -- both operands to ~22 bits, the
+# lo x lo term is below fp32's own rounding.  No kernel knows about it: the GroupNorm / split launches write the operand form
+# (mobi_groupnorm out_mode 1 / 3, mobi_split_f32), the implicit GEMM sees a wider k.  Both decoders; fp16 end to end (DDIM): camera
+# picture 8.5e-4 -> 3.7e-4, range view 1.13e-3 -> 7.0e-4; a decode of 8 images at 512 x 512 takes 75 / 86 ms
+# instead of 37 / 46 (camera / lidar).  Default: level 2 with the fp32 streams (fp16
+# storage), 0 with bf16; MOBI_VAE_PRECISE=0 / 1 / 2 forces it.
+_PRECISE_ENV = os.environ.get("MOBI_VAE_PRECISE", "")
+
+
+def precise_level():
+    if _PRECISE_ENV in ("0", "1", "2"):
+        return int(_PRECISE_ENV)
+    return 2 if (fp32_trunk() and fp32_streams()) else 0
+
+
+def _gn_split(norm, x32, level, silu=True):
+    """GroupNorm (+ swish) of an fp32 stream -> the hi | lo (| hi) operand of a convolution with _w_split weights."""
+    g, b = norm.affine()
+    return ops.groupnorm(x32, g, b, norm.eps, silu=silu, out_mode=ops.GN_OUT_SPLIT3 if level == 2 else ops.GN_OUT_SPLIT,
+                         dtype=engine_dtype())
+
+
+def _split(t32, level):
+    return ops.split_f32(t32, engine_dtype(), 3 if level == 2 else 2)
+
+
+def _w_split(conv, level):
+    return conv.packed_dup3() if level == 2 else conv.packed_dup()
 
 
 def _gn32(norm, x32, silu=True):
@@ -142,11 +176,12 @@ class ResnetBlock(nn.Module):
             t32 = ops.igemm(ops.trunk_add(t32, None, engine_dtype()), self.nin_shortcut.packed(), out_mode=OUT_ROWS_F32)
         return ops.lincomb4([t32, d32], [1.0, 1.0])
 
-    def forward_precise(self, t32):
-        """The block on an fp32 stream, activations as hi | lo pairs (see precise_tail): fp32 [N,H,W,C] -> fp32."""
-        assert self.in_channels == self.out_channels
-        h32 = ops.igemm(_gn_pair(self.norm1, t32), self.conv1.packed_dup(), pad=self.conv1.padding, out_mode=OUT_ROWS_F32)
-        d32 = ops.igemm(_gn_pair(self.norm2, h32), self.conv2.packed_dup(), pad=self.conv2.padding, out_mode=OUT_ROWS_F32)
+    def forward_precise(self, t32, level=1):
+        """The block on an fp32 stream, the convolutions' operands split (see precise_level): fp32 [N,H,W,Cin] -> fp32 [N,H,W,Cout]."""
+        h32 = ops.igemm(_gn_split(self.norm1, t32, level), _w_split(self.conv1, level), pad=self.conv1.padding, out_mode=OUT_ROWS_F32)
+        d32 = ops.igemm(_gn_split(self.norm2, h32, level), _w_split(self.conv2, level), pad=self.conv2.padding, out_mode=OUT_ROWS_F32)
+        if self.in_channels != self.out_channels:
+            t32 = ops.igemm(_split(t32, level), _w_split(self.nin_shortcut, level), out_mode=OUT_ROWS_F32)
         return ops.lincomb4([t32, d32], [1.0, 1.0])
 
 
@@ -308,25 +343,43 @@ class Decoder(nn.Module):
         zin = ops.pack_sources([z.float().contiguous()], engine_dtype())
         if fp32_trunk() and fp32_streams():
             dt = engine_dtype()
-            t32 = ops.igemm(zin, self.conv_in.packed_thin(), pad=(1, 1), out_mode=OUT_ROWS_F32)
-            t32 = self.mid.block_2.forward_stream(self.mid.attn_1.forward_stream(self.mid.block_1.forward_stream(t32)))
+            lvl = precise_level()
+            rb = (lambda blk, t: blk.forward_precise(t, lvl)) if lvl else (lambda blk, t: blk.forward_stream(t))
+            if lvl:
+                # the latent as hi | lo (| hi) channels of the thin first convolution (4 -> 8 | 12 of its 32 padded input channels)
+                zf = z.float().contiguous()
+                zhi = zf.to(dt).float()
+                ci = self.conv_in
+
+                def thin_split():
+                    w = ci.weight.detach().float()
+                    parts = [w, w] + ([w - w.to(dt).float()] if lvl == 2 else [])
+                    return ops.pack_conv_padded_cin(torch.cat(parts, dim=1), ci.bias, dt, ci.weight.device)
+                t32 = ops.igemm(ops.pack_sources([zhi, zf - zhi] + ([zhi] if lvl == 2 else []), dt), ci._cached(f"thin_split{lvl}", thin_split),
+                                pad=(1, 1), out_mode=OUT_ROWS_F32)
+            else:
+                t32 = ops.igemm(zin, self.conv_in.packed_thin(), pad=(1, 1), out_mode=OUT_ROWS_F32)
+            t32 = rb(self.mid.block_2, self.mid.attn_1.forward_stream(rb(self.mid.block_1, t32)))
             for i_level in reversed(range(self.num_resolutions)):
                 for i_block in range(self.num_res_blocks + 1):
-                    t32 = self.up[i_level].block[i_block].forward_stream(t32)
+                    t32 = rb(self.up[i_level].block[i_block], t32)
                 if i_level != 0:
                     up = self.up[i_level].upsample
-                    t32 = ops.igemm(ops.trunk_add(t32, None, dt), up.conv.packed(), upsample=True, pad=(1, 1), out_mode=OUT_ROWS_F32)
+                    if lvl:
+                        t32 = ops.igemm(_split(t32, lvl), _w_split(up.conv, lvl), upsample=True, pad=(1, 1), out_mode=OUT_ROWS_F32)
+                    else:
+                        t32 = ops.igemm(ops.trunk_add(t32, None, dt), up.conv.packed(), upsample=True, pad=(1, 1), out_mode=OUT_ROWS_F32)
+            tail = lvl or (1 if precise_tail() else 0)            # the adapter's tail (model.py:612-623) alone: MOBI_VAE_PRECISE_TAIL
             if self.lidar_adapter:
-                # the adapter's tail (model.py:612-623): hi | lo operands where precise_tail() says so
-                blk = ResnetBlock.forward_precise if precise_tail() else ResnetBlock.forward_stream
-                t32 = blk(self.res_block_lidar1, t32)
+                rbt = (lambda blk, t: blk.forward_precise(t, tail)) if tail else (lambda blk, t: blk.forward_stream(t))
+                t32 = rbt(self.res_block_lidar1, t32)
                 g, b = self.norm_out_lidar1.affine()                       # (a new fp32 stream -- model.py:617-618)
                 u32 = ops.groupnorm(t32, g, b, self.norm_out_lidar1.eps, silu=True, out_mode=ops.GN_OUT_F32, dtype=dt)
-                u32 = blk(self.res_block_lidar2, u32)
+                u32 = rbt(self.res_block_lidar2, u32)
                 norm, cout = self.norm_out_lidar2, self.conv_out_lidar
             else:
                 u32, norm, cout = t32, self.norm_out, self.conv_out
-            if precise_tail():
+            if tail:                                               # (the small-cout kernel: hi | lo pairs at every level)
                 return ops.conv_small_cout(_gn_pair(norm, u32), cout.packed_dup(), pad=cout.padding, clamp=clamp)
             return ops.conv_small_cout(_gn32(norm, u32), cout.packed_tap_major(), pad=cout.padding, clamp=clamp)
         if fp32_trunk():

@@ -160,6 +160,15 @@ class Conv2d(_Holder):
         return self._cached("dup", lambda: ops.pack_conv(torch.cat([self.weight, self.weight], dim=1), self.bias, engine_dtype(),
                                                          self.weight.device))
 
+    def packed_dup3(self):
+        """[W ; W ; W - round(W)]: against a `hi | lo | hi` operand the launch computes round(W) hi + round(W) lo + (W - round(W)) hi --
+        activations AND weights to ~22 bits (the hi x lo-of-W term; lo x lo-of-W is below fp32's own rounding)."""
+        def build():
+            w = self.weight.detach().float()
+            wlo = w - w.to(engine_dtype()).float()
+            return ops.pack_conv(torch.cat([w, w, wlo], dim=1), self.bias, engine_dtype(), self.weight.device)
+        return self._cached("dup3", build)
+
     def packed_thin(self):
         """as packed(), with the (< 32) input channels zero-padded to 32 for ops.pack_sources inputs."""
         return self._cached("thin", lambda: ops.pack_conv_padded_cin(self.weight, self.bias, engine_dtype(),

@@ -481,6 +481,16 @@ def trunk_add(trunk, inc, dtype):
     return x16
 
 
+def split_f32(x32, dtype, parts=2):
+    """fp32 [..., C] dense -> T [..., parts * C] = hi | lo (| hi): the operand form of groupnorm's GN_OUT_SPLIT / GN_OUT_SPLIT3 outputs."""
+    lib = _lib.load()
+    assert x32.dtype == torch.float32 and x32.is_contiguous() and parts in (2, 3)
+    c = x32.shape[-1]
+    out = torch.empty(tuple(x32.shape[:-1]) + (parts * c,), device=x32.device, dtype=dtype)
+    _lib.check(lib.mobi_split_f32(_ptr(x32), _ptr(out), x32.numel() // c, c, parts, _dt(dtype), _stream()), "mobi_split_f32")
+    return out
+
+
 def transpose(x):
     """T [rows, cols] (row stride free) -> T [cols, rows] dense."""
     lib = _lib.load()
@@ -747,12 +757,13 @@ def linear(x, pw: Packed, **kw):
     return y if y.dim() == 3 else y.squeeze(2)
 
 
-GN_OUT_T, GN_OUT_SPLIT, GN_OUT_F32 = 0, 1, 2
+GN_OUT_T, GN_OUT_SPLIT, GN_OUT_F32, GN_OUT_SPLIT3 = 0, 1, 2, 3
 
 
 def groupnorm(x, gamma, beta, eps, silu, x2=None, out_mode=GN_OUT_T, dtype=None):
     """x: T or fp32 (one source) [N,H,W,C].  out_mode GN_OUT_SPLIT: T [N,H,W,2C] = hi | lo (hi = T(y), lo = T(y - hi)) for a
-    consumer whose weights are duplicated along its input channels; GN_OUT_F32: fp32 [N,H,W,C].  dtype: the storage type T when
+    consumer whose weights are duplicated along its input channels; GN_OUT_SPLIT3: T [N,H,W,3C] = hi | lo | hi for weights
+    [W ; W ; W - T(W)] (Conv2d.packed_split: the weights' rounding corrected too); GN_OUT_F32: fp32 [N,H,W,C].  dtype: the storage type T when
     x is fp32."""
     lib = _lib.load()
     n, h, w, c0 = x.shape
@@ -761,7 +772,7 @@ def groupnorm(x, gamma, beta, eps, silu, x2=None, out_mode=GN_OUT_T, dtype=None)
     src_f32 = x.dtype == torch.float32
     t = dtype if dtype is not None else x.dtype
     assert t in (torch.float16, torch.bfloat16) and not (src_f32 and x2 is not None)
-    oc = (c0 + c1) * (2 if out_mode == GN_OUT_SPLIT else 1)
+    oc = (c0 + c1) * {GN_OUT_SPLIT: 2, GN_OUT_SPLIT3: 3}.get(out_mode, 1)
     out = torch.empty((n, h, w, oc), device=x.device, dtype=torch.float32 if out_mode == GN_OUT_F32 else t)
     ws = torch.empty(lib.mobi_groupnorm_workspace_bytes(n, h * w), device=x.device, dtype=torch.uint8)
     p = _lib.GroupNormParams()

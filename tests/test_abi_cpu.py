@@ -66,8 +66,11 @@ def test_argument_validation_without_gpu(lib):
     assert lib.mobi_groupnorm_workspace_bytes(2, 256) == 2 * 32 * 32 * 2 * 4     # (at least 32 chunks per image: the chunked kernel)
     g.c0, g.src_f32, g.c1, g.src1 = 64, 1, 32, 16
     assert lib.mobi_groupnorm(C.byref(g), None) == -2                  # an fp32 source is one source
-    g.c1, g.src1, g.out_mode = 0, None, 3
-    assert lib.mobi_groupnorm(C.byref(g), None) == -1                  # out_mode 0 .. 2
+    g.c1, g.src1, g.out_mode = 0, None, 4
+    assert lib.mobi_groupnorm(C.byref(g), None) == -1                  # out_mode 0 .. 3
+    assert lib.mobi_split_f32(16, 16, 4, 64, 4, 0, None) == -1         # parts 2 | 3
+    assert lib.mobi_split_f32(16, 16, 4, 60, 2, 0, None) == -1         # channels % 8
+    assert lib.mobi_split_f32(16, 24, 4, 64, 2, 0, None) == -4         # 16-byte alignment
     g.src_f32, g.out_mode, g.c0 = 0, 0, 48
     assert lib.mobi_groupnorm_workspace_bytes(0, 10) == 0
     assert lib.mobi_tile_weights(16, 4096, 24, 32, None) == -2         # rows % 16

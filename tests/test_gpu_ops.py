@@ -137,6 +137,33 @@ def test_groupnorm_fp32_source_and_precise_outputs(ops, dtype):
     assert torch.equal(pair[..., :c], y32.to(dtype))                          # hi = T(y)
     both = pair[..., :c].double() + pair[..., c:].double()
     assert rel(both.float(), y32) < (2e-6 if dtype == torch.float16 else 2e-5)  # hi + lo: 22 (fp16) / 16 (bf16) bits of y
+    # hi | lo | hi (for weights [W ; W ; W - T(W)]) and the same operand forms of a tensor no GroupNorm stands in front of
+    tri = ops.groupnorm(x, g.cuda(), b.cuda(), 1e-6, True, out_mode=ops.GN_OUT_SPLIT3, dtype=dtype)
+    assert tri.shape == (n, 32, 32, 3 * c) and torch.equal(tri[..., :2 * c], pair) and torch.equal(tri[..., 2 * c:], pair[..., :c])
+    for parts in (2, 3):
+        sp = ops.split_f32(y32, dtype, parts)
+        assert sp.shape == (n, 32, 32, parts * c) and torch.equal(sp[..., :c], y32.to(dtype))
+        assert torch.equal(sp[..., c:2 * c], (y32 - y32.to(dtype).float()).to(dtype))
+        assert parts == 2 or torch.equal(sp[..., 2 * c:], sp[..., :c])
+    # a convolution on the split operands against fp64: both operands to ~22 bits (fp16) where the plain launch has 11
+    torch.manual_seed(5)
+    conv = torch.nn.Conv2d(c, 64, 3, padding=1)
+    from mobi_amd.ldm.modules.diffusionmodules.util import Conv2d
+    mine = Conv2d(c, 64, 3, padding=1)
+    mine.load_state_dict(conv.state_dict())
+    mine = mine.cuda()
+    import mobi_amd
+    was = mobi_amd.engine_dtype()
+    mobi_amd.set_engine_dtype(dtype)
+    try:
+        want = F.conv2d(y32.cpu().double().permute(0, 3, 1, 2), conv.weight.double(), conv.bias.double(), padding=1).permute(0, 2, 3, 1)
+        e_plain = rel(ops.igemm(y32.to(dtype), mine.packed(), out_mode=ops.OUT_ROWS_F32), want.float())
+        e_pair = rel(ops.igemm(pair, mine.packed_dup(), out_mode=ops.OUT_ROWS_F32), want.float())
+        e_tri = rel(ops.igemm(tri, mine.packed_dup3(), out_mode=ops.OUT_ROWS_F32), want.float())
+    finally:
+        mobi_amd.set_engine_dtype(was)
+    assert e_tri < 0.2 * e_pair < 0.2 * e_plain, (e_plain, e_pair, e_tri)
+    assert e_tri < (3e-6 if dtype == torch.float16 else 3e-4), e_tri
     # the storage-type source through the same kernels
     xs = x.to(dtype)
     p2 = ops.groupnorm(xs, g.cuda(), b.cuda(), 1e-6, True, out_mode=ops.GN_OUT_F32)

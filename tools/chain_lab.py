@@ -15,7 +15,7 @@ sys.path.insert(0, HERE)
 import mobi_amd  # noqa: E402
 from mobi_amd import ops  # noqa: E402
 from mobi_amd.ldm.modules import attention as A  # noqa: E402
-from oracle import weights as W  # noqa: E402
+from tools import _synth as W  # noqa: E402
 
 
 def main():

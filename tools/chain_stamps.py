@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, HERE)
 import mobi_amd  # noqa: E402
 from mobi_amd import _lib, ops  # noqa: E402
-from oracle import weights as W  # noqa: E402
+from tools import _synth as W  # noqa: E402
 
 
 def main():
@@ -30,7 +30,7 @@ def main():
     n, t, c = 16, 4096, 320
     mk = lambda name, *shape: W.synth_input(name, shape).to(dt).cuda()
     a, x = mk("st.a", n, t, c), mk("st.x", n, t, c)
-    w = lambda name, **kw: ops.pack_chain_weight(torch.from_numpy(W.synth_param(name + ".weight", (c, c))), None, dt, "cuda", **kw)
+    w = lambda name, **kw: ops.pack_chain_weight(W.synth_weight(name + ".weight", (c, c)), None, dt, "cuda", **kw)
     g, b = torch.ones(c), torch.zeros(c)
     cw = {k: w(k) for k in ("to_out", "k", "v")}
     cw["q"] = w("q", ln=(g, b), scale=0.2)

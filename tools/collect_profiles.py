@@ -154,7 +154,7 @@ def main():
              ("ab_grouped_q_ln_fold.txt", "whole-step A/B of the grouped cross-modal to_q launch and of the LayerNorm fold (tools/ab_cfg.sh)"),
              ("ln_fold_launches.txt", "per-launch times with the LayerNorm fold on / off"),
              ("gn_lab.txt", "GroupNorm forms per shape incl. the chunked one-launch kernel (tools/gn_lab.py)"),
-             ("decoder_err.txt", "the decoders' own error on the oracle's latent, by precision option (tools/decoder_err.py)"),
+             ("decoder_err.txt", "the decoders' own error on the oracle's latent, by precision option (tests/decoder_err.py)"),
              ("conc_lab.txt", "two independent half batches on two streams against one batch (tools/conc_lab.py)"),
              ("mall_share.txt", "Infinity-Cache share of the ring kernel's counter traffic: the step's launch against one scaled past 256 MiB (tools/mall_share.sh)"),
              ("vae_decode_fp16.txt", "fp16 VAE decode / encode of 8 images at 512 x 512 by precision option (fp32 trunk / streams / hi | lo tail)"),

@@ -15,8 +15,7 @@ HERE = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, HERE)
 import mobi_amd  # noqa: E402
 from mobi_amd import ops, train  # noqa: E402
-from oracle import unet as ounet, weights as W  # noqa: E402
-from tests.test_gpu_models import _unet  # noqa: E402
+from tools import _synth as W  # noqa: E402
 
 
 def main():
@@ -29,8 +28,12 @@ def main():
     a = ap.parse_args()
     dt = torch.bfloat16 if a.dtype == "bf16" else torch.float16
     mobi_amd.set_engine_dtype(dt)
-    cfg = ounet.UNetConfig(model_channels=a.mc)
-    net = _unet(cfg, a.side)
+    from mobi_amd.ldm.util import instantiate_from_config, load_config
+    ucfg = load_config(os.path.join(HERE, "configs", "mobi_nusc_512.yaml"),
+                       ["model.params.lidar_stage_config.params.ckpt_path=null"])["model"]["params"]["unet_config"]
+    ucfg["params"]["model_channels"] = a.mc                   # (the UNet of configs/mobi_nusc_512.yaml; --mc narrows it for quick runs)
+    ucfg["params"]["image_size"] = a.side
+    net = instantiate_from_config(ucfg)
     W.fill_module_(net, seed=3)
     net = net.cuda()
     x = W.synth_input("tb.x", (a.n, 9, a.side, a.side)).cuda()
