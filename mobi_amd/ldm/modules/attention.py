@@ -426,7 +426,8 @@ class BasicTransformerBlock(nn.Module):
             adapter = self._two_key_terms(kv) if self.bbox_cond and ctx.shape[1] == 2 else None
             # the same tables as the LDS images the row-chain kernel copies in (C = 320 blocks: csrc/chain.hip)
             image = None
-            if adapter is not None and ROW_CHAIN and ops.row_chain_supported(adapter[0].shape[2], 128):
+            # (the chain kernel's adapter tables hold up to 8 heads: a num_head_channels config with more keeps the one-by-one launches)
+            if adapter is not None and ROW_CHAIN and self.cond_adapter_attn.heads <= 8 and ops.row_chain_supported(adapter[0].shape[2], 128):
                 image = ops.chain_adapter_image(adapter[0], adapter[2], adapter[3], adapter[4], engine_dtype())
             # results live in PERSISTENT buffers, refreshed in place while their shapes stay the same (they do for one
             # context tensor): a denoising step captured in a HIP graph (mobi_amd/graph.py) keeps reading these addresses
