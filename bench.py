@@ -79,10 +79,15 @@ def parity_record(side, dtype):
                         "pixel_rel_l2_range": r["pixel_rel_l2_range"]}
 
             other = "fp16" if dtype == "bf16" else "bf16"
-            sha = pj.get("lib_sha16")
+            sha, ssha = pj.get("lib_sha16"), pj.get("src_sha16")
+            from mobi_amd import build as _build
+            same_bin, same_src = bool(sha) and sha == lib_sha16(), bool(ssha) and ssha == _build.sources_sha16()
+            # (a rebuild in another directory need not reproduce the binary's hash: the hash over the kernel sources + flags is
+            #  the identity that survives it)
             parity = {**one(dtype), "other_storage_type": one(other), "case": key, "source": rel_path,
-                      "measured_with_lib_sha16": sha, "measured_at_commit": pj.get("commit"),
-                      "matches_this_build": bool(sha) and sha == lib_sha16()}
+                      "measured_with_lib_sha16": sha, "measured_with_src_sha16": ssha, "measured_at_commit": pj.get("commit"),
+                      "matches_this_binary": same_bin, "matches_these_sources": same_src,
+                      "matches_this_build": same_bin or same_src}
             qs = ("latent_rel_l2", "pixel_rel_l2_camera", "pixel_rel_l2_range")
             # a storage type MEETS the tolerance when every DDIM run measured for it does -- the DDIM-10 case and, where the suite
             # wrote it, the DDIM-50 case (every BASELINE configuration samples with DDIM); the shipped script's PLMS-50 at guidance

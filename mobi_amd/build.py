@@ -36,6 +36,21 @@ def _deps_mtime():
 STAMP = LIB + ".flags"
 
 
+def sources_sha16():
+    """sha256 over what the library is built from (every .hip / .h of csrc/, include/mobi_engine.h, the flags): the identity of a
+    build that survives a rebuild in another directory (the binary's own hash need not)."""
+    import hashlib
+    h = hashlib.sha256()
+    deps = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h")))
+    deps.append(os.path.join(os.path.dirname(HERE), "include", "mobi_engine.h"))
+    for d in deps:
+        h.update(os.path.basename(d).encode())
+        with open(d, "rb") as f:
+            h.update(f.read())
+    h.update(_flags_id().encode())
+    return h.hexdigest()[:16]
+
+
 def _flags_id():
     """What the library was compiled with besides the sources: a library built with A/B or debug flags
     (`MOBI_HIPCC_FLAGS=-DMOBI_DBG_...`, timing-only variants with WRONG results) must never pass as current

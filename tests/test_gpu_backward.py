@@ -212,7 +212,8 @@ TOL_UNET_FULL = {(16, torch.float16): (4e-3, 3e-2), (16, torch.bfloat16): (2.7e-
 
 
 @pytest.mark.parametrize("side,dtype,loss_scale", [(16, torch.float16, 256.0), (16, torch.bfloat16, 1.0),
-                                                   (64, torch.float16, 8192.0), (64, torch.bfloat16, 1.0)])
+                                                   (64, torch.float16, 8192.0), (64, torch.bfloat16, 1.0)],
+                         ids=["side16-dtype0", "side16-dtype1", "side64-dtype0", "side64-dtype1"])
 def test_unet_training_step_gradients_full_width(side, dtype, loss_scale):
     """The PRODUCTION network (model_channels 320, 1.04 B parameters) on one camera / lidar pair: loss, the gradient of all 432
     adapter tensors and of the box token against torch.autograd through the CPU oracle's UNet.  side = 16: the K = 23,040 data

@@ -226,6 +226,7 @@ def _write_parity(side, dtype, numbers, kind=None):
     except (OSError, ValueError):
         doc = {}
     doc["lib_sha16"] = sha
+    doc["src_sha16"] = build.sources_sha16()
     doc["source"] = ("tests/test_gpu_production.py::test_end_to_end_pixel_space on the MI355X: get_input -> DDIM-10 -> decode_sample -> "
                      "decode_first_stage + clamp at FULL width (1.04 B-parameter UNet, ch = 128 VAEs), one object, against the CPU "
                      "oracle's run of the same sequence (tests/oracle_cases.py e2e, oracle_outputs.npz); rel-L2")
