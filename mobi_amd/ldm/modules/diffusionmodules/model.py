@@ -75,9 +75,9 @@ _PRECISE_ENV = os.environ.get("MOBI_VAE_PRECISE", "")
 
 
 def precise_level():
-    if _PRECISE_ENV in ("0", "1", "2"):
-        return int(_PRECISE_ENV)
-    return 2 if (fp32_trunk() and fp32_streams()) else 0
+    if not (fp32_trunk() and fp32_streams()):    # the split operands are read from / written beside the fp32 streams
+        return 0
+    return int(_PRECISE_ENV) if _PRECISE_ENV in ("0", "1", "2") else 2
 
 
 def _gn_split(norm, x32, level, silu=True):

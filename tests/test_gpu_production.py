@@ -24,7 +24,7 @@ import pytest
 import torch
 
 from oracle import sampler as osampler, unet as ounet, vae as ovae, weights as W
-from tests.golden_cases import check, rel_l2
+from tests.golden_cases import check, record, rel_l2
 from tests.test_gpu_models import _unet, _vae
 
 pytestmark = pytest.mark.gpu
@@ -182,6 +182,36 @@ def test_full_width_vae_512(dtype, lidar):
     tag = "lidar" if lidar else "camera"
     check(rel_l2(vae.encode(x.cuda()).parameters.cpu(), ref_m), TOL_VAE[dtype], f"vae128_512_{tag}_encode_{dtype}")
     check(rel_l2(vae.decode(z.cuda()).cpu(), ref_rec), TOL_VAE[dtype], f"vae128_512_{tag}_decode_{dtype}")
+
+
+@pytest.mark.parametrize("lidar", [False, True], ids=["camera", "lidar"])
+def test_vae_decoder_precision_levels(lidar):
+    """The fp16 decoders' operand forms (model.py precise_level): 16-bit operands on fp32 streams (0), hi | lo activations against
+    [W ; W] (1), hi | lo | hi against [W ; W ; W - T(W)] (2, the default with fp16 storage) on the ch = 128 decoder at 256 x 256 against
+    the oracle's decode: every level is a launch-for-launch different path, each has to beat the one before by what the split buys
+    (measured: 7.9e-4 -> 5.6e-4 -> 1.8e-4 camera, 9.2e-4 -> 6.2e-4 -> 1.8e-4 range view at 512 x 512, profiles/r05_decoder_err.txt)."""
+    from mobi_amd.ldm.modules.diffusionmodules import model as M
+    _set(torch.float16)
+    _threads()
+    cfg = ovae.VAEConfig(in_channels=2 if lidar else 3, out_ch=2 if lidar else 3, ch=128, lidar_adapter=lidar)
+    sd = W.synth_state_dict(ovae.vae_param_shapes(cfg), 23)
+    z = W.synth_input(f"prod.vae.z.{lidar}", (1, 4, 32, 32))
+    ref_rec = ovae.decode(sd, cfg, z)
+    vae = _vae(cfg, res=256)
+    vae.load_state_dict(sd)
+    vae = vae.cuda()
+    was = M._PRECISE_ENV
+    errs = []
+    try:
+        for level in ("0", "1", "2"):
+            M._PRECISE_ENV = level
+            errs.append(rel_l2(vae.decode(z.cuda()).cpu(), ref_rec))
+            record(f"vae128_{'lidar' if lidar else 'camera'}_decode_precise{level}", errs[-1])
+    finally:
+        M._PRECISE_ENV = was
+    print("decoder error by operand form:", [f"{e:.3e}" for e in errs])
+    assert errs[1] < 0.85 * errs[0] and errs[2] < 0.5 * errs[1], errs
+    assert errs[2] < 4e-4, errs
 
 
 def test_pingpong_race_screen():
