@@ -2844,13 +2844,23 @@ static int plan_splits(long long M, int n_packed, int ktot) {
   const int bn = (n_packed % 160) == 0 ? 160 : 128;
   const long long tiles = ((M + 127) / 128) * ((n_packed + bn - 1) / bn);
   const int nk = (ktot + 63) / 64;
-  if (tiles >= 384 || nk < 16) return 1;
-  if (tiles >= 256 && nk < 40) return 1;        // measured (tools/sweep_split.py): one full wave of blocks, short k
+  // round 5 (profiles/r05_split_sweep.txt, slabs + reduce launch timed together): 20 k-tiles never pay for a second launch
+  // ([2048 | 1024 x 1280 x 1280] 22.2 / 20.7 us unsplit against 23.3 / 21.1 split in two; [8192 x 320 x 1280] 21.9 against 23.3)
+  const bool r5 = tuning().split_round4 != 0;   // MOBI_IGEMM_SPLIT_ROUND4=0: round 4's plan (A/B)
+  if (tiles >= 384 || nk < (r5 ? 24 : 16)) return 1;
+  if (tiles >= 256 && (r5 ? nk <= 40 : nk < 40)) return 1;   // one full wave of blocks, short k ([4096 x 1280 x 2560]: 40.3 us unsplit, 44.1 in two)
   const long long target = tuning().split_target > 0 ? tuning().split_target : 512;      // MOBI_IGEMM_SPLIT_TARGET (sweeps)
   long long s = (target + tiles - 1) / tiles;
   const long long cap = tiles <= 16 ? 16 : 8;               // a handful of tiles (the 4x4 / 8x8 levels): measured best at 16
   if (s > cap) s = cap;
   if (s > nk / 8) s = nk / 8;
+  // the reduce launch sums four slabs per round: 5 .. 7 splits buy a second round for little more parallelism ([1024 x 1280 x 2560]
+  // 23.6 us at 4 against 29.5 at 5; [2048 x 640 x 2560] 23.0 against 28.3), and so do 8 on 64 tiles or more with at most 96 k-tiles
+  // ([1024 x 1280 x 5120] 31.3 against 35.7, [2048 x 640 x 5760] 32.6 against 35.7; fewer tiles still want 8: [512 x 1280 x 5120])
+  if (r5) {
+    if (s > 4 && s < 8) s = 4;
+    if (s == 8 && nk <= 96 && tiles >= 64) s = 4;
+  }
   // one round of 128-pixel tiles and a very long k range per split (the 16 x 16 level's 1280 -> 1280 and 2560 -> 1280 3 x 3
   // convolutions: 90 / 180 k-tiles per split at s = 2): twice the splits -- 114.7 against 126.3 us and 198.8 against 225.3
   // (tools/sweep_split.py), -0.08 ms per step; MOBI_IGEMM_SPLIT_LONGK=0 keeps the old plan (A/B)

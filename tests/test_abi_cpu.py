@@ -266,7 +266,8 @@ def test_igemm_plan_routes_small_problems_at_the_boundary(lib, monkeypatch):
             setattr(p, key, v)
         return lib.mobi_igemm_kernel_variant(C.byref(p)), lib.mobi_igemm_plan_splits(C.byref(p))
 
-    for key in ("MOBI_IGEMM_SMALL", "MOBI_IGEMM_SMALL_MFLOP", "MOBI_IGEMM_SMALL_CONV_M", "MOBI_IGEMM_WM", "MOBI_IGEMM_WIDE", "MOBI_IGEMM_SM"):
+    for key in ("MOBI_IGEMM_SMALL", "MOBI_IGEMM_SMALL_MFLOP", "MOBI_IGEMM_SMALL_CONV_M", "MOBI_IGEMM_WM", "MOBI_IGEMM_WIDE", "MOBI_IGEMM_SM",
+                "MOBI_IGEMM_SPLIT_ROUND4"):
         monkeypatch.delenv(key, raising=False)
     lib.mobi_tuning_reload()
     try:
@@ -291,7 +292,16 @@ def test_igemm_plan_routes_small_problems_at_the_boundary(lib, monkeypatch):
         assert plan(256, 1280, 1280, out_mode=2)[0] == SMALL             # fp32 rows
         monkeypatch.setenv("MOBI_IGEMM_SMALL", "0")
         lib.mobi_tuning_reload()
-        assert plan(256, 1280, 1280)[0] == RING128 and plan(256, 1280, 1280)[1] > 1
+        assert plan(256, 1280, 1280) == (RING128, 1)                      # 20 k-tiles: never worth a second launch (round 5)
+        assert plan(256, 2560, 1280) == (RING128, 4)                      # 40 k-tiles on 16 tiles: 5 by the arithmetic, 4 by the reduce's rounds
+        assert plan(1024, 5120, 1280)[1] == 4 and plan(512, 5120, 1280)[1] == 8     # 64 tiles: 4; 32 tiles still want 8
+        assert plan(4096, 2560, 1280)[1] == 1 and plan(4096, 5120, 1280)[1] == 2     # one full wave of blocks: 40 k-tiles unsplit, 80 in two
+        assert plan(1024, 1280, 1280, kh=3, kw=3, pad_h=1, pad_w=1, hin=32, win=32, hout=32, wout=32)[1] == 8   # 180 k-tiles: 8 stay 8
+        monkeypatch.setenv("MOBI_IGEMM_SPLIT_ROUND4", "0")
+        lib.mobi_tuning_reload()
+        assert plan(256, 1280, 1280)[1] == 2 and plan(256, 2560, 1280)[1] == 5      # round 4's plan (A/B)
+        monkeypatch.delenv("MOBI_IGEMM_SPLIT_ROUND4")
+        lib.mobi_tuning_reload()
         monkeypatch.setenv("MOBI_IGEMM_SMALL", "32")
         lib.mobi_tuning_reload()
         assert plan(65536, 320, 320)[0] == SMALL                         # forced: whatever the size

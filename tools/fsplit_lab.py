@@ -19,6 +19,7 @@ def main():
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--iters", type=int, default=30)
     ap.add_argument("--set", default="512", choices=["512", "256"])
+    ap.add_argument("--modes", default="012", help="0: reduce launch, 1 / 2: the two in-launch finishes")
     a = ap.parse_args()
     from mobi_amd import build, ops
     build.build(verbose=False)
@@ -34,7 +35,7 @@ def main():
         cells = []
         best = (1e9, None)
         from mobi_amd import _lib
-        for mode in ("0", "1", "2"):                       # u: reduce launch; D: device-coherent finish; X: same-XCD finish
+        for mode in a.modes:                       # u: reduce launch; D: device-coherent finish; X: same-XCD finish
             os.environ["MOBI_IGEMM_FUSED_SPLIT"] = mode
             _lib.load().mobi_tuning_reload()
             for s in ((None, 1, 2, 3, 4, 6, 8, 12, 16) if mode == "0" else (None, 2, 3, 4)):
