@@ -36,7 +36,7 @@ FUSED_FF_MIN_ROWS = int(os.environ.get("MOBI_FUSED_FF_MIN_ROWS", "24576"))   # 1
 FUSED_LN = os.environ.get("MOBI_FUSED_LN", "1") != "0"      # A/B: 0 = the cross-modal LayerNorms as launches of their own
 ROW_CHAIN = os.environ.get("MOBI_ROW_CHAIN", "1") != "0"    # A/B: 0 = the launches between the attention kernels one by one
 LN_FOLD = os.environ.get("MOBI_LN_FOLD", "1") != "0"        # A/B: 0 = norm1 / norm3 as LayerNorm launches in front of their projections
-LN_FOLD_MIN_ROWS = int(os.environ.get("MOBI_LN_FOLD_MIN_ROWS", "2048"))   # below: the ping-pong / small kernels + a LayerNorm launch win
+LN_FOLD_MIN_ROWS = int(os.environ.get("MOBI_LN_FOLD_MIN_ROWS", "512"))    # below: a LayerNorm launch in front of the small kernels; 2048 -> 512: -0.03 ms per step of both workloads (profiles/r05_ab_ln_fold_rows.txt)
 GROUPED_Q = os.environ.get("MOBI_GROUPED_Q", "1") != "0"    # A/B: 0 = the two cross-modal to_q projections as launches of their own
 ROW_CHAIN_MIN_ROWS = int(os.environ.get("MOBI_ROW_CHAIN_MIN_ROWS", "24576"))   # 128 rows per workgroup: 192 workgroups
 # GroupNorm, proj_in, norm1 and the q | k | v projection of a C = 320 block as ONE chain launch (+ a statistics pass): built, tested,
