@@ -403,7 +403,8 @@ typedef struct mobi_attention_bwd_params {
   const void* q; int64_t q_img_stride, q_row_stride;       /* T [image][tq][>= heads*dh], strides in elements */
   const void* k; int64_t k_img_stride, k_row_stride;       /* T [image][tk][..] */
   const void* v; int64_t v_img_stride, v_row_stride;
-  const void* o; int64_t o_img_stride, o_row_stride;       /* the forward result */
+  const void* o; int64_t o_img_stride, o_row_stride;       /* the forward result (read only by the A/B form of the row term, D = do . o;
+                                                              the default takes D = sum_j P dP from the pass's own P and dP) */
   const void* dout; int64_t dout_img_stride, dout_row_stride;
   void* dq; void* dk; void* dv;                            /* T [image][t][heads*dh] dense */
   float* lse; float* dvec;                                 /* f32 [image][heads][tq] scratch each */

@@ -8,6 +8,7 @@
 // counts (self / cross-modal attention; two context tokens for the bbox adapter), column sums (bias gradients), a 16-bit
 // transpose, the reduction of per-block partials (fixed order: bit-reproducible).
 #include "common.h"
+#include "tuning.h"
 
 namespace mobi {
 namespace {
@@ -216,54 +217,79 @@ struct AttnBwdArgs {
   float *lse, *dvec;                                                          // fp32 [image][head][tq]
   int heads, dh, tq, tk;
   float scale;
+  int exact_d;     // 1: D = sum_j P_ij dP_ij from the pass's own P and dP (fp32); 0: D = do . o with the STORED o (A/B)
 };
+
+// D, the row term of the softmax backward (dS = P (dP - D)): the textbook form do . o reads the output as it was STORED -- rounded
+// to 16 bits.  When the values share a common component (every token the same offset: LayerNorm biases, smooth feature maps) that
+// rounding is an error of D proportional to the offset, dS = P (dP - D) picks it up on EVERY key with weight P_ij, and the products
+// with K then add it up instead of cancelling it: sum_j P_ij K_j is the keys' own common component.  Measured (tests/attn_bwd_err.py,
+// bf16, offsets 3 / 10 of unit-variance keys and values): dQ 28 % / 315 % off, fp16 3.5 % / 39 %.  With D = sum_j P_ij dP_ij from the
+// SAME P and dP the later passes compute, sum_j dS_ij = 0 holds to fp32 rounding and the offset cancels as it does in exact arithmetic.
+// Cost: the statistics pass stages V as well and multiplies dO V^T (what the dQ pass does anyway).
 
 template <typename T>
 __global__ __launch_bounds__(256) void attn_bwd_stats_kernel(const AttnBwdArgs a) {
-  __shared__ float sQ[BW_TILE * BW_LD], sK[BW_TILE * BW_LD];
+  __shared__ float sQ[BW_TILE * BW_LD], sK[BW_TILE * BW_LD], sO[BW_TILE * BW_LD], sV[BW_TILE * BW_LD];
   const int tid = threadIdx.x, r = tid >> 3, cg = tid & 7;
   const int q0 = blockIdx.x * BW_TILE, h = blockIdx.y, img = blockIdx.z;
   const int qv = min(BW_TILE, a.tq - q0);
   const T* qp = reinterpret_cast<const T*>(a.q) + img * a.q_is + (long long)q0 * a.q_rs + h * a.dh;
   load_tile(sQ, qp, a.q_rs, qv, a.dh, tid);
-  float m = -3.0e38f, l = 0.f;
+  if (a.exact_d)
+    load_tile(sO, reinterpret_cast<const T*>(a.dout) + img * a.do_is + (long long)q0 * a.do_rs + h * a.dh, a.do_rs, qv, a.dh, tid);
+  float m = -3.0e38f, l = 0.f, da = 0.f;           // da = sum_j exp(s_j - m) dP_j, rescaled with l
   for (int k0 = 0; k0 < a.tk; k0 += BW_TILE) {
     const int kv = min(BW_TILE, a.tk - k0);
     __syncthreads();
     load_tile(sK, reinterpret_cast<const T*>(a.k) + img * a.k_is + (long long)k0 * a.k_rs + h * a.dh, a.k_rs, kv, a.dh, tid);
+    if (a.exact_d)
+      load_tile(sV, reinterpret_cast<const T*>(a.v) + img * a.v_is + (long long)k0 * a.v_rs + h * a.dh, a.v_rs, kv, a.dh, tid);
     __syncthreads();
-    float s[4] = {0.f, 0.f, 0.f, 0.f};
+    float s[4] = {0.f, 0.f, 0.f, 0.f}, dp[4] = {0.f, 0.f, 0.f, 0.f};
     for (int d = 0; d < a.dh; ++d) {
       const float qd = sQ[r * BW_LD + d];
 #pragma unroll
       for (int j = 0; j < 4; ++j) s[j] += qd * sK[(4 * cg + j) * BW_LD + d];
     }
+    if (a.exact_d)
+      for (int d = 0; d < a.dh; ++d) {
+        const float od = sO[r * BW_LD + d];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dp[j] += od * sV[(4 * cg + j) * BW_LD + d];
+      }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       if (4 * cg + j < kv) {
         const float sv = s[j] * a.scale;
         const float mn = fmaxf(m, sv);
-        l = l * __expf(m - mn) + __expf(sv - mn);
+        const float c = __expf(m - mn), e = __expf(sv - mn);
+        l = l * c + e;
+        da = da * c + e * dp[j];
         m = mn;
       }
     }
   }
-  // the eight threads of a row (consecutive lanes) combine their (m, l)
+  // the eight threads of a row (consecutive lanes) combine their (m, l, da)
 #pragma unroll
   for (int o = 1; o < 8; o <<= 1) {
-    const float m2 = __shfl_xor(m, o, 64), l2 = __shfl_xor(l, o, 64);
+    const float m2 = __shfl_xor(m, o, 64), l2 = __shfl_xor(l, o, 64), d2 = __shfl_xor(da, o, 64);
     const float mn = fmaxf(m, m2);
-    l = l * __expf(m - mn) + l2 * __expf(m2 - mn);
+    const float c1 = __expf(m - mn), c2 = __expf(m2 - mn);
+    l = l * c1 + l2 * c2;
+    da = da * c1 + d2 * c2;
     m = mn;
   }
-  // D = do . o over the head's channels
-  const T* op = reinterpret_cast<const T*>(a.o) + img * a.o_is + (long long)(q0 + r) * a.o_rs + h * a.dh;
-  const T* dp = reinterpret_cast<const T*>(a.dout) + img * a.do_is + (long long)(q0 + r) * a.do_rs + h * a.dh;
-  float dd = 0.f;
-  if (r < qv)
-    for (int d = cg; d < a.dh; d += 8) dd += (float)op[d] * (float)dp[d];
+  float dd = da / l;
+  if (!a.exact_d) {                                // D = do . o over the head's channels (the stored output)
+    const T* op = reinterpret_cast<const T*>(a.o) + img * a.o_is + (long long)(q0 + r) * a.o_rs + h * a.dh;
+    const T* dp = reinterpret_cast<const T*>(a.dout) + img * a.do_is + (long long)(q0 + r) * a.do_rs + h * a.dh;
+    dd = 0.f;
+    if (r < qv)
+      for (int d = cg; d < a.dh; d += 8) dd += (float)op[d] * (float)dp[d];
 #pragma unroll
-  for (int o = 1; o < 8; o <<= 1) dd += __shfl_xor(dd, o, 64);
+    for (int o = 1; o < 8; o <<= 1) dd += __shfl_xor(dd, o, 64);
+  }
   if (cg == 0 && r < qv) {
     const long long idx = ((long long)img * a.heads + h) * a.tq + q0 + r;
     a.lse[idx] = m + __logf(l);
@@ -447,12 +473,13 @@ __device__ __forceinline__ typename Vec8<T>::type bm_frag_t(const T* tile, int s
 }
 
 // pass 1 on the matrix cores: L = log-sum-exp of the scaled scores (online maximum / sum over the key tiles, a query per lane),
-// D = do . o
-template <typename T, int KD>
+// D = sum_j P_ij dP_ij (EXACT: the values are staged too and dP^T = V dO^T is multiplied beside S^T = K Q^T) or do . o
+template <typename T, int KD, bool EXACT>
 __global__ __launch_bounds__(256) void attn_bwd_stats_mfma_kernel(const AttnBwdArgs a) {
   typedef typename Vec8<T>::type frag_t;
   constexpr int DHP = 16 * KD, PITCH = DHP + BM_PITCH_PAD;
   __shared__ __attribute__((aligned(16))) T sK2[2][32 * PITCH];          // two tiles: tile t + 1 is written while tile t is read
+  __shared__ __attribute__((aligned(16))) T sV2[EXACT ? 2 : 1][EXACT ? 32 * PITCH : 8];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, ql = lane & 31, half = lane >> 5;
   const int h = blockIdx.y, img = blockIdx.z;
   const int q = blockIdx.x * 128 + wave * 32 + ql;
@@ -460,14 +487,16 @@ __global__ __launch_bounds__(256) void attn_bwd_stats_mfma_kernel(const AttnBwdA
   const T* qp = reinterpret_cast<const T*>(a.q) + img * a.q_is + (long long)(qok ? q : 0) * a.q_rs + h * a.dh;
   const T* dp_ = reinterpret_cast<const T*>(a.dout) + img * a.do_is + (long long)(qok ? q : 0) * a.do_rs + h * a.dh;
   const T* op_ = reinterpret_cast<const T*>(a.o) + img * a.o_is + (long long)(qok ? q : 0) * a.o_rs + h * a.dh;
-  frag_t qf[KD];
+  frag_t qf[KD], dof[EXACT ? KD : 1];
   float dd = 0.f;
 #pragma unroll
   for (int s = 0; s < KD; ++s) {
     const int d0 = 16 * s + 8 * half;
     const bool ok = qok && d0 < a.dh;
     qf[s] = ok ? __builtin_bit_cast(frag_t, ld16(qp + d0)) : __builtin_bit_cast(frag_t, u32x4{0u, 0u, 0u, 0u});
-    if (ok) {
+    if constexpr (EXACT) {
+      dof[s] = ok ? __builtin_bit_cast(frag_t, ld16(dp_ + d0)) : __builtin_bit_cast(frag_t, u32x4{0u, 0u, 0u, 0u});
+    } else if (ok) {
       float x[8], y[8];
       unpack8<T>(ld16(dp_ + d0), x);
       unpack8<T>(ld16(op_ + d0), y);
@@ -476,22 +505,34 @@ __global__ __launch_bounds__(256) void attn_bwd_stats_mfma_kernel(const AttnBwdA
     }
   }
   dd += __shfl_xor(dd, 32, 64);
-  float m = -3.0e38f, l = 0.f;
+  float m = -3.0e38f, l = 0.f, da = 0.f;            // da = sum_j exp(s_j - m) dP_j, rescaled with l
   const T* kbase = reinterpret_cast<const T*>(a.k) + img * a.k_is + h * a.dh;
-  BmRegs<KD> gk;
+  const T* vbase = reinterpret_cast<const T*>(a.v) + img * a.v_is + h * a.dh;
+  BmRegs<KD> gk, gv;
   bm_fetch<T, KD>(gk, kbase, a.k_rs, min(32, a.tk), a.dh, tid);
+  if constexpr (EXACT) bm_fetch<T, KD>(gv, vbase, a.v_rs, min(32, a.tk), a.dh, tid);
   bm_put<T, KD, PITCH>(gk, sK2[0], tid);
+  if constexpr (EXACT) bm_put<T, KD, PITCH>(gv, sV2[0], tid);
   __syncthreads();
   for (int k0 = 0, it = 0; k0 < a.tk; k0 += 32, ++it) {
     const int kv = min(32, a.tk - k0);
     const T* sK = sK2[it & 1];
     const bool more = k0 + 32 < a.tk;
-    if (more) bm_fetch<T, KD>(gk, kbase + (long long)(k0 + 32) * a.k_rs, a.k_rs, min(32, a.tk - k0 - 32), a.dh, tid);
-    f32x16 st;
+    if (more) {
+      bm_fetch<T, KD>(gk, kbase + (long long)(k0 + 32) * a.k_rs, a.k_rs, min(32, a.tk - k0 - 32), a.dh, tid);
+      if constexpr (EXACT) bm_fetch<T, KD>(gv, vbase + (long long)(k0 + 32) * a.v_rs, a.v_rs, min(32, a.tk - k0 - 32), a.dh, tid);
+    }
+    f32x16 st, dpt;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) st[r] = 0.f;
+    for (int r = 0; r < 16; ++r) { st[r] = 0.f; dpt[r] = 0.f; }
 #pragma unroll
-    for (int s = 0; s < KD; ++s) st = mfma32(__builtin_bit_cast(frag_t, ld16(sK + ql * PITCH + 16 * s + 8 * half)), qf[s], st);
+    for (int s = 0; s < KD; ++s) {
+      st = mfma32(__builtin_bit_cast(frag_t, ld16(sK + ql * PITCH + 16 * s + 8 * half)), qf[s], st);
+      if constexpr (EXACT) {
+        const T* sV = sV2[it & 1];
+        dpt = mfma32(__builtin_bit_cast(frag_t, ld16(sV + ql * PITCH + 16 * s + 8 * half)), dof[s], dpt);
+      }
+    }
     float tm = -3.0e38f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -500,20 +541,32 @@ __global__ __launch_bounds__(256) void attn_bwd_stats_mfma_kernel(const AttnBwdA
       tm = fmaxf(tm, st[r]);
     }
     const float mn = fmaxf(m, tm);
-    float ts = 0.f;
+    float ts = 0.f, td = 0.f;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) ts += __expf(st[r] - mn);
-    l = l * __expf(m - mn) + ts;
+    for (int r = 0; r < 16; ++r) {
+      const float e = __expf(st[r] - mn);
+      ts += e;
+      if constexpr (EXACT) td += e * dpt[r];
+    }
+    const float c = __expf(m - mn);
+    l = l * c + ts;
+    da = da * c + td;
     m = mn;
-    if (more) bm_put<T, KD, PITCH>(gk, sK2[(it + 1) & 1], tid);      // the other tile: everyone was done with it a barrier ago
+    if (more) {                                                      // the other tile: everyone was done with it a barrier ago
+      bm_put<T, KD, PITCH>(gk, sK2[(it + 1) & 1], tid);
+      if constexpr (EXACT) bm_put<T, KD, PITCH>(gv, sV2[(it + 1) & 1], tid);
+    }
     __syncthreads();
   }
   {                                                 // the two lanes of a query combine their halves of the keys
-    const float m2 = __shfl_xor(m, 32, 64), l2 = __shfl_xor(l, 32, 64);
+    const float m2 = __shfl_xor(m, 32, 64), l2 = __shfl_xor(l, 32, 64), d2 = __shfl_xor(da, 32, 64);
     const float mn = fmaxf(m, m2);
-    l = l * __expf(m - mn) + l2 * __expf(m2 - mn);
+    const float c1 = __expf(m - mn), c2 = __expf(m2 - mn);
+    l = l * c1 + l2 * c2;
+    da = da * c1 + d2 * c2;
     m = mn;
   }
+  if constexpr (EXACT) dd = da / l;
   if (qok && half == 0) {
     const long long idx = ((long long)img * a.heads + h) * a.tq + q;
     a.lse[idx] = m + __logf(l);
@@ -1080,6 +1133,7 @@ extern "C" int mobi_attention_bwd(const mobi_attention_bwd_params* p, void* stre
   a.do_is = p->dout_img_stride; a.do_rs = p->dout_row_stride;
   a.dq = p->dq; a.dk = p->dk; a.dv = p->dv; a.lse = p->lse; a.dvec = p->dvec;
   a.heads = p->heads; a.dh = p->dh; a.tq = p->tq; a.tk = p->tk; a.scale = p->scale;
+  a.exact_d = tuning().attn_bwd_exact_d != 0;       // MOBI_ATTN_BWD_EXACT_D=0: D = do . o with the stored output (A/B)
   const dim3 gq((p->tq + BW_TILE - 1) / BW_TILE, p->heads, p->images), gk((p->tk + BW_TILE - 1) / BW_TILE, p->heads, p->images);
   // the matrix-core passes need 8-element pieces of a head row to be 16-byte aligned loads: dh % 8 == 0, strides % 8 == 0
   const int kd = (p->dh + 15) / 16;
@@ -1092,11 +1146,13 @@ extern "C" int mobi_attention_bwd(const mobi_attention_bwd_params* p, void* stre
 #define BM_CASE(KD_)                                                                                                       \
   case KD_:                                                                                                                \
     if (p->dtype == MOBI_F16) {                                                                                            \
-      hipLaunchKernelGGL((attn_bwd_stats_mfma_kernel<f16_t, KD_>), gq4, dim3(256), 0, ST(stream), a);                      \
+      if (a.exact_d) hipLaunchKernelGGL((attn_bwd_stats_mfma_kernel<f16_t, KD_, true>), gq4, dim3(256), 0, ST(stream), a);  \
+      else hipLaunchKernelGGL((attn_bwd_stats_mfma_kernel<f16_t, KD_, false>), gq4, dim3(256), 0, ST(stream), a);          \
       hipLaunchKernelGGL((attn_bwd_dq_mfma_kernel<f16_t, KD_>), gq4, dim3(256), 0, ST(stream), a);                         \
       hipLaunchKernelGGL((attn_bwd_dkv_mfma_kernel<f16_t, KD_>), gk4, dim3(256), 0, ST(stream), a);                        \
     } else {                                                                                                               \
-      hipLaunchKernelGGL((attn_bwd_stats_mfma_kernel<bf16_t, KD_>), gq4, dim3(256), 0, ST(stream), a);                     \
+      if (a.exact_d) hipLaunchKernelGGL((attn_bwd_stats_mfma_kernel<bf16_t, KD_, true>), gq4, dim3(256), 0, ST(stream), a); \
+      else hipLaunchKernelGGL((attn_bwd_stats_mfma_kernel<bf16_t, KD_, false>), gq4, dim3(256), 0, ST(stream), a);         \
       hipLaunchKernelGGL((attn_bwd_dq_mfma_kernel<bf16_t, KD_>), gq4, dim3(256), 0, ST(stream), a);                        \
       hipLaunchKernelGGL((attn_bwd_dkv_mfma_kernel<bf16_t, KD_>), gk4, dim3(256), 0, ST(stream), a);                       \
     }                                                                                                                      \

@@ -24,6 +24,7 @@ struct Tuning {
   int fused_split;      // MOBI_IGEMM_FUSED_SPLIT     0: split-K launches always finish in igemm_splitk_reduce_kernel, also with `sync` given (A/B)
   int split_longk;      // MOBI_IGEMM_SPLIT_LONGK     0: no extra doubling of the splits on one-round launches with >= 80 k-tiles per split (A/B)
   int split_round4;     // MOBI_IGEMM_SPLIT_ROUND4    0: the split plan of round 4 for 5 .. 8 splits (A/B); default: 4 where the reduce's rounds say so
+  int attn_bwd_exact_d; // MOBI_ATTN_BWD_EXACT_D      0: the softmax backward's row term from the STORED output (do . o; A/B); default: sum_j P dP
   int small;            // MOBI_IGEMM_SMALL           0: never the small-problem kernel (igemm_small.hip); 32: every eligible launch (A/B)
   int small_mflop;      // MOBI_IGEMM_SMALL_MFLOP     largest 2 M N K (MFLOP) of a 1 x 1 launch routed to it (sweeps)
   int small_conv_m;     // MOBI_IGEMM_SMALL_CONV_M    most output pixels of a 3 x 3 launch routed to it (sweeps)

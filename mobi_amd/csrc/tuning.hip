@@ -34,6 +34,7 @@ void read_env() {
   g_tuning.split_target = env_int("MOBI_IGEMM_SPLIT_TARGET");
   g_tuning.split_longk = env_int("MOBI_IGEMM_SPLIT_LONGK");
   g_tuning.split_round4 = env_int("MOBI_IGEMM_SPLIT_ROUND4");
+  g_tuning.attn_bwd_exact_d = env_int("MOBI_ATTN_BWD_EXACT_D");
   g_tuning.fused_split = env_int("MOBI_IGEMM_FUSED_SPLIT");
   g_tuning.small = env_int("MOBI_IGEMM_SMALL");
   g_tuning.small_mflop = env_int("MOBI_IGEMM_SMALL_MFLOP");
