@@ -14,14 +14,14 @@ from tests.test_gpu_ops import DT, rnd
 pytestmark = pytest.mark.gpu
 # gradients are 16-bit tensors between the kernels (as the activations are): 2x the values measured on the MI355X
 # (profiles/r05_error_table.txt) -- one kernel; the block's data gradient; its worst parameter gradient
-# measured: one kernel 4.0e-4 / 3.3e-3 (fp16 / bf16, attention dK); the block's forward 6.8e-4 / 5.5e-3, its data gradient
-# 9.2e-4 / 7.5e-3, its worst parameter gradient 5.5e-3 / 3.4e-2
+# measured: one kernel 3.3e-4 / 2.5e-3 (fp16 / bf16, attention dK); the block's forward 6.8e-4 / 5.5e-3, its data gradient
+# 9.2e-4 / 7.5e-3, its worst parameter gradient 1.9e-3 / 1.4e-2 (5.5e-3 / 3.4e-2 before the softmax row term was made exact)
 TOL1 = {torch.float16: 8e-4, torch.bfloat16: 6.6e-3}
 TOL_DX = {torch.float16: 1.9e-3, torch.bfloat16: 1.5e-2}
-TOL_DW = {torch.float16: 1.1e-2, torch.bfloat16: 6.8e-2}
+TOL_DW = {torch.float16: 3.8e-3, torch.bfloat16: 2.9e-2}
 # the reduced UNet's training step: (all 432 adapter gradients as one vector, the worst single tensor); measured
-# 2.9e-3 / 1.1e-2 (fp16), 1.6e-2 / 8.3e-2 (bf16)
-TOL_UNET = {torch.float16: (6e-3, 2.3e-2), torch.bfloat16: (3.3e-2, 1.7e-1)}
+# 2.9e-3 / 6.7e-3 (fp16), 1.5e-2 / 3.9e-2 (bf16) (worst tensors 1.1e-2 / 8.3e-2 before the exact row term)
+TOL_UNET = {torch.float16: (6e-3, 1.4e-2), torch.bfloat16: (3e-2, 7.8e-2)}
 
 
 def rel(a, b, name="rel"):
