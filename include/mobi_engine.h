@@ -42,8 +42,11 @@ extern "C" {
  *      MOBI_IGEMM_SMALL; mobi_tile_weights
  *   5  mobi_igemm_params.sync + mobi_igemm_sync_bytes (split-K finished inside the launch); mobi_igemm_params.groups may be
  *      any divisor of batch; mobi_igemm_params.ln_svec / ln_eps (LayerNorm folded into the consuming launch);
- *      mobi_groupnorm_params.src_f32 / out_mode (0..3); mobi_split_f32 */
-#define MOBI_ABI_VERSION 5
+ *      mobi_groupnorm_params.src_f32 / out_mode (0..3); mobi_split_f32
+ *   6  mobi_igemm_params.defer_finish + mobi_igemm_slab_count / mobi_igemm_finish; mobi_split_source (struct id 19) and
+ *      mobi_groupnorm_params.src0_split + mobi_groupnorm_takes_split: a split-K launch's partial sums are summed by the
+ *      GroupNorm that consumes them instead of by a reduce launch of their own */
+#define MOBI_ABI_VERSION 6
 
 enum { MOBI_OK = 0, MOBI_ERR_ARG = -1, MOBI_ERR_UNSUPPORTED = -2, MOBI_ERR_LAUNCH = -3, MOBI_ERR_ALIGN = -4 };
 enum { MOBI_F16 = 0, MOBI_BF16 = 1 };
@@ -54,7 +57,7 @@ const char* mobi_error_string(int code);
  * their own layout before the first call.  id: 0 igemm, 1 groupnorm, 2 layernorm,
  * 3 attention, 4 ctx_attention, 5 skinny_linear, 6 conv_small_cin, 7 conv_small_cout,
  * 8 ddim_step, 9 two_key_adapter, 10 range_paste, 11 lidar_metrics, 12 range_prepare, 13 image_prepare, 14 ff_geglu,
- * 15 row_chain, 16 chain_op, 17 layernorm_bwd, 18 attention_bwd.  Returns 0 for an unknown id. */
+ * 15 row_chain, 16 chain_op, 17 layernorm_bwd, 18 attention_bwd, 19 split_source.  Returns 0 for an unknown id. */
 size_t mobi_struct_size(int id);
 /* Development hook: the library reads its MOBI_* A/B environment variables once, at the first launch
  * (mobi_amd/csrc/tuning.h lists them); this re-reads them.  Not needed by a product caller. */
@@ -139,9 +142,19 @@ typedef struct mobi_igemm_params {
                             rstd (x W'^T - mean ln_svec) + bias == Linear(LayerNorm(x)) (ldm/modules/attention.py:234, :264:
                             `attn1(norm1(x))`, `ff(norm3(x))`) without a normalised copy of x.  Runs on the LDS-DMA ring kernels. */
   float ln_eps;
+  int32_t defer_finish;  /* split_k > 1, no `sync`, out_mode MOBI_OUT_ROWS: 1 = launch the k ranges only.  `ws` then holds
+                            mobi_igemm_slab_count(p) slabs f32 [rows][n_packed] of partial sums and `out` is NOT written: the
+                            caller hands them to the consumer (mobi_groupnorm_params.src0_split: a ResBlock's GroupNorm behind
+                            its 3 x 3 convolution, openaimodel.py:255-275, or the next block's) or calls mobi_igemm_finish. */
 } mobi_igemm_params;
 
 int mobi_igemm(const mobi_igemm_params* p, void* stream);
+/* The number of slabs a launch of these parameters writes (k ranges are never empty: it can be less than split_k); 1: no
+ * split.  Negative = the error mobi_igemm would return. */
+int32_t mobi_igemm_slab_count(const mobi_igemm_params* p);
+/* The second half of a split-K launch on its own (same parameters as the mobi_igemm call that ran with defer_finish = 1):
+ * sums the slabs in ascending order, adds bias / per-image vector / residual, writes `out`. */
+int mobi_igemm_finish(const mobi_igemm_params* p, void* stream);
 /* Library heuristic for split_k (1 = do not split) and the workspace it needs. */
 int mobi_igemm_plan_splits(const mobi_igemm_params* p);
 /* Which main loop mobi_igemm would run for these parameters (no launch; measurement / tests):
@@ -160,6 +173,22 @@ size_t mobi_igemm_sync_bytes(const mobi_igemm_params* p, int32_t splits);
  * 832-836), Normalize (attention.py:77-78, model.py:38-39) + nonlinearity
  * (model.py:33-35), and the torch.cat in front of an output ResBlock.
  * ------------------------------------------------------------------------- */
+/* A tensor T [batch][hw][channels] given as the UNFINISHED partial sums of the split-K mobi_igemm that produces it
+ * (mobi_igemm_params.defer_finish = 1).  Element (row, c) = T( sum_s slabs[s][row][c] (s ascending) + bias[c] + rowvec[image][c]
+ * + residual[row][c] ), in that order: bit for bit what mobi_igemm_finish writes. */
+typedef struct mobi_split_source {
+  const float* slabs;      /* f32 [count][batch * hw][row_stride] (the producer's `ws`) */
+  int32_t count;           /* mobi_igemm_slab_count of the producer, 2 .. 64 */
+  int32_t row_stride;      /* the producer's n_packed (>= channels) */
+  const float* bias;       /* f32 [channels] or NULL */
+  const float* rowvec;     /* f32 [batch][channels] or NULL */
+  int32_t rowvec_stride;   /* elements between images of rowvec; 0 = channels */
+  const void* residual;    /* T [batch][hw][channels] or NULL */
+  int64_t res_img_stride;  /* elements between images of residual; 0 = dense */
+  void* finished;          /* T [batch][hw][channels] or NULL: the finished tensor is ALSO written here (a ResBlock's output is
+                              the next GroupNorm's input and a residual / skip connection, openaimodel.py:275, 893-894) */
+} mobi_split_source;
+
 typedef struct mobi_groupnorm_params {
   const void* src0;
   const void* src1;        /* or NULL */
@@ -181,9 +210,15 @@ typedef struct mobi_groupnorm_params {
   void* sync;              /* optional: int32 [batch] arrival counters, ZERO before the launch and zero again after it (one buffer
                               serves every launch of a stream).  With them the library may run the one-launch form whose workgroups
                               own pixel chunks and meet through memory (large groups: the 64 x 64 level); NULL: never. */
+  const mobi_split_source* src0_split; /* optional (then src0 may be NULL; T sources, out_mode 0): src0 as the partial sums of the
+                              launch that produces it -- this launch sums them while it loads its rows, so the producer needs
+                              no reduce launch.  Only where mobi_groupnorm_takes_split says so. */
 } mobi_groupnorm_params;
 
 size_t mobi_groupnorm_workspace_bytes(int32_t batch, int32_t hw);
+/* 1: mobi_groupnorm accepts src0_split for these sizes (the one-launch register form holds the tensor); 0: finish the
+ * producer with mobi_igemm_finish first. */
+int mobi_groupnorm_takes_split(int32_t c0, int32_t c1, int32_t batch, int32_t hw);
 int mobi_groupnorm(const mobi_groupnorm_params* p, void* stream);
 
 /* LayerNorm over the channel axis of token rows (nn.LayerNorm, eps 1e-5,

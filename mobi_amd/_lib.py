@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libmobi_hip.so")
 
 MOBI_F16, MOBI_BF16 = 0, 1
-ABI_VERSION = 5            # include/mobi_engine.h MOBI_ABI_VERSION
+ABI_VERSION = 6            # include/mobi_engine.h MOBI_ABI_VERSION
 EPI_NONE, EPI_GEGLU = 0, 1
 OUT_ROWS, OUT_TRANSPOSED, OUT_ROWS_F32 = 0, 1, 2
 ACT_NONE, ACT_SILU, ACT_GELU = 0, 1, 2
@@ -34,13 +34,18 @@ class IgemmParams(C.Structure):
                 ("w_group_stride", i64), ("n_packed", i32), ("cout", i32), ("bias", vp), ("rowvec", vp), ("rowvec_stride", i32),
                 ("residual", vp), ("res_img_stride", i64), ("out", vp), ("out_img_stride", i64),
                 ("out_mode", i32), ("epilogue", i32), ("scale", f32), ("dtype", i32), ("split_k", i32), ("ws", vp), ("k_order", i32),
-                ("weight_tiled", vp), ("sync", vp), ("ln_svec", vp), ("ln_eps", f32)]
+                ("weight_tiled", vp), ("sync", vp), ("ln_svec", vp), ("ln_eps", f32), ("defer_finish", i32)]
+
+
+class SplitSource(C.Structure):
+    _fields_ = [("slabs", vp), ("count", i32), ("row_stride", i32), ("bias", vp), ("rowvec", vp), ("rowvec_stride", i32),
+                ("residual", vp), ("res_img_stride", i64), ("finished", vp)]
 
 
 class GroupNormParams(C.Structure):
     _fields_ = [("src0", vp), ("src1", vp), ("c0", i32), ("c1", i32), ("batch", i32), ("hw", i32), ("gamma", vp),
                 ("beta", vp), ("eps", f32), ("silu", i32), ("out", vp), ("ws", vp), ("dtype", i32), ("src_f32", i32),
-                ("out_mode", i32), ("sync", vp)]
+                ("out_mode", i32), ("sync", vp), ("src0_split", C.POINTER(SplitSource))]
 
 
 class LayerNormParams(C.Structure):
@@ -157,7 +162,7 @@ STRUCT_IDS = {0: IgemmParams, 1: GroupNormParams, 2: LayerNormParams, 3: Attenti
               5: SkinnyLinearParams, 6: ConvSmallCinParams, 7: ConvSmallCoutParams, 8: DdimStepParams, 9: TwoKeyAdapterParams,
               10: RangePasteParams, 11: LidarMetricsParams, 12: RangePrepareParams, 13: ImagePrepareParams,
               14: FfGegluParams, 15: RowChainParams, 16: ChainOp,
-              17: LayerNormBwdParams, 18: AttentionBwdParams}
+              17: LayerNormBwdParams, 18: AttentionBwdParams, 19: SplitSource}
 
 # every symbol include/mobi_engine.h declares: name -> (restype, argtypes)
 SYMBOLS = {
@@ -171,6 +176,9 @@ SYMBOLS = {
     "mobi_igemm_kernel_variant": (C.c_int, [C.POINTER(IgemmParams)]),
     "mobi_igemm_workspace_bytes": (C.c_size_t, [C.POINTER(IgemmParams), i32]),
     "mobi_igemm_sync_bytes": (C.c_size_t, [C.POINTER(IgemmParams), i32]),
+    "mobi_igemm_slab_count": (i32, [C.POINTER(IgemmParams)]),
+    "mobi_igemm_finish": (C.c_int, [C.POINTER(IgemmParams), vp]),
+    "mobi_groupnorm_takes_split": (C.c_int, [i32, i32, i32, i32]),
     "mobi_groupnorm_workspace_bytes": (C.c_size_t, [i32, i32]),
     "mobi_groupnorm": (C.c_int, [C.POINTER(GroupNormParams), vp]),
     "mobi_layernorm": (C.c_int, [C.POINTER(LayerNormParams), vp]),

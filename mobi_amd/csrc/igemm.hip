@@ -2711,6 +2711,15 @@ static int compute_units() {
 }
 
 template <typename T>
+static int launch_splitk_reduce(const IgemmArgs& a, hipStream_t st) {
+  long long blocks = ((long long)a.M * (a.cout >> 3) + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL((igemm_splitk_reduce_kernel<T>), dim3((unsigned)blocks), dim3(256), 0, st, a);
+  MOBI_CHECK_LAUNCH();
+  return MOBI_OK;
+}
+
+template <typename T>
 static int launch_igemm(const mobi_igemm_params* p, const IgemmArgs& a, int groups, hipStream_t st) {
   const bool tr = p->out_mode == MOBI_OUT_TRANSPOSED;
   const bool nt5 = (a.n_packed % 160) == 0;
@@ -2793,12 +2802,9 @@ static int launch_igemm(const mobi_igemm_params* p, const IgemmArgs& a, int grou
 #undef MOBI_IGEMM_BY_FAST
 #undef MOBI_IGEMM_LAUNCH
   MOBI_CHECK_LAUNCH();
-  if (a.split_ws && !a.sync) {                               // (with `sync` the tile's last block has summed the slabs)
-    long long blocks = ((long long)a.M * (a.cout >> 3) + 255) / 256;
-    if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL((igemm_splitk_reduce_kernel<T>), dim3((unsigned)blocks), dim3(256), 0, st, a);
-    MOBI_CHECK_LAUNCH();
-  }
+  // (with `sync` the tile's last block has summed the slabs; with defer_finish the consumer does -- mobi_groupnorm's src0_split --
+  //  or a later mobi_igemm_finish)
+  if (a.split_ws && !a.sync && !p->defer_finish) return launch_splitk_reduce<T>(a, st);
   return MOBI_OK;
 }
 
@@ -3006,6 +3012,9 @@ static int igemm_prepare(const mobi_igemm_params* p, mobi::IgemmArgs& a) {
     a.splits = (a.nk + a.nk_per - 1) / a.nk_per;            // no empty k ranges: every slab that is summed is written
     a.split_ws = reinterpret_cast<float*>(p->ws);
   }
+  if (p->defer_finish != 0 && p->defer_finish != 1) return MOBI_ERR_ARG;
+  // deferred finish: the slabs are the launch's result -- T rows only (what a consumer reconstructs), never with `sync`
+  if (p->defer_finish && (!a.split_ws || p->sync || p->out_mode != MOBI_OUT_ROWS)) return MOBI_ERR_UNSUPPORTED;
   // (taps-innermost k order only: it changes tap every k-tile; measured 1.5-3 % slower than the window re-derivation
   //  on tap-major k, where a tap lasts C/64 k-tiles -- tools/sweep_korder.py)
   a.lin_window = p->k_order == 1 && p->upsample == 0 && p->kh * p->kw <= 16;
@@ -3150,6 +3159,23 @@ extern "C" int mobi_igemm(const mobi_igemm_params* p, void* stream) {
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (a.small) return launch_small(p, a, st);
   return p->dtype == MOBI_F16 ? launch_igemm<f16_t>(p, a, p->groups, st) : launch_igemm<bf16_t>(p, a, p->groups, st);
+}
+
+extern "C" int32_t mobi_igemm_slab_count(const mobi_igemm_params* p) {
+  mobi::IgemmArgs a;
+  const int rc = igemm_prepare(p, a);
+  if (rc != MOBI_OK) return rc;
+  return a.small ? 1 : a.splits;
+}
+
+extern "C" int mobi_igemm_finish(const mobi_igemm_params* p, void* stream) {
+  using namespace mobi;
+  IgemmArgs a;
+  const int rc = igemm_prepare(p, a);
+  if (rc != MOBI_OK) return rc;
+  if (!a.split_ws || a.small || a.sync) return MOBI_ERR_ARG;       // nothing was deferred
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  return p->dtype == MOBI_F16 ? launch_splitk_reduce<f16_t>(a, st) : launch_splitk_reduce<bf16_t>(a, st);
 }
 
 extern "C" int mobi_igemm_kernel_variant(const mobi_igemm_params* p) {

@@ -33,6 +33,11 @@ struct GnArgs {
   int out_mode;    // 0: T [..][C];  1: T [..][2 C] = hi | lo with hi = T(y), lo = T(y - hi) (a consumer with duplicated weights then
                    //    multiplies y to ~22 bits);  2: f32 [..][C];  3: T [..][3 C] = hi | lo | hi (weights [W ; W ; W - T(W)]: the weights'
                    //    rounding corrected too)
+  // src0 as the unfinished split-K partial sums of its producer (mobi_split_source; gn_regs_kernel<.., SLAB = true> only)
+  const float* slabs; int splits, slab_row; long long slab_stride;
+  const float* s_bias; const float* s_rowvec; int s_rowvec_stride;
+  const void* s_resid; long long s_res_img;
+  void* finished;
 };
 
 template <typename T>
@@ -385,7 +390,12 @@ __global__ __launch_bounds__(256) void gn_fused_kernel(const GnArgs a) {
 // Algorithmic bytes: 2 B read + 2 B written per element.
 struct GnRegsGeom { int gb, ppr, slots; };               // groups per block, pieces per pixel segment, pixel slots
 
-template <typename T, int THREADS, int ITEMS, int PW>
+// SLAB: the columns of src0 are not loaded but RECONSTRUCTED from the fp32 partial sums of the split-K launch that produces
+// src0 -- slabs summed in ascending order from zero, + bias, + per-image vector, + residual, one rounding to T: the arithmetic
+// of igemm_splitk_reduce_kernel (csrc/igemm.hip) bit for bit, which this launch replaces; the rounded pieces are what the
+// statistics and the output see (the same tensor the two launches would have passed through memory), and they are written to
+// `finished` when the tensor has other readers (a ResBlock's output: residual / skip connection of what follows).
+template <typename T, int THREADS, int ITEMS, int PW, bool SLAB = false>
 __global__ __launch_bounds__(THREADS) void gn_regs_kernel(const GnArgs a, const GnRegsGeom geo) {
   constexpr int NW = THREADS / 64, PR = PW / 2;
   __shared__ float s_part[4][THREADS];                    // per-thread partial of each of the block's groups
@@ -415,13 +425,89 @@ __global__ __launch_bounds__(THREADS) void gn_regs_kernel(const GnArgs a, const 
   typedef unsigned piece_t __attribute__((ext_vector_type(PR)));
   typedef T T2 __attribute__((ext_vector_type(2)));
   unsigned raw[ITEMS][PR];
+  if (SLAB && !second) {
+    float bia[PW], rvv[PW];                               // bias, per-image vector of this column (added one after the other, as the reduce kernel does)
 #pragma unroll
-  for (int i = 0; i < ITEMS; ++i) {
-    const int p = slot + i * SLOTS;
-    piece_t r = piece_t(0u);
-    if (live && p < a.hw) r = *reinterpret_cast<const piece_t*>(src + (long long)p * cs);
+    for (int j = 0; j < PW; j += 4) {
+      const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+      const f32x4 b4 = a.s_bias ? *reinterpret_cast<const f32x4*>(a.s_bias + c + j) : z;
+      const f32x4 r4 = a.s_rowvec ? *reinterpret_cast<const f32x4*>(a.s_rowvec + (long long)img * a.s_rowvec_stride + c + j) : z;
 #pragma unroll
-    for (int j = 0; j < PR; ++j) raw[i][j] = r[j];
+      for (int e = 0; e < 4; ++e) { bia[j + e] = b4[e]; rvv[j + e] = r4[e]; }
+    }
+    const T* __restrict__ resid = reinterpret_cast<const T*>(a.s_resid);
+    T* __restrict__ fin = reinterpret_cast<T*>(a.finished);
+    const long long row0 = (long long)img * a.hw;
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) {
+      const int p = slot + i * SLOTS;
+      piece_t r = piece_t(0u);
+      if (live && p < a.hw) {
+        float o[PW];
+#pragma unroll
+        for (int j = 0; j < PW; ++j) o[j] = 0.f;
+        const float* q = a.slabs + (row0 + p) * a.slab_row + c;
+        int sp = 0;
+        for (; sp + 4 <= a.splits; sp += 4) {             // four slabs requested at once, summed in ascending order
+          f32x4 v[4][PW / 4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int j = 0; j < PW / 4; ++j) v[u][j] = *reinterpret_cast<const f32x4*>(q + (sp + u) * a.slab_stride + 4 * j);
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int j = 0; j < PW; ++j) o[j] += v[u][j >> 2][j & 3];
+        }
+        for (; sp < a.splits; ++sp) {
+#pragma unroll
+          for (int j = 0; j < PW / 4; ++j) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(q + sp * a.slab_stride + 4 * j);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[4 * j + e] += v[e];
+          }
+        }
+        if (a.s_bias) {
+#pragma unroll
+          for (int j = 0; j < PW; ++j) o[j] += bia[j];
+        }
+        if (a.s_rowvec) {
+#pragma unroll
+          for (int j = 0; j < PW; ++j) o[j] += rvv[j];
+        }
+        if (resid) {
+          piece_t rr = *reinterpret_cast<const piece_t*>(resid + (long long)img * a.s_res_img + (long long)p * a.c0 + c);
+          unsigned rw[PR];
+#pragma unroll
+          for (int j = 0; j < PR; ++j) rw[j] = rr[j];
+#pragma unroll
+          for (int j = 0; j < PR; ++j) {
+            const T2 v = __builtin_bit_cast(T2, rw[j]);
+            o[2 * j] += (float)v[0];
+            o[2 * j + 1] += (float)v[1];
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < PR; ++j) {
+          T2 v;
+          v[0] = (T)o[2 * j];
+          v[1] = (T)o[2 * j + 1];
+          r[j] = __builtin_bit_cast(unsigned, v);
+        }
+        if (fin) *reinterpret_cast<piece_t*>(fin + (row0 + p) * a.c0 + c) = r;
+      }
+#pragma unroll
+      for (int j = 0; j < PR; ++j) raw[i][j] = r[j];
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) {
+      const int p = slot + i * SLOTS;
+      piece_t r = piece_t(0u);
+      if (live && p < a.hw) r = *reinterpret_cast<const piece_t*>(src + (long long)p * cs);
+#pragma unroll
+      for (int j = 0; j < PR; ++j) raw[i][j] = r[j];
+    }
   }
   auto unpack = [&](const unsigned (&r)[PR], float (&f)[PW]) {
 #pragma unroll
@@ -580,6 +666,38 @@ static bool gn_regs_geometry(int C, int hw, int batch, GnRegsGeom* geo, int* thr
     found = true;
   }
   return found;
+}
+
+// src0 from split-K slabs: the register form with at most 8 pieces per thread (split launches have few pixels: the 32 x 32
+// level's 320-channel tensors are the largest -- 8 pieces of 8 bytes), both sources split at a piece boundary
+static bool gn_regs_takes_split(int c0, int c1, int hw, int batch) {
+  GnRegsGeom geo;
+  int th, it, pw;
+  if (!gn_regs_geometry(c0 + c1, hw, batch, &geo, &th, &it, &pw)) return false;
+  return it <= 8 && c0 % pw == 0;
+}
+
+template <typename T>
+static bool launch_gn_regs_split(const GnArgs& a, int batch, hipStream_t st) {
+  GnRegsGeom geo;
+  int th, it, pw;
+  if (!gn_regs_geometry(a.C, a.hw, batch, &geo, &th, &it, &pw) || it > 8 || a.c0 % pw) return false;
+  const dim3 grid((unsigned)(32 / geo.gb * batch));
+#define MOBI_GNS(TH_, IT_, PW_) hipLaunchKernelGGL((gn_regs_kernel<T, TH_, IT_, PW_, true>), grid, dim3(TH_), 0, st, a, geo)
+  if (pw == 4) MOBI_GNS(1024, 8, 4);
+  else if (th == 256) {
+    switch (it) {
+      case 1: MOBI_GNS(256, 1, 8); break;   case 2: MOBI_GNS(256, 2, 8); break;   case 3: MOBI_GNS(256, 3, 8); break;
+      case 4: MOBI_GNS(256, 4, 8); break;   case 6: MOBI_GNS(256, 6, 8); break;   default: MOBI_GNS(256, 8, 8); break;
+    }
+  } else {
+    switch (it) {
+      case 1: MOBI_GNS(1024, 1, 8); break;   case 2: MOBI_GNS(1024, 2, 8); break;   case 3: MOBI_GNS(1024, 3, 8); break;
+      case 4: MOBI_GNS(1024, 4, 8); break;   case 6: MOBI_GNS(1024, 6, 8); break;   default: MOBI_GNS(1024, 8, 8); break;
+    }
+  }
+#undef MOBI_GNS
+  return true;
 }
 
 template <typename T>
@@ -903,6 +1021,11 @@ template <typename T>
 static int launch_gn(const GnArgs& a, int batch, hipStream_t st) {
   // small tensors: one launch, the group's slab in LDS (channel pairs: C / 32 even; both sources split at an even channel)
   const int cpg = a.C / 32;
+  if (a.slabs) {                                        // src0 from its producer's split-K slabs: the register form or nothing
+    if (!launch_gn_regs_split<T>(a, batch, st)) return MOBI_ERR_UNSUPPORTED;
+    MOBI_CHECK_LAUNCH();
+    return MOBI_OK;
+  }
   if (a.src_f32 || a.out_mode) {                        // fp32 source / precise outputs: the two-launch form of their own
     if (a.src_f32) hipLaunchKernelGGL(gn_stats_f32_kernel, dim3(a.chunks, batch), dim3(256), 0, st, a);
     else hipLaunchKernelGGL((gn_stats_kernel<T>), dim3(a.chunks, batch), dim3(256), 0, st, a);
@@ -973,9 +1096,15 @@ extern "C" size_t mobi_groupnorm_workspace_bytes(int32_t batch, int32_t hw) {
   return (size_t)batch * chunks * 32 * 2 * sizeof(float);
 }
 
+extern "C" int mobi_groupnorm_takes_split(int32_t c0, int32_t c1, int32_t batch, int32_t hw) {
+  if (c0 <= 0 || (c0 & 31) || c1 < 0 || (c1 & 31) || batch <= 0 || hw <= 0 || c0 + c1 > 2560) return 0;
+  if (mobi::tuning().gn_fused == 0 || mobi::tuning().gn_fused == 1) return 0;      // a forced other form (A/B): no register form
+  return mobi::gn_regs_takes_split(c0, c1, hw, batch) ? 1 : 0;
+}
+
 extern "C" int mobi_groupnorm(const mobi_groupnorm_params* p, void* stream) {
   using namespace mobi;
-  if (!p || !p->src0 || !p->out || !p->ws || !p->gamma || !p->beta) return MOBI_ERR_ARG;
+  if (!p || (!p->src0 && !p->src0_split) || !p->out || !p->ws || !p->gamma || !p->beta) return MOBI_ERR_ARG;
   if (p->dtype != MOBI_F16 && p->dtype != MOBI_BF16) return MOBI_ERR_ARG;
   if (p->c0 <= 0 || (p->c0 & 31) || p->c1 < 0 || (p->c1 & 31) || (p->c1 > 0 && !p->src1)) return MOBI_ERR_UNSUPPORTED;
   if (p->batch <= 0 || p->hw <= 0 || p->batch > 65535) return MOBI_ERR_ARG;
@@ -994,6 +1123,21 @@ extern "C" int mobi_groupnorm(const mobi_groupnorm_params* p, void* stream) {
   a.src_f32 = p->src_f32; a.out_mode = p->out_mode;
   if (reinterpret_cast<uintptr_t>(p->sync) & 3) return MOBI_ERR_ALIGN;
   a.sync = reinterpret_cast<int*>(p->sync);
+  a.slabs = nullptr; a.splits = 0; a.slab_row = 0; a.slab_stride = 0;
+  a.s_bias = nullptr; a.s_rowvec = nullptr; a.s_rowvec_stride = 0; a.s_resid = nullptr; a.s_res_img = 0; a.finished = nullptr;
+  if (const mobi_split_source* ss = p->src0_split) {
+    if (!ss->slabs || ss->count < 2 || ss->count > 64 || ss->row_stride < p->c0 || (ss->row_stride & 3)) return MOBI_ERR_ARG;
+    if (p->src_f32 || p->out_mode) return MOBI_ERR_UNSUPPORTED;
+    if ((reinterpret_cast<uintptr_t>(ss->slabs) | reinterpret_cast<uintptr_t>(ss->bias) | reinterpret_cast<uintptr_t>(ss->rowvec) |
+         reinterpret_cast<uintptr_t>(ss->residual) | reinterpret_cast<uintptr_t>(ss->finished)) & 15) return MOBI_ERR_ALIGN;
+    if ((ss->rowvec_stride & 3) || (ss->res_img_stride & 7)) return MOBI_ERR_ALIGN;
+    if (!mobi_groupnorm_takes_split(p->c0, p->c1, p->batch, p->hw)) return MOBI_ERR_UNSUPPORTED;
+    a.slabs = ss->slabs; a.splits = ss->count; a.slab_row = ss->row_stride;
+    a.slab_stride = (long long)p->batch * p->hw * ss->row_stride;
+    a.s_bias = ss->bias; a.s_rowvec = ss->rowvec; a.s_rowvec_stride = ss->rowvec_stride ? ss->rowvec_stride : p->c0;
+    a.s_resid = ss->residual; a.s_res_img = ss->res_img_stride ? ss->res_img_stride : (long long)p->hw * p->c0;
+    a.finished = ss->finished;
+  }
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   return p->dtype == MOBI_F16 ? launch_gn<f16_t>(a, p->batch, st) : launch_gn<bf16_t>(a, p->batch, st);
 }

@@ -234,6 +234,7 @@ extern "C" size_t mobi_struct_size(int id) {
     case 16: return sizeof(mobi_chain_op);
     case 17: return sizeof(mobi_layernorm_bwd_params);
     case 18: return sizeof(mobi_attention_bwd_params);
+    case 19: return sizeof(mobi_split_source);
     default: return 0;
   }
 }

@@ -586,7 +586,9 @@ class SpatialTransformer(nn.Module):
         x, ext = enter(x)
         n, h, w, c = x.shape
         g, b = self.norm.affine()
-        if self._pre_chain_ok(x):
+        if isinstance(x, ops.Deferred) and self._pre_chain_ok(x.tensor):
+            x = x.finish()
+        if not isinstance(x, ops.Deferred) and self._pre_chain_ok(x):
             # GroupNorm -> proj_in -> norm1 -> to_q | to_k | to_v as ONE chain launch on the token rows (+ a statistics pass that
             # turns the GroupNorm into a per-image scale / shift): attention.py:306-307 and :234 of the reference
             blk = self.transformer_blocks[0]
@@ -602,7 +604,10 @@ class SpatialTransformer(nn.Module):
             t = blk(t, context=context, qkv=qkv)
             y = ops.igemm(t.view(n, h, w, t.shape[2]), self.proj_out.packed(), residual=x)
             return leave(y, ext)
-        t = ops.igemm(ops.groupnorm(x, g, b, self.norm.eps, silu=False), self.proj_in.packed())
+        # (a Deferred x -- the partial sums of the ResBlock's last convolution -- is summed by this GroupNorm, its first reader)
+        xn = ops.groupnorm(x, g, b, self.norm.eps, silu=False)
+        x = ops.finished(x)
+        t = ops.igemm(xn, self.proj_in.packed())
         t = t.view(n, h * w, t.shape[3])
         for block in self.transformer_blocks:
             t = block(t, context=context)

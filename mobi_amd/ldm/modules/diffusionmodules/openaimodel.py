@@ -27,18 +27,33 @@ class TimestepBlock(nn.Module):
     pass
 
 
+def _opens_with_groupnorm(layer):
+    """The first reader of `layer`'s input is a GroupNorm over all of it (ResBlock.in_layers[0], SpatialTransformer.norm;
+    a Sequential: its first layer's)."""
+    if isinstance(layer, nn.Sequential):
+        return len(layer) > 0 and _opens_with_groupnorm(layer[0])
+    return isinstance(layer, (ResBlock, SpatialTransformer))
+
+
 class TimestepEmbedSequential(nn.Sequential, TimestepBlock):
-    def forward(self, x, emb, context=None, skip=None):
-        for layer in self:
+    def forward(self, x, emb, context=None, skip=None, then_groupnorm=False):
+        """then_groupnorm: the caller's next reader of the result is a GroupNorm (the next block's first layer, or
+        UNetModel.out): a convolution that splits k may then hand over its partial sums (ops.Deferred) instead of running a
+        reduce launch.  Between the layers of the sequence that is decided here."""
+        layers = list(self)
+        for i, layer in enumerate(layers):
+            defer = _opens_with_groupnorm(layers[i + 1]) if i + 1 < len(layers) else then_groupnorm
             if isinstance(layer, TimestepBlock):
-                x = layer(x, emb, skip=skip)
+                x = layer(x, emb, skip=skip, defer_out=defer)
                 skip = None
             elif isinstance(layer, SpatialTransformer):
                 x = layer(x, context)
             elif isinstance(layer, Conv2d):
-                x = _plain_conv(layer, x)
+                x = _plain_conv(layer, ops.finished(x))
+            elif isinstance(layer, (Upsample, Downsample)):
+                x = layer(x, defer_out=defer)
             else:
-                x = layer(x)
+                x = layer(ops.finished(x))
         return x
 
 
@@ -60,10 +75,11 @@ class Upsample(nn.Module):
         self.out_channels = out_channels or channels
         self.conv = conv_nd(dims, self.channels, self.out_channels, 3, padding=padding)
 
-    def forward(self, x):
-        x, ext = enter(x)
+    def forward(self, x, defer_out=False):
+        x, ext = enter(ops.finished(x))
         assert x.shape[3] == self.channels
-        return leave(ops.igemm(x, self.conv.packed(), upsample=True, pad=self.conv.padding), ext)
+        defer = "keep" if defer_out and not ext else None
+        return leave(ops.igemm(x, self.conv.packed(), upsample=True, pad=self.conv.padding, defer=defer), ext)
 
 
 class Downsample(nn.Module):
@@ -74,10 +90,11 @@ class Downsample(nn.Module):
         self.out_channels = out_channels or channels
         self.op = conv_nd(dims, self.channels, self.out_channels, 3, stride=2, padding=padding)
 
-    def forward(self, x):
-        x, ext = enter(x)
+    def forward(self, x, defer_out=False):
+        x, ext = enter(ops.finished(x))
         assert x.shape[3] == self.channels
-        return leave(ops.igemm(x, self.op.packed(), stride=2, pad=self.op.padding), ext)
+        defer = "keep" if defer_out and not ext else None
+        return leave(ops.igemm(x, self.op.packed(), stride=2, pad=self.op.padding, defer=defer), ext)
 
 
 class ResBlock(TimestepBlock):
@@ -100,13 +117,15 @@ class ResBlock(TimestepBlock):
             self.skip_connection = conv_nd(dims, channels, self.out_channels, 1)
         self._emb_slice = None          # set by UNetModel: column range inside the batched projection
 
-    def forward(self, x, emb, skip=None):
-        """x: engine tensor [N,H,W,C0] (or fp32 NCHW); skip: optional second source whose channels
+    def forward(self, x, emb, skip=None, defer_out=False):
+        """x: engine tensor [N,H,W,C0] (or fp32 NCHW, or an ops.Deferred: the partial sums of the split-K launch that
+        produces it -- in_layers' GroupNorm sums them); skip: optional second source whose channels
         follow x's (the un-materialised concat); emb: fp32 [N, emb_channels] or a dict holding the
-        pre-projected `emb_layers` outputs (UNetModel)."""
+        pre-projected `emb_layers` outputs (UNetModel).  defer_out: the caller's next reader of the result is a GroupNorm
+        (TimestepEmbedSequential.forward): the result may then be an ops.Deferred."""
         x, ext = enter(x)
         if skip is not None:
-            skip, _ = enter(skip)
+            skip, _ = enter(ops.finished(skip))
         # emb_out already carries conv1's bias (one fp32 add at pack time instead of one per pixel; the launch
         # then needs only ONE per-image vector, which keeps it on the register-epilogue kernels)
         if isinstance(emb, dict):
@@ -118,10 +137,14 @@ class ResBlock(TimestepBlock):
                                         pre_act=ACT_SILU)
         n1, n2 = self.in_layers[0], self.out_layers[0]
 
+        # in_layers' GroupNorm is x's first reader: a Deferred x is summed there (and written: x has more readers below)
+        g, b = n1.affine()
+        h1 = ops.groupnorm(x, g, b, n1.eps, silu=True, x2=skip)
+        x = ops.finished(x)
+
         def main_path():
-            g, b = n1.affine()
-            h = ops.groupnorm(x, g, b, n1.eps, silu=True, x2=skip)
-            h = ops.igemm(h, self.in_layers[2].packed(), rowvec=emb_out, rowvec_has_bias=True)
+            # conv1's only reader is out_layers' GroupNorm: a split launch leaves its partial sums to it
+            h = ops.igemm(h1, self.in_layers[2].packed(), rowvec=emb_out, rowvec_has_bias=True, defer="drop")
             g, b = n2.affine()
             return ops.groupnorm(h, g, b, n2.eps, silu=True)
 
@@ -130,7 +153,8 @@ class ResBlock(TimestepBlock):
         else:
             assert skip is None
             h, xs = main_path(), x
-        return leave(ops.igemm(h, self.out_layers[3].packed(), residual=xs), ext)
+        defer = "keep" if defer_out and not ext else None
+        return leave(ops.igemm(h, self.out_layers[3].packed(), residual=xs, defer=defer), ext)
 
 
 class UNetModel(nn.Module):
@@ -246,14 +270,21 @@ class UNetModel(nn.Module):
         embd = {"emb": emb, "proj": ops.skinny_linear(emb, we, be, pre_act=ACT_SILU)}
         context = context.float().contiguous()
 
+        # (a block whose successor opens with a GroupNorm may return an ops.Deferred: the successor's GroupNorm sums the split-K
+        #  slabs and writes the tensor -- which is what `hs` then holds by the time an output block pops it)
         hs = []
         h = x
-        for module in self.input_blocks:
-            h = module(h, embd, context)
-            hs.append(h)
-        h = self.middle_block(h, embd, context)
-        for module in self.output_blocks:
-            h = module(h, embd, context, skip=hs.pop())
+        blocks = list(self.input_blocks) + [self.middle_block] + list(self.output_blocks)
+        nin = len(self.input_blocks)
+        for i, module in enumerate(blocks):
+            then_gn = _opens_with_groupnorm(blocks[i + 1]) if i + 1 < len(blocks) else True      # self.out[0]
+            if i < nin:
+                h = module(h, embd, context, then_groupnorm=then_gn)
+                hs.append(h)
+            elif i == nin:
+                h = module(h, embd, context, then_groupnorm=then_gn)
+            else:
+                h = module(h, embd, context, skip=hs.pop(), then_groupnorm=then_gn)
         n0 = self.out[0]
         g, b = n0.affine()
         h = ops.groupnorm(h, g, b, n0.eps, silu=True)

@@ -659,15 +659,68 @@ def _sync_counters(device, nbytes):
     return buf
 
 
+# A split-K launch's partial sums handed to the GroupNorm that consumes the result (mobi_split_source: the consumer sums the
+# slabs while it loads its rows -- bit for bit the reduce launch's arithmetic -- so the producer needs no second launch).
+# MOBI_DEFER_SPLIT=0: every split launch finishes itself with its reduce launch (A/B).
+DEFER_SPLIT = os.environ.get("MOBI_DEFER_SPLIT", "1") != "0"
+
+
+class Deferred:
+    """The output of a split-K `igemm(..., defer=True)` that has not been summed yet.  `tensor` is the allocated result
+    [N,H,W,cout]; it holds the result only after a GroupNorm has consumed the slabs (`groupnorm(x=deferred)` writes it when
+    `keep`) or after `finish()`.  Everything that is not a GroupNorm takes `ops.finished(x)`."""
+
+    def __init__(self, tensor, params, ws, refs, keep):
+        self.tensor, self.params, self.ws, self.refs, self.keep = tensor, params, ws, refs, keep
+        self.count = _lib.load().mobi_igemm_slab_count(C.byref(params))
+        assert self.count >= 2, self.count
+        self.done = False
+
+    @property
+    def shape(self):
+        return self.tensor.shape
+
+    @property
+    def dtype(self):
+        return self.tensor.dtype
+
+    @property
+    def device(self):
+        return self.tensor.device
+
+    def finish(self):
+        """The reduce launch after all (a consumer that is not a GroupNorm of a shape the register form takes)."""
+        if not self.done:
+            m = self.tensor.numel() // self.tensor.shape[3]
+            with _Timed("split_finish", 0.0, self.count * m * self.params.n_packed * 4.0 + self.tensor.numel() * 2.0,
+                        f"m={m} n={self.params.n_packed} slabs={self.count}"):
+                _lib.check(_lib.load().mobi_igemm_finish(C.byref(self.params), _stream()), "mobi_igemm_finish")
+            self._release()
+        return self.tensor
+
+    def _release(self):
+        self.done = True
+        self.ws = self.refs = None
+
+
+def finished(x):
+    """x, or the summed tensor of a Deferred x."""
+    return x.finish() if isinstance(x, Deferred) else x
+
+
 def igemm(x, pw: Packed, *, x2=None, stride=1, pad=None, upsample=False, hout=None, wout=None, rowvec=None,
           rowvec_has_bias=False, residual=None, out=None, out_mode=OUT_ROWS, scale=1.0, weight_per_image=False,
-          w_group_stride=0, split_k=None, groups=1):
+          w_group_stride=0, split_k=None, groups=1, defer=None):
     """x: [N,H,W,C0] (tokens: [N,T,1,C]); x2: optional second source concatenated on channels.
+    defer: None, or "keep" / "drop" -- the caller promises that the result's FIRST reader is a GroupNorm over it: a launch that
+    splits k then returns a `Deferred` (no reduce launch; "keep": the GroupNorm also writes the summed tensor, "drop": nobody
+    else reads it).  A launch that does not split returns its tensor as always.
     rowvec: fp32 [N, cout] added per image; rowvec_has_bias: its producer already added this layer's bias (the
     launch then passes no bias, which keeps it on the register-epilogue kernels).
     groups = g > 1: `pw` holds g stacked matrices [g * cout][k]; image i is multiplied by matrix i // (N / g) (ONE launch for
     the camera images' and the lidar images' projections of a [camera ; lidar] batch); no bias."""
     lib = _lib.load()
+    x, x2, residual = finished(x), finished(x2), finished(residual)
     n, hin, win, c0 = x.shape
     c1 = 0 if x2 is None else x2.shape[3]
     assert c0 + c1 == pw.cin, (c0, c1, pw.cin)
@@ -739,8 +792,15 @@ def igemm(x, pw: Packed, *, x2=None, stride=1, pad=None, upsample=False, hout=No
             kern += "_ln"                                    # the LayerNorm-folded instantiation (another kernel symbol)
         tag = f"kern={kern} m={n * hout * wout} n={pw.n_packed} k={pw.kh * pw.kw * pw.cin} tap={pw.kh}x{pw.kw} " \
               f"split={splits} mode={out_mode}"
+    deferred = (defer is not None and DEFER_SPLIT and splits > 1 and not FUSED_SPLIT and out_mode == OUT_ROWS and out.is_contiguous()
+                and (residual is None or residual.is_contiguous()))
+    if deferred:
+        p.defer_finish = 1
     with _Timed("igemm", flops, nbytes, tag):
         _lib.check(lib.mobi_igemm(C.byref(p), _stream()), "mobi_igemm")
+    if deferred:
+        # (`refs`: the operands the finishing launch reads must outlive this call)
+        return Deferred(out, p, ws, (pw, rowvec, residual, x, x2), keep=defer == "keep")
     return out
 
 
@@ -766,6 +826,15 @@ def groupnorm(x, gamma, beta, eps, silu, x2=None, out_mode=GN_OUT_T, dtype=None)
     [W ; W ; W - T(W)] (Conv2d.packed_split: the weights' rounding corrected too); GN_OUT_F32: fp32 [N,H,W,C].  dtype: the storage type T when
     x is fp32."""
     lib = _lib.load()
+    x2 = finished(x2)
+    split = None
+    if isinstance(x, Deferred):
+        n, h, w, c0 = x.shape
+        if (x.done or out_mode != GN_OUT_T or dtype not in (None, x.dtype)
+                or not lib.mobi_groupnorm_takes_split(c0, 0 if x2 is None else x2.shape[3], n, h * w)):
+            x = x.finish()
+        else:
+            split, x = x, x.tensor
     n, h, w, c0 = x.shape
     c1 = 0 if x2 is None else x2.shape[3]
     assert x.is_contiguous() and (x2 is None or x2.is_contiguous())
@@ -777,13 +846,31 @@ def groupnorm(x, gamma, beta, eps, silu, x2=None, out_mode=GN_OUT_T, dtype=None)
     ws = torch.empty(lib.mobi_groupnorm_workspace_bytes(n, h * w), device=x.device, dtype=torch.uint8)
     p = _lib.GroupNormParams()
     p.src0, p.src1, p.c0, p.c1, p.batch, p.hw = _ptr(x), _ptr(x2), c0, c1, n, h * w
+    if split is not None:
+        q = split.params
+        ss = _lib.SplitSource()
+        ss.slabs, ss.count, ss.row_stride = q.ws, split.count, q.n_packed
+        ss.bias, ss.rowvec, ss.rowvec_stride = q.bias, q.rowvec, q.rowvec_stride
+        ss.residual, ss.res_img_stride = q.residual, q.res_img_stride
+        ss.finished = _ptr(x) if split.keep else None
+        p.src0 = None
+        p.src0_split = C.pointer(ss)
     p.gamma, p.beta, p.eps, p.silu = _ptr(gamma), _ptr(beta), eps, int(silu)
     p.out, p.ws, p.dtype = _ptr(out), _ptr(ws), _dt(t)
     p.src_f32, p.out_mode = int(src_f32), out_mode
     p.sync = _ptr(_sync_counters(x.device, 4 * n))
     # algorithmic bytes: the tensor read once and written once (2 B per element each way)
-    with _Timed("groupnorm", 0.0, 2.0 * out.numel() * 2, f"n={n} hw={h * w} c={c0 + c1}"):
+    tag = f"n={n} hw={h * w} c={c0 + c1}"
+    nbytes = 2.0 * out.numel() * 2
+    if split is not None:
+        tag += f" slabs={split.count}"
+        nbytes += split.count * n * h * w * split.params.n_packed * 4.0 - c0 * n * h * w * 2.0 * (0 if split.keep else 1)
+    with _Timed("groupnorm", 0.0, nbytes, tag):
         _lib.check(lib.mobi_groupnorm(C.byref(p), _stream()), "mobi_groupnorm")
+    if split is not None:
+        split._release()
+        if not split.keep:
+            split.tensor = None                              # (never written: nobody may read it)
     return out
 
 

@@ -33,7 +33,7 @@ def test_struct_layouts_match(lib):
     for sid, cls in _lib.STRUCT_IDS.items():
         assert lib.mobi_struct_size(sid) == C.sizeof(cls), cls.__name__
     assert lib.mobi_struct_size(99) == 0
-    assert lib.mobi_abi_version() == 5 == _lib.ABI_VERSION
+    assert lib.mobi_abi_version() == 6 == _lib.ABI_VERSION
     assert lib.mobi_error_string(-2) == b"unsupported shape or mode"
 
 

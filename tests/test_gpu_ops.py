@@ -654,6 +654,105 @@ def test_igemm_split_k(ops, dtype, split):
 
 
 @pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("case", [
+    # n, side, cin, cout, taps, split, c1 of the GroupNorm's second source, operands of the producer's epilogue, keep
+    dict(n=16, side=8, cin=640, cout=1280, k=3, split=8, c1=0, rowvec=True, resid=False, keep=False),     # 8 x 8 level, conv1 -> out_layers
+    dict(n=16, side=8, cin=640, cout=1280, k=3, split=8, c1=1280, rowvec=False, resid=True, keep=True),   # ... -> next block's concat
+    dict(n=16, side=16, cin=320, cout=1280, k=3, split=4, c1=0, rowvec=False, resid=True, keep=True),     # 16 x 16 level
+    dict(n=8, side=32, cin=320, cout=320, k=3, split=4, c1=0, rowvec=True, resid=False, keep=False),      # 8-byte pieces (mobi_nusc_256's top level)
+    dict(n=8, side=4, cin=640, cout=1280, k=3, split=16, c1=1280, rowvec=False, resid=False, keep=True),  # 4 x 4 level, 16 slabs
+    dict(n=4, side=8, cin=640, cout=640, k=1, split=3, c1=320, rowvec=False, resid=True, keep=True),      # ragged slab count, 1 x 1
+    dict(n=3, side=5, cin=320, cout=640, k=3, split=5, c1=0, rowvec=True, resid=True, keep=True),         # ragged rows, every operand
+], ids=lambda c: f"n{c['n']}s{c['side']}c{c['cout']}+{c['c1']}x{c['split']}")
+def test_groupnorm_sums_split_k_slabs(ops, dtype, case):
+    """mobi_split_source: a split-K launch with defer_finish leaves its fp32 slabs, the GroupNorm that consumes the result
+    sums them while it loads (ascending from zero, + bias, + per-image vector, + residual, one rounding): BIT FOR BIT the
+    reduce launch followed by the plain GroupNorm, in the output, in the `finished` tensor it writes for the other readers,
+    and through mobi_igemm_finish; and against fp32 torch like every GroupNorm."""
+    from mobi_amd import _lib
+    n, side, cin, cout, k, c1 = case["n"], case["side"], case["cin"], case["cout"], case["k"], case["c1"]
+    tag = f"ss{n}.{side}.{cin}.{cout}.{k}"
+    xf, xd = rnd(tag + ".x", (n, side, side, cin), dtype)
+    wf = (torch.from_numpy(W.synth_param(tag + ".weight", (cout, cin, k, k))) * 2.0).to(dtype).float()
+    bias = torch.from_numpy(W.synth_param(tag + ".bias", (cout,)))
+    rv = W.synth_input(tag + ".rowvec", (n, cout)).cuda() if case["rowvec"] else None
+    rf, rd = rnd(tag + ".res", (n, side, side, cout), dtype) if case["resid"] else (None, None)
+    x2f, x2d = rnd(tag + ".x2", (n, side, side, c1), dtype) if c1 else (None, None)
+    C = cout + c1
+    g = torch.from_numpy(W.synth_param(tag + ".g.weight", (C,))).cuda()
+    b = torch.from_numpy(W.synth_param(tag + ".g.bias", (C,))).cuda()
+    pw = ops.pack_conv(wf, bias, dtype, "cuda")
+    assert _lib.load().mobi_groupnorm_takes_split(cout, c1, n, side * side) == 1
+
+    # the two launches + the plain GroupNorm
+    y0 = ops.igemm(xd, pw, rowvec=rv, residual=rd, split_k=case["split"])
+    o0 = ops.groupnorm(y0, g, b, 1e-5, True, x2=x2d)
+    # deferred: no reduce launch, the GroupNorm sums the slabs
+    d = ops.igemm(xd, pw, rowvec=rv, residual=rd, split_k=case["split"], defer="keep" if case["keep"] else "drop")
+    assert isinstance(d, ops.Deferred) and 2 <= d.count <= case["split"]
+    if case["keep"]:
+        d.tensor.fill_(float("nan"))                         # (whatever the GroupNorm does not write would show)
+    o1 = ops.groupnorm(d, g, b, 1e-5, True, x2=x2d)
+    assert d.done and torch.equal(o1, o0)
+    if case["keep"]:
+        assert torch.equal(ops.finished(d), y0)
+    # ... or mobi_igemm_finish does, for a reader that is not a GroupNorm
+    d2 = ops.igemm(xd, pw, rowvec=rv, residual=rd, split_k=case["split"], defer="keep")
+    assert torch.equal(ops.finished(d2), y0) and d2.done
+    # and a Deferred that reaches igemm as a source / residual is finished on the way
+    d3 = ops.igemm(xd, pw, rowvec=rv, residual=rd, split_k=case["split"], defer="keep")
+    pw1 = ops.pack_conv(torch.eye(cout).view(cout, cout, 1, 1), None, dtype, "cuda")
+    assert torch.equal(ops.igemm(d3, pw1), ops.igemm(y0, pw1))
+
+    ref = _conv_ref(xf, wf, bias, pad=(k // 2, k // 2))
+    if rv is not None:
+        ref = ref + rv.cpu()[:, None, None, :]
+    if rf is not None:
+        ref = ref + rf
+    assert rel(y0.float(), ref) < TOL[dtype]
+    ref_in = y0.float().cpu() if x2f is None else torch.cat([y0.float().cpu(), x2f], dim=3)
+    gref = F.silu(F.group_norm(ref_in.permute(0, 3, 1, 2), 32, g.cpu(), b.cpu(), 1e-5))
+    assert rel(o1.float().permute(0, 3, 1, 2), gref) < TOL[dtype]
+
+
+def test_split_source_argument_checks(ops):
+    """What mobi_groupnorm refuses of a split source, and what mobi_igemm refuses of defer_finish (no launch happens)."""
+    import ctypes as C
+    from mobi_amd import _lib
+    lib = _lib.load()
+    dtype = torch.float16
+    xd = torch.zeros(2, 8, 8, 640, dtype=dtype, device="cuda")
+    pw = ops.pack_conv(torch.zeros(640, 640, 3, 3), None, dtype, "cuda")
+    assert isinstance(ops.igemm(xd, pw, split_k=1, defer="keep"), torch.Tensor)            # no split: a tensor as always
+    d = ops.igemm(xd, pw, split_k=4, defer="keep")
+    q = d.params
+    assert lib.mobi_igemm_slab_count(C.byref(q)) == d.count == 4
+    q.out_mode = 2                                                                          # fp32 rows cannot be deferred
+    assert lib.mobi_igemm(C.byref(q), None) == -2
+    q.out_mode = 0
+    g = torch.ones(640, device="cuda")
+    ws = torch.empty(lib.mobi_groupnorm_workspace_bytes(2, 64), dtype=torch.uint8, device="cuda")
+    out = torch.empty(2, 8, 8, 640, dtype=dtype, device="cuda")
+    ss = _lib.SplitSource()
+    ss.slabs, ss.count, ss.row_stride = q.ws, 4, 640
+    p = _lib.GroupNormParams()
+    p.c0, p.batch, p.hw, p.gamma, p.beta, p.eps, p.silu = 640, 2, 64, g.data_ptr(), g.data_ptr(), 1e-5, 1
+    p.out, p.ws, p.dtype, p.src0_split = out.data_ptr(), ws.data_ptr(), 0, C.pointer(ss)
+    assert lib.mobi_groupnorm(C.byref(p), None) == 0
+    ss.count = 1
+    assert lib.mobi_groupnorm(C.byref(p), None) == -1                                       # fewer than two slabs
+    ss.count, ss.row_stride = 4, 320
+    assert lib.mobi_groupnorm(C.byref(p), None) == -1                                       # rows shorter than the tensor's
+    ss.row_stride, p.out_mode = 640, 2
+    assert lib.mobi_groupnorm(C.byref(p), None) == -2                                       # precise outputs: the two-launch form
+    p.out_mode, p.hw = 0, 64 * 64 * 4
+    assert lib.mobi_groupnorm_takes_split(640, 0, 2, 64 * 64 * 4) == 0
+    assert lib.mobi_groupnorm(C.byref(p), None) == -2                                       # too large for the register form
+    d.finish()
+    torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("dtype", DT)
 @pytest.mark.parametrize("wm", ["2", "4"])
 def test_igemm_block_heights(ops, dtype, wm, tune):
     """Both block shapes of the implicit-GEMM kernel (4 waves x 128 pixels, 8 waves x 256 pixels) on the same

@@ -79,6 +79,16 @@ def test_full_width_forward_vs_oracle(dtype, side, n):
     # every pair on its own is within the same bound (an error concentrated in one image must not hide in the norm)
     worst = max(rel_l2(y[i:i + 2].cpu(), ref[i:i + 2]) for i in range(0, n, 2))
     check(worst, TOL_FULL[dtype] * 1.4, f"unet_full_width_{side}x{side}_b{n}_{dtype}_worst_pair")
+    # split-K slabs summed by the consuming GroupNorm (ops.Deferred, the default) against every split launch finishing itself
+    # with its reduce launch: the same arithmetic in the same order, so the same bits
+    from mobi_amd import ops
+    assert ops.DEFER_SPLIT
+    ops.DEFER_SPLIT = False
+    try:
+        y2 = net(x.cuda(), t.cuda(), context=ctx.cuda())
+    finally:
+        ops.DEFER_SPLIT = True
+    assert torch.equal(y, y2)
 
 
 def _traj_case(S):
