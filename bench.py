@@ -575,6 +575,11 @@ def main():
         roofline["ms_per_step_every_launch_at_its_better_roof"] = round(ideal * 1e3, 3)
         roofline["ms_per_step_sum_of_launches"] = round(sum(e0.elapsed_time(e1) for _, _, e0, e1, _, _ in sink), 3)
         roofline["launches_per_step_all"] = len(sink)
+        # split-K launches of the step: how many leave their slabs to the GroupNorm that reads the result (ops.Deferred) and how
+        # many are followed by a reduce launch of their own (inside their igemm bracket, or a later mobi_igemm_finish)
+        n_split = sum(1 for kind, *_, tag in sink if kind == "igemm" and " split=" in tag and " split=1 " not in tag)
+        n_gn = sum(1 for kind, *_, tag in sink if kind == "groupnorm" and " slabs=" in tag)
+        roofline["split_k_launches"] = {"all": n_split, "summed_by_the_consuming_groupnorm": n_gn, "reduce_launches": n_split - n_gn}
         if os.path.exists(pmc):
             traffic = {}
             for fam_k in ("igemm_ring_kernel", "igemm_pp_kernel", "attention_rows_kernel", "attention_kernel", "ff_geglu_kernel",

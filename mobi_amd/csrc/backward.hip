@@ -935,28 +935,33 @@ __global__ __launch_bounds__(256) void gnb_pass_kernel(const GnbArgs a) {
 // one wave per (image, group): fold the chunk partials of the group's channels (fixed order), write the statistics
 template <int PASS>
 __global__ __launch_bounds__(64) void gnb_fold_kernel(const GnbArgs a) {
+  // (the chunk partials meet in fp64, as in the forward's two-launch form (csrc/norm.hip, gn_apply_kernel): E[x^2] - mean^2 of
+  //  a group whose mean is large against its spread then loses the partials' fp32 rounding only, not the difference's)
   const int g = blockIdx.x, img = blockIdx.y, lane = threadIdx.x, G = a.C / 32;
-  float t0 = 0.f, t1 = 0.f;
+  double t0 = 0.0, t1 = 0.0;
   for (int i = lane; i < a.chunks * G; i += 64) {
     const int ch = i / G, c = g * G + (i - ch * G);
     const float* pp = a.partial + (((long long)img * a.chunks + ch) * 2) * a.C;
-    t0 += pp[c];
-    t1 += pp[a.C + c];
+    t0 += (double)pp[c];
+    t1 += (double)pp[a.C + c];
   }
-  t0 = wave_sum(t0);
-  t1 = wave_sum(t1);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    t0 += __shfl_xor(t0, o, 64);
+    t1 += __shfl_xor(t1, o, 64);
+  }
   if (lane == 0) {
     float* st = a.stats + ((long long)img * 32 + g) * 4;
-    const float inv_m = 1.0f / ((float)G * (float)a.hw);
+    const double inv_m = 1.0 / ((double)G * (double)a.hw);
     if (PASS == 1) {
-      const float mean = t0 * inv_m;
-      float var = t1 * inv_m - mean * mean;
-      var = var < 0.f ? 0.f : var;
-      st[0] = mean;
-      st[1] = rsqrtf(var + a.eps);
+      const double mean = t0 * inv_m;
+      double var = t1 * inv_m - mean * mean;
+      var = var < 0.0 ? 0.0 : var;
+      st[0] = (float)mean;
+      st[1] = (float)(1.0 / sqrt(var + (double)a.eps));
     } else {
-      st[2] = t0 * inv_m;
-      st[3] = t1 * inv_m;
+      st[2] = (float)(t0 * inv_m);
+      st[3] = (float)(t1 * inv_m);
     }
   }
 }

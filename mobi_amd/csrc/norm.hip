@@ -476,6 +476,8 @@ __global__ __launch_bounds__(THREADS) void gn_regs_kernel(const GnArgs a, const 
           for (int j = 0; j < PW; ++j) o[j] += rvv[j];
         }
         if (resid) {
+          // (the words go through a plain array: `__builtin_bit_cast(T2, rr[j])` straight on the elements of a `const piece_t`
+          //  compiled -- hipcc of ROCm 7.2 -- to ONE 4-byte load of element 0 used for every j: 6 of 8 channels without residual)
           piece_t rr = *reinterpret_cast<const piece_t*>(resid + (long long)img * a.s_res_img + (long long)p * a.c0 + c);
           unsigned rw[PR];
 #pragma unroll
