@@ -170,7 +170,16 @@ def main():
              ("vae_decode_fp16.txt", "fp16 VAE decode / encode of 8 images at 512 x 512 by precision option (fp32 trunk / streams / hi | lo tail)"),
              ("ab_ln_fold.txt", "whole-step A/B of the shipped LayerNorm fold, both workloads (slow-group box)"),
              ("ab_chain_ff.txt", "row chains / one-launch feed-forward re-measured against the one-by-one sequences as they are now"),
-             ("tile_geometry_lab.txt", "the small-m 1 x 1 shapes on every tile geometry: ~10 us of fixed cost per launch (tools/wide_lab.py)")]
+             ("tile_geometry_lab.txt", "the small-m 1 x 1 shapes on every tile geometry: ~10 us of fixed cost per launch (tools/wide_lab.py)"),
+             ("ab_defer_split.txt", "split-K slabs summed by the consuming GroupNorm against the reduce launches: parity tests, then the whole-step A/B (tools/ab_defer.sh)"),
+             ("ab_runtime_env.txt", "HIP runtime launch switches on the replayed mobi_nusc_256 graph (nothing to gain)"),
+             ("ab_fp32_outer_stream.txt", "the UNet's outer residual stream carried in fp32 beside its 16-bit copy: not where the fp16 error comes from"),
+             ("ab_graph_branches.txt", "the ResBlocks' 1 x 1 skip convolution on a forked branch of the step graph (slower: fork / join edges)"),
+             ("ab_ln_fold_rows.txt", "the LayerNorm fold's row threshold (LN_FOLD_MIN_ROWS), whole-step A/B"),
+             ("ab_split_round4.txt", "round 5's split-K plan against round 4's, whole-step A/B"),
+             ("split_sweep.txt", "split-K sweeps of both workloads with the reduce launch timed in (tools/sweep_split.py)"),
+             ("attn_bwd_err.txt", "the softmax backward's row term: D from the stored output against D = sum_j P dP (tests/attn_bwd_err.py)"),
+             ("e2e_idle_gap.txt", "end-to-end phases after a host-side gap: an idle GPU drops its clocks")]
     have = set(os.listdir(dst))
     for suffix, what in known:
         if f"{tag}_{suffix}" in have:
@@ -179,6 +188,9 @@ def main():
     for name in sorted(have):
         if name.startswith(tag + "_") and name not in listed:
             lines.append(f"* `{name}`")
+    lines.append("* `graph_breakdown`, `nusc256_kernel_stats`, `nusc256_pmc_traffic`, `train_*`, `mall_share`, `vae_decode_fp16` come from "
+                 "`tools/profile_more.sh` / `tools/profile_extra.sh`, last run on the build of commit 73e84cb (before the GroupNorm summed "
+                 "split-K slabs: those files still show the 37 / 64 reduce launches per step)")
     lines.append("* the igemm main-loop A/Bs, split-K sweeps and the attention / adapter / feed-forward / row-chain labs of the kernels this "
                  "round left untouched are rounds 2-4's (`r02_*`, `r03_*`, `r04_*`)")
     with open(os.path.join(dst, f"{tag}_README.md"), "w") as f:
