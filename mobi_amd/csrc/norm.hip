@@ -448,6 +448,10 @@ __global__ __launch_bounds__(THREADS) void gn_regs_kernel(const GnArgs a, const 
         for (int j = 0; j < PW; ++j) o[j] = 0.f;
         const float* q = a.slabs + (row0 + p) * a.slab_row + c;
         int sp = 0;
+        // (more loads in flight -- a batch of items x slabs requested before anything is added, 16-24 sixteen-byte loads per
+        //  thread -- did NOT help: 15.5 against 14.3 us on [8, 256, 640] x 4 slabs, 23.8 against 22.2 on [16, 256, 1280] x 4: the
+        //  launch is bound by the slabs' bytes (84 MB in the 13 us it takes beyond the plain GroupNorm), and the batches' registers
+        //  cost occupancy; profiles/r05_defer_breakdown.txt)
         for (; sp + 4 <= a.splits; sp += 4) {             // four slabs requested at once, summed in ascending order
           f32x4 v[4][PW / 4];
 #pragma unroll
@@ -676,6 +680,9 @@ static bool gn_regs_takes_split(int c0, int c1, int hw, int batch) {
   GnRegsGeom geo;
   int th, it, pw;
   if (!gn_regs_geometry(c0 + c1, hw, batch, &geo, &th, &it, &pw)) return false;
+  // 8-byte pieces (C = 320: the 32 x 32 level of mobi_nusc_256) only on request: in the step graph 21.0 us against 9.8 + 6.5 for
+  // GroupNorm + reduce launch on [8, 1024, 320] x 4 slabs (tools/defer_breakdown.sh) -- 128 blocks read 42 MB of slabs
+  if (pw == 4 && tuning().gn_split_pw4 != 1) return false;
   return it <= 8 && c0 % pw == 0;
 }
 
@@ -684,6 +691,7 @@ static bool launch_gn_regs_split(const GnArgs& a, int batch, hipStream_t st) {
   GnRegsGeom geo;
   int th, it, pw;
   if (!gn_regs_geometry(a.C, a.hw, batch, &geo, &th, &it, &pw) || it > 8 || a.c0 % pw) return false;
+  if (pw == 4 && tuning().gn_split_pw4 != 1) return false;
   const dim3 grid((unsigned)(32 / geo.gb * batch));
 #define MOBI_GNS(TH_, IT_, PW_) hipLaunchKernelGGL((gn_regs_kernel<T, TH_, IT_, PW_, true>), grid, dim3(TH_), 0, st, a, geo)
   if (pw == 4) MOBI_GNS(1024, 8, 4);

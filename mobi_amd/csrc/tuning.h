@@ -39,6 +39,7 @@ struct Tuning {
   int skinny_mfma;      // MOBI_SKINNY_MFMA           0: fp32-row linears on the vector-ALU kernel (A/B)
   int gn_coop;          // MOBI_GN_COOP               1: GroupNorm as pixel chunks meeting through memory wherever the geometry fits; 0: never (A/B)
   int gn_fused;         // MOBI_GN_FUSED              0: two-launch GroupNorm; 1: one launch, slab in LDS, where it fits (A/B)
+  int gn_split_pw4;     // MOBI_GN_SPLIT_PW4          1: split-K slabs also into the 8-byte-piece geometry of the register GroupNorm (A/B; default: 16-byte pieces only)
   int attn_v3;          // MOBI_ATTN_V3               0: V row-major launches stay on attention_kernel (A/B); development build: 2 / 3 = the
                         //                            software-pipelined variants of attention_rows_kernel
 };

@@ -45,6 +45,7 @@ void read_env() {
   g_tuning.attn_v3 = env_int("MOBI_ATTN_V3");
   g_tuning.gn_fused = env_int("MOBI_GN_FUSED");
   g_tuning.gn_coop = env_int("MOBI_GN_COOP");
+  g_tuning.gn_split_pw4 = env_int("MOBI_GN_SPLIT_PW4");
   g_tuning.skinny_mfma = env_int("MOBI_SKINNY_MFMA");
   g_tuning.cout_mfma = env_int("MOBI_COUT_MFMA");
   g_tuning.attn_xcd = env_int("MOBI_ATTN_XCD");

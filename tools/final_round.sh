@@ -14,3 +14,9 @@ tail -4 gpurun_out/gpu_tests.log
 bash tools/profile_round.sh $TAG > gpurun_out/profile_round.log 2>&1
 echo "profile rc=$?"
 head -c 1500 gpurun_out/$TAG/bench.json
+# the records tools/profile_more.sh refreshes that depend on the GroupNorm / split-K kernels: in-graph breakdown, the
+# mobi_nusc_256 and training-step kernel stats (the Infinity-Cache and VAE-decoder records are other kernels': not re-run)
+bash tools/graph_breakdown.sh > gpurun_out/$TAG/graph_breakdown.log 2>&1 && cp gpurun_out/gb/graph_breakdown.txt gpurun_out/$TAG/graph_breakdown.txt
+bash tools/profile_extra.sh > gpurun_out/$TAG/profile_extra.log 2>&1
+cp gpurun_out/extra/nusc256_kernel_stats.csv gpurun_out/extra/train_kernel_stats.csv gpurun_out/extra/nusc256_pmc_traffic.json gpurun_out/$TAG/ 2>/dev/null
+echo; tail -1 gpurun_out/extra/train_trace.log
