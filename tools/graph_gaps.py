@@ -11,7 +11,10 @@ import sys
 
 def main():
     d = sys.argv[1]
-    n_per_step = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    # launches per step: given, or (`ms=<the traced bench line's ms_per_step>`) derived per run as dispatches x ms_per_step / span
+    arg = sys.argv[2] if len(sys.argv) > 2 else "0"
+    ms_per_step = float(arg[3:]) if arg.startswith("ms=") else 0.0
+    n_per_step = 0 if ms_per_step else int(arg)
     rows = []
     for f in glob.glob(d + "/**/*kernel_trace.csv", recursive=True):
         for r in csv.DictReader(open(f)):
@@ -32,6 +35,8 @@ def main():
         busy = sum(e - s for s, e, _ in run)
         gaps = [max(0, b[0] - a[1]) for a, b in zip(run, run[1:])]
         span = run[-1][1] - run[0][0]
+        if ms_per_step:
+            n_per_step = max(1, round(len(run) * ms_per_step * 1e6 / span))
         gs = sorted(gaps)
         print(f"run of {len(run)} dispatches: span {span / 1e6:.3f} ms, busy {busy / 1e6:.3f} ms, gaps {sum(gaps) / 1e6:.3f} ms "
               f"(median {gs[len(gs) // 2] / 1e3:.2f} us, p90 {gs[int(len(gs) * 0.9)] / 1e3:.2f} us, max {gs[-1] / 1e3:.1f} us)")
