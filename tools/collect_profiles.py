@@ -179,7 +179,9 @@ def main():
              ("ab_split_round4.txt", "round 5's split-K plan against round 4's, whole-step A/B"),
              ("split_sweep.txt", "split-K sweeps of both workloads with the reduce launch timed in (tools/sweep_split.py)"),
              ("attn_bwd_err.txt", "the softmax backward's row term: D from the stored output against D = sum_j P dP (tests/attn_bwd_err.py)"),
-             ("e2e_idle_gap.txt", "end-to-end phases after a host-side gap: an idle GPU drops its clocks")]
+             ("e2e_idle_gap.txt", "end-to-end phases after a host-side gap: an idle GPU drops its clocks"),
+             ("defer_breakdown.txt", "the slab-summing GroupNorm inside the replayed step graphs, per kernel instantiation (tools/defer_breakdown.sh)"),
+             ("grid_barrier_probe.txt", "a dependent launch in a replayed graph (1.6 us) against a grid barrier inside one persistent launch (3.8 / 13.7 us): tools/probes/grid_barrier.hip")]
     have = set(os.listdir(dst))
     for suffix, what in known:
         if f"{tag}_{suffix}" in have:
