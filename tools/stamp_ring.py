@@ -82,7 +82,8 @@ def main():
               f"{np.mean(gaps) if gaps else 0:.2f} (median {np.median(gaps) if gaps else 0:.2f}), last entry at {t[:, 0].max() - t0:.1f}",
               flush=True)
     os.environ["MOBI_HIPCC_FLAGS"] = os.environ["MOBI_HIPCC_FLAGS"].replace("-DMOBI_STAMP=1", "").strip()
-    build.build(force=True, verbose=False)
+    if os.environ.get("MOBI_STAMP_NO_RESTORE") != "1":       # (on a throw-away GPU box the stamped library need not be rebuilt)
+        build.build(force=True, verbose=False)
 
 
 if __name__ == "__main__":
