@@ -182,6 +182,7 @@ def main():
              ("e2e_idle_gap.txt", "end-to-end phases after a host-side gap: an idle GPU drops its clocks"),
              ("defer_breakdown.txt", "the slab-summing GroupNorm inside the replayed step graphs, per kernel instantiation (tools/defer_breakdown.sh)"),
              ("stamp_ring.txt", "in-kernel phases of the 256 x 320 ring tiles on the final library (tools/stamp_ring.py): entry -> first k-step 2.4-3.7 us, drain + epilogue + stores 8-12 us"),
+             ("icache_cold_probe.txt", "cold instruction fetch: ~650 cycles once per launch, nothing per KiB of code (tools/probes/icache_cold.hip; a refuted hypothesis about the launches' prologue / epilogue)"),
              ("grid_barrier_probe.txt", "a dependent launch in a replayed graph (1.6 us) against a grid barrier inside one persistent launch (3.8 / 13.7 us): tools/probes/grid_barrier.hip")]
     have = set(os.listdir(dst))
     for suffix, what in known:
