@@ -137,6 +137,82 @@ def test_state_dict_keys_match_reference_layout():
         assert got == {k: tuple(s) for k, s in want.items()}
 
 
+def test_split_k_slabs_are_promised_to_groupnorms_only():
+    """ops.Deferred (a split-K launch's unsummed slabs) is handed to the NEXT layer only where that layer opens with a GroupNorm
+    over its whole input (ResBlock.in_layers[0], SpatialTransformer.norm: openaimodel.py:255-275, attention.py:306 of the
+    reference): the routing predicate on the production UNet's layout, block by block."""
+    from mobi_amd.ldm.modules.attention import SpatialTransformer
+    from mobi_amd.ldm.modules.diffusionmodules.openaimodel import (Downsample, ResBlock, UNetModel, Upsample,
+                                                                   _opens_with_groupnorm)
+    from mobi_amd.ldm.modules.diffusionmodules.util import Conv2d
+    net = UNetModel(image_size=8, in_channels=9, out_channels=4, model_channels=64, attention_resolutions=[4, 2, 1],
+                    num_res_blocks=2, channel_mult=[1, 2, 4, 4], num_heads=8, use_spatial_transformer=True,
+                    transformer_depth=1, context_dim=768, legacy=False, bbox_cond=True, use_camera=True,
+                    use_lidar=True)
+    blocks = list(net.input_blocks) + [net.middle_block] + list(net.output_blocks)
+    firsts = [type(b[0]) for b in blocks]
+    assert firsts[0] is Conv2d and not _opens_with_groupnorm(blocks[0])           # input_blocks.0: a bare convolution
+    n_down = sum(1 for b in net.input_blocks if isinstance(b[0], Downsample))
+    assert n_down == 3
+    for b in blocks[1:]:
+        assert _opens_with_groupnorm(b) == isinstance(b[0], ResBlock), type(b[0])
+        assert isinstance(b[0], (ResBlock, Downsample))
+    # inside a block: a ResBlock hands over to a SpatialTransformer, never to an Upsample convolution
+    seen = set()
+    for b in blocks:
+        layers = list(b)
+        for a, nxt in zip(layers, layers[1:]):
+            seen.add((type(a).__name__, type(nxt).__name__, _opens_with_groupnorm(nxt)))
+    assert ("ResBlock", "SpatialTransformer", True) in seen
+    assert any(k[1] == "Upsample" and k[2] is False for k in seen)
+    assert all(k[2] == (k[1] in ("ResBlock", "SpatialTransformer")) for k in seen)
+    assert not _opens_with_groupnorm(Upsample(64, True)) and not _opens_with_groupnorm(torch.nn.Identity())
+
+
+def test_split_source_entry_points_validate_on_the_host(lib):
+    """mobi_igemm_slab_count / mobi_igemm_finish / mobi_groupnorm_takes_split / mobi_groupnorm with a split source refuse bad
+    arguments before anything is launched (no GPU here: every call below must return on the host)."""
+    from mobi_amd import _lib
+    assert lib.mobi_igemm_slab_count(None) == -1 and lib.mobi_igemm_finish(None, None) == -1
+    assert lib.mobi_groupnorm_takes_split(1280, 0, 16, 64) == 1           # 8 x 8 level, 16-byte pieces
+    assert lib.mobi_groupnorm_takes_split(1280, 1280, 16, 256) == 1       # a concat's first source
+    assert lib.mobi_groupnorm_takes_split(320, 0, 16, 4096) == 0          # too large for the register form's slab path
+    assert lib.mobi_groupnorm_takes_split(320, 0, 8, 1024) == 0           # 8-byte pieces: only with MOBI_GN_SPLIT_PW4=1
+    assert lib.mobi_groupnorm_takes_split(48, 0, 1, 64) == 0 and lib.mobi_groupnorm_takes_split(64, 0, 0, 64) == 0
+    p = _lib.IgemmParams()
+    p.src0 = p.weight = p.out = 16
+    p.c0, p.batch, p.hin, p.win, p.hout, p.wout = 640, 2, 8, 8, 8, 8
+    p.kh = p.kw = 3
+    p.stride, p.pad_h, p.pad_w, p.groups, p.n_packed, p.cout, p.scale, p.dtype = 1, 1, 1, 1, 640, 640, 1.0, 0
+    assert lib.mobi_igemm_slab_count(C.byref(p)) == 1                     # no split asked
+    p.defer_finish = 1
+    assert lib.mobi_igemm_slab_count(C.byref(p)) == -2                    # nothing to defer without a split
+    p.split_k, p.ws = 4, 32
+    assert lib.mobi_igemm_slab_count(C.byref(p)) == 4
+    p.split_k = 64                                                        # 90 k-tiles in 64 ranges of 2: 45 slabs are written
+    assert lib.mobi_igemm_slab_count(C.byref(p)) == 45
+    p.split_k, p.out_mode = 4, 2
+    assert lib.mobi_igemm_slab_count(C.byref(p)) == -2                    # fp32 rows are not what a consumer reconstructs
+    p.out_mode, p.defer_finish = 0, 2
+    assert lib.mobi_igemm_slab_count(C.byref(p)) == -1
+    ss = _lib.SplitSource()
+    ss.slabs, ss.count, ss.row_stride = 48, 4, 640
+    g = _lib.GroupNormParams()
+    g.c0, g.batch, g.hw, g.gamma, g.beta, g.eps, g.out, g.ws, g.dtype = 640, 2, 64, 16, 16, 1e-5, 16, 16, 0
+    g.src0_split = C.pointer(ss)
+    ss.count = 65
+    assert lib.mobi_groupnorm(C.byref(g), None) == -1
+    ss.count, ss.row_stride = 4, 642
+    assert lib.mobi_groupnorm(C.byref(g), None) == -1                     # rows of slabs are 16-byte aligned
+    ss.row_stride, ss.slabs = 640, 52
+    assert lib.mobi_groupnorm(C.byref(g), None) == -4
+    ss.slabs, g.src_f32 = 48, 1
+    assert lib.mobi_groupnorm(C.byref(g), None) == -2
+    g.src_f32 = 0
+    g.src0_split = None
+    assert lib.mobi_groupnorm(C.byref(g), None) == -1                     # neither a tensor nor its slabs
+
+
 def test_config_loader_and_instantiate(tmp_path):
     from mobi_amd.ldm.util import instantiate_from_config, load_config
     y = tmp_path / "c.yaml"
