@@ -213,6 +213,20 @@ def test_split_source_entry_points_validate_on_the_host(lib):
     assert lib.mobi_groupnorm(C.byref(g), None) == -1                     # neither a tensor nor its slabs
 
 
+def test_integration_md_stub_matches_the_library(monkeypatch):
+    """The ctypes stub INTEGRATION.md shows a maintainer is executed as written (from the repo root): its own ABI-version and
+    struct-size assertions run against the built library, so the document cannot fall behind the header again."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "INTEGRATION.md")).read()
+    blocks = re.findall(r"```python\n(.*?)```", text, flags=re.S)
+    stub = [b for b in blocks if "class GroupNormParams" in b]
+    assert len(stub) == 1 and "mobi_struct_size(1)" in stub[0] and "mobi_abi_version()" in stub[0]
+    monkeypatch.chdir(root)
+    ns = {}
+    exec(compile(stub[0], "INTEGRATION.md", "exec"), ns)                  # defines the struct, runs the layout assertions
+    assert callable(ns["groupnorm_silu"])
+
+
 def test_config_loader_and_instantiate(tmp_path):
     from mobi_amd.ldm.util import instantiate_from_config, load_config
     y = tmp_path / "c.yaml"
